@@ -1,0 +1,189 @@
+/*
+ * pbrt_hip.h — C ABI of the MI355X (gfx950) ray/path-tracing hot path.
+ *
+ * The reference (lazytiger/pbrt-rs, /root/reference) has no FFI for this path; its boundary
+ * is a set of Rust trait objects. Each entry point below states the trait
+ * method(s) it stands in for (file:line relative to /root/reference). A Rust caller wraps
+ * them as `impl Integrator for HipIntegrator` / `impl Primitive for HipAggregate`
+ * (INTEGRATION.md shows the binding).
+ *
+ * Conventions: plain C, int status returns (0 = PBRT_HIP_OK), no exceptions cross the
+ * boundary; host buffers are borrowed for the duration of the call; the library owns all
+ * device memory behind the opaque handles; a handle is used from one thread at a time; one
+ * device per context. Float = f32 everywhere (src/core/pbrt.rs:16).
+ */
+#ifndef PBRT_HIP_H
+#define PBRT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PbrtHipContext PbrtHipContext;
+typedef struct PbrtHipScene PbrtHipScene;
+
+enum PbrtHipStatus {
+    PBRT_HIP_OK = 0,
+    PBRT_HIP_ERR_INVALID = 1,   /* bad argument (null pointer, negative count, index out of range) */
+    PBRT_HIP_ERR_DEVICE = 2,    /* a HIP runtime call failed; see pbrt_hip_last_error */
+    PBRT_HIP_ERR_NO_DEVICE = 3, /* no gfx950 device visible */
+    PBRT_HIP_ERR_OOM = 4
+};
+
+/* src/accelerators/bvh.rs:129-135 LinearBVHNode, packed to pbrt-v3's 32 bytes (the reference's
+ * 48 B is usize padding). Interior: first child = self + 1, `offset` = second child.
+ * Leaf (n_primitives > 0): `offset` = first slot in the leaf-ordered primitive list. */
+typedef struct PbrtLinearBVHNode {
+    float bounds_min[3];
+    float bounds_max[3];
+    int32_t offset;
+    uint16_t n_primitives;
+    uint8_t axis;
+    uint8_t pad;
+} PbrtLinearBVHNode;
+
+/* src/core/geometry.rs:757-763 Ray {o, d, t_max, time} (medium dropped: handle_media is false
+ * on every call of this path, path.rs:117, directlighting.rs:114). */
+typedef struct PbrtRay {
+    float o[3];
+    float d[3];
+    float t_max;
+    float time;
+} PbrtRay;
+
+/* What Primitive::intersect leaves behind that the shade stage needs (SurfaceInteraction,
+ * src/core/interaction.rs:224-245, is rebuilt from it): the shrunk ray.t_max
+ * (src/core/primitive.rs:70), the watertight barycentrics (src/shapes/triangle.rs:134-137)
+ * and the primitive. prim_id = -1 and t = +inf on a miss. prim_id indexes the caller's
+ * triangle order (not the leaf order). */
+typedef struct PbrtHit {
+    float t;
+    float b0, b1, b2;
+    int32_t prim_id;
+    int32_t pad[3];
+} PbrtHit;
+
+/* src/materials/*.rs are empty stubs; the three materials are pbrt-v3's on the reference's
+ * BxDFs (src/core/reflection.rs:821-855, 614-659, 733-819). */
+enum PbrtMaterialType { PBRT_MAT_NONE = 0, PBRT_MAT_MATTE = 1, PBRT_MAT_MIRROR = 2, PBRT_MAT_GLASS = 3 };
+typedef struct PbrtMaterial {
+    int32_t type;
+    float kd[3]; /* matte Kd; mirror / glass Kr */
+    float kt[3]; /* glass Kt */
+    float eta;   /* glass index of refraction */
+} PbrtMaterial;
+
+/* src/lights/diffuse.rs:19-27 DiffuseAreaLight on one triangle; src/lights/infinite.rs:23-31
+ * InfiniteAreaLight with a constant (1x1) map. */
+enum PbrtLightType { PBRT_LIGHT_DIFFUSE_AREA = 0, PBRT_LIGHT_INFINITE = 1 };
+typedef struct PbrtLight {
+    int32_t type;
+    float L[3];
+    int32_t prim;      /* area light: triangle index (caller's order) */
+    int32_t two_sided; /* src/lights/diffuse.rs:25 */
+    int32_t n_samples; /* src/core/light.rs:76 */
+    int32_t pad;
+} PbrtLight;
+
+/* src/cameras/perspective.rs:19-32: the two matrices the ray generator applies. Row-major. */
+typedef struct PbrtCamera {
+    float camera_to_world[16];
+    float raster_to_camera[16];
+    float lens_radius;
+    float focal_distance;
+    float shutter_open;
+    float shutter_close;
+} PbrtCamera;
+
+enum PbrtIntegratorKind { PBRT_INTEGRATOR_PATH = 0, PBRT_INTEGRATOR_DIRECT = 1 };
+
+/* Constructor arguments of PathIntegrator (src/integrators/path.rs:31-46) /
+ * DirectLightingIntegrator (src/integrators/directlighting.rs:33-46) plus the sampler and film
+ * plumbing of SamplerIntegrator::render (src/core/integrator.rs:399-480). */
+typedef struct PbrtRenderParams {
+    int32_t integrator;     /* PbrtIntegratorKind */
+    int32_t max_depth;
+    float rr_threshold;     /* path only */
+    int32_t light_strategy; /* path: 0 "uniform", 1 "power"; direct: 0 UniformSampleAll, 1 UniformSampleOne */
+    int32_t spp;            /* RandomSampler samples per pixel */
+    int32_t width, height;  /* film full_resolution */
+    int32_t x0, y0, x1, y1; /* pixel_bounds [x0,x1) x [y0,y1) */
+    uint64_t seed;          /* stream of (pixel, sample) = seed ^ ((y*width + x)*spp + s) */
+    int32_t tile_rank;      /* this GPU renders the 16x16 tiles whose index % tile_world == tile_rank */
+    int32_t tile_world;     /* 1 = all tiles */
+    int32_t spp_per_pass;   /* 0 = library default; samples of one pixel traced concurrently */
+    int32_t pad;
+} PbrtRenderParams;
+
+typedef struct PbrtRenderStats {
+    uint64_t camera_samples;
+    uint64_t rays_closest;   /* Scene::intersect calls (camera, bounce and MIS rays) */
+    uint64_t rays_shadow;    /* Scene::intersect_p calls */
+    uint64_t trace_launches; /* launches of the traversal kernel */
+    double trace_ms;         /* HIP-event time spent in the traversal kernel */
+    double total_ms;         /* HIP-event time of the whole render (scene resident, film on device) */
+} PbrtRenderStats;
+
+/* ---- context ---- */
+int pbrt_hip_context_create(int device_id, PbrtHipContext** out);
+void pbrt_hip_context_destroy(PbrtHipContext* ctx);
+/* Last error text for this context (or for context creation when ctx == NULL). */
+const char* pbrt_hip_last_error(const PbrtHipContext* ctx);
+
+/* ---- host side: BVHAccel::new (src/accelerators/bvh.rs:216-271) ----
+ * Builds the flat DFS node array and the leaf order over world-space triangles
+ * (split_method: 0 SAH, 2 Middle, 3 EqualCounts, numbering of bvh.rs:200-205).
+ * Outputs are allocated by the library; release with pbrt_hip_free. */
+int pbrt_hip_bvh_build(const float* positions, int32_t n_verts, const int32_t* indices, int32_t n_tris,
+                       int32_t max_prims_in_node, int32_t split_method, PbrtLinearBVHNode** nodes_out,
+                       int32_t* n_nodes_out, int32_t** prim_order_out);
+void pbrt_hip_free(void* p);
+
+/* ---- scene: Scene::new (src/core/scene.rs:18-34) over GeometricPrimitive triangles
+ * (src/core/primitive.rs:33-55) inside a BVHAccel ----
+ * nodes / prim_order come from the host BVH builder in the reference's DFS order;
+ * prim_order[slot] = caller's triangle index held at leaf slot `slot`.
+ * tri_material[i] indexes materials; tri_light[i] indexes lights or is -1. */
+int pbrt_hip_scene_create(PbrtHipContext* ctx, const float* positions, int32_t n_verts, const int32_t* indices,
+                          int32_t n_tris, const int32_t* tri_material, const PbrtMaterial* materials,
+                          int32_t n_materials, const int32_t* tri_light, const PbrtLight* lights, int32_t n_lights,
+                          const PbrtLinearBVHNode* nodes, int32_t n_nodes, const int32_t* prim_order,
+                          PbrtHipScene** out);
+void pbrt_hip_scene_destroy(PbrtHipScene* scene);
+
+/* ---- batch Primitive::intersect / intersect_p (src/core/primitive.rs:17-30 via
+ * Scene::intersect / intersect_p, src/core/scene.rs:40-46) ----
+ * rays[i].t_max is the input upper bound; out[i].t <= it on a hit. Host buffers. */
+int pbrt_hip_intersect(PbrtHipScene* scene, const PbrtRay* rays, int64_t n, PbrtHit* out);
+int pbrt_hip_intersect_p(PbrtHipScene* scene, const PbrtRay* rays, int64_t n, uint8_t* out);
+/* Same with device-resident buffers on the context's stream; returns after enqueueing.
+ * `out_flags` (any-hit) may alias nothing else. */
+int pbrt_hip_intersect_device(PbrtHipScene* scene, const PbrtRay* d_rays, int64_t n, PbrtHit* d_out);
+int pbrt_hip_intersect_p_device(PbrtHipScene* scene, const PbrtRay* d_rays, int64_t n, uint8_t* d_out);
+/* Blocks until everything enqueued on the context's stream has finished. */
+int pbrt_hip_synchronize(PbrtHipContext* ctx);
+/* Average duration (ms, HIP events on the context's stream) of the traversal-kernel launches
+ * since the last call with reset != 0, and their count. */
+int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* total_ms, uint64_t* launches);
+
+/* ---- Integrator::render (src/core/integrator.rs:29-42, 399-480) for this GPU's tile set ----
+ * film_xyzw: width*height*4 floats {xyz[3], filter_weight_sum} = the first 16 bytes of the
+ * reference's Pixel (src/core/film.rs:9-15); pixels outside this GPU's tiles are zero, so the
+ * per-GPU films sum to the frame. pbrt_hip_render writes a host buffer; _device leaves the
+ * film in a caller-supplied device buffer (e.g. for an RCCL reduce). stats may be NULL. */
+int pbrt_hip_render(PbrtHipScene* scene, const PbrtCamera* camera, const PbrtRenderParams* params,
+                    float* film_xyzw, PbrtRenderStats* stats);
+int pbrt_hip_render_device(PbrtHipScene* scene, const PbrtCamera* camera, const PbrtRenderParams* params,
+                           float* d_film_xyzw, PbrtRenderStats* stats);
+
+/* Film::write_image's per-pixel arithmetic (src/core/film.rs:153-178, without the file
+ * writer, which is todo!() in the reference): rgb = max(0, xyz_to_rgb(xyz) / filter_weight_sum). Host. */
+void pbrt_hip_film_to_rgb(const float* film_xyzw, int64_t n_pixels, float* rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBRT_HIP_H */

@@ -1,0 +1,175 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so).
+
+ORACLE — TEST INFRASTRUCTURE ONLY. May be imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, and nowhere else; the product path (pbrt-rs_amd/) never touches it.
+Parity unpinned: the reference (lazytiger/pbrt-rs) holds no golden vectors for this path and
+can be neither built nor run here (no rustc/cargo), so this restatement is
+pinned only by its own known-answer and analytic tests (tests/test_oracle_*.py).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+QUIRKS = dict(D2=1 << 0, D9=1 << 1, D10=1 << 2, D11=1 << 3, D13=1 << 4, D36=1 << 5, D37=1 << 6, D39=1 << 7)
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        fp, ip, vp = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p
+        L.orc_scene_create.restype = vp
+        L.orc_scene_create.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
+        L.orc_scene_destroy.argtypes = [vp]
+        L.orc_scene_num_nodes.argtypes = [vp]
+        L.orc_scene_get_nodes.argtypes = [vp, vp]
+        L.orc_scene_get_prim_order.argtypes = [vp, vp]
+        L.orc_intersect.argtypes = [vp, vp, ctypes.c_int64, vp, vp, ctypes.c_int]
+        L.orc_intersect_p.argtypes = [vp, vp, ctypes.c_int64, vp, vp, ctypes.c_int]
+        L.orc_render.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int,
+                                 ctypes.c_uint64] + [ctypes.c_int] * 7 + [vp, vp]
+        L.orc_triangle_test.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, vp]
+        L.orc_bounds_intersect_p.argtypes = [vp, vp, ctypes.c_uint32]
+        L.orc_bounds_intersect_p.restype = ctypes.c_int
+        L.orc_offset_ray_origin.argtypes = [vp, vp, vp, vp, vp]
+        for name in ("orc_next_float_up", "orc_next_float_down", "orc_gamma"):
+            getattr(L, name).restype = ctypes.c_float
+            getattr(L, name).argtypes = [ctypes.c_float]
+        L.orc_pcg32.argtypes = [ctypes.c_uint64, ctypes.c_int, vp, vp]
+        L.orc_elementary.argtypes = [ctypes.c_int, vp, vp, ctypes.c_int64, vp]
+        L.orc_sample.argtypes = [ctypes.c_int, vp, ctypes.c_int64, ctypes.c_uint32, vp]
+        L.orc_fr_dielectric.restype = ctypes.c_float
+        L.orc_fr_dielectric.argtypes = [ctypes.c_float] * 3
+        L.orc_refract.argtypes = [vp, vp, ctypes.c_float, ctypes.c_uint32, vp]
+        L.orc_refract.restype = ctypes.c_int
+        L.orc_local_to_world.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _materials_flat(materials):
+    m = np.zeros((len(materials), 8), dtype=np.float32)
+    m[:, 0] = materials["type"]
+    m[:, 1:4] = materials["kd"]
+    m[:, 4:7] = materials["kt"]
+    m[:, 7] = materials["eta"]
+    return m
+
+
+def _lights_flat(lights):
+    l = np.zeros((len(lights), 8), dtype=np.float32)
+    l[:, 0] = lights["type"]
+    l[:, 1:4] = lights["L"]
+    l[:, 4] = lights["prim"]
+    l[:, 5] = lights["two_sided"]
+    l[:, 6] = lights["n_samples"]
+    return l
+
+
+HIT_DTYPE = np.dtype([("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"), ("prim_id", "<i4"),
+                      ("pad", "<i4", 3)])
+NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"), ("n_primitives", "<u2"),
+                       ("axis", "u1"), ("pad", "u1")])
+
+
+class OracleScene:
+    """Scene::new over GeometricPrimitive triangles in a BVHAccel (CPU restatement)."""
+
+    def __init__(self, scene, max_prims_in_node=4, split_method=0, quirks=0, normals=None, uvs=None):
+        L = lib()
+        self._keep = dict(
+            positions=_f32(scene["positions"]), indices=np.ascontiguousarray(scene["indices"], dtype=np.int32),
+            tri_material=np.ascontiguousarray(scene["tri_material"], dtype=np.int32),
+            materials=_materials_flat(scene["materials"]),
+            tri_light=np.ascontiguousarray(scene["tri_light"], dtype=np.int32),
+            lights=_lights_flat(scene["lights"]),
+            normals=None if normals is None else _f32(normals), uvs=None if uvs is None else _f32(uvs))
+        k = self._keep
+        self.n_tris = k["indices"].shape[0]
+        self.h = L.orc_scene_create(_p(k["positions"]), k["positions"].shape[0], _p(k["indices"]), self.n_tris,
+                                    _p(k["normals"]), _p(k["uvs"]), _p(k["tri_material"]), _p(k["materials"]),
+                                    len(k["materials"]), _p(k["tri_light"]), _p(k["lights"]), len(k["lights"]),
+                                    max_prims_in_node, split_method, quirks)
+
+    def close(self):
+        if self.h:
+            lib().orc_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def nodes(self):
+        n = lib().orc_scene_num_nodes(self.h)
+        out = np.zeros(n, dtype=NODE_DTYPE)
+        lib().orc_scene_get_nodes(self.h, _p(out))
+        return out
+
+    def prim_order(self):
+        out = np.zeros(self.n_tris, dtype=np.int32)
+        lib().orc_scene_get_prim_order(self.h, _p(out))
+        return out
+
+    def intersect(self, rays, n_threads=8):
+        rays = np.ascontiguousarray(rays)
+        out = np.zeros(len(rays), dtype=HIT_DTYPE)
+        ctr = np.zeros(3, dtype=np.uint64)
+        lib().orc_intersect(self.h, _p(rays), len(rays), _p(out), _p(ctr), n_threads)
+        return out, dict(rays=int(ctr[0]), node_tests=int(ctr[1]), prim_tests=int(ctr[2]))
+
+    def intersect_p(self, rays, n_threads=8):
+        rays = np.ascontiguousarray(rays)
+        out = np.zeros(len(rays), dtype=np.uint8)
+        ctr = np.zeros(3, dtype=np.uint64)
+        lib().orc_intersect_p(self.h, _p(rays), len(rays), _p(out), _p(ctr), n_threads)
+        return out, dict(rays=int(ctr[0]), node_tests=int(ctr[1]), prim_tests=int(ctr[2]))
+
+    def render(self, cam36, width, height, spp, integrator=0, max_depth=5, rr_threshold=1.0, light_strategy=1,
+               seed=0, bounds=None, n_threads=8):
+        x0, y0, x1, y1 = bounds if bounds is not None else (0, 0, width, height)
+        film = np.zeros((height, width, 4), dtype=np.float32)
+        stats = np.zeros(5, dtype=np.uint64)
+        cam36 = _f32(cam36)
+        lib().orc_render(self.h, _p(cam36), integrator, max_depth, rr_threshold, light_strategy, spp, seed, width,
+                         height, x0, y0, x1, y1, n_threads, _p(film), _p(stats))
+        return film, dict(rays=int(stats[0]), node_tests=int(stats[1]), prim_tests=int(stats[2]),
+                          camera_samples=int(stats[3]), seconds=float(stats[4]) * 1e-9)
+
+
+def film_to_rgb(film):
+    """Film::write_image arithmetic (src/core/film.rs:153-178): max(0, xyz_to_rgb(xyz) / weight)."""
+    xyz = film[..., :3].astype(np.float32)
+    w = film[..., 3:4]
+    m = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556],
+                  [0.055648, -0.204043, 1.057311]], dtype=np.float32)
+    rgb = np.stack([m[i, 0] * xyz[..., 0] + m[i, 1] * xyz[..., 1] + m[i, 2] * xyz[..., 2] for i in range(3)], axis=-1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out = np.where(w != 0, np.maximum(rgb * (np.float32(1.0) / w), 0), rgb)
+    return out.astype(np.float32)

@@ -1,0 +1,633 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see o_math.h header / oracle/README.md).
+//
+// o_render.h — lights, Scene, light distributions, integrators, camera, film, render loop.
+//
+// Follows:
+//   src/core/light.rs:18-72, 114-135     LightFlags, is_delta_light, trait Light, VisibilityTester::un_occluded
+//   src/lights/diffuse.rs:19-90, 150-156 DiffuseAreaLight::{sample_li, pdf_li, l, power}
+//   src/lights/infinite.rs:23-155        InfiniteAreaLight (constant 1x1 map only; le :84-88,
+//                                        sample_li :96-129, pdf_li :140-151, power :131-133, pre_process :135-139)
+//   src/core/scene.rs:11-46              Scene
+//   src/core/lightdistrib.rs:21-69, 222-232  Uniform / Power light distributions
+//   src/core/integrator.rs:44-90         uniform_sample_all_lights
+//   src/core/integrator.rs:92-134        uniform_sample_one_light
+//   src/core/integrator.rs:136-266       estimate_direct
+//   src/core/integrator.rs:268-277       compute_light_power_distribution
+//   src/core/integrator.rs:294-392       specular_reflect / specular_transmit (without ray differentials)
+//   src/core/integrator.rs:399-480       SamplerIntegrator::render
+//   src/integrators/path.rs:31-213       PathIntegrator
+//   src/integrators/directlighting.rs:17-127  DirectLightingIntegrator
+//   src/core/interaction.rs:387-395      SurfaceInteraction::le
+//   src/cameras/perspective.rs:34-161    PerspectiveCamera
+//   src/core/transform.rs:351-385        Transform * Point / Vector
+//   src/core/geometry.rs:865-881, 898-935  Ray through a Transform with origin error
+//   src/core/film.rs:9-123, 252-295      Film / FilmTile (box filter, src/filters/boxf.rs:14-27)
+// Defect dispositions, all intended: D22 (render -> derived li), D23 (is_infinite),
+// D24 (non-specular mask), D25 (hot-loop log dropped), D26 (MIS ray: Le only if the hit primitive's
+// area light is this light; light.le on miss), D27 (RR q = max(0.05, 1 - max(beta))), D28
+// (DirectLighting adds isect.Le), D29 (infinite_lights holds lights WITH the INFINITE flag), D30
+// (delta if either bit), D31 (un_occluded = !intersect_p), D32/D33/D34, D42 (film bounds / clamp),
+// D43 (box radius 0.5 x 0.5).
+#pragma once
+#include <atomic>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+
+#include "o_bvh.h"
+#include "o_reflection.h"
+
+namespace oracle {
+
+enum LightFlags : uint8_t { LIGHT_DELTA_POSITION = 1, LIGHT_DELTA_DIRECTION = 2, LIGHT_AREA = 4, LIGHT_INFINITE = 8 };
+// light.rs:28-31 (D30: intended)
+inline bool is_delta_light(uint8_t flags) { return (flags & LIGHT_DELTA_POSITION) || (flags & LIGHT_DELTA_DIRECTION); }
+
+struct Scene;
+
+// light.rs:114-135
+struct VisibilityTester {
+    BaseInteraction p0, p1;
+    bool un_occluded(const Scene& scene, TraversalCounters* ctr) const;
+};
+
+// light.rs:33-72
+struct Light {
+    uint8_t flags;
+    int n_samples;
+    explicit Light(uint8_t f, int ns = 1) : flags(f), n_samples(std::max(1, ns)) {}
+    virtual ~Light() {}
+    virtual Spectrum sample_li(const BaseInteraction& ref, const Point2f& u, Vector3f* wi, Float* pdf,
+                               VisibilityTester* vis) const = 0;
+    virtual Spectrum power() const = 0;
+    virtual void pre_process(const Scene&) {}
+    virtual Spectrum le(const Ray&) const { return Spectrum(0.0f); }
+    virtual Float pdf_li(const BaseInteraction& ref, const Vector3f& wi) const = 0;
+    virtual Spectrum l(const BaseInteraction&, const Vector3f&) const { return Spectrum(0.0f); }
+};
+
+// lights/diffuse.rs
+struct DiffuseAreaLight : Light {
+    Spectrum l_emit;
+    std::shared_ptr<Shape> shape;
+    bool two_sided;
+    Float area;
+    DiffuseAreaLight(const Spectrum& le, int ns, const std::shared_ptr<Shape>& s, bool two)
+        : Light(LIGHT_AREA, ns), l_emit(le), shape(s), two_sided(two), area(s->area()) {}
+    // diffuse.rs:60-81
+    Spectrum sample_li(const BaseInteraction& ref, const Point2f& u, Vector3f* wi, Float* pdf,
+                       VisibilityTester* vis) const override {
+        BaseInteraction p_shape = shape->sample2(ref, u, pdf);
+        if (*pdf == 0.0f || (p_shape.p - ref.p).length_squared() == 0.0f) {
+            *pdf = 0.0f;
+            return Spectrum(0.0f);
+        }
+        *wi = (p_shape.p - ref.p).normalize();
+        vis->p0 = ref;
+        vis->p1 = p_shape;
+        return l(p_shape, -*wi);
+    }
+    // diffuse.rs:83-85
+    Spectrum power() const override { return l_emit * ((two_sided ? 2.0f : 1.0f) * area * PI); }
+    // diffuse.rs:87-90
+    Float pdf_li(const BaseInteraction& ref, const Vector3f& wi) const override { return shape->pdf2(ref, wi); }
+    // diffuse.rs:150-156
+    Spectrum l(const BaseInteraction& si, const Vector3f& w) const override {
+        return (two_sided || si.n.dot(w) > 0.0f) ? l_emit : Spectrum(0.0f);
+    }
+};
+
+// geometry.rs:1196-1209
+inline Float spherical_theta(const Vector3f& v) { return det_acos(clampf(v.z, -1.0f, 1.0f)); }
+inline Float spherical_phi(const Vector3f& v) {
+    Float p = det_atan2(v.y, v.x);
+    return p < 0.0f ? p + 2.0f * PI : p;
+}
+
+// lights/infinite.rs with a 1x1 (constant) map and identity light_to_world. The reference's
+// constructor builds a 2x2 sin-weighted Distribution2D from the 1x1 MIPMap (:59-73); the
+// MIPMap's bilinear lookup of a single texel (mipmap.rs:283-295) is taken as that texel.
+struct InfiniteAreaLight : Light {
+    Spectrum l_const;
+    Point3f world_center;
+    Float world_radius = 0.0f;
+    Distribution2D distribution;
+    InfiniteAreaLight(const Spectrum& power, int ns) : Light(LIGHT_INFINITE, ns), l_const(power) {
+        const int width = 2, height = 2;
+        Float img[width * height];
+        for (int v = 0; v < height; ++v) {
+            Float vp = ((Float)v + 0.5f) / (Float)height;
+            Float sin_theta = det_sin(PI * vp);
+            for (int u = 0; u < width; ++u) {
+                img[u + v * width] = l_const.y_value();
+                img[u + v * width] *= sin_theta;
+            }
+        }
+        distribution = Distribution2D(img, width, height);
+    }
+    // infinite.rs:84-88
+    Spectrum le(const Ray&) const override { return l_const; }
+    // infinite.rs:96-129
+    Spectrum sample_li(const BaseInteraction& ref, const Point2f& u, Vector3f* wi, Float* pdf,
+                       VisibilityTester* vis) const override {
+        Float map_pdf = 0.0f;
+        Point2f uv = distribution.sample_continuous(u, &map_pdf);
+        if (map_pdf == 0.0f) return Spectrum(0.0f);
+        Float theta = uv.y * PI, phi = uv.x * 2.0f * PI;
+        Float cos_theta, sin_theta, sin_phi, cos_phi;
+        det_sincos(theta, &sin_theta, &cos_theta);
+        det_sincos(phi, &sin_phi, &cos_phi);
+        *wi = Vector3f(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
+        *pdf = map_pdf / (2.0f * PI * PI * sin_theta);
+        if (sin_theta == 0.0f) *pdf = 0.0f;
+        vis->p0 = ref;
+        vis->p1 = BaseInteraction();
+        vis->p1.p = ref.p + *wi * (2.0f * world_radius);
+        vis->p1.time = ref.time;
+        return l_const;
+    }
+    // infinite.rs:131-133
+    Spectrum power() const override { return l_const * (PI * world_radius * world_radius); }
+    // infinite.rs:135-139
+    void pre_process(const Scene& scene) override;
+    // infinite.rs:140-151
+    Float pdf_li(const BaseInteraction&, const Vector3f& w) const override {
+        Float theta = spherical_theta(w), phi = spherical_phi(w);
+        Float sin_theta = det_sin(theta);
+        if (sin_theta == 0.0f) return 0.0f;
+        return distribution.pdf(Point2f(phi * INV_2_PI, theta * INV_PI)) / (2.0f * PI * PI * sin_theta);
+    }
+};
+
+// scene.rs:11-46
+struct Scene {
+    std::vector<std::shared_ptr<Light>> lights;
+    std::vector<std::shared_ptr<Light>> infinite_lights;
+    std::shared_ptr<BVHAccel> aggregate;
+    Bounds3f world_bound;
+    std::vector<MaterialDesc> materials;
+    // per caller-order primitive: material / area light ids (GeometricPrimitive fields)
+    std::vector<int> prim_material, prim_light;
+    uint32_t quirks = 0;
+    void finish() {
+        world_bound = aggregate->world_bound();
+        for (auto& l : lights) {
+            l->pre_process(*this);
+            if (l->flags & LIGHT_INFINITE) infinite_lights.push_back(l);  // D29: intended
+        }
+    }
+    bool intersect(const Ray& ray, SurfaceInteraction* isect, TraversalCounters* ctr) const {
+        return aggregate->intersect(ray, isect, ctr);
+    }
+    bool intersect_p(const Ray& ray, TraversalCounters* ctr) const { return aggregate->intersect_p(ray, ctr); }
+};
+inline void InfiniteAreaLight::pre_process(const Scene& scene) {
+    scene.world_bound.bounding_sphere(&world_center, &world_radius);
+}
+// light.rs:126-135 (D31: intended negation)
+inline bool VisibilityTester::un_occluded(const Scene& scene, TraversalCounters* ctr) const {
+    return !scene.intersect_p(p0.spawn_ray_to(p1), ctr);
+}
+
+// interaction.rs:387-395
+inline Spectrum surface_le(const Scene& scene, const SurfaceInteraction& si, const Vector3f& w) {
+    int lid = si.prim_id >= 0 ? scene.prim_light[si.prim_id] : -1;
+    if (lid >= 0) return scene.lights[lid]->l(si, w);
+    return Spectrum(0.0f);
+}
+
+// integrator.rs:268-277
+inline std::shared_ptr<Distribution1D> compute_light_power_distribution(const Scene& scene) {
+    if (scene.lights.empty()) return nullptr;
+    std::vector<Float> light_power;
+    for (auto& l : scene.lights) light_power.push_back(l->power().y_value());
+    return std::make_shared<Distribution1D>(light_power.data(), (int)light_power.size());
+}
+// lightdistrib.rs:222-232 ("spatial" is out of scope)
+inline std::shared_ptr<Distribution1D> create_light_sample_distribution(const std::string& name, const Scene& scene) {
+    if (scene.lights.empty()) return nullptr;
+    if (name == "uniform" || scene.lights.size() == 1) {
+        std::vector<Float> prob(scene.lights.size(), 1.0f);
+        return std::make_shared<Distribution1D>(prob.data(), (int)prob.size());
+    }
+    return compute_light_power_distribution(scene);
+}
+
+struct RenderCtx {  // per-thread state threaded through li()
+    Sampler sampler;
+    TraversalCounters ctr;
+};
+
+// integrator.rs:136-266
+inline Spectrum estimate_direct(const SurfaceInteraction& it, const BSDF& bsdf, const Point2f& u_scattering,
+                                const Light& light, int light_id, const Point2f& u_light, const Scene& scene,
+                                RenderCtx& rc, bool specular = false) {
+    uint8_t bsdf_flags = specular ? (uint8_t)BSDF_ALL : (uint8_t)(BSDF_ALL & ~BSDF_SPECULAR);  // D24
+    Spectrum ld(0.0f);
+    Vector3f wi;
+    Float light_pdf = 0.0f, scattering_pdf = 0.0f;
+    VisibilityTester visibility;
+    Spectrum li = light.sample_li(it, u_light, &wi, &light_pdf, &visibility);
+    if (light_pdf > 0.0f && !li.is_black()) {
+        scattering_pdf = bsdf.pdf(it.wo, wi, bsdf_flags);
+        Spectrum f = bsdf.f(it.wo, wi, bsdf_flags) * wi.abs_dot(it.shading.n);
+        if (!f.is_black()) {
+            if (!visibility.un_occluded(scene, &rc.ctr)) li = Spectrum(0.0f);
+            if (!li.is_black()) {
+                if (is_delta_light(light.flags)) {
+                    ld += li * f / light_pdf;
+                } else {
+                    Float weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
+                    ld += li * f * weight / light_pdf;
+                }
+            }
+        }
+    }
+    if (!is_delta_light(light.flags)) {
+        uint8_t sampled_type = BSDF_NONE;
+        Spectrum f = bsdf.sample_f(it.wo, &wi, u_scattering, &scattering_pdf, bsdf_flags, &sampled_type);
+        f *= wi.abs_dot(it.shading.n);
+        bool sampled_specular = (sampled_type & BSDF_SPECULAR) != 0;
+        if (!f.is_black() && scattering_pdf > 0.0f) {
+            Float weight = 1.0f;
+            if (!sampled_specular) {
+                light_pdf = light.pdf_li(it, wi);
+                if (light_pdf == 0.0f) return ld;
+                weight = power_heuristic(1, scattering_pdf, 1, light_pdf);
+            }
+            SurfaceInteraction light_isect;
+            Ray ray = it.spawn_ray(wi);
+            bool found = scene.intersect(ray, &light_isect, &rc.ctr);
+            Spectrum li2(0.0f);
+            if (found) {
+                // D26: Le only if the hit primitive's area light is this light
+                if (light_isect.prim_id >= 0 && scene.prim_light[light_isect.prim_id] == light_id)
+                    li2 = surface_le(scene, light_isect, -wi);
+            } else {
+                li2 = light.le(ray);
+            }
+            if (!li2.is_black()) ld += li2 * f * weight / scattering_pdf;
+        }
+    }
+    return ld;
+}
+
+// integrator.rs:92-134
+inline Spectrum uniform_sample_one_light(const SurfaceInteraction& it, const BSDF& bsdf, const Scene& scene,
+                                         RenderCtx& rc, const Distribution1D* light_distrib) {
+    int n_lights = (int)scene.lights.size();
+    if (n_lights == 0) return Spectrum(0.0f);
+    int light_num;
+    Float light_pdf;
+    if (light_distrib) {
+        light_num = light_distrib->sample_discrete(rc.sampler.get_1d(), &light_pdf);
+        if (light_pdf == 0.0f) return Spectrum(0.0f);
+    } else {
+        light_num = (int)fminr(rc.sampler.get_1d() * (Float)n_lights, (Float)n_lights - 1.0f);
+        light_pdf = 1.0f / (Float)n_lights;
+    }
+    const Light& light = *scene.lights[light_num];
+    Point2f u_light = rc.sampler.get_2d();
+    Point2f u_scattering = rc.sampler.get_2d();
+    return estimate_direct(it, bsdf, u_scattering, light, light_num, u_light, scene, rc) / light_pdf;
+}
+
+// integrator.rs:44-90. The reference pre-requests per-light sample arrays in pre_process
+// (directlighting.rs:58-78) and RandomSampler::start_pixel fills them for all spp at once
+// (random.rs:29-42); with per-(pixel,sample) streams the entries are drawn on demand, in the
+// same per-light (u_light[k], u_scatter[k]) order.
+inline Spectrum uniform_sample_all_lights(const SurfaceInteraction& it, const BSDF& bsdf, const Scene& scene,
+                                          RenderCtx& rc, const std::vector<int>& n_light_samples) {
+    Spectrum l(0.0f);
+    for (size_t j = 0; j < scene.lights.size(); ++j) {
+        const Light& light = *scene.lights[j];
+        int n_samples = n_light_samples[j];
+        Spectrum ld(0.0f);
+        for (int k = 0; k < n_samples; ++k) {
+            Point2f u_light = rc.sampler.get_2d();
+            Point2f u_scattering = rc.sampler.get_2d();
+            ld += estimate_direct(it, bsdf, u_scattering, light, (int)j, u_light, scene, rc);
+        }
+        l += ld / (Float)n_samples;
+    }
+    return l;
+}
+
+// integrator.rs:29-42
+struct Integrator {
+    virtual ~Integrator() {}
+    virtual void pre_process(const Scene&) {}
+    virtual Spectrum li(Ray ray, const Scene& scene, RenderCtx& rc, int depth) const = 0;
+};
+
+// integrators/path.rs
+struct PathIntegrator : Integrator {
+    int max_depth;
+    Float rr_threshold;
+    std::string light_sample_strategy;
+    std::shared_ptr<Distribution1D> light_distribution;
+    PathIntegrator(int md, Float rr, const std::string& strat)
+        : max_depth(md), rr_threshold(rr), light_sample_strategy(strat) {}
+    void pre_process(const Scene& scene) override {
+        light_distribution = create_light_sample_distribution(light_sample_strategy, scene);
+    }
+    // path.rs:65-213
+    Spectrum li(Ray ray, const Scene& scene, RenderCtx& rc, int) const override {
+        Spectrum l(0.0f), beta(1.0f);
+        bool specular_bounce = false;
+        int bounces = 0;
+        Float eta_scale = 1.0f;
+        for (;;) {
+            SurfaceInteraction isect;
+            bool found = scene.intersect(ray, &isect, &rc.ctr);
+            if (bounces == 0 || specular_bounce) {
+                if (found) {
+                    l += beta * surface_le(scene, isect, -ray.d);
+                } else {
+                    for (auto& light : scene.infinite_lights) l += beta * light->le(ray);
+                }
+            }
+            if (!found || bounces >= max_depth) break;
+            const MaterialDesc& mat = scene.materials[scene.prim_material[isect.prim_id]];
+            std::shared_ptr<BSDF> bsdf = compute_scattering_functions(mat, isect, MODE_RADIANCE, true, scene.quirks);
+            if (!bsdf) {
+                ray = isect.spawn_ray(ray.d);
+                continue;
+            }
+            if (bsdf->num_components((uint8_t)(BSDF_ALL & ~BSDF_SPECULAR)) > 0) {
+                Spectrum ld = beta * uniform_sample_one_light(isect, *bsdf, scene, rc, light_distribution.get());
+                l += ld;
+            }
+            Vector3f wo = -ray.d, wi;
+            Float pdf = 0.0f;
+            uint8_t flags = BSDF_NONE;
+            Spectrum f = bsdf->sample_f(wo, &wi, rc.sampler.get_2d(), &pdf, BSDF_ALL, &flags);
+            if (f.is_black() || pdf == 0.0f) break;
+            beta *= f * (wi.abs_dot(isect.shading.n) / pdf);
+            specular_bounce = (flags & BSDF_SPECULAR) != 0;
+            if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+                Float eta = bsdf->eta;
+                eta_scale *= (wo.dot(isect.n) > 0.0f) ? (eta * eta) : 1.0f / (eta * eta);
+            }
+            ray = isect.spawn_ray(wi);
+            // path.rs:154-198 BSSRDF branch: no material sets a bssrdf.
+            Spectrum rr_beta = beta * eta_scale;
+            if (rr_beta.max_component_value() < rr_threshold && bounces > 3) {
+                Float q = fmaxr(0.05f, 1.0f - rr_beta.max_component_value());  // D27
+                if (rc.sampler.get_1d() < q) break;
+                beta /= 1.0f - q;
+            }
+            bounces += 1;
+        }
+        return l;
+    }
+};
+
+// integrators/directlighting.rs
+enum LightStrategy { UNIFORM_SAMPLE_ALL = 0, UNIFORM_SAMPLE_ONE = 1 };
+struct DirectLightingIntegrator : Integrator {
+    LightStrategy strategy;
+    int max_depth;
+    std::vector<int> n_light_samples;
+    DirectLightingIntegrator(LightStrategy s, int md) : strategy(s), max_depth(md) {}
+    // directlighting.rs:58-78
+    void pre_process(const Scene& scene) override {
+        n_light_samples.clear();
+        if (strategy == UNIFORM_SAMPLE_ALL)
+            for (auto& l : scene.lights) n_light_samples.push_back(l->n_samples);
+    }
+    // directlighting.rs:79-127
+    Spectrum li(Ray ray, const Scene& scene, RenderCtx& rc, int depth) const override {
+        Spectrum l(0.0f);
+        SurfaceInteraction isect;
+        if (!scene.intersect(ray, &isect, &rc.ctr)) {
+            for (auto& light : scene.lights) l += light->le(ray);
+            return l;
+        }
+        const MaterialDesc& mat = scene.materials[scene.prim_material[isect.prim_id]];
+        std::shared_ptr<BSDF> bsdf = compute_scattering_functions(mat, isect, MODE_RADIANCE, false, scene.quirks);
+        if (!bsdf) return li(isect.spawn_ray(ray.d), scene, rc, depth);
+        Vector3f wo = isect.wo;
+        l += surface_le(scene, isect, wo);  // D28
+        if (!scene.lights.empty()) {
+            if (strategy == UNIFORM_SAMPLE_ALL)
+                l += uniform_sample_all_lights(isect, *bsdf, scene, rc, n_light_samples);
+            else
+                l += uniform_sample_one_light(isect, *bsdf, scene, rc, nullptr);
+        }
+        if (depth + 1 < max_depth) {
+            l += specular_bounce(ray, isect, *bsdf, scene, rc, depth, (uint8_t)(BSDF_REFLECTION | BSDF_SPECULAR));
+            l += specular_bounce(ray, isect, *bsdf, scene, rc, depth, (uint8_t)(BSDF_TRANSMISSION | BSDF_SPECULAR));
+        }
+        return l;
+    }
+    // integrator.rs:294-334 specular_reflect, :336-392 specular_transmit (differentials dropped)
+    Spectrum specular_bounce(const Ray&, const SurfaceInteraction& isect, const BSDF& bsdf, const Scene& scene,
+                             RenderCtx& rc, int depth, uint8_t type) const {
+        Vector3f wo = isect.wo, wi;
+        Float pdf = 0.0f;
+        uint8_t sampled = BSDF_NONE;
+        Spectrum f = bsdf.sample_f(wo, &wi, rc.sampler.get_2d(), &pdf, type, &sampled);
+        const Normal3f& ns = isect.shading.n;
+        if (pdf > 0.0f && !f.is_black() && wi.abs_dot(ns) != 0.0f) {
+            Ray rd = isect.spawn_ray(wi);
+            return f * li(rd, scene, rc, depth + 1) * wi.abs_dot(ns) / pdf;
+        }
+        return Spectrum(0.0f);
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// Camera — cameras/perspective.rs. The 4x4 matrices are supplied by the caller (the host side
+// computes Transform::perspective / look_at, transform.rs:510-566); the oracle applies them.
+// ---------------------------------------------------------------------------------
+struct Matrix4 {
+    Float m[4][4];
+};
+// transform.rs:351-370
+inline Point3f xform_point(const Matrix4& t, const Point3f& p) {
+    Float x = p.x, y = p.y, z = p.z;
+    Float xp = t.m[0][0] * x + t.m[0][1] * y + t.m[0][2] * z + t.m[0][3];
+    Float yp = t.m[1][0] * x + t.m[1][1] * y + t.m[1][2] * z + t.m[1][3];
+    Float zp = t.m[2][0] * x + t.m[2][1] * y + t.m[2][2] * z + t.m[2][3];
+    Float wp = t.m[3][0] * x + t.m[3][1] * y + t.m[3][2] * z + t.m[3][3];
+    if (wp == 1.0f) return Point3f(xp, yp, zp);
+    return Point3f(xp, yp, zp) / wp;
+}
+// transform.rs:372-385
+inline Vector3f xform_vector(const Matrix4& t, const Vector3f& v) {
+    Float x = v.x, y = v.y, z = v.z;
+    return Vector3f(t.m[0][0] * x + t.m[0][1] * y + t.m[0][2] * z, t.m[1][0] * x + t.m[1][1] * y + t.m[1][2] * z,
+                    t.m[2][0] * x + t.m[2][1] * y + t.m[2][2] * z);
+}
+// geometry.rs:898-935 (point with absolute error) + :865-881 (ray through a transform)
+inline Ray xform_ray(const Matrix4& t, const Ray& r) {
+    Float x = r.o.x, y = r.o.y, z = r.o.z;
+    Point3f o = xform_point(t, r.o);
+    Float x_abs = std::fabs(t.m[0][0] * x) + std::fabs(t.m[0][1] * y) + std::fabs(t.m[0][2] * z) + std::fabs(t.m[0][3]);
+    Float y_abs = std::fabs(t.m[1][0] * x) + std::fabs(t.m[1][1] * y) + std::fabs(t.m[1][2] * z) + std::fabs(t.m[1][3]);
+    Float z_abs = std::fabs(t.m[2][0] * x) + std::fabs(t.m[2][1] * y) + std::fabs(t.m[2][2] * z) + std::fabs(t.m[2][3]);
+    Vector3f o_error = Vector3f(x_abs, y_abs, z_abs) * gamma(3.0f);
+    Vector3f d = xform_vector(t, r.d);
+    Float length_squared = d.length_squared();
+    Float t_max = r.t_max;
+    if (length_squared > 0.0f) {
+        Float dt = d.abs().dot(o_error) / length_squared;
+        o += d * dt;
+        t_max -= dt;
+    }
+    return Ray(o, d, t_max, r.time);
+}
+
+struct PerspectiveCamera {
+    Matrix4 camera_to_world, raster_to_camera;
+    Float lens_radius = 0.0f, focal_distance = 1e6f;
+    Float shutter_open = 0.0f, shutter_close = 1.0f;
+    // perspective.rs:90-112 (generate_ray_differential :114-161 differs only in the differentials)
+    Float generate_ray(const CameraSample& sample, Ray* ray) const {
+        Point3f p_film(sample.p_film.x, sample.p_film.y, 0.0f);
+        Point3f p_camera = xform_point(raster_to_camera, p_film);
+        *ray = Ray(Point3f(0.0f, 0.0f, 0.0f), p_camera.normalize(), FLOAT_INF, 0.0f);
+        if (lens_radius > 0.0f) {
+            Point2f pl = concentric_sample_disk(sample.p_lens);
+            Point2f p_lens(pl.x * lens_radius, pl.y * lens_radius);
+            Float ft = focal_distance / ray->d.z;
+            Point3f p_focus = ray->at(ft);
+            ray->o = Point3f(p_lens.x, p_lens.y, 0.0f);
+            ray->d = (p_focus - ray->o).normalize();
+        }
+        // lerp(t, a, b) = (1 - t) * a + t * b  (pbrt.rs:222-226)
+        ray->time = (1.0f - sample.time) * shutter_open + sample.time * shutter_close;
+        *ray = xform_ray(camera_to_world, *ray);
+        return 1.0f;
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// Film — core/film.rs with the box filter (filters/boxf.rs; radius 0.5 x 0.5, D43).
+// Output pixel = {xyz[3], filter_weight_sum} (film.rs:9-15, the 16 bytes SamplerIntegrator writes).
+// ---------------------------------------------------------------------------------
+struct Film {
+    int width, height;
+    Float filter_radius_x = 0.5f, filter_radius_y = 0.5f;
+    Float max_sample_luminance = FLOAT_INF;
+    static const int FILTER_TABLE_WIDTH = 16;
+    Float filter_table[FILTER_TABLE_WIDTH * FILTER_TABLE_WIDTH];
+    std::vector<Float> pixels;  // width*height*4: xyz + filter_weight_sum
+    Film(int w, int h) : width(w), height(h), pixels((size_t)w * h * 4, 0.0f) {
+        for (int i = 0; i < FILTER_TABLE_WIDTH * FILTER_TABLE_WIDTH; ++i) filter_table[i] = 1.0f;  // film.rs:52-63, boxf.rs:25-27
+    }
+};
+struct FilmTilePixel {
+    Spectrum contrib_sum;
+    Float filter_weight_sum = 0.0f;
+};
+// film.rs:231-295; pixel bounds [x0,x1) x [y0,y1)
+struct FilmTile {
+    int x0, y0, x1, y1;
+    const Film& film;
+    std::vector<FilmTilePixel> pixels;
+    FilmTile(const Film& f, int x0_, int y0_, int x1_, int y1_)
+        : x0(x0_), y0(y0_), x1(x1_), y1(y1_), film(f), pixels((size_t)std::max(0, (x1_ - x0_) * (y1_ - y0_))) {}
+    // film.rs:252-295 (D42: p1 clamped with min; coordinates stay signed)
+    void add_sample(const Point2f& p_film, Spectrum l, Float sample_weight) {
+        if (l.y_value() > film.max_sample_luminance) l *= film.max_sample_luminance / l.y_value();
+        Float dx = p_film.x - 0.5f, dy = p_film.y - 0.5f;
+        int px0 = std::max((int)std::ceil(dx - film.filter_radius_x), x0);
+        int py0 = std::max((int)std::ceil(dy - film.filter_radius_y), y0);
+        int px1 = std::min((int)std::floor(dx + film.filter_radius_x) + 1, x1);
+        int py1 = std::min((int)std::floor(dy + film.filter_radius_y) + 1, y1);
+        const int ts = Film::FILTER_TABLE_WIDTH;
+        for (int y = py0; y < py1; ++y) {
+            Float fy = std::fabs(((Float)y - dy) * (1.0f / film.filter_radius_y) * (Float)ts);
+            int ify = std::min(ts - 1, (int)std::floor(fy));
+            for (int x = px0; x < px1; ++x) {
+                Float fx = std::fabs(((Float)x - dx) * (1.0f / film.filter_radius_x) * (Float)ts);
+                int ifx = std::min(ts - 1, (int)std::floor(fx));
+                Float filter_weight = film.filter_table[ify * ts + ifx];
+                FilmTilePixel& pixel = pixels[(size_t)(y - y0) * (x1 - x0) + (x - x0)];
+                pixel.contrib_sum += l * sample_weight * filter_weight;
+                pixel.filter_weight_sum += filter_weight;
+            }
+        }
+    }
+};
+
+struct RenderParams {
+    int spp = 1;
+    uint64_t seed = 0;
+    // rectangle of pixels to render [x0,x1) x [y0,y1) (pixel_bounds of SamplerIntegrator)
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    int n_threads = 1;
+};
+struct RenderStats {
+    TraversalCounters ctr;
+    uint64_t camera_samples = 0;
+    double seconds = 0.0;
+};
+
+// integrator.rs:399-480 — 16x16 tiles, one task per tile (parallel.rs:4-21 -> std::thread pool).
+inline void render(const Scene& scene, const PerspectiveCamera& camera, Integrator& integrator, Film& film,
+                   const RenderParams& rp, RenderStats* stats) {
+    integrator.pre_process(scene);
+    const int TILE_SIZE = 16;
+    // get_sample_bounds with a 0.5 box filter = the pixel rectangle itself (film.rs:76-81, D42)
+    int sx0 = rp.x0, sy0 = rp.y0, sx1 = rp.x1, sy1 = rp.y1;
+    int ntx = (sx1 - sx0 + TILE_SIZE - 1) / TILE_SIZE, nty = (sy1 - sy0 + TILE_SIZE - 1) / TILE_SIZE;
+    std::atomic<int> next_tile(0);
+    std::mutex film_mutex;
+    int n_threads = std::max(1, rp.n_threads);
+    std::vector<RenderStats> tstats(n_threads);
+    auto worker = [&](int tid) {
+        RenderCtx rc;
+        for (;;) {
+            int tile = next_tile.fetch_add(1);
+            if (tile >= ntx * nty) break;
+            int tx = tile % ntx, ty = tile / ntx;
+            int x0 = sx0 + tx * TILE_SIZE, x1 = std::min(x0 + TILE_SIZE, sx1);
+            int y0 = sy0 + ty * TILE_SIZE, y1 = std::min(y0 + TILE_SIZE, sy1);
+            // get_film_tile (film.rs:93-109): tile pixel bounds = [ceil(min - 0.5 - r), floor(max - 0.5 + r))
+            // = [x0 - 1, x1) x [y0 - 1, y1) for r = 0.5, clipped to the film. The extra row/column
+            // only ever receives samples whose film offset is exactly 0.0 (add_sample's ceil).
+            FilmTile film_tile(film, std::max(x0 - 1, 0), std::max(y0 - 1, 0), std::min(x1, film.width), std::min(y1, film.height));
+            for (int py = y0; py < y1; ++py)
+                for (int px = x0; px < x1; ++px) {
+                    for (int s = 0; s < rp.spp; ++s) {
+                        rc.sampler.start_sample(rp.seed, (int64_t)py * film.width + px, rp.spp, s);
+                        CameraSample cs = rc.sampler.get_camera_sample(px, py);
+                        Ray ray;
+                        Float ray_weight = camera.generate_ray(cs, &ray);
+                        Spectrum l(0.0f);
+                        if (ray_weight > 0.0f) l = integrator.li(ray, scene, rc, 0);
+                        if (l.has_nans() || l.y_value() < -1e-5f || std::isinf(l.y_value())) l = Spectrum(0.0f);  // D23
+                        film_tile.add_sample(cs.p_film, l, ray_weight);
+                        tstats[tid].camera_samples++;
+                    }
+                }
+            // merge_film_tile (film.rs:111-123) under the film's write lock (camera.rs:95 RwLock)
+            std::lock_guard<std::mutex> guard(film_mutex);
+            for (int y = film_tile.y0; y < film_tile.y1; ++y)
+                for (int x = film_tile.x0; x < film_tile.x1; ++x) {
+                    const FilmTilePixel& tp = film_tile.pixels[(size_t)(y - film_tile.y0) * (film_tile.x1 - film_tile.x0) + (x - film_tile.x0)];
+                    Float xyz[3];
+                    tp.contrib_sum.to_xyz(xyz);
+                    Float* mp = &film.pixels[((size_t)y * film.width + x) * 4];
+                    for (int i = 0; i < 3; ++i) mp[i] += xyz[i];
+                    mp[3] += tp.filter_weight_sum;
+                }
+        }
+        tstats[tid].ctr = rc.ctr;
+    };
+    std::vector<std::thread> threads;
+    for (int t = 1; t < n_threads; ++t) threads.emplace_back(worker, t);
+    worker(0);
+    for (auto& t : threads) t.join();
+    if (stats)
+        for (auto& s : tstats) {
+            stats->ctr.add(s.ctr);
+            stats->camera_samples += s.camera_samples;
+        }
+}
+
+}  // namespace oracle

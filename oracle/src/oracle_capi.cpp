@@ -1,0 +1,294 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may load this library, and only as the checker (see oracle/README.md).
+// Parity unpinned: the reference has no fixtures for this path and cannot be built here.
+//
+// Flat C entry points (ctypes) over the CPU restatement in o_*.h.
+#include <chrono>
+
+#include "o_render.h"
+
+using namespace oracle;
+
+namespace {
+struct OracleScene {
+    Scene scene;
+    std::shared_ptr<TriangleMesh> mesh;
+};
+
+struct OrcHit {  // same 32-byte layout as PbrtHit (include/pbrt_hip.h)
+    float t, b0, b1, b2;
+    int32_t prim_id;
+    int32_t pad[3];
+};
+
+template <class F>
+void parallel_chunks(int64_t n, int n_threads, F f) {
+    n_threads = std::max(1, n_threads);
+    std::vector<std::thread> th;
+    int64_t chunk = (n + n_threads - 1) / n_threads;
+    for (int t = 0; t < n_threads; ++t) {
+        int64_t b = t * chunk, e = std::min(n, b + chunk);
+        if (b >= e) break;
+        th.emplace_back(f, t, b, e);
+    }
+    for (auto& x : th) x.join();
+}
+}  // namespace
+
+extern "C" {
+
+// materials: n_mat x 8 floats {type, kd.r, kd.g, kd.b, kt.r, kt.g, kt.b, eta}
+// lights:    n_light x 8 floats {type(0 = diffuse area, 1 = infinite), L.r, L.g, L.b, tri, two_sided, n_samples, 0}
+void* orc_scene_create(const float* positions, int n_verts, const int32_t* indices, int n_tris,
+                       const float* normals, const float* uvs, const int32_t* tri_material,
+                       const float* materials, int n_mat, const int32_t* tri_light, const float* lights,
+                       int n_light, int max_prims_in_node, int split_method, uint32_t quirks) {
+    OracleScene* os = new OracleScene();
+    auto mesh = std::make_shared<TriangleMesh>();
+    mesh->n_vertices = n_verts;
+    mesh->n_triangles = n_tris;
+    mesh->p.resize(n_verts);
+    for (int i = 0; i < n_verts; ++i) mesh->p[i] = Point3f(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]);
+    mesh->vertex_indices.assign(indices, indices + 3 * (size_t)n_tris);
+    if (normals) {
+        mesh->n.resize(n_verts);
+        for (int i = 0; i < n_verts; ++i) mesh->n[i] = Normal3f(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]);
+    }
+    if (uvs) {
+        mesh->uv.resize(n_verts);
+        for (int i = 0; i < n_verts; ++i) mesh->uv[i] = Point2f(uvs[2 * i], uvs[2 * i + 1]);
+    }
+    os->mesh = mesh;
+    Scene& sc = os->scene;
+    sc.quirks = quirks;
+    for (int i = 0; i < n_mat; ++i) {
+        const float* m = materials + 8 * i;
+        MaterialDesc d;
+        d.type = (int)m[0];
+        d.kd = Spectrum(m[1], m[2], m[3]);
+        d.kt = Spectrum(m[4], m[5], m[6]);
+        d.eta = m[7];
+        sc.materials.push_back(d);
+    }
+    std::vector<std::shared_ptr<Shape>> shapes(n_tris);
+    for (int i = 0; i < n_tris; ++i) shapes[i] = std::make_shared<Triangle>(mesh, i, false, quirks);
+    for (int i = 0; i < n_light; ++i) {
+        const float* l = lights + 8 * i;
+        Spectrum L(l[1], l[2], l[3]);
+        if ((int)l[0] == 0)
+            sc.lights.push_back(std::make_shared<DiffuseAreaLight>(L, (int)l[6], shapes[(int)l[4]], l[5] != 0.0f));
+        else
+            sc.lights.push_back(std::make_shared<InfiniteAreaLight>(L, (int)l[6]));
+    }
+    std::vector<std::shared_ptr<Primitive>> prims(n_tris);
+    sc.prim_material.resize(n_tris);
+    sc.prim_light.resize(n_tris);
+    for (int i = 0; i < n_tris; ++i) {
+        sc.prim_material[i] = tri_material ? tri_material[i] : 0;
+        sc.prim_light[i] = tri_light ? tri_light[i] : -1;
+        prims[i] = std::make_shared<GeometricPrimitive>(shapes[i], sc.prim_material[i], sc.prim_light[i], i);
+    }
+    sc.aggregate = std::make_shared<BVHAccel>(prims, max_prims_in_node, (SplitMethod)split_method, quirks);
+    sc.finish();
+    return os;
+}
+void orc_scene_destroy(void* h) { delete (OracleScene*)h; }
+int orc_scene_num_nodes(void* h) { return (int)((OracleScene*)h)->scene.aggregate->nodes.size(); }
+void orc_scene_get_nodes(void* h, void* out) {
+    auto& n = ((OracleScene*)h)->scene.aggregate->nodes;
+    std::memcpy(out, n.data(), n.size() * sizeof(LinearBVHNode));
+}
+void orc_scene_get_prim_order(void* h, int32_t* out) {
+    auto& o = ((OracleScene*)h)->scene.aggregate->ordered_prims;
+    std::memcpy(out, o.data(), o.size() * sizeof(int32_t));
+}
+
+// rays: n x 8 floats {o.xyz, d.xyz, t_max, time}; counters: {rays, node_tests, prim_tests}
+void orc_intersect(void* h, const float* rays, int64_t n, void* out_hits, uint64_t* counters, int n_threads) {
+    const Scene& sc = ((OracleScene*)h)->scene;
+    OrcHit* out = (OrcHit*)out_hits;
+    std::vector<TraversalCounters> tc(std::max(1, n_threads));
+    parallel_chunks(n, n_threads, [&](int tid, int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i) {
+            const float* r = rays + 8 * i;
+            Ray ray(Point3f(r[0], r[1], r[2]), Vector3f(r[3], r[4], r[5]), r[6], r[7]);
+            // re-run the winning triangle's test to report its barycentrics (the SurfaceInteraction
+            // does not keep them)
+            SurfaceInteraction si;
+            OrcHit hit = {FLOAT_INF, 0, 0, 0, -1, {0, 0, 0}};
+            if (sc.intersect(ray, &si, &tc[tid])) {
+                hit.t = ray.t_max;
+                hit.prim_id = si.prim_id;
+                const TriangleMesh& m = *((OracleScene*)h)->mesh;
+                const int32_t* v = &m.vertex_indices[3 * (size_t)si.prim_id];
+                Ray r0(Point3f(r[0], r[1], r[2]), Vector3f(r[3], r[4], r[5]), r[6], r[7]);
+                TriHit th = triangle_intersect_test(m.p[v[0]], m.p[v[1]], m.p[v[2]], r0, sc.quirks);
+                hit.b0 = th.b0;
+                hit.b1 = th.b1;
+                hit.b2 = th.b2;
+            }
+            out[i] = hit;
+        }
+    });
+    if (counters) {
+        TraversalCounters s;
+        for (auto& c : tc) s.add(c);
+        counters[0] = s.rays;
+        counters[1] = s.node_tests;
+        counters[2] = s.prim_tests;
+    }
+}
+void orc_intersect_p(void* h, const float* rays, int64_t n, uint8_t* out, uint64_t* counters, int n_threads) {
+    const Scene& sc = ((OracleScene*)h)->scene;
+    std::vector<TraversalCounters> tc(std::max(1, n_threads));
+    parallel_chunks(n, n_threads, [&](int tid, int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i) {
+            const float* r = rays + 8 * i;
+            Ray ray(Point3f(r[0], r[1], r[2]), Vector3f(r[3], r[4], r[5]), r[6], r[7]);
+            out[i] = sc.intersect_p(ray, &tc[tid]) ? 1 : 0;
+        }
+    });
+    if (counters) {
+        TraversalCounters s;
+        for (auto& c : tc) s.add(c);
+        counters[0] = s.rays;
+        counters[1] = s.node_tests;
+        counters[2] = s.prim_tests;
+    }
+}
+
+// camera: 36 floats {camera_to_world[16] row-major, raster_to_camera[16], lens_radius, focal_distance, shutter_open, shutter_close}
+// integrator: 0 = path, 1 = direct lighting. light_strategy: path {0 uniform, 1 power}; direct {0 all, 1 one}
+// stats: {rays, node_tests, prim_tests, camera_samples, nanoseconds}
+void orc_render(void* h, const float* cam, int integrator, int max_depth, float rr_threshold, int light_strategy,
+                int spp, uint64_t seed, int width, int height, int x0, int y0, int x1, int y1, int n_threads,
+                float* film_out, uint64_t* stats) {
+    const Scene& sc = ((OracleScene*)h)->scene;
+    PerspectiveCamera camera;
+    std::memcpy(camera.camera_to_world.m, cam, 64);
+    std::memcpy(camera.raster_to_camera.m, cam + 16, 64);
+    camera.lens_radius = cam[32];
+    camera.focal_distance = cam[33];
+    camera.shutter_open = cam[34];
+    camera.shutter_close = cam[35];
+    Film film(width, height);
+    RenderParams rp;
+    rp.spp = spp;
+    rp.seed = seed;
+    rp.x0 = x0;
+    rp.y0 = y0;
+    rp.x1 = x1;
+    rp.y1 = y1;
+    rp.n_threads = n_threads;
+    RenderStats st;
+    std::unique_ptr<Integrator> integ;
+    if (integrator == 0)
+        integ.reset(new PathIntegrator(max_depth, rr_threshold, light_strategy == 0 ? "uniform" : "power"));
+    else
+        integ.reset(new DirectLightingIntegrator((LightStrategy)light_strategy, max_depth));
+    auto t0 = std::chrono::steady_clock::now();
+    render(sc, camera, *integ, film, rp, &st);
+    auto t1 = std::chrono::steady_clock::now();
+    std::memcpy(film_out, film.pixels.data(), film.pixels.size() * sizeof(float));
+    if (stats) {
+        stats[0] = st.ctr.rays;
+        stats[1] = st.ctr.node_tests;
+        stats[2] = st.ctr.prim_tests;
+        stats[3] = st.camera_samples;
+        stats[4] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+    }
+}
+
+// ---- unit entry points for known-answer tests ----
+void orc_triangle_test(const float* p0, const float* p1, const float* p2, const float* ray8, uint32_t quirks,
+                       float* out5) {
+    Ray ray(Point3f(ray8[0], ray8[1], ray8[2]), Vector3f(ray8[3], ray8[4], ray8[5]), ray8[6], ray8[7]);
+    TriHit h = triangle_intersect_test(Point3f(p0[0], p0[1], p0[2]), Point3f(p1[0], p1[1], p1[2]),
+                                       Point3f(p2[0], p2[1], p2[2]), ray, quirks);
+    out5[0] = h.hit ? 1.0f : 0.0f;
+    out5[1] = h.b0;
+    out5[2] = h.b1;
+    out5[3] = h.b2;
+    out5[4] = h.t;
+}
+int orc_bounds_intersect_p(const float* b6, const float* ray8, uint32_t quirks) {
+    Bounds3f b;
+    b.min = Point3f(b6[0], b6[1], b6[2]);
+    b.max = Point3f(b6[3], b6[4], b6[5]);
+    Ray ray(Point3f(ray8[0], ray8[1], ray8[2]), Vector3f(ray8[3], ray8[4], ray8[5]), ray8[6], ray8[7]);
+    Vector3f inv_dir(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    int dir_is_neg[3] = {inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f};
+    return bounds_intersect_p(b, ray, inv_dir, dir_is_neg, quirks) ? 1 : 0;
+}
+void orc_offset_ray_origin(const float* p, const float* err, const float* n, const float* w, float* out3) {
+    Point3f r = offset_ray_origin(Point3f(p[0], p[1], p[2]), Vector3f(err[0], err[1], err[2]),
+                                  Normal3f(n[0], n[1], n[2]), Vector3f(w[0], w[1], w[2]));
+    out3[0] = r.x;
+    out3[1] = r.y;
+    out3[2] = r.z;
+}
+float orc_next_float_up(float v) { return next_float_up(v); }
+float orc_next_float_down(float v) { return next_float_down(v); }
+float orc_gamma(float n) { return gamma(n); }
+void orc_pcg32(uint64_t sequence, int n, uint32_t* out_u32, float* out_f32) {
+    RNG a(sequence), b(sequence);
+    for (int i = 0; i < n; ++i) {
+        if (out_u32) out_u32[i] = a.uniform_u32();
+        if (out_f32) out_f32[i] = b.uniform_float();
+    }
+}
+// elementary functions, batch form: op 0 sin, 1 cos, 2 acos, 3 atan2(x = y-arg, y = x-arg)
+void orc_elementary(int op, const float* x, const float* y, int64_t n, float* out) {
+    for (int64_t i = 0; i < n; ++i) {
+        switch (op) {
+            case 0: out[i] = det_sin(x[i]); break;
+            case 1: out[i] = det_cos(x[i]); break;
+            case 2: out[i] = det_acos(x[i]); break;
+            default: out[i] = det_atan2(x[i], y[i]); break;
+        }
+    }
+}
+// op 0 concentric_sample_disk (2), 1 cosine_sample_hemisphere (3), 2 uniform_sample_triangle (2)
+void orc_sample(int op, const float* u2, int64_t n, uint32_t quirks, float* out) {
+    for (int64_t i = 0; i < n; ++i) {
+        Point2f u(u2[2 * i], u2[2 * i + 1]);
+        if (op == 0) {
+            Point2f d = concentric_sample_disk(u);
+            out[2 * i] = d.x;
+            out[2 * i + 1] = d.y;
+        } else if (op == 1) {
+            Vector3f w = cosine_sample_hemisphere(u, quirks);
+            out[3 * i] = w.x;
+            out[3 * i + 1] = w.y;
+            out[3 * i + 2] = w.z;
+        } else {
+            Point2f b = uniform_sample_triangle(u);
+            out[2 * i] = b.x;
+            out[2 * i + 1] = b.y;
+        }
+    }
+}
+float orc_fr_dielectric(float cos_theta_i, float eta_i, float eta_t) { return fr_dielectric(cos_theta_i, eta_i, eta_t); }
+int orc_refract(const float* wi, const float* n, float eta, uint32_t quirks, float* wt) {
+    Vector3f t;
+    bool ok = refract(Vector3f(wi[0], wi[1], wi[2]), Normal3f(n[0], n[1], n[2]), eta, &t, quirks);
+    wt[0] = t.x;
+    wt[1] = t.y;
+    wt[2] = t.z;
+    return ok ? 1 : 0;
+}
+// BSDF local_to_world with an explicit frame (D36 KAT)
+void orc_local_to_world(const float* ss, const float* ts, const float* ns, const float* v, uint32_t quirks,
+                        float* out3) {
+    SurfaceInteraction si;
+    BSDF b(si, 1.0f, quirks);
+    b.ss = Vector3f(ss[0], ss[1], ss[2]);
+    b.ts = Vector3f(ts[0], ts[1], ts[2]);
+    b.ns = Vector3f(ns[0], ns[1], ns[2]);
+    Vector3f r = b.local_to_world(Vector3f(v[0], v[1], v[2]));
+    out3[0] = r.x;
+    out3[1] = r.y;
+    out3[2] = r.z;
+}
+
+}  // extern "C"

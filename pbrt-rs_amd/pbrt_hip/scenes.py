@@ -1,0 +1,274 @@
+"""Synthetic scenes and cameras for the BASELINE.json configs.
+
+Everything is generated from fixed seeds with a vectorised PCG32 (same generator as
+src/core/rng.rs:5-48 of the reference), so inputs are identical on every box.
+
+A scene is a plain dict of numpy arrays in the C-ABI layout of include/pbrt_hip.h:
+  positions (nv,3) f32, indices (nt,3) i32, tri_material (nt,) i32, materials (nm,) PbrtMaterial,
+  tri_light (nt,) i32, lights (nl,) PbrtLight.
+"""
+import numpy as np
+
+MATERIAL_DTYPE = np.dtype([("type", "<i4"), ("kd", "<f4", 3), ("kt", "<f4", 3), ("eta", "<f4")])
+LIGHT_DTYPE = np.dtype([("type", "<i4"), ("L", "<f4", 3), ("prim", "<i4"), ("two_sided", "<i4"),
+                        ("n_samples", "<i4"), ("pad", "<i4")])
+CAMERA_DTYPE = np.dtype([("camera_to_world", "<f4", 16), ("raster_to_camera", "<f4", 16),
+                         ("lens_radius", "<f4"), ("focal_distance", "<f4"),
+                         ("shutter_open", "<f4"), ("shutter_close", "<f4")])
+RAY_DTYPE = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("t_max", "<f4"), ("time", "<f4")])
+HIT_DTYPE = np.dtype([("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"), ("prim_id", "<i4"),
+                      ("pad", "<i4", 3)])
+NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"), ("n_primitives", "<u2"),
+                       ("axis", "u1"), ("pad", "u1")])
+assert MATERIAL_DTYPE.itemsize == 32 and LIGHT_DTYPE.itemsize == 32
+assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 32 and NODE_DTYPE.itemsize == 32
+
+MAT_NONE, MAT_MATTE, MAT_MIRROR, MAT_GLASS = 0, 1, 2, 3
+LIGHT_DIFFUSE_AREA, LIGHT_INFINITE = 0, 1
+
+_PCG32_MULT = np.uint64(0x5851F42D4C957F2D)
+_PCG32_DEFAULT_STATE = np.uint64(0x853C49E6748FEA9B)
+
+
+def pcg32_u32(sequence, n):
+    """First n outputs of RNG::new(sequence) (src/core/rng.rs:15-35), vectorised by LCG jump-ahead."""
+    with np.errstate(over="ignore"):
+        inc = np.uint64((int(sequence) << 1 | 1) & 0xFFFFFFFFFFFFFFFF)
+        # set_sequence: state = 0; step; state += default; step
+        s0 = np.uint64(0) * _PCG32_MULT + inc
+        s0 = (s0 + _PCG32_DEFAULT_STATE) * _PCG32_MULT + inc
+        # state_k = A_k * s0 + inc * S_k, A_k = mult^k, S_k = sum_{j<k} mult^j
+        a = np.empty(n, dtype=np.uint64)
+        a[0] = 1
+        if n > 1:
+            a[1:] = _PCG32_MULT
+            a = np.multiply.accumulate(a)
+        s = np.empty(n, dtype=np.uint64)
+        s[0] = 0
+        if n > 1:
+            s[1:] = np.add.accumulate(a[:-1])
+        old = a * s0 + inc * s
+        xorshifted = (((old >> np.uint64(18)) ^ old) >> np.uint64(27)).astype(np.uint32)
+        rot = (old >> np.uint64(59)).astype(np.uint32)
+        return (xorshifted >> rot) | (xorshifted << ((~rot + np.uint32(1)) & np.uint32(31)))
+
+
+def pcg32_float(sequence, n):
+    """uniform_float (src/core/rng.rs:46-48)."""
+    u = pcg32_u32(sequence, n)
+    f = u.astype(np.float32) * np.float32(2.3283064365386963e-10)
+    return np.minimum(f, np.float32(1.0) - np.float32(np.finfo(np.float32).eps))
+
+
+def _materials(rows):
+    m = np.zeros(len(rows), dtype=MATERIAL_DTYPE)
+    for i, (t, kd, kt, eta) in enumerate(rows):
+        m[i] = (t, kd, kt, eta)
+    return m
+
+
+def _lights(rows):
+    l = np.zeros(len(rows), dtype=LIGHT_DTYPE)
+    for i, (t, L, prim, two_sided, ns) in enumerate(rows):
+        l[i] = (t, L, prim, two_sided, ns, 0)
+    return l
+
+
+def _quad(a, b, c, d):
+    """Two triangles (a,b,c), (a,c,d)."""
+    return [a, b, c, d], [(0, 1, 2), (0, 2, 3)]
+
+
+def _box(corners_floor, height):
+    """Closed box: 4 floor corners (counter-clockwise seen from above), extruded by `height` in y."""
+    f = [np.array(c, dtype=np.float64) for c in corners_floor]
+    t = [c + np.array([0.0, height, 0.0]) for c in f]
+    quads = [
+        (t[0], t[1], t[2], t[3]),  # top
+        (f[3], f[2], f[1], f[0]),  # bottom
+        (f[0], f[1], t[1], t[0]),
+        (f[1], f[2], t[2], t[1]),
+        (f[2], f[3], t[3], t[2]),
+        (f[3], f[0], t[0], t[3]),
+    ]
+    return quads
+
+
+def cornell_box():
+    """Config 2: Cornell box, 36 triangles (5 walls x2, light x2, short box 12, tall box 12);
+    matte white/red/green; emitter Le = (17, 12, 4) facing down."""
+    white, red, green = (0.73, 0.73, 0.73), (0.65, 0.05, 0.05), (0.12, 0.45, 0.15)
+    S = 555.0
+    quads = []  # (quad corners, material id, emissive)
+    quads.append((((0, 0, 0), (S, 0, 0), (S, 0, S), (0, 0, S)), 0, False))      # floor
+    quads.append((((0, S, 0), (0, S, S), (S, S, S), (S, S, 0)), 0, False))      # ceiling
+    quads.append((((0, 0, S), (S, 0, S), (S, S, S), (0, S, S)), 0, False))      # back wall
+    quads.append((((S, 0, 0), (S, S, 0), (S, S, S), (S, 0, S)), 1, False))      # left (red) wall at x = S
+    quads.append((((0, 0, 0), (0, 0, S), (0, S, S), (0, S, 0)), 2, False))      # right (green) wall at x = 0
+    # light: winding chosen so the geometric normal normalize(dp02 x dp12) points down (-y)
+    quads.append((((213, 554, 227), (343, 554, 227), (343, 554, 332), (213, 554, 332)), 0, True))
+    short = _box([(130, 0, 65), (82, 0, 225), (240, 0, 272), (290, 0, 114)], 165.0)
+    tall = _box([(265, 0, 296), (314, 0, 456), (472, 0, 406), (423, 0, 247)], 330.0)
+    for q in short + tall:
+        quads.append((q, 0, False))
+    positions, indices, tri_mat, tri_light, lights = [], [], [], [], []
+    for q, mat, emissive in quads:
+        base = len(positions)
+        verts, tris = _quad(*q)
+        positions.extend(verts)
+        for t in tris:
+            if emissive:
+                tri_light.append(len(lights))
+                lights.append((LIGHT_DIFFUSE_AREA, (17.0, 12.0, 4.0), len(indices), 0, 1))
+            else:
+                tri_light.append(-1)
+            indices.append([base + t[0], base + t[1], base + t[2]])
+            tri_mat.append(mat)
+    scene = dict(
+        positions=np.asarray(positions, dtype=np.float32),
+        indices=np.asarray(indices, dtype=np.int32),
+        tri_material=np.asarray(tri_mat, dtype=np.int32),
+        materials=_materials([(MAT_MATTE, white, (0, 0, 0), 1.0), (MAT_MATTE, red, (0, 0, 0), 1.0),
+                              (MAT_MATTE, green, (0, 0, 0), 1.0)]),
+        tri_light=np.asarray(tri_light, dtype=np.int32),
+        lights=_lights(lights),
+    )
+    assert scene["indices"].shape[0] == 36
+    return scene
+
+
+def cornell_camera(width, height):
+    return perspective_camera((278.0, 273.0, -800.0), (278.0, 273.0, 0.0), (0.0, 1.0, 0.0), 39.3, width, height)
+
+
+def random_triangles(n_tris=1_000_000, seq=1, extent=1.0, size=0.01, env_L=(1.0, 1.0, 1.0), rho=0.5):
+    """Config 3/4: n triangles, centres U[-extent,extent]^3, each vertex = centre + U[-size,size]^3;
+    all matte rho; one constant white infinite light."""
+    u = pcg32_float(seq, n_tris * 12).reshape(n_tris, 4, 3)
+    centre = (u[:, 0, :] * np.float32(2.0) - np.float32(1.0)) * np.float32(extent)
+    off = (u[:, 1:, :] * np.float32(2.0) - np.float32(1.0)) * np.float32(size)
+    positions = (centre[:, None, :] + off).reshape(n_tris * 3, 3).astype(np.float32)
+    indices = np.arange(n_tris * 3, dtype=np.int32).reshape(n_tris, 3)
+    return dict(
+        positions=positions,
+        indices=indices,
+        tri_material=np.zeros(n_tris, dtype=np.int32),
+        materials=_materials([(MAT_MATTE, (rho, rho, rho), (0, 0, 0), 1.0)]),
+        tri_light=np.full(n_tris, -1, dtype=np.int32),
+        lights=_lights([(LIGHT_INFINITE, env_L, -1, 0, 1)]),
+    )
+
+
+def random_triangles_camera(width, height):
+    return perspective_camera((0.0, 0.0, 3.5), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 40.0, width, height)
+
+
+def mixed_materials_scene(n_tris=20000, seq=7):
+    """Small stress scene with matte / mirror / glass triangles, an area light and an env light
+    (exercises every BxDF and both light types; a scaled-down stand-in for config 5's material mix)."""
+    sc = random_triangles(n_tris, seq=seq, extent=1.0, size=0.08, env_L=(0.6, 0.7, 0.9))
+    tri_material = (np.arange(n_tris) % 3).astype(np.int32)
+    materials = _materials([
+        (MAT_MATTE, (0.6, 0.5, 0.4), (0, 0, 0), 1.0),
+        (MAT_MIRROR, (0.9, 0.9, 0.9), (0, 0, 0), 1.0),
+        (MAT_GLASS, (1.0, 1.0, 1.0), (0.95, 0.95, 0.95), 1.5),
+    ])
+    # a two-triangle emitter above the cloud
+    quad = np.array([[-0.5, 1.6, -0.5], [0.5, 1.6, -0.5], [0.5, 1.6, 0.5], [-0.5, 1.6, 0.5]], dtype=np.float32)
+    base = sc["positions"].shape[0]
+    positions = np.concatenate([sc["positions"], quad])
+    indices = np.concatenate([sc["indices"], np.array([[base, base + 1, base + 2], [base, base + 2, base + 3]],
+                                                      dtype=np.int32)])
+    tri_material = np.concatenate([tri_material, np.zeros(2, dtype=np.int32)])
+    tri_light = np.concatenate([sc["tri_light"], np.array([1, 2], dtype=np.int32)])
+    lights = _lights([(LIGHT_INFINITE, (0.6, 0.7, 0.9), -1, 0, 1),
+                      (LIGHT_DIFFUSE_AREA, (20.0, 18.0, 15.0), n_tris, 1, 1),
+                      (LIGHT_DIFFUSE_AREA, (20.0, 18.0, 15.0), n_tris + 1, 1, 1)])
+    return dict(positions=positions, indices=indices, tri_material=tri_material, materials=materials,
+                tri_light=tri_light, lights=lights)
+
+
+def furnace_scene(rho=0.5, Le=1.0):
+    """White-furnace check: a closed matte cube (rho) lit only by a constant env light cannot be
+    reached by it, so use the open form: a single matte quad under a constant environment.
+    Radiance leaving a Lambertian surface under uniform illumination Le is rho * Le exactly."""
+    quad = np.array([[-1e3, 0, -1e3], [-1e3, 0, 1e3], [1e3, 0, 1e3], [1e3, 0, -1e3]], dtype=np.float32)
+    return dict(
+        positions=quad,
+        indices=np.array([[0, 1, 2], [0, 2, 3]], dtype=np.int32),
+        tri_material=np.zeros(2, dtype=np.int32),
+        materials=_materials([(MAT_MATTE, (rho, rho, rho), (0, 0, 0), 1.0)]),
+        tri_light=np.full(2, -1, dtype=np.int32),
+        lights=_lights([(LIGHT_INFINITE, (Le, Le, Le), -1, 0, 1)]),
+    )
+
+
+# ---------------------------------------------------------------------------------------
+# Camera matrices: Transform::look_at / perspective / PerspectiveCamera::new
+# (src/core/transform.rs:510-566, src/cameras/perspective.rs:34-82), computed in float64 and
+# rounded once; both the oracle and the HIP path receive the same float32 matrices.
+# ---------------------------------------------------------------------------------------
+def look_at(pos, look, up):
+    pos, look, up = (np.asarray(v, dtype=np.float64) for v in (pos, look, up))
+    d = look - pos
+    d /= np.linalg.norm(d)
+    right = np.cross(up / np.linalg.norm(up), d)
+    right /= np.linalg.norm(right)
+    new_up = np.cross(d, right)
+    c2w = np.eye(4)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, new_up, d, pos
+    return c2w
+
+
+def perspective_camera(eye, look, up, fov_deg, width, height, lens_radius=0.0, focal_distance=1e6):
+    c2w = look_at(eye, look, up)
+    n, f = 1e-2, 1000.0
+    persp = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, f / (f - n), -f * n / (f - n)], [0, 0, 1, 0]], dtype=np.float64)
+    inv_tan = 1.0 / np.tan(np.radians(fov_deg) / 2.0)
+    camera_to_screen = np.diag([inv_tan, inv_tan, 1.0, 1.0]) @ persp
+    # pbrt screen window: the shorter axis spans [-1, 1]
+    aspect = width / height
+    if aspect > 1.0:
+        sw = (-aspect, aspect, -1.0, 1.0)
+    else:
+        sw = (-1.0, 1.0, -1.0 / aspect, 1.0 / aspect)
+    screen_to_raster = (np.diag([width, height, 1.0, 1.0]) @
+                        np.diag([1.0 / (sw[1] - sw[0]), 1.0 / (sw[2] - sw[3]), 1.0, 1.0]) @
+                        _translate(-sw[0], -sw[3], 0.0))
+    raster_to_camera = np.linalg.inv(camera_to_screen) @ np.linalg.inv(screen_to_raster)
+    cam = np.zeros((), dtype=CAMERA_DTYPE)
+    cam["camera_to_world"] = c2w.astype(np.float32).reshape(16)
+    cam["raster_to_camera"] = raster_to_camera.astype(np.float32).reshape(16)
+    cam["lens_radius"] = lens_radius
+    cam["focal_distance"] = focal_distance
+    cam["shutter_open"] = 0.0
+    cam["shutter_close"] = 1.0
+    return cam
+
+
+def _translate(x, y, z):
+    m = np.eye(4)
+    m[:3, 3] = (x, y, z)
+    return m
+
+
+def random_rays(n, seq, origin_extent=1.5, t_max=np.inf):
+    """n rays with origins U[-e,e]^3 and directions uniform on the sphere (by normalising a
+    Gaussian-free cube rejection surrogate: U[-1,1]^3 direction, not normalised — pbrt rays
+    need not be unit length, shadow rays are not)."""
+    u = pcg32_float(seq, n * 6).reshape(n, 6)
+    rays = np.zeros(n, dtype=RAY_DTYPE)
+    rays["o"] = (u[:, :3] * 2 - 1) * origin_extent
+    d = u[:, 3:] * 2 - 1
+    d[np.all(d == 0, axis=1)] = (0, 0, 1)
+    rays["d"] = d
+    rays["t_max"] = t_max
+    rays["time"] = 0
+    return rays
+
+
+def camera_dict_to_floats(cam):
+    """36 floats for the oracle's flat entry point."""
+    return np.concatenate([cam["camera_to_world"].reshape(-1), cam["raster_to_camera"].reshape(-1),
+                           [cam["lens_radius"], cam["focal_distance"], cam["shutter_open"], cam["shutter_close"]]]
+                          ).astype(np.float32)
