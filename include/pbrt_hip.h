@@ -66,7 +66,7 @@ typedef struct PbrtHit {
     int32_t pad[3];
 } PbrtHit;
 
-/* src/materials/*.rs are empty stubs; the three materials are pbrt-v3's on the reference's
+/* The material files under src/materials/ are empty stubs; the three materials are pbrt-v3's on the reference's
  * BxDFs (src/core/reflection.rs:821-855, 614-659, 733-819). */
 enum PbrtMaterialType { PBRT_MAT_NONE = 0, PBRT_MAT_MATTE = 1, PBRT_MAT_MIRROR = 2, PBRT_MAT_GLASS = 3 };
 typedef struct PbrtMaterial {

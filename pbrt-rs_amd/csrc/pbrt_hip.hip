@@ -1,0 +1,733 @@
+// pbrt_hip.hip — C ABI (include/pbrt_hip.h) over the gfx950 kernels.
+//
+// Stands in for the reference's Integrator / Primitive / Scene trait objects:
+//   pbrt_hip_scene_create   Scene::new, src/core/scene.rs:18-34
+//   pbrt_hip_intersect[_p]  Scene::intersect / intersect_p, src/core/scene.rs:40-46
+//   pbrt_hip_render         SamplerIntegrator::render, src/core/integrator.rs:399-480
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "scene.h"
+#include "trace.h"
+#include "wavefront.h"
+
+using namespace pb;
+
+static std::string g_create_error;
+
+#define HIP_TRY(ctx, call)                                        \
+    do {                                                          \
+        if (!hip_ok((ctx), (call), #call)) return PBRT_HIP_ERR_DEVICE; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------
+extern "C" int pbrt_hip_context_create(int device_id, PbrtHipContext** out) {
+    if (!out) return PBRT_HIP_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        g_create_error = "no HIP device visible: the MI355X kernels cannot run (there is no CPU fallback)";
+        return PBRT_HIP_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) {
+        g_create_error = "device_id out of range";
+        return PBRT_HIP_ERR_INVALID;
+    }
+    PbrtHipContext* ctx = new PbrtHipContext();
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) {
+        g_create_error = "hipSetDevice failed";
+        delete ctx;
+        return PBRT_HIP_ERR_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) {
+        g_create_error = "hipGetDeviceProperties failed";
+        delete ctx;
+        return PBRT_HIP_ERR_DEVICE;
+    }
+    ctx->n_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        g_create_error = "stream / event creation failed";
+        delete ctx;
+        return PBRT_HIP_ERR_DEVICE;
+    }
+    *out = ctx;
+    return PBRT_HIP_OK;
+}
+
+extern "C" void pbrt_hip_context_destroy(PbrtHipContext* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+extern "C" const char* pbrt_hip_last_error(const PbrtHipContext* ctx) {
+    return ctx ? ctx->last_error.c_str() : g_create_error.c_str();
+}
+
+extern "C" int pbrt_hip_synchronize(PbrtHipContext* ctx) {
+    if (!ctx) return PBRT_HIP_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PBRT_HIP_OK;
+}
+
+extern "C" int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* total_ms, uint64_t* launches) {
+    if (!ctx) return PBRT_HIP_ERR_INVALID;
+    if (total_ms) *total_ms = ctx->trace_ms;
+    if (launches) *launches = ctx->trace_launches;
+    if (reset) {
+        ctx->trace_ms = 0.0;
+        ctx->trace_launches = 0;
+    }
+    return PBRT_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// scene
+// ------------------------------------------------------------------------------------
+static float tri_area(const float* a, const float* b, const float* c) {  // triangle.rs:323-328
+    float e1[3], e2[3];
+    for (int k = 0; k < 3; ++k) {
+        e1[k] = b[k] - a[k];
+        e2[k] = c[k] - a[k];
+    }
+    float cx = e1[1] * e2[2] - e1[2] * e2[1];
+    float cy = e1[2] * e2[0] - e1[0] * e2[2];
+    float cz = e1[0] * e2[1] - e1[1] * e2[0];
+    return std::sqrt(cx * cx + cy * cy + cz * cz) * 0.5f;
+}
+
+// Distribution1D::new (sampling.rs:69-93), intended (D40)
+static void make_distribution(const std::vector<float>& f, std::vector<float>* cdf, float* func_int) {
+    int n = (int)f.size();
+    cdf->assign(n + 1, 0.0f);
+    for (int i = 1; i < n + 1; ++i) (*cdf)[i] = (*cdf)[i - 1] + f[i - 1] / (float)n;
+    *func_int = (*cdf)[n];
+    if (*func_int == 0.0f) {
+        for (int i = 1; i < n + 1; ++i) (*cdf)[i] = (float)i / (float)n;
+    } else {
+        for (int i = 1; i < n + 1; ++i) (*cdf)[i] /= *func_int;
+    }
+}
+
+// host replica of det_sincos (dev_math.h) for the env light's sin-weighted table
+static float host_det_sin(float x) {
+    float q = x * 0.63661977236758134308f;
+    float k = __builtin_rintf(q);
+    float r = __builtin_fmaf(-k, 1.5707397460937500f, x);
+    r = __builtin_fmaf(-k, 5.6579709053039550781e-05f, r);
+    r = __builtin_fmaf(-k, 9.9209362947050294680e-10f, r);
+    float z = r * r;
+    float ps = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+    float sr = __builtin_fmaf(ps * z, r, r);
+    float pc = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+    float cr = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    int ki = (int)k & 3;
+    return (ki == 0) ? sr : (ki == 1) ? cr : (ki == 2) ? -sr : -cr;
+}
+
+extern "C" int pbrt_hip_scene_create(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
+                                     const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
+                                     const PbrtMaterial* materials, int32_t n_materials, const int32_t* tri_light,
+                                     const PbrtLight* lights, int32_t n_lights, const PbrtLinearBVHNode* nodes,
+                                     int32_t n_nodes, const int32_t* prim_order, PbrtHipScene** out) {
+    if (!ctx || !out) return PBRT_HIP_ERR_INVALID;
+    *out = nullptr;
+    auto fail = [&](const char* msg) {
+        ctx->last_error = msg;
+        return PBRT_HIP_ERR_INVALID;
+    };
+    if (n_tris <= 0 || n_verts <= 0 || n_nodes <= 0) return fail("empty scene: n_tris, n_verts and n_nodes must be > 0");
+    if (!positions || !indices || !nodes || !prim_order) return fail("null geometry / BVH pointer");
+    if (n_materials <= 0 || !materials) return fail("at least one material is required");
+    if (n_lights < 0 || (n_lights > 0 && !lights)) return fail("bad light table");
+    for (int64_t i = 0; i < 3 * (int64_t)n_tris; ++i)
+        if (indices[i] < 0 || indices[i] >= n_verts) return fail("vertex index out of range");
+    for (int32_t i = 0; i < n_tris; ++i) {
+        if (prim_order[i] < 0 || prim_order[i] >= n_tris) return fail("prim_order entry out of range");
+        if (tri_material && (tri_material[i] < 0 || tri_material[i] >= n_materials)) return fail("tri_material out of range");
+        if (tri_light && (tri_light[i] < -1 || tri_light[i] >= n_lights)) return fail("tri_light out of range");
+    }
+    for (int32_t i = 0; i < n_lights; ++i)
+        if (lights[i].type == PBRT_LIGHT_DIFFUSE_AREA && (lights[i].prim < 0 || lights[i].prim >= n_tris))
+            return fail("area light triangle out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // ---- validate the tree and number interior nodes in DFS order ----
+    std::vector<int32_t> interior_index(n_nodes, -1);
+    int n_interior = 0, max_count = 1;
+    int64_t leaf_prims = 0;
+    for (int32_t i = 0; i < n_nodes; ++i) {
+        const PbrtLinearBVHNode& nd = nodes[i];
+        if (nd.n_primitives > 0) {
+            if (nd.offset < 0 || (int64_t)nd.offset + nd.n_primitives > n_tris) return fail("leaf range outside the primitive list");
+            max_count = std::max<int>(max_count, nd.n_primitives);
+            leaf_prims += nd.n_primitives;
+        } else {
+            if (nd.axis > 2) return fail("interior node axis > 2");
+            if (nd.offset <= i + 1 || nd.offset >= n_nodes || i + 1 >= n_nodes) return fail("second-child offset out of range");
+            interior_index[i] = n_interior++;
+        }
+    }
+    if (leaf_prims != n_tris) return fail("leaves do not cover the primitive list exactly once");
+    if (n_interior != (n_nodes - 1) / 2 || (n_nodes & 1) == 0) return fail("node array is not a full binary tree");
+    int count_bits = 0;
+    while ((1 << count_bits) < max_count) ++count_bits;
+    if (((int64_t)n_tris << count_bits) >= (1ll << 31)) return fail("scene too large for 31-bit leaf references");
+    auto child_ref = [&](int32_t node) -> int32_t {
+        const PbrtLinearBVHNode& nd = nodes[node];
+        if (nd.n_primitives > 0) return ~(int32_t)(((uint32_t)nd.offset << count_bits) | (uint32_t)(nd.n_primitives - 1));
+        return interior_index[node];
+    };
+
+    PbrtHipScene* s = new PbrtHipScene();
+    s->ctx = ctx;
+    s->n_tris = n_tris;
+    s->n_nodes = n_nodes;
+    s->n_interior = n_interior;
+    bool ok = true;
+
+    // ---- interior records: both children's boxes + references + axis (64 B) ----
+    std::vector<float> inodes((size_t)std::max(1, n_interior) * 16, 0.0f);
+    for (int32_t i = 0; i < n_nodes; ++i) {
+        if (interior_index[i] < 0) continue;
+        const PbrtLinearBVHNode& c0 = nodes[i + 1];
+        const PbrtLinearBVHNode& c1 = nodes[nodes[i].offset];
+        float* r = &inodes[(size_t)interior_index[i] * 16];
+        r[0] = c0.bounds_min[0]; r[1] = c0.bounds_min[1]; r[2] = c0.bounds_min[2];
+        r[3] = c0.bounds_max[0]; r[4] = c0.bounds_max[1]; r[5] = c0.bounds_max[2];
+        r[6] = c1.bounds_min[0]; r[7] = c1.bounds_min[1]; r[8] = c1.bounds_min[2];
+        r[9] = c1.bounds_max[0]; r[10] = c1.bounds_max[1]; r[11] = c1.bounds_max[2];
+        int32_t refs[4] = {child_ref(i + 1), child_ref(nodes[i].offset), (int32_t)nodes[i].axis, 0};
+        std::memcpy(r + 12, refs, 16);
+    }
+    // ---- triangles in leaf order (48 B) ----
+    std::vector<float> tris((size_t)n_tris * 12);
+    std::vector<int32_t> prim_slot(n_tris, -1);
+    for (int32_t slot = 0; slot < n_tris; ++slot) {
+        int32_t prim = prim_order[slot];
+        if (prim_slot[prim] != -1) {
+            delete s;
+            return fail("prim_order is not a permutation");
+        }
+        prim_slot[prim] = slot;
+        const float* a = positions + 3 * (size_t)indices[3 * (size_t)prim];
+        const float* b = positions + 3 * (size_t)indices[3 * (size_t)prim + 1];
+        const float* c = positions + 3 * (size_t)indices[3 * (size_t)prim + 2];
+        float* t = &tris[(size_t)slot * 12];
+        t[0] = a[0]; t[1] = a[1]; t[2] = a[2];
+        t[3] = b[0]; t[4] = b[1]; t[5] = b[2];
+        t[6] = c[0]; t[7] = c[1]; t[8] = c[2];
+        int32_t meta[3];
+        meta[0] = prim;
+        meta[1] = tri_material ? tri_material[prim] : 0;
+        meta[2] = (tri_light ? tri_light[prim] + 1 : 0) | (triangle_rejected_by_intersect(a, b, c) ? kTriDegenerate : 0);
+        std::memcpy(t + 9, meta, 12);
+    }
+    // ---- lights / materials ----
+    std::vector<DevLight> dl(std::max(1, n_lights));
+    std::vector<int> infinite_ids;
+    float world_center[3], world_radius;
+    {
+        // Bounds3::bounding_sphere of the root bounds (infinite.rs:135-139)
+        const float* mn = nodes[0].bounds_min;
+        const float* mx = nodes[0].bounds_max;
+        float dx[3];
+        for (int k = 0; k < 3; ++k) {
+            world_center[k] = (mn[k] + mx[k]) / 2.0f;
+            dx[k] = world_center[k] - mx[k];
+        }
+        bool inside = true;
+        for (int k = 0; k < 3; ++k) inside = inside && world_center[k] >= mn[k] && world_center[k] <= mx[k];
+        world_radius = inside ? std::sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]) : 0.0f;
+    }
+    std::vector<float> power_y(n_lights);
+    for (int32_t i = 0; i < n_lights; ++i) {
+        DevLight& l = dl[i];
+        l.type = lights[i].type;
+        std::memcpy(l.L, lights[i].L, 12);
+        l.two_sided = lights[i].two_sided;
+        l.slot = -1;
+        l.area = 0.0f;
+        float scale;
+        if (l.type == PBRT_LIGHT_DIFFUSE_AREA) {
+            int32_t prim = lights[i].prim;
+            l.slot = prim_slot[prim];
+            const float* a = positions + 3 * (size_t)indices[3 * (size_t)prim];
+            const float* b = positions + 3 * (size_t)indices[3 * (size_t)prim + 1];
+            const float* c = positions + 3 * (size_t)indices[3 * (size_t)prim + 2];
+            l.area = tri_area(a, b, c);
+            scale = (l.two_sided ? 2.0f : 1.0f) * l.area * kPi;  // diffuse.rs:83-85
+        } else {
+            infinite_ids.push_back(i);
+            scale = kPi * world_radius * world_radius;  // infinite.rs:131-133
+        }
+        float p[3] = {l.L[0] * scale, l.L[1] * scale, l.L[2] * scale};
+        l.power_y = 0.212671f * p[0] + 0.715160f * p[1] + 0.072169f * p[2];  // spectrum.rs:679-682
+        power_y[i] = l.power_y;
+    }
+    s->h_lights = dl;
+    std::vector<DevMaterial> dm(n_materials);
+    for (int32_t i = 0; i < n_materials; ++i) {
+        dm[i].type = materials[i].type;
+        std::memcpy(dm[i].kd, materials[i].kd, 12);
+        std::memcpy(dm[i].kt, materials[i].kt, 12);
+        dm[i].eta = materials[i].eta;
+    }
+
+    DevSceneData& d = s->d;
+    std::memset(&d, 0, sizeof(d));
+    d.bvh.inodes = (const float4*)dev_upload(s, inodes.data(), inodes.size(), &ok);
+    d.bvh.tris = (const float4*)dev_upload(s, tris.data(), tris.size(), &ok);
+    std::memcpy(d.bvh.root_min, nodes[0].bounds_min, 12);
+    std::memcpy(d.bvh.root_max, nodes[0].bounds_max, 12);
+    d.bvh.root_ref = child_ref(0);
+    d.bvh.count_bits = count_bits;
+    d.bvh.n_slots = n_tris;
+    // spill slab for the deepest 40 stack entries of every resident lane of the traversal grid
+    s->spill_lanes = ctx->n_cus * 2048;
+    {
+        void* p = nullptr;
+        if (!hip_ok(ctx, hipMalloc(&p, (size_t)s->spill_lanes * kStackSpill * sizeof(uint2)), "hipMalloc spill")) ok = false;
+        else s->allocs.push_back(p);
+        d.bvh.spill = (uint2*)p;
+        d.bvh.spill_stride = s->spill_lanes;
+    }
+    d.slot_prim = dev_upload(s, prim_order, n_tris, &ok);
+    d.materials = dev_upload(s, dm.data(), dm.size(), &ok);
+    d.lights = dev_upload(s, dl.data(), dl.size(), &ok);
+    d.n_lights = n_lights;
+    d.n_materials = n_materials;
+    d.n_infinite = (int)infinite_ids.size();
+    d.infinite_ids = dev_upload(s, infinite_ids.data(), infinite_ids.size(), &ok);
+    std::memcpy(d.world_center, world_center, 12);
+    d.world_radius = world_radius;
+    // InfiniteAreaLight's Distribution2D over a 2x2 sin-weighted image of the constant map
+    // (infinite.rs:59-73); all infinite lights here are constant so one table per light would be
+    // identical up to the luminance scale -- built for the first infinite light, rescaled per use.
+    {
+        for (int v = 0; v < 2; ++v) {
+            float vp = ((float)v + 0.5f) / 2.0f;
+            float sin_theta = host_det_sin(kPi * vp);
+            std::vector<float> row(2);
+            for (int u = 0; u < 2; ++u) {
+                float y = 1.0f;
+                if (!infinite_ids.empty()) {
+                    const float* L = dl[infinite_ids[0]].L;
+                    y = 0.212671f * L[0] + 0.715160f * L[1] + 0.072169f * L[2];
+                }
+                row[u] = y;
+                row[u] *= sin_theta;
+            }
+            std::vector<float> cdf;
+            float fi;
+            make_distribution(row, &cdf, &fi);
+            for (int u = 0; u < 2; ++u) d.env_cond_func[v][u] = row[u];
+            for (int u = 0; u < 3; ++u) d.env_cond_cdf[v][u] = cdf[u];
+            d.env_cond_int[v] = fi;
+        }
+        std::vector<float> mf = {d.env_cond_int[0], d.env_cond_int[1]}, cdf;
+        float fi;
+        make_distribution(mf, &cdf, &fi);
+        for (int u = 0; u < 2; ++u) d.env_marg_func[u] = mf[u];
+        for (int u = 0; u < 3; ++u) d.env_marg_cdf[u] = cdf[u];
+        d.env_marg_int = fi;
+    }
+    // light sampling distributions (lightdistrib.rs:21-69, integrator.rs:268-277)
+    if (n_lights > 0) {
+        std::vector<float> uni(n_lights, 1.0f), cdf;
+        float fi;
+        make_distribution(uni, &cdf, &fi);
+        d.light_distrib_uniform.func = dev_upload(s, uni.data(), uni.size(), &ok);
+        d.light_distrib_uniform.cdf = dev_upload(s, cdf.data(), cdf.size(), &ok);
+        d.light_distrib_uniform.func_int = fi;
+        d.light_distrib_uniform.n = n_lights;
+        make_distribution(power_y, &cdf, &fi);
+        d.light_distrib_power.func = dev_upload(s, power_y.data(), power_y.size(), &ok);
+        d.light_distrib_power.cdf = dev_upload(s, cdf.data(), cdf.size(), &ok);
+        d.light_distrib_power.func_int = fi;
+        d.light_distrib_power.n = n_lights;
+    }
+    if (!ok) {
+        pbrt_hip_scene_destroy(s);
+        return PBRT_HIP_ERR_DEVICE;
+    }
+    *out = s;
+    return PBRT_HIP_OK;
+}
+
+extern "C" void pbrt_hip_scene_destroy(PbrtHipScene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    for (void* p : s->allocs) (void)hipFree(p);
+    delete s;
+}
+
+// ------------------------------------------------------------------------------------
+// batch intersect
+// ------------------------------------------------------------------------------------
+template <bool ANY>
+__global__ void __launch_bounds__(kTraceBlock) k_intersect_batch(DevBVH bvh, const int* __restrict__ slot_prim,
+                                                                   const PbrtRay* __restrict__ rays, int64_t n,
+                                                                   PbrtHit* __restrict__ out_hits,
+                                                                   uint8_t* __restrict__ out_flags) {
+    __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
+    const int lane_slot = blockIdx.x * kTraceBlock + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * kTraceBlock;
+    for (int64_t i = lane_slot; i < n; i += stride) {
+        const float4* rp = reinterpret_cast<const float4*>(rays + i);
+        float4 a = rp[0], b = rp[1];
+        TravRay r{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+        TravHit h;
+        bool found = traverse<ANY>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot);
+        if (ANY) {
+            out_flags[i] = found ? 1 : 0;
+        } else {
+            float4 o0 = make_float4(found ? h.t : kInf, h.b0, h.b1, h.b2);
+            int prim = found ? slot_prim[h.slot] : -1;
+            float4 o1 = make_float4(__int_as_float(prim), 0.0f, 0.0f, 0.0f);
+            float4* op = reinterpret_cast<float4*>(out_hits + i);
+            op[0] = o0;
+            op[1] = o1;
+        }
+    }
+}
+
+static int trace_grid(PbrtHipScene* s, int64_t n) {
+    int64_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
+    int64_t cap = s->spill_lanes / kTraceBlock;
+    return (int)std::max<int64_t>(1, std::min(blocks, cap));
+}
+
+template <bool ANY>
+static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtHit* d_hits, uint8_t* d_flags) {
+    PbrtHipContext* ctx = s->ctx;
+    if (n == 0) return PBRT_HIP_OK;
+    if (ctx->time_trace) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_intersect_batch<ANY>, dim3(trace_grid(s, n)), dim3(kTraceBlock), 0, ctx->stream, s->d.bvh,
+                       s->d.slot_prim, d_rays, n, d_hits, d_flags);
+    HIP_TRY(ctx, hipGetLastError());
+    if (ctx->time_trace) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ctx->trace_ms += ms;
+        ctx->trace_launches += 1;
+    }
+    return PBRT_HIP_OK;
+}
+
+extern "C" int pbrt_hip_intersect_device(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtHit* d_out) {
+    if (!s || n < 0 || (n > 0 && (!d_rays || !d_out))) return PBRT_HIP_ERR_INVALID;
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    return launch_batch<false>(s, d_rays, n, d_out, nullptr);
+}
+extern "C" int pbrt_hip_intersect_p_device(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, uint8_t* d_out) {
+    if (!s || n < 0 || (n > 0 && (!d_rays || !d_out))) return PBRT_HIP_ERR_INVALID;
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    return launch_batch<true>(s, d_rays, n, nullptr, d_out);
+}
+
+template <bool ANY>
+static int intersect_host(PbrtHipScene* s, const PbrtRay* rays, int64_t n, void* out) {
+    if (!s || n < 0 || (n > 0 && (!rays || !out))) return PBRT_HIP_ERR_INVALID;
+    if (n == 0) return PBRT_HIP_OK;
+    PbrtHipContext* ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    PbrtRay* d_rays = nullptr;
+    void* d_out = nullptr;
+    size_t out_bytes = ANY ? (size_t)n : (size_t)n * sizeof(PbrtHit);
+    HIP_TRY(ctx, hipMalloc((void**)&d_rays, (size_t)n * sizeof(PbrtRay)));
+    if (!hip_ok(ctx, hipMalloc(&d_out, out_bytes), "hipMalloc")) {
+        (void)hipFree(d_rays);
+        return PBRT_HIP_ERR_DEVICE;
+    }
+    int rc = PBRT_HIP_OK;
+    if (!hip_ok(ctx, hipMemcpyAsync(d_rays, rays, (size_t)n * sizeof(PbrtRay), hipMemcpyHostToDevice, ctx->stream), "H2D"))
+        rc = PBRT_HIP_ERR_DEVICE;
+    if (rc == PBRT_HIP_OK) rc = launch_batch<ANY>(s, d_rays, n, (PbrtHit*)d_out, (uint8_t*)d_out);
+    if (rc == PBRT_HIP_OK &&
+        !hip_ok(ctx, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H"))
+        rc = PBRT_HIP_ERR_DEVICE;
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync") && rc == PBRT_HIP_OK) rc = PBRT_HIP_ERR_DEVICE;
+    (void)hipFree(d_rays);
+    (void)hipFree(d_out);
+    return rc;
+}
+extern "C" int pbrt_hip_intersect(PbrtHipScene* s, const PbrtRay* rays, int64_t n, PbrtHit* out) {
+    return intersect_host<false>(s, rays, n, out);
+}
+extern "C" int pbrt_hip_intersect_p(PbrtHipScene* s, const PbrtRay* rays, int64_t n, uint8_t* out) {
+    return intersect_host<true>(s, rays, n, out);
+}
+
+extern "C" void pbrt_hip_film_to_rgb(const float* film, int64_t n_pixels, float* rgb) {
+    for (int64_t i = 0; i < n_pixels; ++i) {
+        const float* p = film + 4 * i;
+        float r = 3.240479f * p[0] - 1.537150f * p[1] - 0.498535f * p[2];
+        float g = -0.969256f * p[0] + 1.875991f * p[1] + 0.041556f * p[2];
+        float b = 0.055648f * p[0] - 0.204043f * p[1] + 1.057311f * p[2];
+        if (p[3] != 0.0f) {
+            float inv = 1.0f / p[3];
+            r = std::max(r * inv, 0.0f);
+            g = std::max(g * inv, 0.0f);
+            b = std::max(b * inv, 0.0f);
+        }
+        rgb[3 * i] = r;
+        rgb[3 * i + 1] = g;
+        rgb[3 * i + 2] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// render: see wavefront.h
+// ------------------------------------------------------------------------------------
+extern "C" int pbrt_hip_render_device(PbrtHipScene* s, const PbrtCamera* camera, const PbrtRenderParams* params,
+                                      float* d_film, PbrtRenderStats* stats) {
+    if (!s || !camera || !params || !d_film) return PBRT_HIP_ERR_INVALID;
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    return wavefront_render(s, *camera, *params, d_film, stats);
+}
+
+extern "C" int pbrt_hip_render(PbrtHipScene* s, const PbrtCamera* camera, const PbrtRenderParams* params,
+                               float* film_xyzw, PbrtRenderStats* stats) {
+    if (!s || !camera || !params || !film_xyzw) return PBRT_HIP_ERR_INVALID;
+    PbrtHipContext* ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (params->width <= 0 || params->height <= 0) return PBRT_HIP_ERR_INVALID;
+    size_t bytes = (size_t)params->width * params->height * 4 * sizeof(float);
+    float* d_film = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_film, bytes));
+    int rc = wavefront_render(s, *camera, *params, d_film, stats);
+    if (rc == PBRT_HIP_OK && !hip_ok(ctx, hipMemcpy(film_xyzw, d_film, bytes, hipMemcpyDeviceToHost), "film D2H"))
+        rc = PBRT_HIP_ERR_DEVICE;
+    (void)hipFree(d_film);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------
+// wavefront_render — host driver of the kernels in wavefront.h
+// ------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    std::vector<void*> ptrs;
+    PbrtHipContext* ctx;
+    explicit DevBuf(PbrtHipContext* c) : ctx(c) {}
+    ~DevBuf() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    T* alloc(size_t n, bool* ok) {
+        void* p = nullptr;
+        if (!hip_ok(ctx, hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)), "hipMalloc (path state)")) {
+            *ok = false;
+            return nullptr;
+        }
+        ptrs.push_back(p);
+        return (T*)p;
+    }
+};
+}  // namespace
+
+int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRenderParams& rp, float* d_film,
+                     PbrtRenderStats* stats) {
+    PbrtHipContext* ctx = s->ctx;
+    auto invalid = [&](const char* m) {
+        ctx->last_error = m;
+        return PBRT_HIP_ERR_INVALID;
+    };
+    if (rp.width <= 0 || rp.height <= 0 || rp.spp <= 0) return invalid("width, height and spp must be positive");
+    if (rp.x0 < 0 || rp.y0 < 0 || rp.x1 > rp.width || rp.y1 > rp.height || rp.x0 > rp.x1 || rp.y0 > rp.y1)
+        return invalid("pixel bounds outside the film");
+    if (rp.integrator != PBRT_INTEGRATOR_PATH)
+        return invalid("only the path integrator runs on the device in this build (direct lighting: oracle only)");
+    if (rp.max_depth < 0 || rp.max_depth > 1 << 20) return invalid("bad max_depth");
+    int world = rp.tile_world <= 0 ? 1 : rp.tile_world;
+    int rank = rp.tile_rank;
+    if (rank < 0 || rank >= world) return invalid("tile_rank outside [0, tile_world)");
+    hipStream_t st = ctx->stream;
+
+    size_t film_bytes = (size_t)rp.width * rp.height * 4 * sizeof(float);
+    HIP_TRY(ctx, hipMemsetAsync(d_film, 0, film_bytes, st));
+
+    // tiles of the sample bounds (integrator.rs:402-409), dealt round-robin to the GPUs
+    int ntx = (rp.x1 - rp.x0 + kTile - 1) / kTile, nty = (rp.y1 - rp.y0 + kTile - 1) / kTile;
+    std::vector<int2> origins;
+    for (int t = 0; t < ntx * nty; ++t)
+        if (t % world == rank) origins.push_back(make_int2(rp.x0 + (t % ntx) * kTile, rp.y0 + (t / ntx) * kTile));
+    PbrtRenderStats local{};
+    if (origins.empty()) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (stats) *stats = local;
+        return PBRT_HIP_OK;
+    }
+    const int n_pix = (int)origins.size() * kTile * kTile;
+    int spp_pass = rp.spp_per_pass > 0 ? rp.spp_per_pass : 0;
+    if (spp_pass == 0) {
+        const int64_t target_paths = 16ll << 20;  // ~16.8 M concurrent paths (~5 GB of state)
+        spp_pass = (int)std::max<int64_t>(1, std::min<int64_t>(rp.spp, target_paths / n_pix));
+    }
+    spp_pass = std::min(spp_pass, rp.spp);
+    const size_t N = (size_t)n_pix * spp_pass;
+    if (N * 4 >= (1ull << 32)) return invalid("too many concurrent paths for 32-bit queue entries; lower spp_per_pass");
+
+    DevBuf buf(ctx);
+    bool ok = true;
+    PathState ps;
+    ps.ray = buf.alloc<float4>(N * 6, &ok);
+    ps.hit = buf.alloc<float4>(N * 6, &ok);
+    ps.rng = buf.alloc<uint64_t>(N, &ok);
+    ps.L = buf.alloc<float4>(N, &ok);
+    ps.beta = buf.alloc<float4>(N, &ok);
+    ps.nee_a = buf.alloc<float4>(N, &ok);
+    ps.nee_f = buf.alloc<float4>(N, &ok);
+    ps.nee_b = buf.alloc<float4>(N, &ok);
+    ps.nee_light = buf.alloc<int>(N, &ok);
+    ps.pfilm = buf.alloc<float2>(N, &ok);
+    Queues q[2];
+    for (int k = 0; k < 2; ++k) {
+        q[k].trace = buf.alloc<uint32_t>(N * 3, &ok);
+        q[k].shade = buf.alloc<uint32_t>(N, &ok);
+        q[k].counts = buf.alloc<uint32_t>(4, &ok);
+    }
+    float4* accum = buf.alloc<float4>(n_pix, &ok);
+    int2* d_origins = buf.alloc<int2>(origins.size(), &ok);
+    if (!ok) return PBRT_HIP_ERR_OOM;
+    HIP_TRY(ctx, hipMemcpyAsync(d_origins, origins.data(), origins.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(accum, 0, (size_t)n_pix * sizeof(float4), st));
+    TileList tiles{d_origins, (int)origins.size()};
+
+    DevCamera cam;
+    std::memcpy(cam.c2w, camera.camera_to_world, 64);
+    std::memcpy(cam.r2c, camera.raster_to_camera, 64);
+    cam.lens_radius = camera.lens_radius;
+    cam.focal_distance = camera.focal_distance;
+    cam.shutter_open = camera.shutter_open;
+    cam.shutter_close = camera.shutter_close;
+
+    ShadeConsts sc;
+    sc.bvh = s->d.bvh;
+    sc.materials = s->d.materials;
+    sc.lights = s->d.lights;
+    sc.n_lights = s->d.n_lights;
+    sc.n_infinite = s->d.n_infinite;
+    sc.infinite_ids = s->d.infinite_ids;
+    // create_light_sample_distribution (lightdistrib.rs:222-232): "uniform", or one light -> uniform
+    sc.distrib = (rp.light_strategy == 0 || s->d.n_lights == 1) ? s->d.light_distrib_uniform : s->d.light_distrib_power;
+    std::memcpy(sc.env_cond_func, s->d.env_cond_func, sizeof(sc.env_cond_func));
+    std::memcpy(sc.env_cond_cdf, s->d.env_cond_cdf, sizeof(sc.env_cond_cdf));
+    std::memcpy(sc.env_cond_int, s->d.env_cond_int, sizeof(sc.env_cond_int));
+    std::memcpy(sc.env_marg_func, s->d.env_marg_func, sizeof(sc.env_marg_func));
+    std::memcpy(sc.env_marg_cdf, s->d.env_marg_cdf, sizeof(sc.env_marg_cdf));
+    sc.env_marg_int = s->d.env_marg_int;
+    sc.world_radius = s->d.world_radius;
+
+    hipEvent_t e_begin, e_end, e_t0, e_t1;
+    HIP_TRY(ctx, hipEventCreate(&e_begin));
+    HIP_TRY(ctx, hipEventCreate(&e_end));
+    HIP_TRY(ctx, hipEventCreate(&e_t0));
+    HIP_TRY(ctx, hipEventCreate(&e_t1));
+    auto cleanup_events = [&]() {
+        (void)hipEventDestroy(e_begin);
+        (void)hipEventDestroy(e_end);
+        (void)hipEventDestroy(e_t0);
+        (void)hipEventDestroy(e_t1);
+    };
+    int rc = PBRT_HIP_OK;
+#define RENDER_TRY(call)                                  \
+    if (rc == PBRT_HIP_OK && !hip_ok(ctx, (call), #call)) rc = PBRT_HIP_ERR_DEVICE;
+
+    RENDER_TRY(hipEventRecord(e_begin, st));
+    for (int s0 = 0; s0 < rp.spp && rc == PBRT_HIP_OK; s0 += spp_pass) {
+        PassParams pp;
+        pp.n_pix = n_pix;
+        pp.n_samples = std::min(spp_pass, rp.spp - s0);
+        pp.sample0 = s0;
+        pp.spp = rp.spp;
+        pp.width = rp.width;
+        pp.height = rp.height;
+        pp.x0 = rp.x0;
+        pp.y0 = rp.y0;
+        pp.x1 = rp.x1;
+        pp.y1 = rp.y1;
+        pp.seed = rp.seed;
+        pp.max_depth = rp.max_depth;
+        pp.rr_threshold = rp.rr_threshold;
+        pp.light_strategy = rp.light_strategy;
+        uint32_t n_paths = (uint32_t)n_pix * pp.n_samples;
+        int cur = 0;
+        RENDER_TRY(hipMemsetAsync(q[cur].counts, 0, 4 * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, st, ps, q[cur], pp, cam, tiles);
+        RENDER_TRY(hipGetLastError());
+        uint32_t counts[4] = {0, 0, 0, 0};
+        RENDER_TRY(hipMemcpyAsync(counts, q[cur].counts, sizeof(counts), hipMemcpyDeviceToHost, st));
+        RENDER_TRY(hipStreamSynchronize(st));
+        local.camera_samples += counts[1];
+        local.rays_closest += counts[0];
+        while (rc == PBRT_HIP_OK && counts[1] > 0) {
+            uint32_t n_trace = counts[0], n_shade = counts[1];
+            if (n_trace > 0) {
+                RENDER_TRY(hipEventRecord(e_t0, st));
+                hipLaunchKernelGGL(k_trace, dim3(trace_grid(s, n_trace)), dim3(kTraceBlock), 0, st, s->d.bvh, ps,
+                                   q[cur].trace, n_trace);
+                RENDER_TRY(hipGetLastError());
+                RENDER_TRY(hipEventRecord(e_t1, st));
+            }
+            int nxt = cur ^ 1;
+            RENDER_TRY(hipMemsetAsync(q[nxt].counts, 0, 4 * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(k_shade, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, q[cur], q[nxt], pp, tiles,
+                               n_shade);
+            RENDER_TRY(hipGetLastError());
+            RENDER_TRY(hipMemcpyAsync(counts, q[nxt].counts, sizeof(counts), hipMemcpyDeviceToHost, st));
+            RENDER_TRY(hipStreamSynchronize(st));
+            if (n_trace > 0 && rc == PBRT_HIP_OK) {
+                float ms = 0.0f;
+                RENDER_TRY(hipEventElapsedTime(&ms, e_t0, e_t1));
+                local.trace_ms += ms;
+                local.trace_launches += 1;
+                ctx->trace_ms += ms;
+                ctx->trace_launches += 1;
+            }
+            local.rays_closest += counts[2];
+            local.rays_shadow += counts[3];
+            cur = nxt;
+        }
+        hipLaunchKernelGGL(k_film_accumulate, dim3((n_pix + 255) / 256), dim3(256), 0, st, ps, pp, tiles, accum, d_film);
+        RENDER_TRY(hipGetLastError());
+        if (s0 + spp_pass >= rp.spp) {
+            hipLaunchKernelGGL(k_film_merge, dim3((n_pix + 255) / 256), dim3(256), 0, st, pp, tiles, accum, d_film);
+            RENDER_TRY(hipGetLastError());
+        }
+    }
+    RENDER_TRY(hipEventRecord(e_end, st));
+    RENDER_TRY(hipStreamSynchronize(st));
+    if (rc == PBRT_HIP_OK) {
+        float ms = 0.0f;
+        RENDER_TRY(hipEventElapsedTime(&ms, e_begin, e_end));
+        local.total_ms = ms;
+    }
+#undef RENDER_TRY
+    cleanup_events();
+    if (stats) *stats = local;
+    return rc;
+}

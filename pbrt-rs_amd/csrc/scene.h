@@ -1,0 +1,142 @@
+// scene.h — context / scene objects behind the C ABI and the host->device re-layout.
+//
+// Scene::new (src/core/scene.rs:18-34) + GeometricPrimitive (src/core/primitive.rs:33-55) +
+// BVHAccel's flat node array (src/accelerators/bvh.rs:129-135, 774-811), re-laid out for the
+// gfx950 traversal kernel (layout described in trace.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pbrt_hip.h"
+#include "trace.h"
+
+struct PbrtHipContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cus = 0;
+    std::string last_error;
+    // traversal-kernel timing (HIP events on `stream`)
+    double trace_ms = 0.0;
+    uint64_t trace_launches = 0;
+    bool time_trace = true;
+};
+
+namespace pb {
+
+// device-side light / material tables
+struct DevLight {
+    int type;       // PbrtLightType
+    float L[3];
+    int slot;       // area light: leaf slot of its triangle
+    int two_sided;
+    float area;     // Triangle::area (triangle.rs:323-328)
+    float power_y;  // Light::power().y_value() for the power distribution
+};
+struct DevMaterial {
+    int type;
+    float kd[3], kt[3];
+    float eta;
+};
+
+// Distribution1D (src/core/sampling.rs:62-154) flattened: func[n], cdf[n+1]
+struct DevDistribution1D {
+    const float* func;
+    const float* cdf;
+    float func_int;
+    int n;
+};
+
+struct DevSceneData {
+    DevBVH bvh;
+    const int* slot_prim;       // leaf slot -> caller's triangle index
+    const DevMaterial* materials;
+    const DevLight* lights;
+    int n_lights;
+    int n_materials;
+    int n_infinite;             // number of lights with the INFINITE flag (scene.rs:29-31, D29 intended)
+    const int* infinite_ids;
+    // InfiniteAreaLight's 2x2 sin-weighted Distribution2D (lights/infinite.rs:59-73): conditional rows + marginal
+    float env_cond_func[2][2], env_cond_cdf[2][3], env_cond_int[2];
+    float env_marg_func[2], env_marg_cdf[3], env_marg_int;
+    float world_center[3], world_radius;  // lights/infinite.rs:135-139
+    DevDistribution1D light_distrib_uniform, light_distrib_power;
+};
+
+}  // namespace pb
+
+struct PbrtHipScene {
+    PbrtHipContext* ctx = nullptr;
+    pb::DevSceneData d;          // device pointers inside
+    std::vector<void*> allocs;   // everything to hipFree
+    int n_tris = 0, n_nodes = 0, n_interior = 0;
+    int spill_lanes = 0;
+    std::vector<pb::DevLight> h_lights;
+};
+
+namespace pb {
+
+inline bool hip_ok(PbrtHipContext* ctx, hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    if (ctx) ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+
+template <class T>
+inline T* dev_upload(PbrtHipScene* s, const T* src, size_t n, bool* ok) {
+    void* p = nullptr;
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    if (!hip_ok(s->ctx, hipMalloc(&p, bytes), "hipMalloc")) {
+        *ok = false;
+        return nullptr;
+    }
+    s->allocs.push_back(p);
+    if (n && !hip_ok(s->ctx, hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D")) *ok = false;
+    return (T*)p;
+}
+
+// Host evaluation of "Triangle::intersect returns false" (triangle.rs:197-216) with the default
+// uv set (triangle.rs:66-70): degenerate uv frame or dpdu x dpdv == 0, and a zero geometric
+// normal. Ray independent, so it is a per-triangle flag. Same float operation order as the kernel
+// side (this file is compiled with -ffp-contract=off).
+inline bool triangle_rejected_by_intersect(const float* a, const float* b, const float* c) {
+    const float uv[3][2] = {{0.0f, 0.0f}, {1.0f, 0.0f}, {1.0f, 1.0f}};
+    float duv02[2] = {uv[0][0] - uv[2][0], uv[0][1] - uv[2][1]};
+    float duv12[2] = {uv[1][0] - uv[2][0], uv[1][1] - uv[2][1]};
+    float dp02[3], dp12[3];
+    for (int k = 0; k < 3; ++k) {
+        dp02[k] = a[k] - c[k];
+        dp12[k] = b[k] - c[k];
+    }
+    float determinant = duv02[0] * duv12[1] - duv02[1] * duv12[0];
+    bool degenerate_uv = std::fabs(determinant) < 1e-8f;
+    float dpdu[3] = {0, 0, 0}, dpdv[3] = {0, 0, 0};
+    if (!degenerate_uv) {
+        float inv_det = 1.0f / determinant;
+        for (int k = 0; k < 3; ++k) {
+            dpdu[k] = (dp02[k] * duv12[1] - dp12[k] * duv02[1]) * inv_det;
+            dpdv[k] = (dp02[k] * -duv12[0] + dp12[k] * duv02[0]) * inv_det;
+        }
+    }
+    float cx = dpdu[1] * dpdv[2] - dpdu[2] * dpdv[1];
+    float cy = dpdu[2] * dpdv[0] - dpdu[0] * dpdv[2];
+    float cz = dpdu[0] * dpdv[1] - dpdu[1] * dpdv[0];
+    if (degenerate_uv || (cx * cx + cy * cy + cz * cz) == 0.0f) {
+        float e1[3], e2[3];
+        for (int k = 0; k < 3; ++k) {
+            e1[k] = c[k] - a[k];
+            e2[k] = b[k] - a[k];
+        }
+        float nx = e1[1] * e2[2] - e1[2] * e2[1];
+        float ny = e1[2] * e2[0] - e1[0] * e2[2];
+        float nz = e1[0] * e2[1] - e1[1] * e2[0];
+        if ((nx * nx + ny * ny + nz * nz) == 0.0f) return true;
+    }
+    return false;
+}
+
+}  // namespace pb

@@ -1,0 +1,761 @@
+// wavefront.h — wavefront path tracer: SamplerIntegrator::render (src/core/integrator.rs:399-480)
+// + PathIntegrator::li (src/integrators/path.rs:65-213) + uniform_sample_one_light / estimate_direct
+// (src/core/integrator.rs:92-266) as a sequence of kernels over SoA path state in HBM.
+//
+// One pass handles `spp_per_pass` samples of every pixel of this GPU's tiles concurrently
+// (N = pixels x samples paths). Per bounce: k_trace traces every pending ray of every path
+// (continuation and MIS rays = Scene::intersect, shadow rays = Scene::intersect_p) in ONE launch;
+// k_shade then, per path, (1) resolves the previous bounce's direct-lighting estimate from the
+// shadow / MIS results, (2) processes the continuation hit: emission, SurfaceInteraction
+// (src/shapes/triangle.rs:193-250), BSDF, light sampling, BSDF sampling, Russian roulette, and
+// appends the next rays with wave-aggregated queue appends. Random numbers are drawn in the
+// reference's order from the path's own PCG32 stream, so every decision matches the CPU path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "scene.h"
+#include "trace.h"
+
+namespace pb {
+
+constexpr int kTile = 16;  // integrator.rs:404 TILE_SIZE
+enum PathFlags : int {
+    PF_SPECULAR_BOUNCE = 1,
+    PF_ALIVE = 2,       // a continuation ray is pending in ray slot 0
+    PF_NEE_SHADOW = 4,  // a shadow ray is pending in slot 2
+    PF_NEE_MIS = 8,     // a BSDF-sampled MIS ray is pending in slot 1
+    PF_VALID = 16,      // the path belongs to a pixel inside pixel_bounds
+};
+enum RaySlot : int { RS_CONT = 0, RS_MIS = 1, RS_SHADOW = 2 };
+
+struct PathState {
+    float4* ray;     // [(p*3 + slot)*2 + k]: (o.xyz, d.x) (d.yz, t_max, -)
+    float4* hit;     // [(p*3 + slot)*2 + k]: (t, b0, b1, b2) (slot, -, -, -); shadow slot: .x = occluded
+    uint64_t* rng;   // PCG32 state (inc is recomputed from the sample index)
+    float4* L;       // L.rgb, eta_scale
+    float4* beta;    // beta.rgb, (bounces << 8 | flags) as int bits
+    float4* nee_a;   // light-sampling contribution (if unoccluded) rgb, light pick pdf
+    float4* nee_f;   // BSDF-sampled f * |cos| rgb, MIS weight
+    float4* nee_b;   // beta at the NEE vertex rgb, scattering pdf
+    int* nee_light;  // light index of the pending estimate
+    float2* pfilm;   // CameraSample::p_film
+};
+
+struct PassParams {
+    int n_pix;         // pixels in this GPU's tile set (n_tiles * 256)
+    int n_samples;     // samples of this pass
+    int sample0;       // first sample index of this pass
+    int spp;           // total samples per pixel (RNG keying)
+    int width, height;
+    int x0, y0, x1, y1;
+    uint64_t seed;
+    int max_depth;
+    float rr_threshold;
+    int light_strategy;
+};
+
+struct Queues {
+    uint32_t* trace;   // entries: path*4 + slot
+    uint32_t* shade;   // entries: path
+    uint32_t* counts;  // [0] trace count, [1] shade count, [2] closest rays, [3] shadow rays
+};
+
+PB_DEV uint64_t sample_sequence(const PassParams& pp, int x, int y, int s) {
+    return pp.seed ^ (uint64_t)(((int64_t)y * pp.width + x) * (int64_t)pp.spp + s);
+}
+
+// wave-aggregated append: one atomic per wave (ballot + mbcnt), returns this lane's slot
+PB_DEV uint32_t queue_append(uint32_t* counter, bool want) {
+    unsigned long long mask = __ballot(want);
+    uint32_t total = (uint32_t)__popcll(mask);
+    uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+    uint32_t base = 0;
+    int leader = __ffsll((long long)mask) - 1;
+    if (want && (int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, total);
+    base = __shfl(base, leader < 0 ? 0 : leader, 64);
+    return base + prefix;
+}
+
+PB_DEV void store_ray(const PathState& ps, uint32_t p, int slot, V3 o, V3 d, float tmax) {
+    size_t i = ((size_t)p * 3 + slot) * 2;
+    ps.ray[i] = make_float4(o.x, o.y, o.z, d.x);
+    ps.ray[i + 1] = make_float4(d.y, d.z, tmax, 0.0f);
+}
+
+// ---- camera: PerspectiveCamera::generate_ray (cameras/perspective.rs:90-112) ----
+struct DevCamera {
+    float c2w[16], r2c[16];
+    float lens_radius, focal_distance, shutter_open, shutter_close;
+};
+PB_DEV V3 xform_point(const float* m, V3 p) {  // transform.rs:351-370
+    float xp = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    float yp = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    float zp = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    float wp = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    if (wp == 1.0f) return V3{xp, yp, zp};
+    return V3{xp, yp, zp} / wp;
+}
+PB_DEV V3 xform_vector(const float* m, V3 v) {  // transform.rs:372-385
+    return V3{m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
+              m[8] * v.x + m[9] * v.y + m[10] * v.z};
+}
+
+struct TileList {
+    const int2* origin;  // tile origins of this GPU
+    int n_tiles;
+};
+
+__global__ void k_generate(PathState ps, Queues q, PassParams pp, DevCamera cam, TileList tiles) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = (uint32_t)pp.n_pix * pp.n_samples;
+    if (p >= n) return;
+    int s_local = p / pp.n_pix, pix = p % pp.n_pix;
+    int tile = pix >> 8, within = pix & 255;
+    int2 org = tiles.origin[tile];
+    int x = org.x + (within & 15), y = org.y + (within >> 4);
+    bool valid = x >= pp.x0 && x < pp.x1 && y >= pp.y0 && y < pp.y1;
+    int flags = 0;
+    if (valid) {
+        int s = pp.sample0 + s_local;
+        Rng rng;
+        rng_set_sequence(rng, sample_sequence(pp, x, y, s));
+        // Sampler::get_camera_sample (sampler.rs:27-33): 2D film, 1D time, 2D lens
+        float u0 = rng_float(rng), u1 = rng_float(rng);
+        float pfx = (float)x + u0, pfy = (float)y + u1;
+        float time_u = rng_float(rng);
+        float l0 = rng_float(rng), l1 = rng_float(rng);
+        V3 p_camera = xform_point(cam.r2c, V3{pfx, pfy, 0.0f});
+        V3 o = V3{0.0f, 0.0f, 0.0f};
+        V3 d = normalize(p_camera);
+        if (cam.lens_radius > 0.0f) {
+            float lx, ly;
+            concentric_sample_disk(l0, l1, &lx, &ly);
+            lx *= cam.lens_radius;
+            ly *= cam.lens_radius;
+            float ft = cam.focal_distance / d.z;
+            V3 p_focus = o + d * ft;
+            o = V3{lx, ly, 0.0f};
+            d = normalize(p_focus - o);
+        }
+        (void)time_u;  // ray.time only feeds animated transforms / media (out of scope)
+        // Ray through camera_to_world with origin error (geometry.rs:865-881, 898-935)
+        const float* m = cam.c2w;
+        V3 ow = xform_point(m, o);
+        float xa = __builtin_fabsf(m[0] * o.x) + __builtin_fabsf(m[1] * o.y) + __builtin_fabsf(m[2] * o.z) + __builtin_fabsf(m[3]);
+        float ya = __builtin_fabsf(m[4] * o.x) + __builtin_fabsf(m[5] * o.y) + __builtin_fabsf(m[6] * o.z) + __builtin_fabsf(m[7]);
+        float za = __builtin_fabsf(m[8] * o.x) + __builtin_fabsf(m[9] * o.y) + __builtin_fabsf(m[10] * o.z) + __builtin_fabsf(m[11]);
+        V3 o_err = V3{xa, ya, za} * kGamma3;
+        V3 dw = xform_vector(m, d);
+        float l2 = len2(dw);
+        float tmax = kInf;
+        if (l2 > 0.0f) {
+            float dt = dot(vabs(dw), o_err) / l2;
+            ow = ow + dw * dt;
+            tmax -= dt;
+        }
+        store_ray(ps, p, RS_CONT, ow, dw, tmax);
+        ps.rng[p] = rng.state;
+        ps.pfilm[p] = make_float2(pfx, pfy);
+        flags = PF_VALID | PF_ALIVE;
+    } else {
+        ps.pfilm[p] = make_float2(0.0f, 0.0f);
+    }
+    ps.L[p] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    ps.beta[p] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(flags));
+    uint32_t ti = queue_append(&q.counts[0], valid);
+    if (valid) q.trace[ti] = p * 4u + RS_CONT;
+    uint32_t si = queue_append(&q.counts[1], valid);
+    if (valid) q.shade[si] = p;
+}
+
+// ---- trace: every pending ray of the wavefront ----
+__global__ void __launch_bounds__(kTraceBlock) k_trace(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue,
+                                                         uint32_t n) {
+    __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
+    const int lane_slot = blockIdx.x * kTraceBlock + threadIdx.x;
+    const uint32_t stride = gridDim.x * kTraceBlock;
+    for (uint32_t i = lane_slot; i < n; i += stride) {
+        uint32_t e = queue[i];
+        uint32_t p = e >> 2, slot = e & 3u;
+        size_t ri = ((size_t)p * 3 + slot) * 2;
+        float4 a = ps.ray[ri], b = ps.ray[ri + 1];
+        TravRay r{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+        TravHit h;
+        bool any = slot == RS_SHADOW;
+        bool found = any ? traverse<true>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot)
+                         : traverse<false>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot);
+        if (any) {
+            ps.hit[ri] = make_float4(found ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
+        } else {
+            ps.hit[ri] = make_float4(h.t, h.b0, h.b1, h.b2);
+            ps.hit[ri + 1] = make_float4(__int_as_float(found ? h.slot : -1), 0.0f, 0.0f, 0.0f);
+        }
+    }
+}
+
+// ---- shading helpers ----
+struct Surf {  // the parts of SurfaceInteraction the path needs
+    V3 p, p_error, n, dpdu, wo;
+    int material, light;  // light = index or -1
+};
+
+PB_DEV void tri_vertices(const DevBVH& bvh, int slot, V3* p0, V3* p1, V3* p2, int* prim, int* mat, int* light) {
+    float4 a = bvh.tris[3 * (size_t)slot], b = bvh.tris[3 * (size_t)slot + 1], c = bvh.tris[3 * (size_t)slot + 2];
+    *p0 = V3{a.x, a.y, a.z};
+    *p1 = V3{a.w, b.x, b.y};
+    *p2 = V3{b.z, b.w, c.x};
+    *prim = __float_as_int(c.y);
+    *mat = __float_as_int(c.z);
+    *light = (__float_as_int(c.w) & 0x3fffffff) - 1;
+}
+
+// Triangle::intersect past the hit test (triangle.rs:193-250), default uvs (:66-70), no per-vertex n/s
+PB_DEV Surf make_surface(const DevBVH& bvh, int slot, float b0, float b1, float b2, V3 ray_d) {
+    V3 p0, p1, p2;
+    int prim;
+    Surf s;
+    tri_vertices(bvh, slot, &p0, &p1, &p2, &prim, &s.material, &s.light);
+    const float duv02x = 0.0f - 1.0f, duv02y = 0.0f - 1.0f, duv12x = 1.0f - 1.0f, duv12y = 0.0f - 1.0f;
+    V3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float determinant = duv02x * duv12y - duv02y * duv12x;
+    float inv_det = 1.0f / determinant;
+    V3 dpdu = (dp02 * duv12y - dp12 * duv02y) * inv_det;
+    V3 dpdv = (dp02 * -duv12x + dp12 * duv02x) * inv_det;
+    if (len2(cross(dpdu, dpdv)) == 0.0f) {
+        V3 ng = cross(p2 - p0, p1 - p0);
+        coordinate_system(normalize(ng), &dpdu, &dpdv);
+    }
+    float xs = __builtin_fabsf(b0 * p0.x) + __builtin_fabsf(b1 * p1.x) + __builtin_fabsf(b2 * p2.x);
+    float ys = __builtin_fabsf(b0 * p0.y) + __builtin_fabsf(b1 * p1.y) + __builtin_fabsf(b2 * p2.y);
+    float zs = __builtin_fabsf(b0 * p0.z) + __builtin_fabsf(b1 * p1.z) + __builtin_fabsf(b2 * p2.z);
+    s.p_error = V3{xs, ys, zs} * kGamma7;
+    s.p = p0 * b0 + p1 * b1 + p2 * b2;
+    s.n = normalize(cross(dp02, dp12));  // triangle.rs:244-245 (no orientation flip: D14)
+    s.dpdu = dpdu;
+    s.wo = -ray_d;
+    return s;
+}
+PB_DEV V3 tri_geometric_normal(const DevBVH& bvh, int slot) {
+    V3 p0, p1, p2;
+    int a, b, c;
+    tri_vertices(bvh, slot, &p0, &p1, &p2, &a, &b, &c);
+    return normalize(cross(p0 - p2, p1 - p2));
+}
+
+struct Frame {  // BSDF::new (reflection.rs:220-234)
+    V3 ss, ts, ns, ng;
+};
+PB_DEV V3 to_local(const Frame& f, V3 v) { return V3{dot(v, f.ss), dot(v, f.ts), dot(v, f.ns)}; }
+PB_DEV V3 to_world(const Frame& f, V3 v) {
+    return V3{f.ss.x * v.x + f.ts.x * v.y + f.ns.x * v.z, f.ss.y * v.x + f.ts.y * v.y + f.ns.y * v.z,
+              f.ss.z * v.x + f.ts.z * v.y + f.ns.z * v.z};
+}
+
+// BSDF::f and BSDF::pdf for the non-specular query of estimate_direct: only the Lambertian lobe of
+// a matte material matches (reflection.rs:264-283, 414-446, 475-481, 840-842).
+PB_DEV void matte_f_pdf(const Frame& fr, V3 kd, V3 wo_w, V3 wi_w, V3* f, float* pdf) {
+    V3 wi = to_local(fr, wi_w), wo = to_local(fr, wo_w);
+    *f = V3{0.0f, 0.0f, 0.0f};
+    *pdf = 0.0f;
+    if (wo.z == 0.0f) return;
+    bool reflect = dot(wi_w, fr.ng) * dot(wo_w, fr.ng) > 0.0f;
+    if (reflect) *f = V3{0.0f + kd.x * kInvPi, 0.0f + kd.y * kInvPi, 0.0f + kd.z * kInvPi};
+    float p = (wo.z * wi.z > 0.0f) ? __builtin_fabsf(wi.z) * kInvPi : 0.0f;
+    *pdf = (0.0f + p) / 1.0f;
+}
+// BSDF::sample_f with one Lambertian lobe (reflection.rs:285-377, 459-472)
+PB_DEV V3 matte_sample_f(const Frame& fr, V3 kd, V3 wo_w, float u0, float u1, V3* wi_w, float* pdf, bool* ok) {
+    *ok = false;
+    V3 zero = V3{0.0f, 0.0f, 0.0f};
+    float ur = fminr(u0 * 1.0f - 0.0f, kOneMinusEpsilon);
+    V3 wo = to_local(fr, wo_w);
+    if (wo.z == 0.0f) return zero;  // pdf keeps the caller's value (reflection.rs:323-326)
+    V3 wi = cosine_sample_hemisphere(ur, u1);
+    if (wo.z < 0.0f) wi.z *= -1.0f;
+    *pdf = (wo.z * wi.z > 0.0f) ? __builtin_fabsf(wi.z) * kInvPi : 0.0f;
+    if (*pdf == 0.0f) return zero;
+    *wi_w = to_world(fr, wi);
+    *ok = true;
+    bool reflect = dot(*wi_w, fr.ng) * dot(wo_w, fr.ng) > 0.0f;
+    if (!reflect) return zero;
+    return V3{0.0f + kd.x * kInvPi, 0.0f + kd.y * kInvPi, 0.0f + kd.z * kInvPi};
+}
+
+PB_DEV bool is_black(V3 c) { return c.x == 0.0f && c.y == 0.0f && c.z == 0.0f; }
+PB_DEV V3 mulv(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+PB_DEV float max_comp(V3 c) {
+    float m = -kFloatMax;
+    m = (m > c.x) ? m : c.x;
+    m = (m > c.y) ? m : c.y;
+    m = (m > c.z) ? m : c.z;
+    return m;
+}
+
+// find_interval over a cdf with predicate cdf[i] < u (pbrt.rs:229-243, sampling.rs:107)
+PB_DEV int find_interval_cdf(const float* cdf, int size, float u) {
+    int first = 0, len = size;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (cdf[middle] < u) {
+            first = middle + 1;
+            len -= half + 1;
+        } else {
+            len = half;
+        }
+    }
+    int v = first - 1;
+    return v < 0 ? 0 : (v > size - 2 ? size - 2 : v);
+}
+// Distribution1D::sample_continuous (sampling.rs:99-123) on a 2-bin table
+PB_DEV float sample_continuous2(const float* func, const float* cdf, float func_int, float u, float* pdf, int* off) {
+    int offset = find_interval_cdf(cdf, 3, u);
+    *off = offset;
+    float du = u - cdf[offset];
+    if (cdf[offset + 1] - cdf[offset] > 0.0f) du /= cdf[offset + 1] - cdf[offset];
+    *pdf = func_int > 0.0f ? func[offset] / func_int : 0.0f;
+    return ((float)offset + du) / 2.0f;
+}
+
+// Full Triangle::intersect of ONE triangle for Shape::pdf2 (shape.rs:54-69): returns hit point and normal
+PB_DEV bool light_triangle_intersect(const DevBVH& bvh, int slot, V3 o, V3 d, V3* p_hit, V3* n_hit) {
+    V3 p0, p1, p2;
+    int flags;
+    load_tri(bvh.tris, slot, &p0, &p1, &p2, &flags);
+    TravRay r{o.x, o.y, o.z, d.x, d.y, d.z, kInf};
+    TriRayConst c = tri_ray_setup(r);
+    float b0, b1, b2, t;
+    if (!triangle_test(p0, p1, p2, r, c, kInf, &b0, &b1, &b2, &t)) return false;
+    if (flags & kTriDegenerate) return false;
+    *p_hit = p0 * b0 + p1 * b1 + p2 * b2;
+    *n_hit = normalize(cross(p0 - p2, p1 - p2));
+    return true;
+}
+
+struct ShadeConsts {
+    DevBVH bvh;
+    const DevMaterial* materials;
+    const DevLight* lights;
+    int n_lights, n_infinite;
+    const int* infinite_ids;
+    DevDistribution1D distrib;  // light_distribution.lookup (lightdistrib.rs:43/66)
+    float env_cond_func[2][2], env_cond_cdf[2][3], env_cond_int[2];
+    float env_marg_func[2], env_marg_cdf[3], env_marg_int;
+    float world_radius;
+};
+
+__global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Queues qin, Queues qout, PassParams pp,
+                                                 TileList tiles, uint32_t n_in) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = i < n_in;
+    uint32_t p = active ? qin.shade[i] : 0u;
+    bool emit_cont = false, emit_mis = false, emit_shadow = false;
+
+    if (active) {
+        float4 Lq = ps.L[p], bq = ps.beta[p];
+        V3 L = V3{Lq.x, Lq.y, Lq.z};
+        float eta_scale = Lq.w;
+        V3 beta = V3{bq.x, bq.y, bq.z};
+        int fb = __float_as_int(bq.w);
+        int flags = fb & 0xff, bounces = fb >> 8;
+        size_t rbase = (size_t)p * 3 * 2;
+
+        // ---- (1) resolve the pending direct-lighting estimate (integrator.rs:136-266) ----
+        if (flags & (PF_NEE_SHADOW | PF_NEE_MIS)) {
+            float4 na = ps.nee_a[p], nf = ps.nee_f[p], nb = ps.nee_b[p];
+            int light_id = ps.nee_light[p];
+            V3 ld = V3{0.0f, 0.0f, 0.0f};
+            if (flags & PF_NEE_SHADOW) {
+                bool occluded = ps.hit[rbase + RS_SHADOW * 2].x != 0.0f;
+                if (!occluded) ld = ld + V3{na.x, na.y, na.z};
+            }
+            if (flags & PF_NEE_MIS) {
+                float4 h0 = ps.hit[rbase + RS_MIS * 2];
+                int hslot = __float_as_int(ps.hit[rbase + RS_MIS * 2 + 1].x);
+                float4 r0 = ps.ray[rbase + RS_MIS * 2], r1 = ps.ray[rbase + RS_MIS * 2 + 1];
+                V3 wi = V3{r0.w, r1.x, r1.y};
+                (void)h0;
+                DevLight lt = sc.lights[light_id];
+                V3 li = V3{0.0f, 0.0f, 0.0f};
+                if (hslot >= 0) {
+                    // D26 (intended): Le only when the hit primitive's area light is this light
+                    int hl = (__float_as_int(sc.bvh.tris[3 * (size_t)hslot + 2].w) & 0x3fffffff) - 1;
+                    if (hl == light_id) {
+                        V3 n = tri_geometric_normal(sc.bvh, hslot);
+                        if (lt.two_sided || dot(n, -wi) > 0.0f) li = V3{lt.L[0], lt.L[1], lt.L[2]};
+                    }
+                } else if (lt.type == PBRT_LIGHT_INFINITE) {
+                    li = V3{lt.L[0], lt.L[1], lt.L[2]};
+                }
+                if (!is_black(li)) {
+                    V3 f = V3{nf.x, nf.y, nf.z};
+                    ld = ld + mulv(li, f) * nf.w / nb.w;
+                }
+            }
+            ld = ld / na.w;
+            L = L + mulv(V3{nb.x, nb.y, nb.z}, ld);
+            flags &= ~(PF_NEE_SHADOW | PF_NEE_MIS);
+        }
+
+        // ---- (2) the continuation hit ----
+        if (flags & PF_ALIVE) {
+            flags &= ~PF_ALIVE;
+            float4 r0 = ps.ray[rbase], r1 = ps.ray[rbase + 1];
+            V3 rd = V3{r0.w, r1.x, r1.y};
+            float4 h0 = ps.hit[rbase];
+            int hslot = __float_as_int(ps.hit[rbase + 1].x);
+            bool found = hslot >= 0;
+            Surf sf;
+            if (found) sf = make_surface(sc.bvh, hslot, h0.y, h0.z, h0.w, rd);
+            // path.rs:80-88
+            if (bounces == 0 || (flags & PF_SPECULAR_BOUNCE)) {
+                if (found) {
+                    if (sf.light >= 0) {
+                        DevLight lt = sc.lights[sf.light];
+                        // DiffuseAreaLight::l (diffuse.rs:150-156) with w = -ray.d
+                        if (lt.two_sided || dot(sf.n, -rd) > 0.0f) L = L + mulv(beta, V3{lt.L[0], lt.L[1], lt.L[2]});
+                        else L = L + mulv(beta, V3{0.0f, 0.0f, 0.0f});
+                    } else {
+                        L = L + mulv(beta, V3{0.0f, 0.0f, 0.0f});
+                    }
+                } else {
+                    for (int k = 0; k < sc.n_infinite; ++k) {
+                        DevLight lt = sc.lights[sc.infinite_ids[k]];
+                        L = L + mulv(beta, V3{lt.L[0], lt.L[1], lt.L[2]});
+                    }
+                }
+            }
+            if (found && bounces < pp.max_depth) {  // path.rs:90
+                DevMaterial mat = sc.materials[sf.material];
+                Rng rng;
+                {
+                    // recover this path's stream: inc from the (pixel, sample) index, state from memory
+                    int s_local = p / pp.n_pix, pix = p % pp.n_pix;
+                    int2 org = tiles.origin[pix >> 8];
+                    int x = org.x + (pix & 15), y = org.y + ((pix & 255) >> 4);
+                    rng.inc = (sample_sequence(pp, x, y, pp.sample0 + s_local) << 1) | 1;
+                    rng.state = ps.rng[p];
+                }
+                if (mat.type == PBRT_MAT_NONE) {
+                    // path.rs:95-98: no BSDF -> continue through the surface, bounces unchanged
+                    V3 o = offset_ray_origin(sf.p, sf.p_error, sf.n, rd);
+                    store_ray(ps, p, RS_CONT, o, rd, kInf);
+                    flags |= PF_ALIVE;
+                    emit_cont = true;
+                } else {
+                    Frame fr;
+                    fr.ns = sf.n;
+                    fr.ng = sf.n;
+                    fr.ss = normalize(sf.dpdu);
+                    fr.ts = cross(fr.ns, fr.ss);
+                    V3 kd = V3{mat.kd[0], mat.kd[1], mat.kd[2]};
+                    V3 kt = V3{mat.kt[0], mat.kt[1], mat.kt[2]};
+                    V3 wo = sf.wo;
+                    bool has_lobe;  // MaterialDesc -> BSDF (see oracle o_reflection.h for the pbrt-v3 rules)
+                    if (mat.type == PBRT_MAT_GLASS) has_lobe = !(is_black(kd) && is_black(kt));
+                    else has_lobe = !is_black(kd);
+                    bool nonspecular = (mat.type == PBRT_MAT_MATTE) && has_lobe;
+
+                    // ---- uniform_sample_one_light (integrator.rs:92-134) ----
+                    if (nonspecular && sc.n_lights > 0) {
+                        float u_pick = rng_float(rng);
+                        int light_num = find_interval_cdf(sc.distrib.cdf, sc.distrib.n + 1, u_pick);
+                        float pick_pdf = sc.distrib.func_int > 0.0f
+                                             ? sc.distrib.func[light_num] / (sc.distrib.func_int * (float)sc.distrib.n)
+                                             : 0.0f;
+                        if (pick_pdf != 0.0f) {
+                            float ul0 = rng_float(rng), ul1 = rng_float(rng);
+                            float us0 = rng_float(rng), us1 = rng_float(rng);
+                            DevLight lt = sc.lights[light_num];
+                            V3 Lc = V3{lt.L[0], lt.L[1], lt.L[2]};
+                            // -- Light::sample_li --
+                            V3 wi = V3{0.0f, 0.0f, 0.0f};
+                            float light_pdf = 0.0f;
+                            V3 li = V3{0.0f, 0.0f, 0.0f};
+                            V3 p1 = V3{0.0f, 0.0f, 0.0f}, p1_err = V3{0.0f, 0.0f, 0.0f}, p1_n = V3{0.0f, 0.0f, 0.0f};
+                            if (lt.type == PBRT_LIGHT_DIFFUSE_AREA) {
+                                // Triangle::sample (triangle.rs:330-348) + Shape::sample2 (shape.rs:38-53)
+                                V3 q0, q1, q2;
+                                int fl;
+                                load_tri(sc.bvh.tris, lt.slot, &q0, &q1, &q2, &fl);
+                                float su0 = __builtin_sqrtf(ul0);
+                                float bx = 1.0f - su0, by = ul1 * su0;
+                                float bz = 1.0f - bx - by;
+                                p1 = q0 * bx + q1 * by + q2 * bz;
+                                p1_n = normalize(cross(q1 - q0, q2 - q0));
+                                p1_err = (vabs(q0 * bx) + vabs(q1 * by) + vabs(q2 * bz)) * kGamma6;
+                                float pdf = 1.0f / lt.area;
+                                V3 w = p1 - sf.p;
+                                if (len2(w) == 0.0f) {
+                                    pdf = 0.0f;
+                                } else {
+                                    w = normalize(w);
+                                    V3 dd = sf.p - p1;
+                                    pdf *= len2(dd) / absdot(p1_n, -w);
+                                    if (__builtin_isinf(pdf)) pdf = 0.0f;
+                                }
+                                // DiffuseAreaLight::sample_li (diffuse.rs:60-81)
+                                if (pdf == 0.0f || len2(p1 - sf.p) == 0.0f) {
+                                    light_pdf = 0.0f;
+                                } else {
+                                    light_pdf = pdf;
+                                    wi = normalize(p1 - sf.p);
+                                    if (lt.two_sided || dot(p1_n, -wi) > 0.0f) li = Lc;
+                                }
+                            } else {
+                                // InfiniteAreaLight::sample_li (infinite.rs:96-129)
+                                float pdf1, pdf0;
+                                int v;
+                                float d1 = sample_continuous2(sc.env_marg_func, sc.env_marg_cdf, sc.env_marg_int, ul1, &pdf1, &v);
+                                int dummy;
+                                float d0 = sample_continuous2(sc.env_cond_func[v], sc.env_cond_cdf[v], sc.env_cond_int[v], ul0, &pdf0, &dummy);
+                                float map_pdf = pdf0 * pdf1;
+                                if (map_pdf != 0.0f) {
+                                    float theta = d1 * kPi, phi = d0 * 2.0f * kPi;
+                                    float st, ct, sp, cp;
+                                    det_sincos(theta, &st, &ct);
+                                    det_sincos(phi, &sp, &cp);
+                                    wi = V3{st * cp, st * sp, ct};
+                                    light_pdf = map_pdf / (2.0f * kPi * kPi * st);
+                                    if (st == 0.0f) light_pdf = 0.0f;
+                                    p1 = sf.p + wi * (2.0f * sc.world_radius);
+                                    li = Lc;
+                                }
+                            }
+                            int nee_flags = 0;
+                            V3 A = V3{0.0f, 0.0f, 0.0f};
+                            if (light_pdf > 0.0f && !is_black(li)) {
+                                V3 f;
+                                float scattering_pdf;
+                                matte_f_pdf(fr, kd, wo, wi, &f, &scattering_pdf);
+                                f = f * absdot(wi, fr.ns);
+                                if (!is_black(f)) {
+                                    // VisibilityTester::un_occluded -> spawn_ray_to (interaction.rs:147-153)
+                                    V3 origin = offset_ray_origin(sf.p, sf.p_error, sf.n, p1 - sf.p);
+                                    V3 target = offset_ray_origin(p1, p1_err, p1_n, origin - p1);
+                                    V3 d = target - origin;
+                                    store_ray(ps, p, RS_SHADOW, origin, d, 1.0f - kShadowEpsilon);
+                                    float weight = power_heuristic1(light_pdf, scattering_pdf);
+                                    A = mulv(li, f) * weight / light_pdf;
+                                    nee_flags |= PF_NEE_SHADOW;
+                                }
+                            }
+                            // -- BSDF sampling half (both light types are non-delta) --
+                            V3 wi2;
+                            float spdf = 0.0f;
+                            bool ok;
+                            {
+                                // scattering_pdf keeps the light-half value if wo.z == 0 (then it is 0 as well)
+                                V3 f2 = matte_sample_f(fr, kd, wo, us0, us1, &wi2, &spdf, &ok);
+                                if (ok) f2 = f2 * absdot(wi2, fr.ns);
+                                if (ok && !is_black(f2) && spdf > 0.0f) {
+                                    float lpdf;
+                                    if (lt.type == PBRT_LIGHT_DIFFUSE_AREA) {
+                                        // Shape::pdf2 (shape.rs:54-69)
+                                        V3 o2 = offset_ray_origin(sf.p, sf.p_error, sf.n, wi2);
+                                        V3 ph, nh;
+                                        if (!light_triangle_intersect(sc.bvh, lt.slot, o2, wi2, &ph, &nh)) {
+                                            lpdf = 0.0f;
+                                        } else {
+                                            lpdf = len2(sf.p - ph) / (absdot(nh, -wi2) * lt.area);
+                                            if (__builtin_isinf(lpdf)) lpdf = 0.0f;
+                                        }
+                                    } else {
+                                        // InfiniteAreaLight::pdf_li (infinite.rs:140-151)
+                                        float theta = det_acos(clampf(wi2.z, -1.0f, 1.0f));
+                                        float ph = det_atan2(wi2.y, wi2.x);
+                                        if (ph < 0.0f) ph = ph + 2.0f * kPi;
+                                        float st = det_sin(theta);
+                                        if (st == 0.0f) {
+                                            lpdf = 0.0f;
+                                        } else {
+                                            int iu = (int)(ph * kInv2Pi * 2.0f);
+                                            iu = iu < 0 ? 0 : (iu > 1 ? 1 : iu);
+                                            int iv = (int)(theta * kInvPi * 2.0f);
+                                            iv = iv < 0 ? 0 : (iv > 1 ? 1 : iv);
+                                            lpdf = sc.env_cond_func[iv][iu] / sc.env_marg_int / (2.0f * kPi * kPi * st);
+                                        }
+                                    }
+                                    if (lpdf != 0.0f) {
+                                        float weight = power_heuristic1(spdf, lpdf);
+                                        V3 o2 = offset_ray_origin(sf.p, sf.p_error, sf.n, wi2);
+                                        store_ray(ps, p, RS_MIS, o2, wi2, kInf);
+                                        ps.nee_f[p] = make_float4(f2.x, f2.y, f2.z, weight);
+                                        nee_flags |= PF_NEE_MIS;
+                                    }
+                                }
+                            }
+                            if (nee_flags) {
+                                ps.nee_a[p] = make_float4(A.x, A.y, A.z, pick_pdf);
+                                ps.nee_b[p] = make_float4(beta.x, beta.y, beta.z, spdf);
+                                ps.nee_light[p] = light_num;
+                                flags |= nee_flags;
+                                emit_shadow = (nee_flags & PF_NEE_SHADOW) != 0;
+                                emit_mis = (nee_flags & PF_NEE_MIS) != 0;
+                            }
+                        }
+                    }
+
+                    // ---- BSDF sampling for the next vertex (path.rs:123-152) ----
+                    float u0 = rng_float(rng), u1 = rng_float(rng);
+                    V3 wi = V3{0.0f, 0.0f, 0.0f}, f = V3{0.0f, 0.0f, 0.0f};
+                    float pdf = 0.0f;
+                    bool sampled_specular = false, sampled_transmission = false;
+                    if (has_lobe) {
+                        if (mat.type == PBRT_MAT_MATTE) {
+                            bool ok;
+                            f = matte_sample_f(fr, kd, wo, u0, u1, &wi, &pdf, &ok);
+                            if (!ok) pdf = 0.0f;
+                        } else {
+                            V3 wol = to_local(fr, wo);
+                            float ur = fminr(u0 * 1.0f - 0.0f, kOneMinusEpsilon);
+                            if (wol.z != 0.0f) {
+                                V3 wil = V3{0.0f, 0.0f, 0.0f};
+                                if (mat.type == PBRT_MAT_MIRROR) {
+                                    // SpecularReflection with FresnelNoOp (reflection.rs:607-659)
+                                    wil = V3{-wol.x, -wol.y, wol.z};
+                                    pdf = 1.0f;
+                                    f = mulv(kd, V3{1.0f, 1.0f, 1.0f}) / __builtin_fabsf(wil.z);
+                                    sampled_specular = true;
+                                } else {
+                                    // FresnelSpecular (reflection.rs:733-819), TransportMode::Radiance
+                                    float F = fr_dielectric(wol.z, 1.0f, mat.eta);
+                                    if (ur < F) {
+                                        wil = V3{-wol.x, -wol.y, wol.z};
+                                        pdf = F;
+                                        f = kd * F / __builtin_fabsf(wil.z);
+                                        sampled_specular = true;
+                                    } else {
+                                        bool entering = wol.z > 0.0f;
+                                        float eta_i = entering ? 1.0f : mat.eta;
+                                        float eta_t = entering ? mat.eta : 1.0f;
+                                        V3 nn = faceforward(V3{0.0f, 0.0f, 1.0f}, wol);
+                                        if (refract(wol, nn, eta_i / eta_t, &wil)) {
+                                            V3 ft = kt * (1.0f - F);
+                                            ft = ft * ((eta_i * eta_i) / (eta_t * eta_t));
+                                            pdf = 1.0f - F;
+                                            f = ft / __builtin_fabsf(wil.z);
+                                            sampled_specular = true;
+                                            sampled_transmission = true;
+                                        }
+                                    }
+                                }
+                                if (pdf != 0.0f) wi = to_world(fr, wil);
+                                else f = V3{0.0f, 0.0f, 0.0f};
+                            }
+                        }
+                    }
+                    if (!(is_black(f) || pdf == 0.0f)) {  // path.rs:136
+                        beta = mulv(beta, f * (absdot(wi, fr.ns) / pdf));
+                        flags = (flags & ~PF_SPECULAR_BOUNCE) | (sampled_specular ? PF_SPECULAR_BOUNCE : 0);
+                        if (sampled_specular && sampled_transmission) {
+                            float eta = mat.eta;
+                            eta_scale *= (dot(wo, sf.n) > 0.0f) ? (eta * eta) : 1.0f / (eta * eta);
+                        }
+                        V3 o = offset_ray_origin(sf.p, sf.p_error, sf.n, wi);
+                        bool alive = true;
+                        // path.rs:200-207 Russian roulette (D27 intended)
+                        V3 rr_beta = beta * eta_scale;
+                        if (max_comp(rr_beta) < pp.rr_threshold && bounces > 3) {
+                            float qq = fmaxr(0.05f, 1.0f - max_comp(rr_beta));
+                            if (rng_float(rng) < qq) alive = false;
+                            else beta = beta / (1.0f - qq);
+                        }
+                        if (alive) {
+                            store_ray(ps, p, RS_CONT, o, wi, kInf);
+                            flags |= PF_ALIVE;
+                            emit_cont = true;
+                            bounces += 1;
+                        }
+                    }
+                }
+                ps.rng[p] = rng.state;
+            }
+        }
+        ps.L[p] = make_float4(L.x, L.y, L.z, eta_scale);
+        ps.beta[p] = make_float4(beta.x, beta.y, beta.z, __int_as_float((bounces << 8) | flags));
+    }
+
+    // ---- queue appends (wave-aggregated) ----
+    uint32_t n_rays = (emit_cont ? 1u : 0u) + (emit_mis ? 1u : 0u);
+    (void)n_rays;
+    uint32_t a = queue_append(&qout.counts[0], emit_cont);
+    if (emit_cont) qout.trace[a] = p * 4u + RS_CONT;
+    uint32_t b = queue_append(&qout.counts[0], emit_mis);
+    if (emit_mis) qout.trace[b] = p * 4u + RS_MIS;
+    uint32_t c = queue_append(&qout.counts[0], emit_shadow);
+    if (emit_shadow) qout.trace[c] = p * 4u + RS_SHADOW;
+    bool again = emit_cont || emit_mis || emit_shadow;
+    uint32_t d = queue_append(&qout.counts[1], again);
+    if (again) qout.shade[d] = p;
+    // ray statistics
+    unsigned long long mc = __ballot(emit_cont), mm = __ballot(emit_mis), ms = __ballot(emit_shadow);
+    if ((threadIdx.x & 63) == 0) {
+        uint32_t nc = (uint32_t)(__popcll(mc) + __popcll(mm)), ns = (uint32_t)__popcll(ms);
+        if (nc) atomicAdd(&qout.counts[2], nc);
+        if (ns) atomicAdd(&qout.counts[3], ns);
+    }
+}
+
+// ---- film: FilmTile::add_sample (film.rs:252-295) with the 0.5 box filter, samples summed in order ----
+__global__ void k_film_accumulate(PathState ps, PassParams pp, TileList tiles, float4* accum, float* d_film) {
+    uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (uint32_t)pp.n_pix) return;
+    int tile = pix >> 8, within = pix & 255;
+    int2 org = tiles.origin[tile];
+    int x = org.x + (within & 15), y = org.y + (within >> 4);
+    if (!(x >= pp.x0 && x < pp.x1 && y >= pp.y0 && y < pp.y1)) return;
+    float4 acc = accum[pix];
+    for (int s = 0; s < pp.n_samples; ++s) {
+        uint32_t p = (uint32_t)s * pp.n_pix + pix;
+        float4 Lq = ps.L[p];
+        V3 L = V3{Lq.x, Lq.y, Lq.z};
+        float yv = 0.212671f * L.x + 0.715160f * L.y + 0.072169f * L.z;
+        // integrator.rs:455 (D23 intended: is_infinite)
+        if (__builtin_isnan(L.x) || __builtin_isnan(L.y) || __builtin_isnan(L.z) || yv < -1e-5f || __builtin_isinf(yv))
+            L = V3{0.0f, 0.0f, 0.0f};
+        float2 pf = ps.pfilm[p];
+        float dx = pf.x - 0.5f, dy = pf.y - 0.5f;
+        int px0 = max((int)__builtin_ceilf(dx - 0.5f), 0), py0 = max((int)__builtin_ceilf(dy - 0.5f), 0);
+        int px1 = min((int)__builtin_floorf(dx + 0.5f) + 1, pp.width), py1 = min((int)__builtin_floorf(dy + 0.5f) + 1, pp.height);
+        for (int yy = py0; yy < py1; ++yy)
+            for (int xx = px0; xx < px1; ++xx) {
+                V3 c = L * 1.0f * 1.0f;  // l * sample_weight * filter_weight (box filter table is all ones)
+                if (xx == x && yy == y) {
+                    acc.x += c.x;
+                    acc.y += c.y;
+                    acc.z += c.z;
+                    acc.w += 1.0f;
+                } else {
+                    // a film offset of exactly 0.0 also lands on the previous pixel (ceil in add_sample);
+                    // that pixel may belong to another tile / GPU: add its XYZ directly to the film
+                    float* fp = d_film + ((size_t)yy * pp.width + xx) * 4;
+                    atomicAdd(fp + 0, 0.412453f * c.x + 0.357580f * c.y + 0.180423f * c.z);
+                    atomicAdd(fp + 1, 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z);
+                    atomicAdd(fp + 2, 0.019334f * c.x + 0.119193f * c.y + 0.950227f * c.z);
+                    atomicAdd(fp + 3, 1.0f);
+                }
+            }
+    }
+    accum[pix] = acc;
+}
+
+// Film::merge_film_tile (film.rs:111-123): contrib_sum -> XYZ, accumulated into the film
+__global__ void k_film_merge(PassParams pp, TileList tiles, const float4* accum, float* d_film) {
+    uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (uint32_t)pp.n_pix) return;
+    int tile = pix >> 8, within = pix & 255;
+    int2 org = tiles.origin[tile];
+    int x = org.x + (within & 15), y = org.y + (within >> 4);
+    if (!(x >= pp.x0 && x < pp.x1 && y >= pp.y0 && y < pp.y1)) return;
+    float4 a = accum[pix];
+    float* fp = d_film + ((size_t)y * pp.width + x) * 4;
+    atomicAdd(fp + 0, 0.412453f * a.x + 0.357580f * a.y + 0.180423f * a.z);
+    atomicAdd(fp + 1, 0.212671f * a.x + 0.715160f * a.y + 0.072169f * a.z);
+    atomicAdd(fp + 2, 0.019334f * a.x + 0.119193f * a.y + 0.950227f * a.z);
+    atomicAdd(fp + 3, a.w);
+}
+
+}  // namespace pb
+
+int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRenderParams& rp, float* d_film,
+                     PbrtRenderStats* stats);

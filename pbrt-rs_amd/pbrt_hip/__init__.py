@@ -1,0 +1,232 @@
+"""ctypes binding of libpbrt_hip.so (C ABI: include/pbrt_hip.h).
+
+Host-side mirror of the reference's interface for the hot path, used by tests and bench.py:
+  BVHAccel.build       BVHAccel::new             src/accelerators/bvh.rs:216-271 (host)
+  Scene                Scene::new                src/core/scene.rs:18-34
+  Scene.intersect/_p   Scene::intersect[_p]      src/core/scene.rs:40-46   (batch form)
+  Scene.render         Integrator::render        src/core/integrator.rs:399-480
+There is no CPU fallback: without the HIP library or without a GPU every compute call raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import scenes
+from .scenes import (CAMERA_DTYPE, HIT_DTYPE, LIGHT_DTYPE, MATERIAL_DTYPE, NODE_DTYPE, RAY_DTYPE)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpbrt_hip.so")
+
+SPLIT_SAH, SPLIT_MIDDLE, SPLIT_EQUAL_COUNTS = 0, 2, 3
+INTEGRATOR_PATH, INTEGRATOR_DIRECT = 0, 1
+
+EXPORTS = [
+    "pbrt_hip_context_create", "pbrt_hip_context_destroy", "pbrt_hip_last_error", "pbrt_hip_bvh_build",
+    "pbrt_hip_free", "pbrt_hip_scene_create", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
+    "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
+    "pbrt_hip_trace_timing", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
+]
+
+
+class RenderParams(ctypes.Structure):
+    _fields_ = [("integrator", ctypes.c_int32), ("max_depth", ctypes.c_int32), ("rr_threshold", ctypes.c_float),
+                ("light_strategy", ctypes.c_int32), ("spp", ctypes.c_int32), ("width", ctypes.c_int32),
+                ("height", ctypes.c_int32), ("x0", ctypes.c_int32), ("y0", ctypes.c_int32), ("x1", ctypes.c_int32),
+                ("y1", ctypes.c_int32), ("seed", ctypes.c_uint64), ("tile_rank", ctypes.c_int32),
+                ("tile_world", ctypes.c_int32), ("spp_per_pass", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+
+class RenderStats(ctypes.Structure):
+    _fields_ = [("camera_samples", ctypes.c_uint64), ("rays_closest", ctypes.c_uint64),
+                ("rays_shadow", ctypes.c_uint64), ("trace_launches", ctypes.c_uint64),
+                ("trace_ms", ctypes.c_double), ("total_ms", ctypes.c_double)]
+
+
+class PbrtHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libpbrt_hip.so. Raises if it has not been built (pbrt-rs_amd/build.sh)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PbrtHipError(f"{LIB_PATH} is missing: build it with pbrt-rs_amd/build.sh "
+                               "(__graft_entry__.build()); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+        L.pbrt_hip_context_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+        L.pbrt_hip_context_destroy.argtypes = [vp]
+        L.pbrt_hip_context_destroy.restype = None
+        L.pbrt_hip_last_error.argtypes = [vp]
+        L.pbrt_hip_last_error.restype = ctypes.c_char_p
+        L.pbrt_hip_bvh_build.argtypes = [vp, i32, vp, i32, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(i32),
+                                         ctypes.POINTER(vp)]
+        L.pbrt_hip_free.argtypes = [vp]
+        L.pbrt_hip_free.restype = None
+        L.pbrt_hip_scene_create.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp,
+                                            ctypes.POINTER(vp)]
+        L.pbrt_hip_scene_destroy.argtypes = [vp]
+        L.pbrt_hip_scene_destroy.restype = None
+        for name in ("pbrt_hip_intersect", "pbrt_hip_intersect_p", "pbrt_hip_intersect_device",
+                     "pbrt_hip_intersect_p_device"):
+            getattr(L, name).argtypes = [vp, vp, i64, vp]
+        L.pbrt_hip_synchronize.argtypes = [vp]
+        L.pbrt_hip_trace_timing.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(ctypes.c_uint64)]
+        L.pbrt_hip_render.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
+        L.pbrt_hip_render_device.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
+        L.pbrt_hip_film_to_rgb.argtypes = [vp, i64, vp]
+        L.pbrt_hip_film_to_rgb.restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Context:
+    """One GPU (one process per GPU)."""
+
+    def __init__(self, device_id=0):
+        L = lib()
+        h = ctypes.c_void_p()
+        rc = L.pbrt_hip_context_create(device_id, ctypes.byref(h))
+        if rc != 0:
+            raise PbrtHipError(f"pbrt_hip_context_create failed ({rc}): {L.pbrt_hip_last_error(None).decode()}")
+        self.h = h
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise PbrtHipError(f"{what} failed ({rc}): {lib().pbrt_hip_last_error(self.h).decode()}")
+
+    def synchronize(self):
+        self.check(lib().pbrt_hip_synchronize(self.h), "synchronize")
+
+    def trace_timing(self, reset=False):
+        ms, n = ctypes.c_double(), ctypes.c_uint64()
+        self.check(lib().pbrt_hip_trace_timing(self.h, int(reset), ctypes.byref(ms), ctypes.byref(n)), "trace_timing")
+        return ms.value, n.value
+
+    def close(self):
+        if self.h:
+            lib().pbrt_hip_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bvh_build(positions, indices, max_prims_in_node=4, split_method=SPLIT_SAH):
+    """BVHAccel::new on the host. Returns (nodes[NODE_DTYPE], prim_order[int32]). Needs no GPU."""
+    L = lib()
+    positions = np.ascontiguousarray(positions, dtype=np.float32)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    nodes_p, order_p, n_nodes = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int32()
+    rc = L.pbrt_hip_bvh_build(_p(positions), positions.shape[0], _p(indices), indices.shape[0], max_prims_in_node,
+                              split_method, ctypes.byref(nodes_p), ctypes.byref(n_nodes), ctypes.byref(order_p))
+    if rc != 0:
+        raise PbrtHipError(f"pbrt_hip_bvh_build failed ({rc})")
+    n = n_nodes.value
+    if n == 0:
+        return np.zeros(0, dtype=NODE_DTYPE), np.zeros(0, dtype=np.int32)
+    try:
+        nodes = np.frombuffer(ctypes.string_at(nodes_p, n * NODE_DTYPE.itemsize), dtype=NODE_DTYPE).copy()
+        order = np.frombuffer(ctypes.string_at(order_p, indices.shape[0] * 4), dtype=np.int32).copy()
+    finally:
+        L.pbrt_hip_free(nodes_p)
+        L.pbrt_hip_free(order_p)
+    return nodes, order
+
+
+class Scene:
+    """Scene::new: triangles as GeometricPrimitives in a BVHAccel, resident in HBM."""
+
+    def __init__(self, ctx, scene, max_prims_in_node=4, split_method=SPLIT_SAH, bvh=None):
+        self.ctx = ctx
+        self.positions = np.ascontiguousarray(scene["positions"], dtype=np.float32)
+        self.indices = np.ascontiguousarray(scene["indices"], dtype=np.int32)
+        tri_material = np.ascontiguousarray(scene["tri_material"], dtype=np.int32)
+        materials = np.ascontiguousarray(scene["materials"], dtype=MATERIAL_DTYPE)
+        tri_light = np.ascontiguousarray(scene["tri_light"], dtype=np.int32)
+        lights = np.ascontiguousarray(scene["lights"], dtype=LIGHT_DTYPE)
+        if bvh is None:
+            bvh = bvh_build(self.positions, self.indices, max_prims_in_node, split_method)
+        self.nodes, self.prim_order = bvh
+        h = ctypes.c_void_p()
+        rc = lib().pbrt_hip_scene_create(ctx.h, _p(self.positions), self.positions.shape[0], _p(self.indices),
+                                         self.indices.shape[0], _p(tri_material), _p(materials), len(materials),
+                                         _p(tri_light), _p(lights) if len(lights) else None, len(lights),
+                                         _p(self.nodes), len(self.nodes), _p(self.prim_order), ctypes.byref(h))
+        ctx.check(rc, "pbrt_hip_scene_create")
+        self.h = h
+
+    def intersect(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        out = np.zeros(len(rays), dtype=HIT_DTYPE)
+        self.ctx.check(lib().pbrt_hip_intersect(self.h, _p(rays), len(rays), _p(out)), "pbrt_hip_intersect")
+        return out
+
+    def intersect_p(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        out = np.zeros(len(rays), dtype=np.uint8)
+        self.ctx.check(lib().pbrt_hip_intersect_p(self.h, _p(rays), len(rays), _p(out)), "pbrt_hip_intersect_p")
+        return out
+
+    def intersect_device(self, d_rays_ptr, n, d_out_ptr):
+        self.ctx.check(lib().pbrt_hip_intersect_device(self.h, ctypes.c_void_p(d_rays_ptr), n,
+                                                       ctypes.c_void_p(d_out_ptr)), "pbrt_hip_intersect_device")
+
+    def intersect_p_device(self, d_rays_ptr, n, d_out_ptr):
+        self.ctx.check(lib().pbrt_hip_intersect_p_device(self.h, ctypes.c_void_p(d_rays_ptr), n,
+                                                         ctypes.c_void_p(d_out_ptr)), "pbrt_hip_intersect_p_device")
+
+    def _params(self, width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
+                tile_rank, tile_world, spp_per_pass):
+        x0, y0, x1, y1 = bounds if bounds is not None else (0, 0, width, height)
+        return RenderParams(integrator, max_depth, rr_threshold, light_strategy, spp, width, height, x0, y0, x1, y1,
+                            seed, tile_rank, tile_world, spp_per_pass, 0)
+
+    def render(self, camera, width, height, spp, integrator=INTEGRATOR_PATH, max_depth=5, rr_threshold=1.0,
+               light_strategy=1, seed=0, bounds=None, tile_rank=0, tile_world=1, spp_per_pass=0, d_film_ptr=None):
+        """Integrator::render. Returns (film[h,w,4] or None when d_film_ptr is given, stats dict)."""
+        camera = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
+        rp = self._params(width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
+                          tile_rank, tile_world, spp_per_pass)
+        st = RenderStats()
+        if d_film_ptr is None:
+            film = np.zeros((height, width, 4), dtype=np.float32)
+            rc = lib().pbrt_hip_render(self.h, _p(camera), ctypes.byref(rp), _p(film), ctypes.byref(st))
+        else:
+            film = None
+            rc = lib().pbrt_hip_render_device(self.h, _p(camera), ctypes.byref(rp), ctypes.c_void_p(d_film_ptr),
+                                              ctypes.byref(st))
+        self.ctx.check(rc, "pbrt_hip_render")
+        stats = {name: getattr(st, name) for name, _ in RenderStats._fields_}
+        return film, stats
+
+    def close(self):
+        if self.h:
+            lib().pbrt_hip_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def film_to_rgb(film):
+    film = np.ascontiguousarray(film, dtype=np.float32)
+    rgb = np.zeros(film.shape[:-1] + (3,), dtype=np.float32)
+    lib().pbrt_hip_film_to_rgb(_p(film), film.size // 4, _p(rgb))
+    return rgb
