@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the MI355X path-tracing hot path on BASELINE.json's config 3/4:
+1 000 000 random triangles + constant env light, PathIntegrator max_depth 5, 1920x1080x64 spp.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one frame through Integrator::render (scene + BVH resident in HBM, film left on the
+device). At N GPUs the frame is 1920x1080 x (64*N) spp with the 16x16 tiles dealt round-robin to
+the ranks (per-GPU work fixed -> weak scaling; config 4 is the N=4 point, 256 spp), followed by
+one RCCL reduce of the W*H*4 film to rank 0. One ray = one Scene::intersect / intersect_p call.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pbrt-rs_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per GPU")
+    ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--max-depth", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crop", type=int, nargs=2, default=[320, 180], help="crop rendered by the CPU oracle")
+    ap.add_argument("--cpu-spp", type=int, default=16)
+    ap.add_argument("--spp-per-pass", type=int, default=0)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(rays_closest, rays_shadow, node_tests, prim_tests):
+    """32 B ray in + 32 B per box test + 48 B per triangle test + 16 B (closest) or 4 B (any) out."""
+    return 32 * (rays_closest + rays_shadow) + 32 * node_tests + 48 * prim_tests + 16 * rays_closest + 4 * rays_shadow
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    import torch
+    import torch.distributed as dist
+    import pbrt_hip
+    from pbrt_hip import scenes
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU is visible (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    W, H = args.width, args.height
+    spp_total = args.spp * world
+    sc = scenes.random_triangles(args.tris, seq=1)
+    cam = scenes.random_triangles_camera(W, H)
+    t0 = time.time()
+    bvh = pbrt_hip.bvh_build(sc["positions"], sc["indices"], 4, pbrt_hip.SPLIT_SAH)
+    t_bvh = time.time() - t0
+    ctx = pbrt_hip.Context(local_rank)
+    scene = pbrt_hip.Scene(ctx, sc, bvh=bvh)
+    film = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+
+    def step():
+        _, st = scene.render(cam, W, H, spp_total, max_depth=args.max_depth, rr_threshold=1.0, light_strategy=1,
+                             seed=0, tile_rank=rank, tile_world=world, spp_per_pass=args.spp_per_pass,
+                             d_film_ptr=film.data_ptr())
+        if world > 1:
+            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)  # the only collective: Film reduce over xGMI
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rays = 0
+    trace_ms = 0.0
+    trace_launches = 0
+    for _ in range(args.steps):
+        st = step()
+        rays += st["rays_closest"] + st["rays_shadow"]
+        trace_ms += st["trace_ms"]
+        trace_launches += st["trace_launches"]
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        elapsed, rays = float(tmax[0]), float(tt[1])
+    value = rays / elapsed / 1e6
+
+    roofline, cpu_baseline = None, None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (k_trace): algorithmic bytes / measured launch time ----
+        # Box / triangle test counts of the reference's loops for exactly this frame's rays, from
+        # one instrumented (untimed) render of this rank's tile set.
+        ctx.set_counting(True)
+        ctx.counters(reset=True)
+        st_c = step() if world == 1 else scene.render(cam, W, H, spp_total, max_depth=args.max_depth, seed=0,
+                                                       tile_rank=rank, tile_world=world,
+                                                       spp_per_pass=args.spp_per_pass, d_film_ptr=film.data_ptr())[1]
+        c = ctx.counters(reset=True)
+        ctx.set_counting(False)
+        frame_bytes = algorithmic_bytes(st_c["rays_closest"], st_c["rays_shadow"], c["node_tests"], c["prim_tests"])
+        launches_per_frame = trace_launches / args.steps
+        trace_s_per_frame = trace_ms / args.steps * 1e-3
+        achieved = frame_bytes / trace_s_per_frame / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("k_trace_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "k_trace",
+            "launches_per_step": launches_per_frame,
+            "avg_launch_ms": round(trace_ms / max(trace_launches, 1), 4),
+            "algorithmic_bytes_per_launch": round(frame_bytes / max(launches_per_frame, 1)),
+            "bytes_per_ray": round(frame_bytes / max(st_c["rays_closest"] + st_c["rays_shadow"], 1), 1),
+            "node_tests_per_ray": round(c["node_tests"] / max(c["rays"], 1), 2),
+            "tri_tests_per_ray": round(c["prim_tests"] / max(c["rays"], 1), 2),
+            "trace_fraction_of_step": round(trace_s_per_frame / (elapsed / args.steps), 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            # ---- CPU baseline: the oracle (C++ restatement; the Rust reference cannot be built) on a
+            # bounded crop of the same frame, all host cores ----
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle
+            cores = os.cpu_count() or 1
+            cw, ch = args.cpu_crop
+            x0, y0 = (W - cw) // 2, (H - ch) // 2
+            osc = oracle.OracleScene(sc)
+            _, st_o = osc.render(scenes.camera_dict_to_floats(cam), W, H, args.cpu_spp, max_depth=args.max_depth,
+                                 rr_threshold=1.0, light_strategy=1, seed=0, bounds=(x0, y0, x0 + cw, y0 + ch),
+                                 n_threads=cores)
+            cpu_baseline = {
+                "value": round(st_o["rays"] / st_o["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": cores,
+                "kind": "port",
+                "sample": f"{cw}x{ch} centre crop of the {W}x{H} frame at {args.cpu_spp} spp, same scene/seed "
+                          f"({st_o['rays']} rays in {st_o['seconds']:.1f} s)",
+            }
+            osc.close()
+        out = {
+            "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"config3: {args.tris} random triangles + constant env light, PathIntegrator "
+                            f"max_depth {args.max_depth}, {W}x{H}x{spp_total}spp ({args.spp} spp per GPU), "
+                            f"SAH BVH <=4 prims/leaf, seed 0",
+                "parallelism": f"tiles16x16 round-robin over {world} GPU(s); RCCL film reduce" if world > 1
+                               else "1 GPU",
+                "sec_per_frame": round(elapsed / args.steps, 4),
+                "rays_per_frame": int(rays / args.steps),
+                "bvh_build_s_host": round(t_bvh, 2),
+            },
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out), flush=True)
+    barrier()
+    scene.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -169,6 +169,13 @@ int pbrt_hip_synchronize(PbrtHipContext* ctx);
  * since the last call with reset != 0, and their count. */
 int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* total_ms, uint64_t* launches);
 
+/* Instrumentation for the roofline accounting: when enabled, traversal launches
+ * run an instrumented variant that counts the box tests (src/accelerators/bvh.rs:841-842) and
+ * triangle tests (src/shapes/triangle.rs:74) the reference's loops perform for the same rays.
+ * counters = {rays, node_tests, prim_tests}. Slower; never enabled in a timed region. */
+int pbrt_hip_set_counting(PbrtHipContext* ctx, int enable);
+int pbrt_hip_get_counters(PbrtHipContext* ctx, int reset, uint64_t counters[3]);
+
 /* ---- Integrator::render (src/core/integrator.rs:29-42, 399-480) for this GPU's tile set ----
  * film_xyzw: width*height*4 floats {xyz[3], filter_weight_sum} = the first 16 bytes of the
  * reference's Pixel (src/core/film.rs:9-15); pixels outside this GPU's tiles are zero, so the

@@ -56,7 +56,9 @@ extern "C" int pbrt_hip_context_create(int device_id, PbrtHipContext** out) {
     }
     ctx->n_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_counters, 2 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->d_counters, 0, 2 * sizeof(unsigned long long)) != hipSuccess) {
         g_create_error = "stream / event creation failed";
         delete ctx;
         return PBRT_HIP_ERR_DEVICE;
@@ -74,6 +76,7 @@ extern "C" void pbrt_hip_context_destroy(PbrtHipContext* ctx) {
     }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     delete ctx;
 }
 
@@ -94,6 +97,28 @@ extern "C" int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* tot
     if (reset) {
         ctx->trace_ms = 0.0;
         ctx->trace_launches = 0;
+    }
+    return PBRT_HIP_OK;
+}
+
+extern "C" int pbrt_hip_set_counting(PbrtHipContext* ctx, int enable) {
+    if (!ctx) return PBRT_HIP_ERR_INVALID;
+    ctx->count_traversal = enable != 0;
+    return PBRT_HIP_OK;
+}
+
+extern "C" int pbrt_hip_get_counters(PbrtHipContext* ctx, int reset, uint64_t counters[3]) {
+    if (!ctx || !counters) return PBRT_HIP_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpy(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    counters[0] = ctx->counted_rays;
+    counters[1] = h[0];
+    counters[2] = h[1];
+    if (reset) {
+        HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, sizeof(h)));
+        ctx->counted_rays = 0;
     }
     return PBRT_HIP_OK;
 }
@@ -385,11 +410,12 @@ extern "C" void pbrt_hip_scene_destroy(PbrtHipScene* s) {
 // ------------------------------------------------------------------------------------
 // batch intersect
 // ------------------------------------------------------------------------------------
-template <bool ANY>
+template <bool ANY, bool COUNT>
 __global__ void __launch_bounds__(kTraceBlock) k_intersect_batch(DevBVH bvh, const int* __restrict__ slot_prim,
                                                                    const PbrtRay* __restrict__ rays, int64_t n,
                                                                    PbrtHit* __restrict__ out_hits,
-                                                                   uint8_t* __restrict__ out_flags) {
+                                                                   uint8_t* __restrict__ out_flags,
+                                                                   unsigned long long* counters) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
     const int lane_slot = blockIdx.x * kTraceBlock + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * kTraceBlock;
@@ -398,7 +424,9 @@ __global__ void __launch_bounds__(kTraceBlock) k_intersect_batch(DevBVH bvh, con
         float4 a = rp[0], b = rp[1];
         TravRay r{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
         TravHit h;
-        bool found = traverse<ANY>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot);
+        uint32_t n_node = 0, n_prim = 0;
+        bool found = traverse<ANY, COUNT>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim);
+        if (COUNT) count_flush(counters, n_node, n_prim);
         if (ANY) {
             out_flags[i] = found ? 1 : 0;
         } else {
@@ -423,8 +451,14 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
     PbrtHipContext* ctx = s->ctx;
     if (n == 0) return PBRT_HIP_OK;
     if (ctx->time_trace) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_intersect_batch<ANY>, dim3(trace_grid(s, n)), dim3(kTraceBlock), 0, ctx->stream, s->d.bvh,
-                       s->d.slot_prim, d_rays, n, d_hits, d_flags);
+    if (ctx->count_traversal) {
+        hipLaunchKernelGGL((k_intersect_batch<ANY, true>), dim3(trace_grid(s, n)), dim3(kTraceBlock), 0, ctx->stream,
+                           s->d.bvh, s->d.slot_prim, d_rays, n, d_hits, d_flags, ctx->d_counters);
+        ctx->counted_rays += (uint64_t)n;
+    } else {
+        hipLaunchKernelGGL((k_intersect_batch<ANY, false>), dim3(trace_grid(s, n)), dim3(kTraceBlock), 0, ctx->stream,
+                           s->d.bvh, s->d.slot_prim, d_rays, n, d_hits, d_flags, ctx->d_counters);
+    }
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->time_trace) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -688,8 +722,14 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             uint32_t n_trace = counts[0], n_shade = counts[1];
             if (n_trace > 0) {
                 RENDER_TRY(hipEventRecord(e_t0, st));
-                hipLaunchKernelGGL(k_trace, dim3(trace_grid(s, n_trace)), dim3(kTraceBlock), 0, st, s->d.bvh, ps,
-                                   q[cur].trace, n_trace);
+                if (ctx->count_traversal) {
+                    hipLaunchKernelGGL(k_trace<true>, dim3(trace_grid(s, n_trace)), dim3(kTraceBlock), 0, st, s->d.bvh,
+                                       ps, q[cur].trace, n_trace, ctx->d_counters);
+                    ctx->counted_rays += n_trace;
+                } else {
+                    hipLaunchKernelGGL(k_trace<false>, dim3(trace_grid(s, n_trace)), dim3(kTraceBlock), 0, st, s->d.bvh,
+                                       ps, q[cur].trace, n_trace, ctx->d_counters);
+                }
                 RENDER_TRY(hipGetLastError());
                 RENDER_TRY(hipEventRecord(e_t1, st));
             }

@@ -24,6 +24,10 @@ struct PbrtHipContext {
     double trace_ms = 0.0;
     uint64_t trace_launches = 0;
     bool time_trace = true;
+    // instrumented traversal (roofline accounting): device counters {node_tests, prim_tests}
+    bool count_traversal = false;
+    unsigned long long* d_counters = nullptr;
+    uint64_t counted_rays = 0;
 };
 
 namespace pb {

@@ -149,8 +149,14 @@ PB_DEV void load_tri(const float4* __restrict__ tris, int slot, V3* p0, V3* p1, 
 
 // One ray per lane. `lds_stack` points at this lane's column: entry e lives at lds_stack[e * kTraceBlock].
 // ANY = true: BVHAccel::intersect_p (returns on the first triangle hit).
-template <bool ANY>
-PB_DEV bool traverse(const DevBVH& bvh, const TravRay& r, TravHit* hit, uint2* lds_stack, int spill_lane) {
+// COUNT = true: instrumented variant that also returns the number of box tests (bvh.rs:841-842)
+// and triangle tests (triangle.rs:74) the REFERENCE's loop performs for this ray: the reference
+// pushes the far child untested and tests it when popped, so here a far child whose box already
+// failed is still pushed (entry distance +inf) and counted when popped; entries never popped
+// (any-hit early exit) are not counted. These counts feed the algorithmic-byte roofline.
+template <bool ANY, bool COUNT = false>
+PB_DEV bool traverse(const DevBVH& bvh, const TravRay& r, TravHit* hit, uint2* lds_stack, int spill_lane,
+                     uint32_t* n_node = nullptr, uint32_t* n_prim = nullptr) {
     float tmax = r.tmax;
     hit->t = tmax;
     hit->slot = -1;
@@ -159,6 +165,7 @@ PB_DEV bool traverse(const DevBVH& bvh, const TravRay& r, TravHit* hit, uint2* l
     const bool nx = idx < 0.0f, ny = idy < 0.0f, nz = idz < 0.0f;       // bvh.rs:832-836
     const TriRayConst trc = tri_ray_setup(r);
     float e;
+    if (COUNT) *n_node += 1;
     if (!slab_test(nx ? bvh.root_max[0] : bvh.root_min[0], nx ? bvh.root_min[0] : bvh.root_max[0],
                    ny ? bvh.root_max[1] : bvh.root_min[1], ny ? bvh.root_min[1] : bvh.root_max[1],
                    nz ? bvh.root_max[2] : bvh.root_min[2], nz ? bvh.root_min[2] : bvh.root_max[2], r, idx, idy, idz,
@@ -186,9 +193,14 @@ PB_DEV bool traverse(const DevBVH& bvh, const TravRay& r, TravHit* hit, uint2* l
             int near_c = neg ? c1 : c0, far_c = neg ? c0 : c1;
             bool near_h = neg ? h1 : h0, far_h = neg ? h0 : h1;
             float far_e = neg ? e0 : e1;
+            if (COUNT) {
+                *n_node += 1;                 // the near child is tested as soon as it is visited
+                if (!near_h) *n_node += 1;    // near missed: the far child is popped and tested next
+                if (!far_h) far_e = kInf;
+            }
             if (near_h) {
                 cur = near_c;
-                if (far_h) {
+                if (far_h || COUNT) {
                     uint2 ent = make_uint2((uint32_t)far_c, __float_as_uint(far_e));
                     if (sp < kStackLds)
                         lds_stack[sp * kTraceBlock] = ent;
@@ -208,6 +220,7 @@ PB_DEV bool traverse(const DevBVH& bvh, const TravRay& r, TravHit* hit, uint2* l
                     --sp;
                     uint2 ent = (sp < kStackLds) ? lds_stack[sp * kTraceBlock]
                                                  : bvh.spill[(size_t)(sp - kStackLds) * bvh.spill_stride + spill_lane];
+                    if (COUNT) *n_node += 1;
                     if (__uint_as_float(ent.y) < tmax) {
                         cur = (int)ent.x;
                         break;
@@ -226,6 +239,7 @@ PB_DEV bool traverse(const DevBVH& bvh, const TravRay& r, TravHit* hit, uint2* l
                 int flags;
                 load_tri(bvh.tris, first + i, &p0, &p1, &p2, &flags);
                 float b0, b1, b2, t;
+                if (COUNT) *n_prim += 1;
                 if (triangle_test(p0, p1, p2, r, trc, tmax, &b0, &b1, &b2, &t)) {
                     if (ANY) return true;
                     if (!(flags & kTriDegenerate)) {
@@ -247,6 +261,7 @@ PB_DEV bool traverse(const DevBVH& bvh, const TravRay& r, TravHit* hit, uint2* l
                 --sp;
                 uint2 ent = (sp < kStackLds) ? lds_stack[sp * kTraceBlock]
                                              : bvh.spill[(size_t)(sp - kStackLds) * bvh.spill_stride + spill_lane];
+                if (COUNT) *n_node += 1;
                 if (__uint_as_float(ent.y) < tmax) {
                     cur = (int)ent.x;
                     break;
@@ -255,6 +270,19 @@ PB_DEV bool traverse(const DevBVH& bvh, const TravRay& r, TravHit* hit, uint2* l
         }
     }
     return found;
+}
+
+// wave-reduce the instrumented counts, one atomic pair per wave
+PB_DEV void count_flush(unsigned long long* counters, uint32_t n_node, uint32_t n_prim) {
+    for (int o = 32; o > 0; o >>= 1) {
+        n_node += __shfl_xor(n_node, o, 64);
+        n_prim += __shfl_xor(n_prim, o, 64);
+    }
+    unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
+        atomicAdd(&counters[0], (unsigned long long)n_node);
+        atomicAdd(&counters[1], (unsigned long long)n_prim);
+    }
 }
 
 }  // namespace pb

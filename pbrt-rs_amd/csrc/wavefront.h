@@ -169,8 +169,9 @@ __global__ void k_generate(PathState ps, Queues q, PassParams pp, DevCamera cam,
 }
 
 // ---- trace: every pending ray of the wavefront ----
+template <bool COUNT>
 __global__ void __launch_bounds__(kTraceBlock) k_trace(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue,
-                                                         uint32_t n) {
+                                                         uint32_t n, unsigned long long* counters) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
     const int lane_slot = blockIdx.x * kTraceBlock + threadIdx.x;
     const uint32_t stride = gridDim.x * kTraceBlock;
@@ -182,8 +183,10 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(DevBVH bvh, PathState ps,
         TravRay r{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
         TravHit h;
         bool any = slot == RS_SHADOW;
-        bool found = any ? traverse<true>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot)
-                         : traverse<false>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot);
+        uint32_t n_node = 0, n_prim = 0;
+        bool found = any ? traverse<true, COUNT>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim)
+                         : traverse<false, COUNT>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim);
+        if (COUNT) count_flush(counters, n_node, n_prim);
         if (any) {
             ps.hit[ri] = make_float4(found ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
         } else {

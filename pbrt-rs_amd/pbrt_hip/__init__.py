@@ -25,7 +25,7 @@ EXPORTS = [
     "pbrt_hip_context_create", "pbrt_hip_context_destroy", "pbrt_hip_last_error", "pbrt_hip_bvh_build",
     "pbrt_hip_free", "pbrt_hip_scene_create", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
     "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
-    "pbrt_hip_trace_timing", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
+    "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
 ]
 
 
@@ -78,6 +78,8 @@ def lib():
         L.pbrt_hip_synchronize.argtypes = [vp]
         L.pbrt_hip_trace_timing.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_uint64)]
+        L.pbrt_hip_set_counting.argtypes = [vp, ctypes.c_int]
+        L.pbrt_hip_get_counters.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64 * 3)]
         L.pbrt_hip_render.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
         L.pbrt_hip_render_device.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
         L.pbrt_hip_film_to_rgb.argtypes = [vp, i64, vp]
@@ -112,6 +114,15 @@ class Context:
         ms, n = ctypes.c_double(), ctypes.c_uint64()
         self.check(lib().pbrt_hip_trace_timing(self.h, int(reset), ctypes.byref(ms), ctypes.byref(n)), "trace_timing")
         return ms.value, n.value
+
+    def set_counting(self, enable):
+        """Instrumented traversal (box / triangle test counts of the reference's loops). Slow."""
+        self.check(lib().pbrt_hip_set_counting(self.h, int(enable)), "set_counting")
+
+    def counters(self, reset=False):
+        c = (ctypes.c_uint64 * 3)()
+        self.check(lib().pbrt_hip_get_counters(self.h, int(reset), ctypes.byref(c)), "get_counters")
+        return dict(rays=int(c[0]), node_tests=int(c[1]), prim_tests=int(c[2]))
 
     def close(self):
         if self.h:
