@@ -58,6 +58,7 @@ extern "C" int pbrt_hip_context_create(int device_id, PbrtHipContext** out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipMalloc((void**)&ctx->d_counters, 2 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_work_counter, sizeof(unsigned int)) != hipSuccess ||
         hipMemset(ctx->d_counters, 0, 2 * sizeof(unsigned long long)) != hipSuccess) {
         g_create_error = "stream / event creation failed";
         delete ctx;
@@ -77,6 +78,7 @@ extern "C" void pbrt_hip_context_destroy(PbrtHipContext* ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
     delete ctx;
 }
 
@@ -410,12 +412,13 @@ extern "C" void pbrt_hip_scene_destroy(PbrtHipScene* s) {
 // ------------------------------------------------------------------------------------
 // batch intersect
 // ------------------------------------------------------------------------------------
-template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock) k_intersect_batch(DevBVH bvh, const int* __restrict__ slot_prim,
-                                                                   const PbrtRay* __restrict__ rays, int64_t n,
-                                                                   PbrtHit* __restrict__ out_hits,
-                                                                   uint8_t* __restrict__ out_flags,
-                                                                   unsigned long long* counters) {
+// Instrumented variant: one ray per lane to completion (traverse<.., COUNT = true>)
+template <bool ANY>
+__global__ void __launch_bounds__(kTraceBlock) k_intersect_batch_count(DevBVH bvh, const int* __restrict__ slot_prim,
+                                                                         const PbrtRay* __restrict__ rays, int64_t n,
+                                                                         PbrtHit* __restrict__ out_hits,
+                                                                         uint8_t* __restrict__ out_flags,
+                                                                         unsigned long long* counters) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
     const int lane_slot = blockIdx.x * kTraceBlock + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * kTraceBlock;
@@ -425,8 +428,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_intersect_batch(DevBVH bvh, con
         TravRay r{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
         TravHit h;
         uint32_t n_node = 0, n_prim = 0;
-        bool found = traverse<ANY, COUNT>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim);
-        if (COUNT) count_flush(counters, n_node, n_prim);
+        bool found = traverse<ANY, true>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim);
+        count_flush(counters, n_node, n_prim);
         if (ANY) {
             out_flags[i] = found ? 1 : 0;
         } else {
@@ -440,24 +443,66 @@ __global__ void __launch_bounds__(kTraceBlock) k_intersect_batch(DevBVH bvh, con
     }
 }
 
+// Production variant: persistent threads (trace_persistent.h)
+template <bool ANY>
+struct BatchRayIO {
+    const int* __restrict__ slot_prim;
+    const PbrtRay* __restrict__ rays;
+    uint32_t count;
+    PbrtHit* __restrict__ out_hits;
+    uint8_t* __restrict__ out_flags;
+    PB_DEV uint32_t n() const { return count; }
+    PB_DEV void load(uint32_t i, TravRay* r, bool* any) const {
+        const float4* rp = reinterpret_cast<const float4*>(rays + i);
+        float4 a = rp[0], b = rp[1];
+        *r = TravRay{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+        *any = ANY;
+    }
+    PB_DEV void store(uint32_t i, bool any, bool found, float t, float b0, float b1, float b2, int slot) const {
+        if (ANY) {
+            out_flags[i] = found ? 1 : 0;
+        } else {
+            float4 o0 = make_float4(found ? t : kInf, found ? b0 : 0.0f, found ? b1 : 0.0f, found ? b2 : 0.0f);
+            int prim = found ? slot_prim[slot] : -1;
+            float4* op = reinterpret_cast<float4*>(out_hits + i);
+            op[0] = o0;
+            op[1] = make_float4(__int_as_float(prim), 0.0f, 0.0f, 0.0f);
+        }
+    }
+};
+template <bool ANY>
+__global__ void __launch_bounds__(kTraceBlock) k_intersect_batch(DevBVH bvh, BatchRayIO<ANY> io, unsigned int* work_counter) {
+    __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
+    trace_persistent(bvh, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x);
+}
+
 static int trace_grid(PbrtHipScene* s, int64_t n) {
     int64_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
     int64_t cap = s->spill_lanes / kTraceBlock;
     return (int)std::max<int64_t>(1, std::min(blocks, cap));
 }
 
+// persistent kernels: enough blocks to fill every CU (LDS admits 160 KiB / 32 KiB = 5 blocks of 256)
+static int persistent_grid(PbrtHipScene* s) { return std::min(s->ctx->n_cus * 5, s->spill_lanes / kTraceBlock); }
+
 template <bool ANY>
 static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtHit* d_hits, uint8_t* d_flags) {
     PbrtHipContext* ctx = s->ctx;
     if (n == 0) return PBRT_HIP_OK;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_work_counter, 0, sizeof(unsigned int), ctx->stream));
     if (ctx->time_trace) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (ctx->count_traversal) {
-        hipLaunchKernelGGL((k_intersect_batch<ANY, true>), dim3(trace_grid(s, n)), dim3(kTraceBlock), 0, ctx->stream,
+        hipLaunchKernelGGL((k_intersect_batch_count<ANY>), dim3(trace_grid(s, n)), dim3(kTraceBlock), 0, ctx->stream,
                            s->d.bvh, s->d.slot_prim, d_rays, n, d_hits, d_flags, ctx->d_counters);
         ctx->counted_rays += (uint64_t)n;
     } else {
-        hipLaunchKernelGGL((k_intersect_batch<ANY, false>), dim3(trace_grid(s, n)), dim3(kTraceBlock), 0, ctx->stream,
-                           s->d.bvh, s->d.slot_prim, d_rays, n, d_hits, d_flags, ctx->d_counters);
+        if (n >= (1ll << 32) - kChunk * 4096ll) {
+            ctx->last_error = "batch too large for one launch (split it below 2^32 rays)";
+            return PBRT_HIP_ERR_INVALID;
+        }
+        BatchRayIO<ANY> io{s->d.slot_prim, d_rays, (uint32_t)n, d_hits, d_flags};
+        hipLaunchKernelGGL((k_intersect_batch<ANY>), dim3(persistent_grid(s)), dim3(kTraceBlock), 0, ctx->stream, s->d.bvh,
+                           io, ctx->d_work_counter);
     }
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->time_trace) {
@@ -721,14 +766,15 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         while (rc == PBRT_HIP_OK && counts[1] > 0) {
             uint32_t n_trace = counts[0], n_shade = counts[1];
             if (n_trace > 0) {
+                RENDER_TRY(hipMemsetAsync(ctx->d_work_counter, 0, sizeof(unsigned int), st));
                 RENDER_TRY(hipEventRecord(e_t0, st));
                 if (ctx->count_traversal) {
-                    hipLaunchKernelGGL(k_trace<true>, dim3(trace_grid(s, n_trace)), dim3(kTraceBlock), 0, st, s->d.bvh,
+                    hipLaunchKernelGGL(k_trace_count, dim3(trace_grid(s, n_trace)), dim3(kTraceBlock), 0, st, s->d.bvh,
                                        ps, q[cur].trace, n_trace, ctx->d_counters);
                     ctx->counted_rays += n_trace;
                 } else {
-                    hipLaunchKernelGGL(k_trace<false>, dim3(trace_grid(s, n_trace)), dim3(kTraceBlock), 0, st, s->d.bvh,
-                                       ps, q[cur].trace, n_trace, ctx->d_counters);
+                    hipLaunchKernelGGL(k_trace, dim3(persistent_grid(s)), dim3(kTraceBlock), 0, st, s->d.bvh, ps,
+                                       q[cur].trace, n_trace, ctx->d_work_counter);
                 }
                 RENDER_TRY(hipGetLastError());
                 RENDER_TRY(hipEventRecord(e_t1, st));

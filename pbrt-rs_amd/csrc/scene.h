@@ -28,6 +28,7 @@ struct PbrtHipContext {
     bool count_traversal = false;
     unsigned long long* d_counters = nullptr;
     uint64_t counted_rays = 0;
+    unsigned int* d_work_counter = nullptr;  // ray-queue head of the persistent traversal kernel
 };
 
 namespace pb {

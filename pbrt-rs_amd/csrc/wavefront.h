@@ -15,6 +15,7 @@
 
 #include "scene.h"
 #include "trace.h"
+#include "trace_persistent.h"
 
 namespace pb {
 
@@ -169,9 +170,9 @@ __global__ void k_generate(PathState ps, Queues q, PassParams pp, DevCamera cam,
 }
 
 // ---- trace: every pending ray of the wavefront ----
-template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock) k_trace(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue,
-                                                         uint32_t n, unsigned long long* counters) {
+// Instrumented variant (COUNT): one ray per lane to completion, counts the reference's box / triangle tests.
+__global__ void __launch_bounds__(kTraceBlock) k_trace_count(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue,
+                                                               uint32_t n, unsigned long long* counters) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
     const int lane_slot = blockIdx.x * kTraceBlock + threadIdx.x;
     const uint32_t stride = gridDim.x * kTraceBlock;
@@ -184,9 +185,9 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(DevBVH bvh, PathState ps,
         TravHit h;
         bool any = slot == RS_SHADOW;
         uint32_t n_node = 0, n_prim = 0;
-        bool found = any ? traverse<true, COUNT>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim)
-                         : traverse<false, COUNT>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim);
-        if (COUNT) count_flush(counters, n_node, n_prim);
+        bool found = any ? traverse<true, true>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim)
+                         : traverse<false, true>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim);
+        count_flush(counters, n_node, n_prim);
         if (any) {
             ps.hit[ri] = make_float4(found ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
         } else {
@@ -194,6 +195,39 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(DevBVH bvh, PathState ps,
             ps.hit[ri + 1] = make_float4(__int_as_float(found ? h.slot : -1), 0.0f, 0.0f, 0.0f);
         }
     }
+}
+
+// Production variant: persistent threads, per-lane ray replacement (trace_persistent.h)
+struct WavefrontRayIO {
+    PathState ps;
+    const uint32_t* __restrict__ queue;
+    uint32_t count;
+    PB_DEV uint32_t n() const { return count; }
+    PB_DEV void load(uint32_t i, TravRay* r, bool* any) const {
+        uint32_t e = queue[i];
+        uint32_t p = e >> 2, slot = e & 3u;
+        size_t ri = ((size_t)p * 3 + slot) * 2;
+        float4 a = ps.ray[ri], b = ps.ray[ri + 1];
+        *r = TravRay{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+        *any = slot == RS_SHADOW;
+    }
+    PB_DEV void store(uint32_t i, bool any, bool found, float t, float b0, float b1, float b2, int slot) const {
+        uint32_t e = queue[i];
+        uint32_t p = e >> 2, rs = e & 3u;
+        size_t ri = ((size_t)p * 3 + rs) * 2;
+        if (any) {
+            ps.hit[ri] = make_float4(found ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
+        } else {
+            ps.hit[ri] = make_float4(t, b0, b1, b2);
+            ps.hit[ri + 1] = make_float4(__int_as_float(found ? slot : -1), 0.0f, 0.0f, 0.0f);
+        }
+    }
+};
+__global__ void __launch_bounds__(kTraceBlock) k_trace(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue,
+                                                         uint32_t n, unsigned int* work_counter) {
+    __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
+    WavefrontRayIO io{ps, queue, n};
+    trace_persistent(bvh, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x);
 }
 
 // ---- shading helpers ----

@@ -94,3 +94,29 @@ def test_single_triangle_scene(hip_ctx):
     assert (cpu["prim_id"] >= 0).any()
     gsc.close()
     osc.close()
+
+
+def test_instrumented_counts_match_reference_loops(hip_ctx):
+    """The instrumented kernel reports exactly the box / triangle test counts of the reference's
+    traversal loops (as counted by the oracle) — the inputs of the roofline's algorithmic bytes."""
+    sc = scenes.random_triangles(20_000, seq=3, size=0.05)
+    osc = oracle.OracleScene(sc)
+    gsc = pbrt_hip.Scene(hip_ctx, sc)
+    rays = _scene_rays(sc, 60_000, 21, 1.5)
+    hip_ctx.set_counting(True)
+    try:
+        hip_ctx.counters(reset=True)
+        gpu = gsc.intersect(rays)
+        c_closest = hip_ctx.counters(reset=True)
+        gpu_p = gsc.intersect_p(rays)
+        c_any = hip_ctx.counters(reset=True)
+    finally:
+        hip_ctx.set_counting(False)
+    cpu, ctr = osc.intersect(rays)
+    cpu_p, ctr_p = osc.intersect_p(rays)
+    _assert_hits_equal(gpu, cpu)
+    assert np.array_equal(gpu_p, cpu_p)
+    assert c_closest == ctr
+    assert c_any == ctr_p
+    gsc.close()
+    osc.close()

@@ -55,6 +55,18 @@ def test_random_triangles_env(hip_ctx):
                                               max_depth=5, seed=3)
     _compare(film_g, film_c)
     assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    # instrumented render: same image, and the reference-loop test counts of the whole frame
+    hip_ctx.set_counting(True)
+    try:
+        hip_ctx.counters(reset=True)
+        gsc = pbrt_hip.Scene(hip_ctx, sc)
+        film_i, _ = gsc.render(scenes.random_triangles_camera(w, h), w, h, 8, max_depth=5, seed=3)
+        c = hip_ctx.counters(reset=True)
+        gsc.close()
+    finally:
+        hip_ctx.set_counting(False)
+    assert np.array_equal(film_i, film_g)
+    assert c == dict(rays=st_c["rays"], node_tests=st_c["node_tests"], prim_tests=st_c["prim_tests"])
 
 
 def test_mixed_materials(hip_ctx):
