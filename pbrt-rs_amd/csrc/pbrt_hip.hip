@@ -57,9 +57,9 @@ extern "C" int pbrt_hip_context_create(int device_id, PbrtHipContext** out) {
     ctx->n_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_counters, 2 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_counters, 3 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_work_counter, sizeof(unsigned int)) != hipSuccess ||
-        hipMemset(ctx->d_counters, 0, 2 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long)) != hipSuccess) {
         g_create_error = "stream / event creation failed";
         delete ctx;
         return PBRT_HIP_ERR_DEVICE;
@@ -113,9 +113,9 @@ extern "C" int pbrt_hip_get_counters(PbrtHipContext* ctx, int reset, uint64_t co
     if (!ctx || !counters) return PBRT_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long h[2] = {0, 0};
+    unsigned long long h[3] = {0, 0, 0};
     HIP_TRY(ctx, hipMemcpy(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost));
-    counters[0] = ctx->counted_rays;
+    counters[0] = h[2];
     counters[1] = h[0];
     counters[2] = h[1];
     if (reset) {
@@ -482,8 +482,11 @@ static int trace_grid(PbrtHipScene* s, int64_t n) {
     return (int)std::max<int64_t>(1, std::min(blocks, cap));
 }
 
-// persistent kernels: enough blocks to fill every CU (LDS admits 160 KiB / 32 KiB = 5 blocks of 256)
-static int persistent_grid(PbrtHipScene* s) { return std::min(s->ctx->n_cus * 5, s->spill_lanes / kTraceBlock); }
+// persistent kernels: enough blocks to fill every CU (LDS: 160 KiB / (kStackLds * 2 KiB) blocks of 256, at most 8)
+static int persistent_grid(PbrtHipScene* s) {
+    int per_cu = std::min(PB_TRACE_WAVES, (160 * 1024) / (kStackLds * kTraceBlock * (int)sizeof(uint2)));
+    return std::min(s->ctx->n_cus * per_cu, s->spill_lanes / kTraceBlock);
+}
 
 template <bool ANY>
 static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtHit* d_hits, uint8_t* d_flags) {
@@ -661,6 +664,9 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         return PBRT_HIP_OK;
     }
     const int n_pix = (int)origins.size() * kTile * kTile;
+    int64_t valid_pixels = 0;
+    for (const int2& o : origins)
+        valid_pixels += (int64_t)(std::min(o.x + kTile, rp.x1) - o.x) * (std::min(o.y + kTile, rp.y1) - o.y);
     int spp_pass = rp.spp_per_pass > 0 ? rp.spp_per_pass : 0;
     if (spp_pass == 0) {
         const int64_t target_paths = 16ll << 20;  // ~16.8 M concurrent paths (~5 GB of state)
@@ -687,7 +693,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     for (int k = 0; k < 2; ++k) {
         q[k].trace = buf.alloc<uint32_t>(N * 3, &ok);
         q[k].shade = buf.alloc<uint32_t>(N, &ok);
-        q[k].counts = buf.alloc<uint32_t>(4, &ok);
+        q[k].counts64 = buf.alloc<unsigned long long>(2, &ok);
     }
     float4* accum = buf.alloc<float4>(n_pix, &ok);
     int2* d_origins = buf.alloc<int2>(origins.size(), &ok);
@@ -755,16 +761,15 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         pp.light_strategy = rp.light_strategy;
         uint32_t n_paths = (uint32_t)n_pix * pp.n_samples;
         int cur = 0;
-        RENDER_TRY(hipMemsetAsync(q[cur].counts, 0, 4 * sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, st, ps, q[cur], pp, cam, tiles);
         RENDER_TRY(hipGetLastError());
-        uint32_t counts[4] = {0, 0, 0, 0};
-        RENDER_TRY(hipMemcpyAsync(counts, q[cur].counts, sizeof(counts), hipMemcpyDeviceToHost, st));
-        RENDER_TRY(hipStreamSynchronize(st));
-        local.camera_samples += counts[1];
-        local.rays_closest += counts[0];
+        // the first wavefront is the identity: every path traces its camera ray and is shaded
+        unsigned long long counts[2] = {n_paths, n_paths};
+        local.camera_samples += (uint64_t)valid_pixels * pp.n_samples;
+        local.rays_closest += (uint64_t)valid_pixels * pp.n_samples;
+        bool first = true;
         while (rc == PBRT_HIP_OK && counts[1] > 0) {
-            uint32_t n_trace = counts[0], n_shade = counts[1];
+            uint32_t n_trace = (uint32_t)counts[0], n_shade = (uint32_t)counts[1];
             if (n_trace > 0) {
                 RENDER_TRY(hipMemsetAsync(ctx->d_work_counter, 0, sizeof(unsigned int), st));
                 RENDER_TRY(hipEventRecord(e_t0, st));
@@ -780,11 +785,11 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                 RENDER_TRY(hipEventRecord(e_t1, st));
             }
             int nxt = cur ^ 1;
-            RENDER_TRY(hipMemsetAsync(q[nxt].counts, 0, 4 * sizeof(uint32_t), st));
+            RENDER_TRY(hipMemsetAsync(q[nxt].counts64, 0, 2 * sizeof(unsigned long long), st));
             hipLaunchKernelGGL(k_shade, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, q[cur], q[nxt], pp, tiles,
                                n_shade);
             RENDER_TRY(hipGetLastError());
-            RENDER_TRY(hipMemcpyAsync(counts, q[nxt].counts, sizeof(counts), hipMemcpyDeviceToHost, st));
+            RENDER_TRY(hipMemcpyAsync(counts, q[nxt].counts64, sizeof(counts), hipMemcpyDeviceToHost, st));
             RENDER_TRY(hipStreamSynchronize(st));
             if (n_trace > 0 && rc == PBRT_HIP_OK) {
                 float ms = 0.0f;
@@ -794,8 +799,14 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                 ctx->trace_ms += ms;
                 ctx->trace_launches += 1;
             }
-            local.rays_closest += counts[2];
-            local.rays_shadow += counts[3];
+            {
+                uint64_t n_rays = counts[0] & 0xffffffffull, n_shadow = counts[0] >> 32;
+                local.rays_closest += n_rays - n_shadow;
+                local.rays_shadow += n_shadow;
+                counts[0] = n_rays;
+            }
+            (void)first;
+            first = false;
             cur = nxt;
         }
         hipLaunchKernelGGL(k_film_accumulate, dim3((n_pix + 255) / 256), dim3(256), 0, st, ps, pp, tiles, accum, d_film);

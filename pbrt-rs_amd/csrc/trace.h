@@ -32,8 +32,11 @@ struct DevBVH {
     int spill_stride;           // number of lanes the slab was sized for
 };
 
-constexpr int kStackLds = 16;
-constexpr int kStackSpill = 48;  // 16 + 48 = the reference's 64-entry stack (bvh.rs:839)
+#ifndef PB_STACK_LDS
+#define PB_STACK_LDS 12
+#endif
+constexpr int kStackLds = PB_STACK_LDS;
+constexpr int kStackSpill = 64 - PB_STACK_LDS;  // together: the reference's 64-entry stack (bvh.rs:839)
 constexpr int kTraceBlock = 256;
 
 struct TravRay {
@@ -273,15 +276,21 @@ PB_DEV bool traverse(const DevBVH& bvh, const TravRay& r, TravHit* hit, uint2* l
 }
 
 // wave-reduce the instrumented counts, one atomic pair per wave
-PB_DEV void count_flush(unsigned long long* counters, uint32_t n_node, uint32_t n_prim) {
-    for (int o = 32; o > 0; o >>= 1) {
-        n_node += __shfl_xor(n_node, o, 64);
-        n_prim += __shfl_xor(n_prim, o, 64);
-    }
+PB_DEV void count_flush(unsigned long long* counters, uint32_t n_node, uint32_t n_prim, uint32_t n_rays = 1) {
+    // inactive lanes contribute 0 to __shfl_xor? No: they return their own stale register, so reduce
+    // with ballot-guarded values instead: every active lane adds through LDS-free wave atomics.
     unsigned long long m = __ballot(1);
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t a = __shfl_xor(n_node, o, 64), b = __shfl_xor(n_prim, o, 64), c = __shfl_xor(n_rays, o, 64);
+        bool peer_active = (m >> ((threadIdx.x & 63) ^ o)) & 1ull;
+        n_node += peer_active ? a : 0u;
+        n_prim += peer_active ? b : 0u;
+        n_rays += peer_active ? c : 0u;
+    }
     if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
         atomicAdd(&counters[0], (unsigned long long)n_node);
         atomicAdd(&counters[1], (unsigned long long)n_prim);
+        atomicAdd(&counters[2], (unsigned long long)n_rays);
     }
 }
 

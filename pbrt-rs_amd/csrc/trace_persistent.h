@@ -16,9 +16,18 @@
 
 namespace pb {
 
-constexpr int kChunk = 512;          // rays per wave-level queue grab
-constexpr int kRefillThresh = 20;    // refill when at least this many lanes are idle
-constexpr int kInteriorThresh = 40;  // keep stepping interior nodes while at least this many lanes do
+#ifndef PB_CHUNK
+#define PB_CHUNK 128
+#endif
+#ifndef PB_REFILL_THRESH
+#define PB_REFILL_THRESH 8
+#endif
+#ifndef PB_INTERIOR_THRESH
+#define PB_INTERIOR_THRESH 32
+#endif
+constexpr int kChunk = PB_CHUNK;                    // rays per wave-level queue grab
+constexpr int kRefillThresh = PB_REFILL_THRESH;     // refill when at least this many lanes are idle
+constexpr int kInteriorThresh = PB_INTERIOR_THRESH; // keep stepping interior nodes while at least this many lanes do
 
 struct LaneState {
     TravRay r;

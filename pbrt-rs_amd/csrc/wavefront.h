@@ -58,23 +58,61 @@ struct PassParams {
 struct Queues {
     uint32_t* trace;   // entries: path*4 + slot
     uint32_t* shade;   // entries: path
-    uint32_t* counts;  // [0] trace count, [1] shade count, [2] closest rays, [3] shadow rays
+    // counts64[0]: low 32 bits = trace-queue length, high 32 bits = shadow rays among them;
+    // counts64[1]: shade-queue length
+    unsigned long long* counts64;
 };
 
 PB_DEV uint64_t sample_sequence(const PassParams& pp, int x, int y, int s) {
     return pp.seed ^ (uint64_t)(((int64_t)y * pp.width + x) * (int64_t)pp.spp + s);
 }
 
-// wave-aggregated append: one atomic per wave (ballot + mbcnt), returns this lane's slot
-PB_DEV uint32_t queue_append(uint32_t* counter, bool want) {
-    unsigned long long mask = __ballot(want);
-    uint32_t total = (uint32_t)__popcll(mask);
-    uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-    uint32_t base = 0;
-    int leader = __ffsll((long long)mask) - 1;
-    if (want && (int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, total);
-    base = __shfl(base, leader < 0 ? 0 : leader, 64);
-    return base + prefix;
+// Block-aggregated queue append. Same-address atomics saturate near 10^2 per microsecond on the
+// whole chip, so one atomic per wave (260 k waves per launch) would cost milliseconds: lanes are
+// ranked inside the wave with ballot + mbcnt, waves inside the block through LDS, and ONE lane
+// per block reserves the block's range with a single 64-bit atomicAdd per queue.
+struct BlockAppend {
+    uint32_t wave_rays[16];   // per-wave totals (blocks of up to 1024 threads)
+    uint32_t wave_shadow[16];
+    uint32_t wave_paths[16];
+    uint32_t base_rays, base_paths;
+};
+PB_DEV uint32_t lane_prefix(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+// Every thread of the block must call this. n_cont/n_mis/n_shadow in {0,1}; again = path stays in the shade queue.
+PB_DEV void block_append(BlockAppend& sh, const Queues& q, uint32_t p, bool cont, bool mis, bool shadow, bool again) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63) >> 6;
+    unsigned long long mc = __ballot(cont), mm = __ballot(mis), ms = __ballot(shadow), ma = __ballot(again);
+    uint32_t wc = (uint32_t)__popcll(mc), wm = (uint32_t)__popcll(mm), ws = (uint32_t)__popcll(ms);
+    if (lane == 0) {
+        sh.wave_rays[wave] = wc + wm + ws;
+        sh.wave_shadow[wave] = ws;
+        sh.wave_paths[wave] = (uint32_t)__popcll(ma);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tr = 0, tsd = 0, tp = 0;
+        for (int w = 0; w < n_waves; ++w) {
+            uint32_t r = sh.wave_rays[w], pth = sh.wave_paths[w];
+            sh.wave_rays[w] = tr;   // exclusive prefix
+            sh.wave_paths[w] = tp;
+            tr += r;
+            tsd += sh.wave_shadow[w];
+            tp += pth;
+        }
+        unsigned long long old = 0;
+        if (tr) old = atomicAdd(&q.counts64[0], (unsigned long long)tr | ((unsigned long long)tsd << 32));
+        sh.base_rays = (uint32_t)old;
+        sh.base_paths = tp ? (uint32_t)atomicAdd(&q.counts64[1], (unsigned long long)tp) : 0u;
+    }
+    __syncthreads();
+    uint32_t rbase = sh.base_rays + sh.wave_rays[wave];
+    // within the wave: all continuation rays, then MIS rays, then shadow rays
+    if (cont) q.trace[rbase + lane_prefix(mc)] = p * 4u + RS_CONT;
+    if (mis) q.trace[rbase + wc + lane_prefix(mm)] = p * 4u + RS_MIS;
+    if (shadow) q.trace[rbase + wc + wm + lane_prefix(ms)] = p * 4u + RS_SHADOW;
+    if (again) q.shade[sh.base_paths + sh.wave_paths[wave] + lane_prefix(ma)] = p;
 }
 
 PB_DEV void store_ray(const PathState& ps, uint32_t p, int slot, V3 o, V3 d, float tmax) {
@@ -163,10 +201,11 @@ __global__ void k_generate(PathState ps, Queues q, PassParams pp, DevCamera cam,
     }
     ps.L[p] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
     ps.beta[p] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(flags));
-    uint32_t ti = queue_append(&q.counts[0], valid);
-    if (valid) q.trace[ti] = p * 4u + RS_CONT;
-    uint32_t si = queue_append(&q.counts[1], valid);
-    if (valid) q.shade[si] = p;
+    // The first wavefront is every path in order: identity queues, no atomics. Paths of pixels
+    // outside pixel_bounds (partial border tiles) carry a ray that misses at once (t_max < 0).
+    if (!valid) store_ray(ps, p, RS_CONT, V3{0.0f, 0.0f, 0.0f}, V3{0.0f, 0.0f, 1.0f}, -1.0f);
+    q.trace[p] = p * 4u + RS_CONT;
+    q.shade[p] = p;
 }
 
 // ---- trace: every pending ray of the wavefront ----
@@ -185,9 +224,14 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace_count(DevBVH bvh, PathSta
         TravHit h;
         bool any = slot == RS_SHADOW;
         uint32_t n_node = 0, n_prim = 0;
-        bool found = any ? traverse<true, true>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim)
-                         : traverse<false, true>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim);
-        count_flush(counters, n_node, n_prim);
+        // t_max < 0 marks the placeholder ray of a path outside pixel_bounds (k_generate): not a ray of the frame
+        bool real = !(r.tmax < 0.0f);
+        bool found = false;
+        h.t = r.tmax; h.b0 = h.b1 = h.b2 = 0.0f; h.slot = -1;
+        if (real)
+            found = any ? traverse<true, true>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim)
+                        : traverse<false, true>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim);
+        count_flush(counters, n_node, n_prim, real ? 1u : 0u);
         if (any) {
             ps.hit[ri] = make_float4(found ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
         } else {
@@ -223,8 +267,12 @@ struct WavefrontRayIO {
         }
     }
 };
-__global__ void __launch_bounds__(kTraceBlock) k_trace(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue,
-                                                         uint32_t n, unsigned int* work_counter) {
+#ifndef PB_TRACE_WAVES
+#define PB_TRACE_WAVES 6
+#endif
+__global__ void __launch_bounds__(kTraceBlock, PB_TRACE_WAVES) k_trace(DevBVH bvh, PathState ps,
+                                                                         const uint32_t* __restrict__ queue, uint32_t n,
+                                                                         unsigned int* work_counter) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
     WavefrontRayIO io{ps, queue, n};
     trace_persistent(bvh, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x);
@@ -712,25 +760,9 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
         ps.beta[p] = make_float4(beta.x, beta.y, beta.z, __int_as_float((bounces << 8) | flags));
     }
 
-    // ---- queue appends (wave-aggregated) ----
-    uint32_t n_rays = (emit_cont ? 1u : 0u) + (emit_mis ? 1u : 0u);
-    (void)n_rays;
-    uint32_t a = queue_append(&qout.counts[0], emit_cont);
-    if (emit_cont) qout.trace[a] = p * 4u + RS_CONT;
-    uint32_t b = queue_append(&qout.counts[0], emit_mis);
-    if (emit_mis) qout.trace[b] = p * 4u + RS_MIS;
-    uint32_t c = queue_append(&qout.counts[0], emit_shadow);
-    if (emit_shadow) qout.trace[c] = p * 4u + RS_SHADOW;
-    bool again = emit_cont || emit_mis || emit_shadow;
-    uint32_t d = queue_append(&qout.counts[1], again);
-    if (again) qout.shade[d] = p;
-    // ray statistics
-    unsigned long long mc = __ballot(emit_cont), mm = __ballot(emit_mis), ms = __ballot(emit_shadow);
-    if ((threadIdx.x & 63) == 0) {
-        uint32_t nc = (uint32_t)(__popcll(mc) + __popcll(mm)), ns = (uint32_t)__popcll(ms);
-        if (nc) atomicAdd(&qout.counts[2], nc);
-        if (ns) atomicAdd(&qout.counts[3], ns);
-    }
+    // ---- queue appends (block-aggregated) ----
+    __shared__ BlockAppend sh;
+    block_append(sh, qout, p, emit_cont, emit_mis, emit_shadow, emit_cont || emit_mis || emit_shadow);
 }
 
 // ---- film: FilmTile::add_sample (film.rs:252-295) with the 0.5 box filter, samples summed in order ----
