@@ -42,6 +42,25 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // period))
+        except Exception:
+            pass
+    return n
+
+
 def algorithmic_bytes(rays_closest, rays_shadow, node_tests, prim_tests):
     """32 B ray in + 32 B per box test + 48 B per triangle test + 16 B (closest) or 4 B (any) out."""
     return 32 * (rays_closest + rays_shadow) + 32 * node_tests + 48 * prim_tests + 16 * rays_closest + 4 * rays_shadow
@@ -151,7 +170,7 @@ def main():
             # bounded crop of the same frame, all host cores ----
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle
-            cores = os.cpu_count() or 1
+            cores = host_cores()
             cw, ch = args.cpu_crop
             x0, y0 = (W - cw) // 2, (H - ch) // 2
             osc = oracle.OracleScene(sc)
