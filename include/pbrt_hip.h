@@ -186,6 +186,13 @@ int pbrt_hip_render(PbrtHipScene* scene, const PbrtCamera* camera, const PbrtRen
 int pbrt_hip_render_device(PbrtHipScene* scene, const PbrtCamera* camera, const PbrtRenderParams* params,
                            float* d_film_xyzw, PbrtRenderStats* stats);
 
+/* Tile partition used by pbrt_hip_render (host only, no GPU needed): the 16x16 tiles of the pixel
+ * bounds (src/core/integrator.rs:402-409) in row-major order; tile t belongs to rank t % world.
+ * Writes this rank's tile origins (x, y pairs) to origins_xy (capacity in tiles) and their count
+ * to n_out; returns PBRT_HIP_ERR_INVALID if the capacity is too small (n_out then holds the need). */
+int pbrt_hip_tile_partition(int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t rank, int32_t world,
+                            int32_t* origins_xy, int32_t capacity, int32_t* n_out);
+
 /* Film::write_image's per-pixel arithmetic (src/core/film.rs:153-178, without the file
  * writer, which is todo!() in the reference): rgb = max(0, xyz_to_rgb(xyz) / filter_weight_sum). Host. */
 void pbrt_hip_film_to_rgb(const float* film_xyzw, int64_t n_pixels, float* rgb);

@@ -607,6 +607,23 @@ extern "C" int pbrt_hip_render(PbrtHipScene* s, const PbrtCamera* camera, const 
     return rc;
 }
 
+extern "C" int pbrt_hip_tile_partition(int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t rank, int32_t world,
+                                       int32_t* origins_xy, int32_t capacity, int32_t* n_out) {
+    if (!n_out || x0 > x1 || y0 > y1 || world <= 0 || rank < 0 || rank >= world) return PBRT_HIP_ERR_INVALID;
+    int ntx = (x1 - x0 + kTile - 1) / kTile, nty = (y1 - y0 + kTile - 1) / kTile;
+    int n = 0;
+    for (int t = 0; t < ntx * nty; ++t) {
+        if (t % world != rank) continue;
+        if (origins_xy && n < capacity) {
+            origins_xy[2 * n] = x0 + (t % ntx) * kTile;
+            origins_xy[2 * n + 1] = y0 + (t / ntx) * kTile;
+        }
+        ++n;
+    }
+    *n_out = n;
+    return (origins_xy && n > capacity) ? PBRT_HIP_ERR_INVALID : PBRT_HIP_OK;
+}
+
 // ------------------------------------------------------------------------------------
 // wavefront_render — host driver of the kernels in wavefront.h
 // ------------------------------------------------------------------------------------
@@ -653,10 +670,13 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     HIP_TRY(ctx, hipMemsetAsync(d_film, 0, film_bytes, st));
 
     // tiles of the sample bounds (integrator.rs:402-409), dealt round-robin to the GPUs
-    int ntx = (rp.x1 - rp.x0 + kTile - 1) / kTile, nty = (rp.y1 - rp.y0 + kTile - 1) / kTile;
     std::vector<int2> origins;
-    for (int t = 0; t < ntx * nty; ++t)
-        if (t % world == rank) origins.push_back(make_int2(rp.x0 + (t % ntx) * kTile, rp.y0 + (t / ntx) * kTile));
+    {
+        int32_t n_mine = 0;
+        pbrt_hip_tile_partition(rp.x0, rp.y0, rp.x1, rp.y1, rank, world, nullptr, 0, &n_mine);
+        origins.resize(n_mine);
+        pbrt_hip_tile_partition(rp.x0, rp.y0, rp.x1, rp.y1, rank, world, (int32_t*)origins.data(), n_mine, &n_mine);
+    }
     PbrtRenderStats local{};
     if (origins.empty()) {
         HIP_TRY(ctx, hipStreamSynchronize(st));

@@ -26,6 +26,7 @@ EXPORTS = [
     "pbrt_hip_free", "pbrt_hip_scene_create", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
     "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
+    "pbrt_hip_tile_partition",
 ]
 
 
@@ -82,6 +83,7 @@ def lib():
         L.pbrt_hip_get_counters.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64 * 3)]
         L.pbrt_hip_render.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
         L.pbrt_hip_render_device.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
+        L.pbrt_hip_tile_partition.argtypes = [i32, i32, i32, i32, i32, i32, vp, i32, ctypes.POINTER(i32)]
         L.pbrt_hip_film_to_rgb.argtypes = [vp, i64, vp]
         L.pbrt_hip_film_to_rgb.restype = None
         _lib = L
@@ -234,6 +236,20 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+
+def tile_partition(bounds, rank, world):
+    """16x16 tile origins of `bounds` = (x0, y0, x1, y1) owned by `rank` (tile t -> rank t % world). Host only."""
+    x0, y0, x1, y1 = bounds
+    n = ctypes.c_int32()
+    rc = lib().pbrt_hip_tile_partition(x0, y0, x1, y1, rank, world, None, 0, ctypes.byref(n))
+    if rc != 0:
+        raise PbrtHipError(f"pbrt_hip_tile_partition failed ({rc})")
+    out = np.zeros((n.value, 2), dtype=np.int32)
+    rc = lib().pbrt_hip_tile_partition(x0, y0, x1, y1, rank, world, _p(out), n.value, ctypes.byref(n))
+    if rc != 0:
+        raise PbrtHipError(f"pbrt_hip_tile_partition failed ({rc})")
+    return out
 
 
 def film_to_rgb(film):

@@ -1,0 +1,332 @@
+"""Known-answer tests that pin the CPU oracle (the reference has no tests on this path).
+
+Expected values come from independent evaluations: pure-Python integer arithmetic (PCG32), numpy
+float32 scalar arithmetic that restates the reference's formulas a second time (triangle, slab
+test), numpy.nextafter, closed forms (Fresnel at normal incidence, sampling identities). The [Q]
+defects are asserted in both the intended and the as-written form.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import QUIRKS
+from pbrt_hip import scenes
+
+f32 = np.float32
+L = oracle.lib()
+
+
+def _arr(*v):
+    return np.array(v, dtype=np.float32)
+
+
+# ---------------- PCG32 (src/core/rng.rs) ----------------
+def _pcg32_python(seq, n):
+    mask = (1 << 64) - 1
+    mult = 0x5851F42D4C957F2D
+    inc = ((seq << 1) | 1) & mask
+    state = 0
+
+    def step():
+        nonlocal state
+        old = state
+        state = (old * mult + inc) & mask
+        xs = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+        rot = old >> 59
+        return ((xs >> rot) | (xs << ((-rot) & 31))) & 0xFFFFFFFF
+
+    step()
+    state = (state + 0x853C49E6748FEA9B) & mask
+    step()
+    return [step() for _ in range(n)]
+
+
+@pytest.mark.parametrize("seq", [0, 1, 2 ** 32, 12345678901234])
+def test_pcg32_matches_integer_reference(seq):
+    u = np.zeros(16, dtype=np.uint32)
+    f = np.zeros(16, dtype=np.float32)
+    L.orc_pcg32(seq, 16, u.ctypes.data, f.ctypes.data)
+    expect = _pcg32_python(seq, 16)
+    assert u.tolist() == expect
+    assert np.array_equal(scenes.pcg32_u32(seq, 16), u)
+    exp_f = np.minimum(np.array(expect, dtype=np.uint32).astype(np.float32) * f32(2.3283064365386963e-10),
+                       f32(1) - f32(np.finfo(np.float32).eps))
+    assert np.array_equal(f, exp_f)
+    assert np.all(f < 1.0)
+
+
+def test_pcg32_default_stream_first_outputs():
+    # pcg32 reference generator, seq 0 after pbrt's SetSequence: fixed regression values
+    assert _pcg32_python(0, 3) == scenes.pcg32_u32(0, 3).tolist()
+
+
+# ---------------- float utilities (src/core/pbrt.rs:43-91) ----------------
+def test_next_float_and_gamma():
+    vals = [0.0, -0.0, 1.0, -1.0, 1e-45, -1e-45, 3.4028234e38, 123.456, -0.001, float("inf"), float("-inf")]
+    for v in vals:
+        v32 = f32(v)
+        up, dn = L.orc_next_float_up(v32), L.orc_next_float_down(v32)
+        if math.isinf(v) and v > 0:
+            assert up == v32
+        else:
+            assert f32(up) == np.nextafter(v32, f32(np.inf))
+        if math.isinf(v) and v < 0:
+            assert dn == v32
+        else:
+            assert f32(dn) == np.nextafter(v32, f32(-np.inf))
+    eps_m = f32(np.finfo(np.float32).eps) * f32(0.5)
+    for n in (1, 2, 3, 5, 6, 7):
+        assert f32(L.orc_gamma(f32(n))) == f32(n) * eps_m / (f32(1) - f32(n) * eps_m)
+
+
+def test_offset_ray_origin():
+    out = np.zeros(3, dtype=np.float32)
+    p, err, n = _arr(1, 2, 3), _arr(1e-6, 2e-6, 3e-6), _arr(0, 0, 1)
+    L.orc_offset_ray_origin(p.ctypes.data, err.ctypes.data, n.ctypes.data, _arr(0.3, 0.1, 0.9).ctypes.data,
+                            out.ctypes.data)
+    d = f32(3e-6)  # |n| . err
+    assert out[0] == 1 and out[1] == 2 and out[2] == np.nextafter(f32(3) + d, f32(np.inf))
+    L.orc_offset_ray_origin(p.ctypes.data, err.ctypes.data, n.ctypes.data, _arr(0.3, 0.1, -0.9).ctypes.data,
+                            out.ctypes.data)
+    assert out[2] == np.nextafter(f32(3) - d, f32(-np.inf))
+
+
+# ---------------- elementary functions ----------------
+def _ulp_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    ulp = np.spacing(np.abs(b).astype(np.float32)).astype(np.float64)
+    return np.abs(a - b) / np.maximum(ulp, 1e-45)
+
+
+def test_elementary_functions_accuracy():
+    n = 200_000
+    x = (scenes.pcg32_float(3, n) * f32(4 * math.pi) - f32(math.pi)).astype(np.float32)
+    out = np.zeros(n, dtype=np.float32)
+    for op, fn in ((0, np.sin), (1, np.cos)):
+        L.orc_elementary(op, x.ctypes.data, None, n, out.ctypes.data)
+        ref = fn(x.astype(np.float64))
+        big = np.abs(ref) > 1e-3
+        assert _ulp_err(out[big], ref[big]).max() <= 3.0
+        assert np.abs(out - ref).max() < 3e-7
+    c = (scenes.pcg32_float(4, n) * 2 - 1).astype(np.float32)
+    L.orc_elementary(2, c.ctypes.data, None, n, out.ctypes.data)
+    assert np.abs(out - np.arccos(c.astype(np.float64))).max() < 1e-6
+    y = (scenes.pcg32_float(5, n) * 2 - 1).astype(np.float32)
+    L.orc_elementary(3, y.ctypes.data, c.ctypes.data, n, out.ctypes.data)
+    assert np.abs(out - np.arctan2(y.astype(np.float64), c.astype(np.float64))).max() < 1e-6
+    # exact values at the points the env light uses to build its table
+    s = np.zeros(2, dtype=np.float32)
+    pts = _arr(math.pi * 0.25, math.pi * 0.75)
+    L.orc_elementary(0, pts.ctypes.data, None, 2, s.ctypes.data)
+    assert abs(s[0] - math.sqrt(0.5)) < 1e-7 and abs(s[1] - math.sqrt(0.5)) < 1e-7
+
+
+# ---------------- sampling (src/core/sampling.rs) ----------------
+def test_sampling_routines():
+    n = 100_000
+    u = scenes.pcg32_float(9, 2 * n).reshape(n, 2).copy()
+    d = np.zeros((n, 2), dtype=np.float32)
+    L.orc_sample(0, u.ctypes.data, n, 0, d.ctypes.data)
+    r2 = (d.astype(np.float64) ** 2).sum(1)
+    assert r2.max() <= 1.0 + 1e-6
+    assert abs(r2.mean() - 0.5) < 5e-3            # uniform on the disk: E[r^2] = 1/2
+    w = np.zeros((n, 3), dtype=np.float32)
+    L.orc_sample(1, u.ctypes.data, n, 0, w.ctypes.data)
+    assert np.abs((w.astype(np.float64) ** 2).sum(1) - 1).max() < 1e-6
+    assert abs(w[:, 2].mean() - 2.0 / 3.0) < 5e-3  # cosine-weighted: E[cos] = 2/3
+    # D39 [Q] as written: z = max(0, 1 - x^2 - y^2) without the square root
+    wq = np.zeros((n, 3), dtype=np.float32)
+    L.orc_sample(1, u.ctypes.data, n, QUIRKS["D39"], wq.ctypes.data)
+    assert np.array_equal(wq[:, :2], w[:, :2])
+    assert np.allclose(wq[:, 2], w[:, 2].astype(np.float64) ** 2, atol=2e-7)
+    b = np.zeros((n, 2), dtype=np.float32)
+    L.orc_sample(2, u.ctypes.data, n, 0, b.ctypes.data)
+    assert np.all(b >= 0) and np.all(b.sum(1) <= 1 + 1e-6)
+    assert np.abs(b.mean(0) - 1.0 / 3.0).max() < 5e-3
+    # the centre of the square maps to the centre of the disk
+    c = np.zeros(2, dtype=np.float32)
+    L.orc_sample(0, _arr(0.5, 0.5).ctypes.data, 1, 0, c.ctypes.data)
+    assert c[0] == 0 and c[1] == 0
+
+
+# ---------------- Fresnel / refraction (src/core/reflection.rs:19-40, 142-156) ----------------
+def test_fresnel_and_refract():
+    assert abs(L.orc_fr_dielectric(1.0, 1.0, 1.5) - 0.04) < 1e-7          # ((n-1)/(n+1))^2
+    assert abs(L.orc_fr_dielectric(-1.0, 1.0, 1.5) - 0.04) < 1e-7         # from inside
+    assert L.orc_fr_dielectric(-0.2, 1.0, 1.5) == 1.0                      # total internal reflection
+    assert L.orc_fr_dielectric(0.0, 1.0, 1.5) == 1.0                       # grazing
+    wt = np.zeros(3, dtype=np.float32)
+    wi = _arr(math.sin(0.5), 0.0, math.cos(0.5))
+    n = _arr(0, 0, 1)
+    assert L.orc_refract(wi.ctypes.data, n.ctypes.data, 1 / 1.5, 0, wt.ctypes.data) == 1
+    assert abs(math.sin(0.5) / 1.5 - abs(wt[0])) < 1e-6 and wt[2] < 0    # Snell
+    # leaving glass beyond the critical angle: intended = total internal reflection.
+    wi = _arr(math.sin(1.0), 0.0, math.cos(1.0))
+    assert L.orc_refract(wi.ctypes.data, n.ctypes.data, 1.5, 0, wt.ctypes.data) == 0
+    # D37 [Q] as written tests sin2_theta_i >= 1 instead, so it "refracts" with a NaN direction
+    assert L.orc_refract(wi.ctypes.data, n.ctypes.data, 1.5, QUIRKS["D37"], wt.ctypes.data) == 1
+    assert np.isnan(wt).any()
+
+
+def test_local_to_world_quirk_d36():
+    ss, ts, ns, v = _arr(1, 2, 3), _arr(4, 5, 6), _arr(7, 8, 9), _arr(0.5, 0.25, 2.0)
+    out = np.zeros(3, dtype=np.float32)
+    L.orc_local_to_world(ss.ctypes.data, ts.ctypes.data, ns.ctypes.data, v.ctypes.data, 0, out.ctypes.data)
+    assert out.tolist() == [1 * 0.5 + 4 * 0.25 + 7 * 2.0, 2 * 0.5 + 5 * 0.25 + 8 * 2.0, 3 * 0.5 + 6 * 0.25 + 9 * 2.0]
+    L.orc_local_to_world(ss.ctypes.data, ts.ctypes.data, ns.ctypes.data, v.ctypes.data, QUIRKS["D36"], out.ctypes.data)
+    assert out[1] == 2 * 0.5 + 5 * 0.25 * 8 * 2.0  # reflection.rs:260 as written: ts.y*v.y * ns.y*v.z
+
+
+# ---------------- slab test (src/core/geometry.rs:709-751) ----------------
+def _ray(o, d, t_max=np.inf):
+    return np.array(list(o) + list(d) + [t_max, 0.0], dtype=np.float32)
+
+
+def test_bounds_intersect_p():
+    box = _arr(-1, -1, -1, 1, 1, 1)
+    cases = [
+        (_ray((0, 0, -5), (0, 0, 1)), 1), (_ray((0, 0, -5), (0, 0, -1)), 0), (_ray((0, 0, -5), (0, 0, 1), 3.9), 0),
+        (_ray((0, 0, -5), (0, 0, 1), 4.1), 1), (_ray((0, 0, 0), (1, 1, 1)), 1), (_ray((3, 3, 3), (-1, -1, -1)), 1),
+        (_ray((3, 0, 0), (0, 1, 0)), 0), (_ray((1.0000001, 0, -5), (0, 0, 1)), 0), (_ray((-2, -2, -2), (1, 1, 1.01)), 1),
+    ]
+    for r, expect in cases:
+        assert L.orc_bounds_intersect_p(box.ctypes.data, r.ctypes.data, 0) == expect
+    # D2 [Q]: the z slab as written is scaled by 1 + 2 + gamma(3) ~ 3, which only makes the test
+    # more conservative: a ray that clears the far z plane by a hair still counts as a hit.
+    g = _ray((0, 0, 2.0), (1, 0, 1))       # starts beyond the box (z > 1), moves away: tz_max < 0 either way
+    assert L.orc_bounds_intersect_p(box.ctypes.data, g.ctypes.data, 0) == 0
+    h = _ray((-2.2, 0, -2.2), (1, 0, 2.4))  # x interval [0.5,1.33]; z interval [0.5, 1.333] as intended
+    assert L.orc_bounds_intersect_p(box.ctypes.data, h.ctypes.data, 0) == 1
+    k = _ray((-3.0, 0, -1.9), (1, 0, 2.9))  # x [2,4]; z [0.31,1.0]: miss; as written z max*3 = 3.0: hit
+    assert L.orc_bounds_intersect_p(box.ctypes.data, k.ctypes.data, 0) == 0
+    assert L.orc_bounds_intersect_p(box.ctypes.data, k.ctypes.data, QUIRKS["D2"]) == 1
+
+
+# ---------------- watertight triangle test (src/shapes/triangle.rs:74-158) ----------------
+def _tri_test_numpy(p0, p1, p2, o, d, t_max, shear_bug=False, precedence_bug=False, delta_e_bug=False):
+    """Second restatement in numpy float32 scalars (float64 only where the reference uses f64)."""
+    p0, p1, p2, o, d = (np.asarray(v, dtype=np.float32) for v in (p0, p1, p2, o, d))
+    t_max = f32(t_max)
+    p0t, p1t, p2t = p0 - o, p1 - o, p2 - o
+    a = np.abs(d)
+    kz = 0 if (a[0] > a[1] and a[0] > a[2]) else (1 if a[1] > a[2] else 2)
+    kx = (kz + 1) % 3
+    ky = (kx + 1) % 3
+    dp = d[[kx, ky, kz]]
+    p0t, p1t, p2t = p0t[[kx, ky, kz]].copy(), p1t[[kx, ky, kz]].copy(), p2t[[kx, ky, kz]].copy()
+    with np.errstate(all="ignore"):
+        sx, sy, sz = -dp[0] / dp[2], -dp[1] / dp[2], f32(1) / dp[2]
+        for p in (p0t, p1t, p2t):
+            p[0] = p[0] + sx * p[2]
+            p[1] = p[1] + sy * p[2]
+        if shear_bug:
+            p2t[1] = (p2 - o)[[kx, ky, kz]][1] + sx * p2t[2]
+        e0 = f32(np.float64(p1t[0]) * np.float64(p2t[1]) - np.float64(p1t[1]) * np.float64(p2t[0]))
+        e1 = f32(np.float64(p2t[0]) * np.float64(p0t[1]) - np.float64(p2t[1]) * np.float64(p0t[0]))
+        e2 = f32(np.float64(p0t[0]) * np.float64(p1t[1]) - np.float64(p0t[1]) * np.float64(p1t[0]))
+        if (e0 < 0 or e1 < 0 or e2 < 0) and (e0 > 0 or e1 > 0 or e2 > 0):
+            return None
+        det = e0 + e1 + e2
+        if det == 0:
+            return None
+        p0t[2], p1t[2], p2t[2] = p0t[2] * sz, p1t[2] * sz, p2t[2] * sz
+        ts = e0 * p0t[2] + e1 * p1t[2] + e2 * p2t[2]
+        if precedence_bug:
+            if (det < 0 and ts >= 0) or ts < t_max * det:
+                return None
+        elif det < 0 and (ts >= 0 or ts < t_max * det):
+            return None
+        if det > 0 and (ts <= 0 or ts > t_max * det):
+            return None
+        inv = f32(1) / det
+        b0, b1, b2, t = e0 * inv, e1 * inv, e2 * inv, ts * inv
+        g = lambda n: f32(n) * f32(2 ** -24) / (f32(1) - f32(n) * f32(2 ** -24))
+        mzt = max(abs(p0t[2]), abs(p1t[2]), abs(p2t[2]))
+        mxt = max(abs(p0t[0]), abs(p1t[0]), abs(p2t[0]))
+        myt = max(abs(p0t[1]), abs(p1t[1]), abs(p2t[1]))
+        dz = g(3) * mzt
+        dx = g(5) * (mxt + mzt)
+        dy = g(5) * (myt + mzt)
+        de = f32(2) * (g(2) * mxt * myt + dy * mxt + (dy if delta_e_bug else dx) * myt)
+        me = max(abs(e0), abs(e1), abs(e2))
+        dt = f32(3) * (g(3) * me * mzt + de * mzt + dz * me) * abs(inv)
+        if t <= dt:
+            return None
+    return (b0, b1, b2, t)
+
+
+TRI = ((0, 0, 0), (1, 0, 0), (0, 1, 0))
+TRI_CASES = [
+    ("centre", TRI, (0.25, 0.25, 1), (0, 0, -1), np.inf, True),
+    ("back face", TRI, (0.25, 0.25, -1), (0, 0, 1), np.inf, True),
+    ("edge p0-p1", TRI, (0.5, 0.0, 1), (0, 0, -1), np.inf, True),
+    ("vertex p0", TRI, (0.0, 0.0, 1), (0, 0, -1), np.inf, True),
+    ("vertex p2", TRI, (0.0, 1.0, 1), (0, 0, -1), np.inf, True),
+    ("outside", TRI, (0.75, 0.75, 1), (0, 0, -1), np.inf, False),
+    ("parallel", TRI, (0.25, 0.25, 1), (1, 0, 0), np.inf, False),
+    ("behind", TRI, (0.25, 0.25, 1), (0, 0, 1), np.inf, False),
+    ("t at t_max", TRI, (0.25, 0.25, 1), (0, 0, -1), 1.0, True),
+    ("t beyond t_max", TRI, (0.25, 0.25, 1), (0, 0, -1), 0.999, False),
+    ("oblique", TRI, (-1.0, -0.5, 2), (0.6, 0.4, -1), np.inf, True),
+    ("x-major", ((0, 0, 0), (0, 1, 0), (0, 0, 1)), (2, 0.2, 0.3), (-1, 0.01, 0.02), np.inf, True),
+    ("y-major", ((0, 0, 0), (1, 0, 0), (0, 0, 1)), (0.2, 3, 0.3), (0.01, -1, 0.02), np.inf, True),
+    ("unnormalised d", TRI, (0.25, 0.25, 1), (0, 0, -4), np.inf, True),
+    ("degenerate", ((0, 0, 0), (1, 1, 0), (2, 2, 0)), (0.5, 0.5, 1), (0, 0, -1), np.inf, False),
+    ("tiny far", ((100, 100, 100), (100.001, 100, 100), (100, 100.001, 100)), (100.0003, 100.0003, 101), (0, 0, -1),
+     np.inf, True),
+    ("grazing start on plane", TRI, (0.25, 0.25, 0), (0, 0, -1), np.inf, False),
+]
+
+
+@pytest.mark.parametrize("name,tri,o,d,t_max,expect_hit", TRI_CASES)
+def test_triangle_kat(name, tri, o, d, t_max, expect_hit):
+    out = np.zeros(5, dtype=np.float32)
+    p = [_arr(*v) for v in tri]
+    r = _ray(o, d, t_max)
+    L.orc_triangle_test(p[0].ctypes.data, p[1].ctypes.data, p[2].ctypes.data, r.ctypes.data, 0, out.ctypes.data)
+    ref = _tri_test_numpy(*tri, o, d, t_max)
+    assert (out[0] == 1.0) == expect_hit == (ref is not None), name
+    if ref is not None:
+        assert out[1:].tolist() == [float(v) for v in ref], name
+        assert abs(out[1] + out[2] + out[3] - 1) < 1e-6
+        hit_p = sum(f32(b) * np.asarray(v, dtype=np.float32) for b, v in zip(out[1:4], tri))
+        assert np.allclose(hit_p, np.asarray(o, dtype=np.float32) + out[4] * np.asarray(d, dtype=np.float32), atol=2e-4)
+
+
+def test_triangle_quirks_as_written():
+    p = [_arr(*v) for v in TRI]
+    out, outq = np.zeros(5, dtype=np.float32), np.zeros(5, dtype=np.float32)
+    # D10: as written `(det<0 && ts>=0) || ts < t_max*det` rejects every det > 0 hit with a finite positive t
+    r = _ray((0.25, 0.25, -1), (0, 0, 1), 5.0)   # back face: det > 0 here
+    L.orc_triangle_test(p[0].ctypes.data, p[1].ctypes.data, p[2].ctypes.data, r.ctypes.data, 0, out.ctypes.data)
+    L.orc_triangle_test(p[0].ctypes.data, p[1].ctypes.data, p[2].ctypes.data, r.ctypes.data, QUIRKS["D10"], outq.ctypes.data)
+    ref, refq = _tri_test_numpy(*TRI, (0.25, 0.25, -1), (0, 0, 1), 5.0), _tri_test_numpy(*TRI, (0.25, 0.25, -1), (0, 0, 1), 5.0, precedence_bug=True)
+    assert out[0] == 1 and ref is not None
+    assert outq[0] == 0 and refq is None
+    # D9: the y-shear of vertex 2 uses sx: a hit near p2 under an oblique ray moves / disappears
+    o, d = (-1.0, -0.5, 2), (0.6, 0.4, -1)
+    r = _ray(o, d)
+    L.orc_triangle_test(p[0].ctypes.data, p[1].ctypes.data, p[2].ctypes.data, r.ctypes.data, 0, out.ctypes.data)
+    L.orc_triangle_test(p[0].ctypes.data, p[1].ctypes.data, p[2].ctypes.data, r.ctypes.data, QUIRKS["D9"], outq.ctypes.data)
+    refq = _tri_test_numpy(*TRI, o, d, np.inf, shear_bug=True)
+    assert out[0] == 1
+    assert (outq[0] == 1) == (refq is not None)
+    if refq is not None:
+        assert outq[1:].tolist() == [float(v) for v in refq] and outq[1:].tolist() != out[1:].tolist()
+    # D11: delta_e as written only changes the error bound, not the hit, on a well-conditioned case
+    L.orc_triangle_test(p[0].ctypes.data, p[1].ctypes.data, p[2].ctypes.data, r.ctypes.data, QUIRKS["D11"], outq.ctypes.data)
+    assert outq.tolist() == out.tolist()
+
+
+def test_degenerate_uv_quirk_d13_changes_shading_frame_only():
+    """D13 [Q]: `determinant < 1e-8` treats every negative-determinant uv frame as degenerate; with
+    the default uvs the determinant is +1, so both variants give the same hits."""
+    sc = scenes.cornell_box()
+    a, b = oracle.OracleScene(sc), oracle.OracleScene(sc, quirks=QUIRKS["D13"])
+    rays = scenes.random_rays(2000, 4, origin_extent=500.0)
+    rays["o"] = np.abs(rays["o"])
+    ha, _ = a.intersect(rays, n_threads=2)
+    hb, _ = b.intersect(rays, n_threads=2)
+    assert ha.tobytes() == hb.tobytes()

@@ -1,0 +1,100 @@
+"""Analytic and structural checks of the oracle's integrators (pin by physics, not by the reference)."""
+import numpy as np
+
+import oracle
+from pbrt_hip import scenes
+
+
+def _cam(sc_cam):
+    return scenes.camera_dict_to_floats(sc_cam)
+
+
+def test_white_furnace_one_bounce():
+    """A Lambertian plane (rho) under a uniform environment Le reflects exactly rho * Le."""
+    w = h = 24
+    for rho, Le in ((0.5, 1.0), (0.8, 2.0)):
+        osc = oracle.OracleScene(scenes.furnace_scene(rho=rho, Le=Le))
+        cam = scenes.perspective_camera((0, 5, 0), (0, 0, 0.001), (0, 0, 1), 30.0, w, h)
+        film, st = osc.render(_cam(cam), w, h, 256, max_depth=1, seed=1)
+        rgb = oracle.film_to_rgb(film)
+        assert abs(rgb.mean() - rho * Le) < 0.01 * Le
+        assert st["camera_samples"] == w * h * 256
+        osc.close()
+
+
+def test_area_light_irradiance_matches_closed_form():
+    """A small diffuse emitter straight above a Lambertian floor point: L = rho/pi * Le * A * cos^2 / d^2."""
+    s = 0.05
+    floor = np.array([[-50, 0, -50], [-50, 0, 50], [50, 0, 50], [50, 0, -50]], dtype=np.float32)
+    lamp = np.array([[-s, 2, -s], [s, 2, -s], [s, 2, s], [-s, 2, s]], dtype=np.float32)  # normal points down
+    sc = dict(
+        positions=np.concatenate([floor, lamp]),
+        indices=np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7]], dtype=np.int32),
+        tri_material=np.zeros(4, dtype=np.int32),
+        materials=scenes._materials([(scenes.MAT_MATTE, (0.6, 0.6, 0.6), (0, 0, 0), 1.0)]),
+        tri_light=np.array([-1, -1, 0, 1], dtype=np.int32),
+        lights=scenes._lights([(scenes.LIGHT_DIFFUSE_AREA, (100.0, 100.0, 100.0), 2, 0, 1),
+                               (scenes.LIGHT_DIFFUSE_AREA, (100.0, 100.0, 100.0), 3, 0, 1)]))
+    osc = oracle.OracleScene(sc)
+    w = h = 8
+    # a narrow camera looking at the floor point under the lamp, from the side so the lamp is not in view
+    cam = scenes.perspective_camera((3, 1.0, 0), (0, 0, 0), (0, 1, 0), 0.5, w, h)
+    expect = 0.6 / np.pi * 100.0 * (2 * s) ** 2 / 4.0
+    for integrator, kw in ((0, dict(max_depth=1, light_strategy=1)), (1, dict(max_depth=1, light_strategy=0))):
+        film, _ = osc.render(_cam(cam), w, h, 512, integrator=integrator, seed=3, **kw)
+        rgb = oracle.film_to_rgb(film)
+        assert abs(rgb.mean() - expect) / expect < 0.03, (integrator, rgb.mean(), expect)
+    osc.close()
+
+
+def test_partition_independence_and_determinism():
+    """Per-(pixel,sample) streams: crops, thread counts and tile splits do not change any pixel."""
+    w, h = 48, 40
+    osc = oracle.OracleScene(scenes.cornell_box())
+    cam = _cam(scenes.cornell_camera(w, h))
+    full, _ = osc.render(cam, w, h, 3, max_depth=8, seed=11, n_threads=8)
+    again, _ = osc.render(cam, w, h, 3, max_depth=8, seed=11, n_threads=1)
+    assert full.tobytes() == again.tobytes()
+    crop, _ = osc.render(cam, w, h, 3, max_depth=8, seed=11, bounds=(7, 5, 33, 29))
+    assert np.array_equal(crop[5:29, 7:33], full[5:29, 7:33])
+    assert np.all(crop[:5] == 0) and np.all(crop[:, :7] == 0)
+    other, _ = osc.render(cam, w, h, 3, max_depth=8, seed=12)
+    assert other.tobytes() != full.tobytes()
+    osc.close()
+
+
+def test_direct_lighting_adds_emission_and_specular_recursion():
+    """D28 disposition: DirectLighting includes Le of directly visible emitters; mirrors recurse."""
+    w = h = 32
+    sc = scenes.cornell_box()
+    osc = oracle.OracleScene(sc)
+    cam = _cam(scenes.cornell_camera(w, h))
+    film, _ = osc.render(cam, w, h, 4, integrator=1, max_depth=5, light_strategy=0, seed=2)
+    rgb = oracle.film_to_rgb(film)
+    assert rgb.max() > 10.0           # the ceiling light itself (Le = 17, 12, 4) is visible
+    path, _ = osc.render(cam, w, h, 4, integrator=0, max_depth=1, light_strategy=1, seed=2)
+    # one-bounce path tracing and direct lighting estimate the same integral
+    assert abs(oracle.film_to_rgb(path).mean() - rgb.mean()) / rgb.mean() < 0.1
+    osc.close()
+    sc2 = dict(sc, materials=sc["materials"].copy())
+    sc2["materials"]["type"][0] = scenes.MAT_MIRROR      # white walls / boxes become mirrors
+    osc2 = oracle.OracleScene(sc2)
+    d1, _ = osc2.render(cam, w, h, 4, integrator=1, max_depth=1, light_strategy=0, seed=2)
+    d5, _ = osc2.render(cam, w, h, 4, integrator=1, max_depth=5, light_strategy=0, seed=2)
+    lit1 = (oracle.film_to_rgb(d1).sum(-1) > 0).mean()
+    lit5 = (oracle.film_to_rgb(d5).sum(-1) > 0).mean()
+    assert lit5 > lit1 + 0.3            # mirror pixels are black without the specular recursion
+    assert oracle.film_to_rgb(d5).mean() > oracle.film_to_rgb(d1).mean() * 1.1
+    osc2.close()
+
+
+def test_quirk_d2_leaves_hits_unchanged_but_visits_more_nodes():
+    sc = scenes.random_triangles(5000, seq=9, size=0.06)
+    a, b = oracle.OracleScene(sc), oracle.OracleScene(sc, quirks=oracle.QUIRKS["D2"])
+    rays = scenes.random_rays(20_000, 10, origin_extent=1.5)
+    ha, ca = a.intersect(rays)
+    hb, cb = b.intersect(rays)
+    assert ha.tobytes() == hb.tobytes()
+    assert cb["node_tests"] > ca["node_tests"]
+    a.close()
+    b.close()
