@@ -312,6 +312,8 @@ extern "C" int pbrt_hip_scene_create(PbrtHipContext* ctx, const float* positions
         power_y[i] = l.power_y;
     }
     s->h_lights = dl;
+    s->light_samples.resize(n_lights);
+    for (int32_t i = 0; i < n_lights; ++i) s->light_samples[i] = std::max(1, lights[i].n_samples);
     std::vector<DevMaterial> dm(n_materials);
     for (int32_t i = 0; i < n_materials; ++i) {
         dm[i].type = materials[i].type;
@@ -658,8 +660,10 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     if (rp.width <= 0 || rp.height <= 0 || rp.spp <= 0) return invalid("width, height and spp must be positive");
     if (rp.x0 < 0 || rp.y0 < 0 || rp.x1 > rp.width || rp.y1 > rp.height || rp.x0 > rp.x1 || rp.y0 > rp.y1)
         return invalid("pixel bounds outside the film");
-    if (rp.integrator != PBRT_INTEGRATOR_PATH)
-        return invalid("only the path integrator runs on the device in this build (direct lighting: oracle only)");
+    if (rp.integrator != PBRT_INTEGRATOR_PATH && rp.integrator != PBRT_INTEGRATOR_DIRECT)
+        return invalid("integrator must be PBRT_INTEGRATOR_PATH or PBRT_INTEGRATOR_DIRECT");
+    const bool direct = rp.integrator == PBRT_INTEGRATOR_DIRECT;
+    if (direct && rp.max_depth > 64) return invalid("direct lighting: max_depth > 64 (frame stack)");
     if (rp.max_depth < 0 || rp.max_depth > 1 << 20) return invalid("bad max_depth");
     int world = rp.tile_world <= 0 ? 1 : rp.tile_world;
     int rank = rp.tile_rank;
@@ -715,11 +719,23 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         q[k].shade = buf.alloc<uint32_t>(N, &ok);
         q[k].counts64 = buf.alloc<unsigned long long>(2, &ok);
     }
+    DirectState ds{};
+    std::vector<int> prefix(s->d.n_lights + 1, 0);
+    for (int i = 0; i < s->d.n_lights; ++i) prefix[i + 1] = prefix[i] + s->light_samples[i];
+    int* d_prefix = buf.alloc<int>(prefix.size(), &ok);
+    if (direct) {
+        ds.stage = buf.alloc<int>(N, &ok);
+        ds.ld_acc = buf.alloc<float4>(N, &ok);
+        ds.frames = buf.alloc<float4>(N * (size_t)std::max(1, rp.max_depth) * 3, &ok);
+        ds.light_strategy = rp.light_strategy;
+        if (prefix.back() >= 0xfff0) return invalid("too many light samples per vertex");
+    }
     float4* accum = buf.alloc<float4>(n_pix, &ok);
     int2* d_origins = buf.alloc<int2>(origins.size(), &ok);
     if (!ok) return PBRT_HIP_ERR_OOM;
     HIP_TRY(ctx, hipMemcpyAsync(d_origins, origins.data(), origins.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(accum, 0, (size_t)n_pix * sizeof(float4), st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_prefix, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice, st));
     TileList tiles{d_origins, (int)origins.size()};
 
     DevCamera cam;
@@ -746,6 +762,8 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     std::memcpy(sc.env_marg_cdf, s->d.env_marg_cdf, sizeof(sc.env_marg_cdf));
     sc.env_marg_int = s->d.env_marg_int;
     sc.world_radius = s->d.world_radius;
+    sc.light_sample_prefix = d_prefix;
+    sc.total_light_samples = prefix.back();
 
     hipEvent_t e_begin, e_end, e_t0, e_t1;
     HIP_TRY(ctx, hipEventCreate(&e_begin));
@@ -783,6 +801,10 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         int cur = 0;
         hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, st, ps, q[cur], pp, cam, tiles);
         RENDER_TRY(hipGetLastError());
+        if (direct) {
+            RENDER_TRY(hipMemsetAsync(ds.stage, 0, (size_t)n_paths * sizeof(int), st));
+            RENDER_TRY(hipMemsetAsync(ds.ld_acc, 0, (size_t)n_paths * sizeof(float4), st));
+        }
         // the first wavefront is the identity: every path traces its camera ray and is shaded
         unsigned long long counts[2] = {n_paths, n_paths};
         local.camera_samples += (uint64_t)valid_pixels * pp.n_samples;
@@ -806,8 +828,12 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             }
             int nxt = cur ^ 1;
             RENDER_TRY(hipMemsetAsync(q[nxt].counts64, 0, 2 * sizeof(unsigned long long), st));
-            hipLaunchKernelGGL(k_shade, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, q[cur], q[nxt], pp, tiles,
-                               n_shade);
+            if (direct)
+                hipLaunchKernelGGL(k_shade_direct, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, ds, q[cur],
+                                   q[nxt], pp, tiles, n_shade);
+            else
+                hipLaunchKernelGGL(k_shade, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, q[cur], q[nxt], pp,
+                                   tiles, n_shade);
             RENDER_TRY(hipGetLastError());
             RENDER_TRY(hipMemcpyAsync(counts, q[nxt].counts64, sizeof(counts), hipMemcpyDeviceToHost, st));
             RENDER_TRY(hipStreamSynchronize(st));

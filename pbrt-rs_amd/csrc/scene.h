@@ -81,6 +81,7 @@ struct PbrtHipScene {
     int n_tris = 0, n_nodes = 0, n_interior = 0;
     int spill_lanes = 0;
     std::vector<pb::DevLight> h_lights;
+    std::vector<int> light_samples;  // max(1, n_samples) per light (light.rs:76)
 };
 
 namespace pb {

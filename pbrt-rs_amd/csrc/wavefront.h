@@ -426,7 +426,265 @@ struct ShadeConsts {
     float env_cond_func[2][2], env_cond_cdf[2][3], env_cond_int[2];
     float env_marg_func[2], env_marg_cdf[3], env_marg_int;
     float world_radius;
+    // DirectLightingIntegrator (directlighting.rs:58-78): per-light sample counts, prefix sums
+    const int* light_sample_prefix;  // [n_lights + 1]
+    int total_light_samples;
 };
+
+PB_DEV Rng path_rng(const PathState& ps, const PassParams& pp, const TileList& tiles, uint32_t p) {
+    // this path's stream: inc from the (pixel, sample) index, state from memory
+    int s_local = p / pp.n_pix, pix = p % pp.n_pix;
+    int2 org = tiles.origin[pix >> 8];
+    int x = org.x + (pix & 15), y = org.y + ((pix & 255) >> 4);
+    Rng rng;
+    rng.inc = (sample_sequence(pp, x, y, pp.sample0 + s_local) << 1) | 1;
+    rng.state = ps.rng[p];
+    return rng;
+}
+
+PB_DEV Frame make_frame(const Surf& sf) {  // BSDF::new (reflection.rs:220-234)
+    Frame fr;
+    fr.ns = sf.n;
+    fr.ng = sf.n;
+    fr.ss = normalize(sf.dpdu);
+    fr.ts = cross(fr.ns, fr.ss);
+    return fr;
+}
+
+// SurfaceInteraction::le (interaction.rs:387-395) -> DiffuseAreaLight::l (diffuse.rs:150-156)
+PB_DEV V3 surface_le(const ShadeConsts& sc, const Surf& sf, V3 w) {
+    if (sf.light >= 0) {
+        DevLight lt = sc.lights[sf.light];
+        if (lt.two_sided || dot(sf.n, w) > 0.0f) return V3{lt.L[0], lt.L[1], lt.L[2]};
+    }
+    return V3{0.0f, 0.0f, 0.0f};
+}
+
+// estimate_direct (integrator.rs:136-266), first part: sample the light, evaluate the BSDF, sample the
+// BSDF, evaluate the light pdf. Writes the shadow ray (slot 2), the MIS ray (slot 1) and the pending
+// terms into the path state; returns PF_NEE_* flags for the rays that must be traced. `matte` = the
+// BSDF has a non-specular (Lambertian) lobe with reflectance kd; otherwise f == 0 and nothing is emitted.
+PB_DEV int estimate_direct_emit(const ShadeConsts& sc, const PathState& ps, uint32_t p, const Surf& sf, const Frame& fr,
+                                bool matte, V3 kd, int light_num, float ul0, float ul1, float us0, float us1,
+                                float pick_pdf, V3 beta) {
+    if (!matte) return 0;
+    V3 wo = sf.wo;
+    DevLight lt = sc.lights[light_num];
+    V3 Lc = V3{lt.L[0], lt.L[1], lt.L[2]};
+    // -- Light::sample_li --
+    V3 wi = V3{0.0f, 0.0f, 0.0f};
+    float light_pdf = 0.0f;
+    V3 li = V3{0.0f, 0.0f, 0.0f};
+    V3 p1 = V3{0.0f, 0.0f, 0.0f}, p1_err = V3{0.0f, 0.0f, 0.0f}, p1_n = V3{0.0f, 0.0f, 0.0f};
+    if (lt.type == PBRT_LIGHT_DIFFUSE_AREA) {
+        // Triangle::sample (triangle.rs:330-348) + Shape::sample2 (shape.rs:38-53)
+        V3 q0, q1, q2;
+        int fl;
+        load_tri(sc.bvh.tris, lt.slot, &q0, &q1, &q2, &fl);
+        float su0 = __builtin_sqrtf(ul0);
+        float bx = 1.0f - su0, by = ul1 * su0;
+        float bz = 1.0f - bx - by;
+        p1 = q0 * bx + q1 * by + q2 * bz;
+        p1_n = normalize(cross(q1 - q0, q2 - q0));
+        p1_err = (vabs(q0 * bx) + vabs(q1 * by) + vabs(q2 * bz)) * kGamma6;
+        float pdf = 1.0f / lt.area;
+        V3 w = p1 - sf.p;
+        if (len2(w) == 0.0f) {
+            pdf = 0.0f;
+        } else {
+            w = normalize(w);
+            V3 dd = sf.p - p1;
+            pdf *= len2(dd) / absdot(p1_n, -w);
+            if (__builtin_isinf(pdf)) pdf = 0.0f;
+        }
+        // DiffuseAreaLight::sample_li (diffuse.rs:60-81)
+        if (pdf == 0.0f || len2(p1 - sf.p) == 0.0f) {
+            light_pdf = 0.0f;
+        } else {
+            light_pdf = pdf;
+            wi = normalize(p1 - sf.p);
+            if (lt.two_sided || dot(p1_n, -wi) > 0.0f) li = Lc;
+        }
+    } else {
+        // InfiniteAreaLight::sample_li (infinite.rs:96-129)
+        float pdf1, pdf0;
+        int v;
+        float d1 = sample_continuous2(sc.env_marg_func, sc.env_marg_cdf, sc.env_marg_int, ul1, &pdf1, &v);
+        int dummy;
+        float d0 = sample_continuous2(sc.env_cond_func[v], sc.env_cond_cdf[v], sc.env_cond_int[v], ul0, &pdf0, &dummy);
+        float map_pdf = pdf0 * pdf1;
+        if (map_pdf != 0.0f) {
+            float theta = d1 * kPi, phi = d0 * 2.0f * kPi;
+            float st, ct, sp, cp;
+            det_sincos(theta, &st, &ct);
+            det_sincos(phi, &sp, &cp);
+            wi = V3{st * cp, st * sp, ct};
+            light_pdf = map_pdf / (2.0f * kPi * kPi * st);
+            if (st == 0.0f) light_pdf = 0.0f;
+            p1 = sf.p + wi * (2.0f * sc.world_radius);
+            li = Lc;
+        }
+    }
+    int nee_flags = 0;
+    V3 A = V3{0.0f, 0.0f, 0.0f};
+    if (light_pdf > 0.0f && !is_black(li)) {
+        V3 f;
+        float scattering_pdf;
+        matte_f_pdf(fr, kd, wo, wi, &f, &scattering_pdf);
+        f = f * absdot(wi, fr.ns);
+        if (!is_black(f)) {
+            // VisibilityTester::un_occluded -> spawn_ray_to (interaction.rs:147-153)
+            V3 origin = offset_ray_origin(sf.p, sf.p_error, sf.n, p1 - sf.p);
+            V3 target = offset_ray_origin(p1, p1_err, p1_n, origin - p1);
+            V3 d = target - origin;
+            store_ray(ps, p, RS_SHADOW, origin, d, 1.0f - kShadowEpsilon);
+            float weight = power_heuristic1(light_pdf, scattering_pdf);
+            A = mulv(li, f) * weight / light_pdf;
+            nee_flags |= PF_NEE_SHADOW;
+        }
+    }
+    // -- BSDF sampling half (both light types are non-delta) --
+    V3 wi2;
+    float spdf = 0.0f;
+    bool ok;
+    // scattering_pdf keeps the light-half value if wo.z == 0 (then it is 0 as well)
+    V3 f2 = matte_sample_f(fr, kd, wo, us0, us1, &wi2, &spdf, &ok);
+    if (ok) f2 = f2 * absdot(wi2, fr.ns);
+    if (ok && !is_black(f2) && spdf > 0.0f) {
+        float lpdf;
+        if (lt.type == PBRT_LIGHT_DIFFUSE_AREA) {
+            // Shape::pdf2 (shape.rs:54-69)
+            V3 o2 = offset_ray_origin(sf.p, sf.p_error, sf.n, wi2);
+            V3 ph, nh;
+            if (!light_triangle_intersect(sc.bvh, lt.slot, o2, wi2, &ph, &nh)) {
+                lpdf = 0.0f;
+            } else {
+                lpdf = len2(sf.p - ph) / (absdot(nh, -wi2) * lt.area);
+                if (__builtin_isinf(lpdf)) lpdf = 0.0f;
+            }
+        } else {
+            // InfiniteAreaLight::pdf_li (infinite.rs:140-151)
+            float theta = det_acos(clampf(wi2.z, -1.0f, 1.0f));
+            float ph = det_atan2(wi2.y, wi2.x);
+            if (ph < 0.0f) ph = ph + 2.0f * kPi;
+            float st = det_sin(theta);
+            if (st == 0.0f) {
+                lpdf = 0.0f;
+            } else {
+                int iu = (int)(ph * kInv2Pi * 2.0f);
+                iu = iu < 0 ? 0 : (iu > 1 ? 1 : iu);
+                int iv = (int)(theta * kInvPi * 2.0f);
+                iv = iv < 0 ? 0 : (iv > 1 ? 1 : iv);
+                lpdf = sc.env_cond_func[iv][iu] / sc.env_marg_int / (2.0f * kPi * kPi * st);
+            }
+        }
+        if (lpdf != 0.0f) {
+            float weight = power_heuristic1(spdf, lpdf);
+            V3 o2 = offset_ray_origin(sf.p, sf.p_error, sf.n, wi2);
+            store_ray(ps, p, RS_MIS, o2, wi2, kInf);
+            ps.nee_f[p] = make_float4(f2.x, f2.y, f2.z, weight);
+            nee_flags |= PF_NEE_MIS;
+        }
+    }
+    if (nee_flags) {
+        ps.nee_a[p] = make_float4(A.x, A.y, A.z, pick_pdf);
+        ps.nee_b[p] = make_float4(beta.x, beta.y, beta.z, spdf);
+        ps.nee_light[p] = light_num;
+    }
+    return nee_flags;
+}
+
+// estimate_direct, second part: combine the traced shadow / MIS results into Ld (before the division
+// by the light-pick pdf). Also returns the pick pdf and the throughput stored with the estimate.
+PB_DEV V3 estimate_direct_resolve(const ShadeConsts& sc, const PathState& ps, uint32_t p, int flags, float* pick_pdf,
+                                  V3* beta_at_vertex) {
+    size_t rbase = (size_t)p * 3 * 2;
+    float4 na = ps.nee_a[p], nf = ps.nee_f[p], nb = ps.nee_b[p];
+    int light_id = ps.nee_light[p];
+    V3 ld = V3{0.0f, 0.0f, 0.0f};
+    if (flags & PF_NEE_SHADOW) {
+        bool occluded = ps.hit[rbase + RS_SHADOW * 2].x != 0.0f;
+        if (!occluded) ld = ld + V3{na.x, na.y, na.z};
+    }
+    if (flags & PF_NEE_MIS) {
+        int hslot = __float_as_int(ps.hit[rbase + RS_MIS * 2 + 1].x);
+        float4 r0 = ps.ray[rbase + RS_MIS * 2], r1 = ps.ray[rbase + RS_MIS * 2 + 1];
+        V3 wi = V3{r0.w, r1.x, r1.y};
+        DevLight lt = sc.lights[light_id];
+        V3 li = V3{0.0f, 0.0f, 0.0f};
+        if (hslot >= 0) {
+            // D26 (intended): Le only when the hit primitive's area light is this light
+            int hl = (__float_as_int(sc.bvh.tris[3 * (size_t)hslot + 2].w) & 0x3fffffff) - 1;
+            if (hl == light_id) {
+                V3 n = tri_geometric_normal(sc.bvh, hslot);
+                if (lt.two_sided || dot(n, -wi) > 0.0f) li = V3{lt.L[0], lt.L[1], lt.L[2]};
+            }
+        } else if (lt.type == PBRT_LIGHT_INFINITE) {
+            li = V3{lt.L[0], lt.L[1], lt.L[2]};
+        }
+        if (!is_black(li)) {
+            V3 f = V3{nf.x, nf.y, nf.z};
+            ld = ld + mulv(li, f) * nf.w / nb.w;
+        }
+    }
+    *pick_pdf = na.w;
+    *beta_at_vertex = V3{nb.x, nb.y, nb.z};
+    return ld;
+}
+
+// Perfect-specular lobes (reflection.rs:614-819). `which`: 0 = FresnelSpecular (glass with
+// allow_multiple_lobes) or the mirror's SpecularReflection(FresnelNoOp); 1 = SpecularReflection lobe only
+// (mirror: FresnelNoOp; glass: FresnelDielectric(1, eta)); 2 = SpecularTransmission lobe only (glass).
+// Returns f (local), sets wi (local), pdf, transmission flag. pdf = 0 when nothing was sampled.
+PB_DEV V3 sample_specular_local(const DevMaterial& mat, V3 kd, V3 kt, V3 wol, float ur, int which, V3* wil, float* pdf,
+                                bool* transmission) {
+    *pdf = 0.0f;
+    *transmission = false;
+    V3 zero = V3{0.0f, 0.0f, 0.0f};
+    if (mat.type == PBRT_MAT_MIRROR) {
+        if (which == 2 || is_black(kd)) return zero;
+        *wil = V3{-wol.x, -wol.y, wol.z};
+        *pdf = 1.0f;
+        return mulv(kd, V3{1.0f, 1.0f, 1.0f}) / __builtin_fabsf(wil->z);
+    }
+    if (mat.type != PBRT_MAT_GLASS) return zero;
+    if (which == 0) {
+        // FresnelSpecular (reflection.rs:733-819), TransportMode::Radiance
+        float F = fr_dielectric(wol.z, 1.0f, mat.eta);
+        if (ur < F) {
+            *wil = V3{-wol.x, -wol.y, wol.z};
+            *pdf = F;
+            return kd * F / __builtin_fabsf(wil->z);
+        }
+        bool entering = wol.z > 0.0f;
+        float eta_i = entering ? 1.0f : mat.eta, eta_t = entering ? mat.eta : 1.0f;
+        if (!refract(wol, faceforward(V3{0.0f, 0.0f, 1.0f}, wol), eta_i / eta_t, wil)) return zero;
+        V3 ft = kt * (1.0f - F);
+        ft = ft * ((eta_i * eta_i) / (eta_t * eta_t));
+        *pdf = 1.0f - F;
+        *transmission = true;
+        return ft / __builtin_fabsf(wil->z);
+    }
+    if (which == 1) {
+        // SpecularReflection with FresnelDielectric(1, eta) (reflection.rs:590-659)
+        if (is_black(kd)) return zero;
+        *wil = V3{-wol.x, -wol.y, wol.z};
+        *pdf = 1.0f;
+        float F = fr_dielectric(wil->z, 1.0f, mat.eta);
+        return mulv(kd, V3{F, F, F}) / __builtin_fabsf(wil->z);
+    }
+    // SpecularTransmission (reflection.rs:661-731)
+    if (is_black(kt)) return zero;
+    bool entering = wol.z > 0.0f;
+    float eta_i = entering ? 1.0f : mat.eta, eta_t = entering ? mat.eta : 1.0f;
+    if (!refract(wol, faceforward(V3{0.0f, 0.0f, 1.0f}, wol), eta_i / eta_t, wil)) return zero;
+    *pdf = 1.0f;
+    *transmission = true;
+    float F = fr_dielectric(wil->z, 1.0f, mat.eta);
+    V3 ft = mulv(kt, V3{1.0f - F, 1.0f - F, 1.0f - F});
+    ft = ft * ((eta_i * eta_i) / (eta_t * eta_t));
+    return ft / __builtin_fabsf(wil->z);
+}
 
 __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Queues qin, Queues qout, PassParams pp,
                                                  TileList tiles, uint32_t n_in) {
@@ -446,38 +704,11 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
 
         // ---- (1) resolve the pending direct-lighting estimate (integrator.rs:136-266) ----
         if (flags & (PF_NEE_SHADOW | PF_NEE_MIS)) {
-            float4 na = ps.nee_a[p], nf = ps.nee_f[p], nb = ps.nee_b[p];
-            int light_id = ps.nee_light[p];
-            V3 ld = V3{0.0f, 0.0f, 0.0f};
-            if (flags & PF_NEE_SHADOW) {
-                bool occluded = ps.hit[rbase + RS_SHADOW * 2].x != 0.0f;
-                if (!occluded) ld = ld + V3{na.x, na.y, na.z};
-            }
-            if (flags & PF_NEE_MIS) {
-                float4 h0 = ps.hit[rbase + RS_MIS * 2];
-                int hslot = __float_as_int(ps.hit[rbase + RS_MIS * 2 + 1].x);
-                float4 r0 = ps.ray[rbase + RS_MIS * 2], r1 = ps.ray[rbase + RS_MIS * 2 + 1];
-                V3 wi = V3{r0.w, r1.x, r1.y};
-                (void)h0;
-                DevLight lt = sc.lights[light_id];
-                V3 li = V3{0.0f, 0.0f, 0.0f};
-                if (hslot >= 0) {
-                    // D26 (intended): Le only when the hit primitive's area light is this light
-                    int hl = (__float_as_int(sc.bvh.tris[3 * (size_t)hslot + 2].w) & 0x3fffffff) - 1;
-                    if (hl == light_id) {
-                        V3 n = tri_geometric_normal(sc.bvh, hslot);
-                        if (lt.two_sided || dot(n, -wi) > 0.0f) li = V3{lt.L[0], lt.L[1], lt.L[2]};
-                    }
-                } else if (lt.type == PBRT_LIGHT_INFINITE) {
-                    li = V3{lt.L[0], lt.L[1], lt.L[2]};
-                }
-                if (!is_black(li)) {
-                    V3 f = V3{nf.x, nf.y, nf.z};
-                    ld = ld + mulv(li, f) * nf.w / nb.w;
-                }
-            }
-            ld = ld / na.w;
-            L = L + mulv(V3{nb.x, nb.y, nb.z}, ld);
+            float pick_pdf;
+            V3 beta_v;
+            V3 ld = estimate_direct_resolve(sc, ps, p, flags, &pick_pdf, &beta_v);
+            ld = ld / pick_pdf;                 // integrator.rs:133
+            L = L + mulv(beta_v, ld);           // path.rs:113-120
             flags &= ~(PF_NEE_SHADOW | PF_NEE_MIS);
         }
 
@@ -494,14 +725,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
             // path.rs:80-88
             if (bounces == 0 || (flags & PF_SPECULAR_BOUNCE)) {
                 if (found) {
-                    if (sf.light >= 0) {
-                        DevLight lt = sc.lights[sf.light];
-                        // DiffuseAreaLight::l (diffuse.rs:150-156) with w = -ray.d
-                        if (lt.two_sided || dot(sf.n, -rd) > 0.0f) L = L + mulv(beta, V3{lt.L[0], lt.L[1], lt.L[2]});
-                        else L = L + mulv(beta, V3{0.0f, 0.0f, 0.0f});
-                    } else {
-                        L = L + mulv(beta, V3{0.0f, 0.0f, 0.0f});
-                    }
+                    L = L + mulv(beta, surface_le(sc, sf, -rd));
                 } else {
                     for (int k = 0; k < sc.n_infinite; ++k) {
                         DevLight lt = sc.lights[sc.infinite_ids[k]];
@@ -511,15 +735,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
             }
             if (found && bounces < pp.max_depth) {  // path.rs:90
                 DevMaterial mat = sc.materials[sf.material];
-                Rng rng;
-                {
-                    // recover this path's stream: inc from the (pixel, sample) index, state from memory
-                    int s_local = p / pp.n_pix, pix = p % pp.n_pix;
-                    int2 org = tiles.origin[pix >> 8];
-                    int x = org.x + (pix & 15), y = org.y + ((pix & 255) >> 4);
-                    rng.inc = (sample_sequence(pp, x, y, pp.sample0 + s_local) << 1) | 1;
-                    rng.state = ps.rng[p];
-                }
+                Rng rng = path_rng(ps, pp, tiles, p);
                 if (mat.type == PBRT_MAT_NONE) {
                     // path.rs:95-98: no BSDF -> continue through the surface, bounces unchanged
                     V3 o = offset_ray_origin(sf.p, sf.p_error, sf.n, rd);
@@ -527,15 +743,11 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
                     flags |= PF_ALIVE;
                     emit_cont = true;
                 } else {
-                    Frame fr;
-                    fr.ns = sf.n;
-                    fr.ng = sf.n;
-                    fr.ss = normalize(sf.dpdu);
-                    fr.ts = cross(fr.ns, fr.ss);
+                    Frame fr = make_frame(sf);
                     V3 kd = V3{mat.kd[0], mat.kd[1], mat.kd[2]};
                     V3 kt = V3{mat.kt[0], mat.kt[1], mat.kt[2]};
                     V3 wo = sf.wo;
-                    bool has_lobe;  // MaterialDesc -> BSDF (see oracle o_reflection.h for the pbrt-v3 rules)
+                    bool has_lobe;  // which BxDFs the material adds: pbrt-v3 rules (matte / mirror / glass)
                     if (mat.type == PBRT_MAT_GLASS) has_lobe = !(is_black(kd) && is_black(kt));
                     else has_lobe = !is_black(kd);
                     bool nonspecular = (mat.type == PBRT_MAT_MATTE) && has_lobe;
@@ -550,133 +762,11 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
                         if (pick_pdf != 0.0f) {
                             float ul0 = rng_float(rng), ul1 = rng_float(rng);
                             float us0 = rng_float(rng), us1 = rng_float(rng);
-                            DevLight lt = sc.lights[light_num];
-                            V3 Lc = V3{lt.L[0], lt.L[1], lt.L[2]};
-                            // -- Light::sample_li --
-                            V3 wi = V3{0.0f, 0.0f, 0.0f};
-                            float light_pdf = 0.0f;
-                            V3 li = V3{0.0f, 0.0f, 0.0f};
-                            V3 p1 = V3{0.0f, 0.0f, 0.0f}, p1_err = V3{0.0f, 0.0f, 0.0f}, p1_n = V3{0.0f, 0.0f, 0.0f};
-                            if (lt.type == PBRT_LIGHT_DIFFUSE_AREA) {
-                                // Triangle::sample (triangle.rs:330-348) + Shape::sample2 (shape.rs:38-53)
-                                V3 q0, q1, q2;
-                                int fl;
-                                load_tri(sc.bvh.tris, lt.slot, &q0, &q1, &q2, &fl);
-                                float su0 = __builtin_sqrtf(ul0);
-                                float bx = 1.0f - su0, by = ul1 * su0;
-                                float bz = 1.0f - bx - by;
-                                p1 = q0 * bx + q1 * by + q2 * bz;
-                                p1_n = normalize(cross(q1 - q0, q2 - q0));
-                                p1_err = (vabs(q0 * bx) + vabs(q1 * by) + vabs(q2 * bz)) * kGamma6;
-                                float pdf = 1.0f / lt.area;
-                                V3 w = p1 - sf.p;
-                                if (len2(w) == 0.0f) {
-                                    pdf = 0.0f;
-                                } else {
-                                    w = normalize(w);
-                                    V3 dd = sf.p - p1;
-                                    pdf *= len2(dd) / absdot(p1_n, -w);
-                                    if (__builtin_isinf(pdf)) pdf = 0.0f;
-                                }
-                                // DiffuseAreaLight::sample_li (diffuse.rs:60-81)
-                                if (pdf == 0.0f || len2(p1 - sf.p) == 0.0f) {
-                                    light_pdf = 0.0f;
-                                } else {
-                                    light_pdf = pdf;
-                                    wi = normalize(p1 - sf.p);
-                                    if (lt.two_sided || dot(p1_n, -wi) > 0.0f) li = Lc;
-                                }
-                            } else {
-                                // InfiniteAreaLight::sample_li (infinite.rs:96-129)
-                                float pdf1, pdf0;
-                                int v;
-                                float d1 = sample_continuous2(sc.env_marg_func, sc.env_marg_cdf, sc.env_marg_int, ul1, &pdf1, &v);
-                                int dummy;
-                                float d0 = sample_continuous2(sc.env_cond_func[v], sc.env_cond_cdf[v], sc.env_cond_int[v], ul0, &pdf0, &dummy);
-                                float map_pdf = pdf0 * pdf1;
-                                if (map_pdf != 0.0f) {
-                                    float theta = d1 * kPi, phi = d0 * 2.0f * kPi;
-                                    float st, ct, sp, cp;
-                                    det_sincos(theta, &st, &ct);
-                                    det_sincos(phi, &sp, &cp);
-                                    wi = V3{st * cp, st * sp, ct};
-                                    light_pdf = map_pdf / (2.0f * kPi * kPi * st);
-                                    if (st == 0.0f) light_pdf = 0.0f;
-                                    p1 = sf.p + wi * (2.0f * sc.world_radius);
-                                    li = Lc;
-                                }
-                            }
-                            int nee_flags = 0;
-                            V3 A = V3{0.0f, 0.0f, 0.0f};
-                            if (light_pdf > 0.0f && !is_black(li)) {
-                                V3 f;
-                                float scattering_pdf;
-                                matte_f_pdf(fr, kd, wo, wi, &f, &scattering_pdf);
-                                f = f * absdot(wi, fr.ns);
-                                if (!is_black(f)) {
-                                    // VisibilityTester::un_occluded -> spawn_ray_to (interaction.rs:147-153)
-                                    V3 origin = offset_ray_origin(sf.p, sf.p_error, sf.n, p1 - sf.p);
-                                    V3 target = offset_ray_origin(p1, p1_err, p1_n, origin - p1);
-                                    V3 d = target - origin;
-                                    store_ray(ps, p, RS_SHADOW, origin, d, 1.0f - kShadowEpsilon);
-                                    float weight = power_heuristic1(light_pdf, scattering_pdf);
-                                    A = mulv(li, f) * weight / light_pdf;
-                                    nee_flags |= PF_NEE_SHADOW;
-                                }
-                            }
-                            // -- BSDF sampling half (both light types are non-delta) --
-                            V3 wi2;
-                            float spdf = 0.0f;
-                            bool ok;
-                            {
-                                // scattering_pdf keeps the light-half value if wo.z == 0 (then it is 0 as well)
-                                V3 f2 = matte_sample_f(fr, kd, wo, us0, us1, &wi2, &spdf, &ok);
-                                if (ok) f2 = f2 * absdot(wi2, fr.ns);
-                                if (ok && !is_black(f2) && spdf > 0.0f) {
-                                    float lpdf;
-                                    if (lt.type == PBRT_LIGHT_DIFFUSE_AREA) {
-                                        // Shape::pdf2 (shape.rs:54-69)
-                                        V3 o2 = offset_ray_origin(sf.p, sf.p_error, sf.n, wi2);
-                                        V3 ph, nh;
-                                        if (!light_triangle_intersect(sc.bvh, lt.slot, o2, wi2, &ph, &nh)) {
-                                            lpdf = 0.0f;
-                                        } else {
-                                            lpdf = len2(sf.p - ph) / (absdot(nh, -wi2) * lt.area);
-                                            if (__builtin_isinf(lpdf)) lpdf = 0.0f;
-                                        }
-                                    } else {
-                                        // InfiniteAreaLight::pdf_li (infinite.rs:140-151)
-                                        float theta = det_acos(clampf(wi2.z, -1.0f, 1.0f));
-                                        float ph = det_atan2(wi2.y, wi2.x);
-                                        if (ph < 0.0f) ph = ph + 2.0f * kPi;
-                                        float st = det_sin(theta);
-                                        if (st == 0.0f) {
-                                            lpdf = 0.0f;
-                                        } else {
-                                            int iu = (int)(ph * kInv2Pi * 2.0f);
-                                            iu = iu < 0 ? 0 : (iu > 1 ? 1 : iu);
-                                            int iv = (int)(theta * kInvPi * 2.0f);
-                                            iv = iv < 0 ? 0 : (iv > 1 ? 1 : iv);
-                                            lpdf = sc.env_cond_func[iv][iu] / sc.env_marg_int / (2.0f * kPi * kPi * st);
-                                        }
-                                    }
-                                    if (lpdf != 0.0f) {
-                                        float weight = power_heuristic1(spdf, lpdf);
-                                        V3 o2 = offset_ray_origin(sf.p, sf.p_error, sf.n, wi2);
-                                        store_ray(ps, p, RS_MIS, o2, wi2, kInf);
-                                        ps.nee_f[p] = make_float4(f2.x, f2.y, f2.z, weight);
-                                        nee_flags |= PF_NEE_MIS;
-                                    }
-                                }
-                            }
-                            if (nee_flags) {
-                                ps.nee_a[p] = make_float4(A.x, A.y, A.z, pick_pdf);
-                                ps.nee_b[p] = make_float4(beta.x, beta.y, beta.z, spdf);
-                                ps.nee_light[p] = light_num;
-                                flags |= nee_flags;
-                                emit_shadow = (nee_flags & PF_NEE_SHADOW) != 0;
-                                emit_mis = (nee_flags & PF_NEE_MIS) != 0;
-                            }
+                            int nee_flags = estimate_direct_emit(sc, ps, p, sf, fr, true, kd, light_num, ul0, ul1, us0, us1,
+                                                                 pick_pdf, beta);
+                            flags |= nee_flags;
+                            emit_shadow = (nee_flags & PF_NEE_SHADOW) != 0;
+                            emit_mis = (nee_flags & PF_NEE_MIS) != 0;
                         }
                     }
 
@@ -695,35 +785,8 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
                             float ur = fminr(u0 * 1.0f - 0.0f, kOneMinusEpsilon);
                             if (wol.z != 0.0f) {
                                 V3 wil = V3{0.0f, 0.0f, 0.0f};
-                                if (mat.type == PBRT_MAT_MIRROR) {
-                                    // SpecularReflection with FresnelNoOp (reflection.rs:607-659)
-                                    wil = V3{-wol.x, -wol.y, wol.z};
-                                    pdf = 1.0f;
-                                    f = mulv(kd, V3{1.0f, 1.0f, 1.0f}) / __builtin_fabsf(wil.z);
-                                    sampled_specular = true;
-                                } else {
-                                    // FresnelSpecular (reflection.rs:733-819), TransportMode::Radiance
-                                    float F = fr_dielectric(wol.z, 1.0f, mat.eta);
-                                    if (ur < F) {
-                                        wil = V3{-wol.x, -wol.y, wol.z};
-                                        pdf = F;
-                                        f = kd * F / __builtin_fabsf(wil.z);
-                                        sampled_specular = true;
-                                    } else {
-                                        bool entering = wol.z > 0.0f;
-                                        float eta_i = entering ? 1.0f : mat.eta;
-                                        float eta_t = entering ? mat.eta : 1.0f;
-                                        V3 nn = faceforward(V3{0.0f, 0.0f, 1.0f}, wol);
-                                        if (refract(wol, nn, eta_i / eta_t, &wil)) {
-                                            V3 ft = kt * (1.0f - F);
-                                            ft = ft * ((eta_i * eta_i) / (eta_t * eta_t));
-                                            pdf = 1.0f - F;
-                                            f = ft / __builtin_fabsf(wil.z);
-                                            sampled_specular = true;
-                                            sampled_transmission = true;
-                                        }
-                                    }
-                                }
+                                f = sample_specular_local(mat, kd, kt, wol, ur, 0, &wil, &pdf, &sampled_transmission);
+                                sampled_specular = pdf != 0.0f;
                                 if (pdf != 0.0f) wi = to_world(fr, wil);
                                 else f = V3{0.0f, 0.0f, 0.0f};
                             }
@@ -761,6 +824,218 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
     }
 
     // ---- queue appends (block-aggregated) ----
+    __shared__ BlockAppend sh;
+    block_append(sh, qout, p, emit_cont, emit_mis, emit_shadow, emit_cont || emit_mis || emit_shadow);
+}
+
+// -----------------------------------------------------------------------------------------------
+// DirectLightingIntegrator::li (directlighting.rs:79-127) with specular_reflect / specular_transmit
+// (integrator.rs:294-392). The reference recurses; here every path carries an explicit stack of
+// vertices whose transmit branch is still to be followed (depth-first, the recursion's order, so the
+// path's random stream is consumed in the reference's order). Per vertex the kernel walks a stage
+// counter: light samples 0..total-1 (one estimate_direct per call when rays must be traced), then the
+// reflect branch, then the transmit branch. L accumulates throughput * (Le + Ld).
+// -----------------------------------------------------------------------------------------------
+struct DirectState {
+    int* stage;        // low 16 bits: stage at the current vertex; high 16 bits: frame stack height
+    float4* ld_acc;    // estimate_direct sum over the samples of the current light
+    float4* frames;    // [p * max_depth * 3 + k*3 + {0,1,2}]: (ray.d xyz, b0) (b1, b2, slot, depth) (T rgb, -)
+    int light_strategy;  // 0 UniformSampleAll, 1 UniformSampleOne
+};
+
+__global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState ps, DirectState ds, Queues qin,
+                                                        Queues qout, PassParams pp, TileList tiles, uint32_t n_in) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = i < n_in;
+    uint32_t p = active ? qin.shade[i] : 0u;
+    bool emit_cont = false, emit_mis = false, emit_shadow = false;
+    if (active && !(__float_as_int(ps.beta[p].w) & PF_VALID)) active = false;  // placeholder path outside pixel_bounds
+
+    if (active) {
+        float4 Lq = ps.L[p], bq = ps.beta[p];
+        V3 L = V3{Lq.x, Lq.y, Lq.z};
+        V3 T = V3{bq.x, bq.y, bq.z};  // throughput of the current vertex
+        int fb = __float_as_int(bq.w);
+        int flags = fb & 0xff, depth = fb >> 8;
+        int sg = ds.stage[p];
+        int stage = sg & 0xffff, sp = sg >> 16;
+        float4 accq = ds.ld_acc[p];
+        V3 ld_acc = V3{accq.x, accq.y, accq.z};
+        size_t rbase = (size_t)p * 3 * 2;
+        const bool sample_all = ds.light_strategy == 0;
+        const int total = (sc.n_lights == 0) ? 0 : (sample_all ? sc.total_light_samples : 1);
+        Rng rng = path_rng(ps, pp, tiles, p);
+        bool have_vertex = !(flags & PF_ALIVE);  // ALIVE: a continuation ray was traced, its hit is a new vertex
+
+        // finish the light sample whose rays were traced
+        if (flags & (PF_NEE_SHADOW | PF_NEE_MIS)) {
+            float pick_pdf;
+            V3 beta_v;
+            V3 ld = estimate_direct_resolve(sc, ps, p, flags, &pick_pdf, &beta_v);
+            flags &= ~(PF_NEE_SHADOW | PF_NEE_MIS);
+            if (sample_all) {
+                ld_acc = ld_acc + ld;
+            } else {
+                L = L + mulv(T, ld / pick_pdf);
+            }
+        }
+        // uniform_sample_all_lights (integrator.rs:44-90): close a light when its last sample is in
+        auto close_light_if_done = [&](int st) {
+            if (!sample_all || st == 0) return;
+            // st = number of light samples finished so far at this vertex
+            int lo = 0;
+            while (sc.light_sample_prefix[lo + 1] < st) ++lo;  // light of sample st-1
+            if (sc.light_sample_prefix[lo + 1] == st) {
+                int ns = sc.light_sample_prefix[lo + 1] - sc.light_sample_prefix[lo];
+                L = L + mulv(T, ld_acc / (float)ns);
+                ld_acc = V3{0.0f, 0.0f, 0.0f};
+            }
+        };
+
+        bool done = false;
+        Surf sf;
+        Frame fr;
+        DevMaterial mat;
+        V3 kd = V3{0, 0, 0}, kt = V3{0, 0, 0}, rd = V3{0, 0, 0};
+        bool surface_ready = false;
+        auto load_surface = [&]() {
+            float4 r0 = ps.ray[rbase], r1 = ps.ray[rbase + 1];
+            rd = V3{r0.w, r1.x, r1.y};
+            float4 h0 = ps.hit[rbase];
+            int hslot = __float_as_int(ps.hit[rbase + 1].x);
+            sf = make_surface(sc.bvh, hslot, h0.y, h0.z, h0.w, rd);
+            mat = sc.materials[sf.material];
+            fr = make_frame(sf);
+            kd = V3{mat.kd[0], mat.kd[1], mat.kd[2]};
+            kt = V3{mat.kt[0], mat.kt[1], mat.kt[2]};
+            surface_ready = true;
+        };
+        if (have_vertex && stage > 0 && stage <= total) close_light_if_done(stage);
+
+        while (!done) {
+            if (!have_vertex) {
+                // ---- arrive at the hit of the continuation ray: directlighting.rs:86-106 ----
+                flags &= ~PF_ALIVE;
+                int hslot = __float_as_int(ps.hit[rbase + 1].x);
+                if (hslot < 0) {
+                    float4 r0 = ps.ray[rbase];
+                    (void)r0;
+                    for (int k = 0; k < sc.n_infinite; ++k) {  // Σ light.le(ray): only infinite lights emit on a miss
+                        DevLight lt = sc.lights[sc.infinite_ids[k]];
+                        L = L + mulv(T, V3{lt.L[0], lt.L[1], lt.L[2]});
+                    }
+                    stage = 0xfffe;  // nothing more at this vertex: unwind
+                } else {
+                    load_surface();
+                    if (mat.type == PBRT_MAT_NONE) {
+                        // directlighting.rs:97-104 (D28): continue through the surface at the same depth
+                        V3 o = offset_ray_origin(sf.p, sf.p_error, sf.n, rd);
+                        store_ray(ps, p, RS_CONT, o, rd, kInf);
+                        flags |= PF_ALIVE;
+                        emit_cont = true;
+                        break;
+                    }
+                    L = L + mulv(T, surface_le(sc, sf, sf.wo));  // D28: + isect.Le(wo)
+                    stage = 0;
+                }
+                have_vertex = true;
+            }
+            if (stage < total) {
+                // ---- one estimate_direct ----
+                if (!surface_ready) load_surface();
+                bool matte = (mat.type == PBRT_MAT_MATTE) && !is_black(kd);
+                int light_num;
+                float pick_pdf = 1.0f;
+                if (sample_all) {
+                    light_num = 0;
+                    while (sc.light_sample_prefix[light_num + 1] <= stage) ++light_num;
+                } else {
+                    // uniform_sample_one_light without a distribution (integrator.rs:113-117)
+                    float nl = (float)sc.n_lights;
+                    light_num = (int)fminr(rng_float(rng) * nl, nl - 1.0f);
+                    pick_pdf = 1.0f / nl;
+                }
+                float ul0 = rng_float(rng), ul1 = rng_float(rng);
+                float us0 = rng_float(rng), us1 = rng_float(rng);
+                int nee_flags = estimate_direct_emit(sc, ps, p, sf, fr, matte, kd, light_num, ul0, ul1, us0, us1, pick_pdf, T);
+                stage += 1;
+                if (nee_flags) {
+                    flags |= nee_flags;
+                    emit_shadow = (nee_flags & PF_NEE_SHADOW) != 0;
+                    emit_mis = (nee_flags & PF_NEE_MIS) != 0;
+                    break;  // trace, then come back to this vertex
+                }
+                close_light_if_done(stage);  // the sample contributed nothing
+                continue;
+            }
+            // ---- specular branches (directlighting.rs:121-125), only while depth + 1 < max_depth ----
+            bool branched = false;
+            if ((stage == total || stage == total + 1) && depth + 1 < pp.max_depth) {
+                if (!surface_ready) load_surface();
+                for (; stage <= total + 1 && !branched; ++stage) {
+                    int which = (stage == total) ? 1 : 2;  // reflect first, then transmit
+                    float u0 = rng_float(rng), u1 = rng_float(rng);
+                    (void)u1;
+                    V3 wol = to_local(fr, sf.wo);
+                    // BSDF::sample_f with type = REFLECTION|SPECULAR or TRANSMISSION|SPECULAR (one matching lobe)
+                    bool lobe = (mat.type == PBRT_MAT_MIRROR && which == 1 && !is_black(kd)) ||
+                                (mat.type == PBRT_MAT_GLASS && ((which == 1 && !is_black(kd)) || (which == 2 && !is_black(kt))));
+                    if (!lobe || wol.z == 0.0f) continue;
+                    float ur = fminr(u0 * 1.0f - 0.0f, kOneMinusEpsilon);
+                    V3 wil = V3{0, 0, 0};
+                    float pdf;
+                    bool tr;
+                    V3 f = sample_specular_local(mat, kd, kt, wol, ur, which, &wil, &pdf, &tr);
+                    if (pdf == 0.0f) continue;
+                    V3 wi = to_world(fr, wil);
+                    float ad = absdot(wi, fr.ns);
+                    if (!(pdf > 0.0f && !is_black(f) && ad != 0.0f)) continue;  // integrator.rs:316
+                    if (which == 1) {
+                        // remember this vertex: its transmit branch runs after the reflected subtree
+                        size_t fi = ((size_t)p * pp.max_depth + sp) * 3;
+                        float4 h0 = ps.hit[rbase];
+                        ds.frames[fi] = make_float4(rd.x, rd.y, rd.z, h0.y);
+                        ds.frames[fi + 1] = make_float4(h0.z, h0.w, ps.hit[rbase + 1].x, __int_as_float(depth));
+                        ds.frames[fi + 2] = make_float4(T.x, T.y, T.z, 0.0f);
+                        sp += 1;
+                    }
+                    T = mulv(T, f * (ad / pdf));
+                    depth += 1;
+                    V3 o = offset_ray_origin(sf.p, sf.p_error, sf.n, wi);
+                    store_ray(ps, p, RS_CONT, o, wi, kInf);
+                    flags |= PF_ALIVE;
+                    emit_cont = true;
+                    branched = true;
+                }
+            }
+            if (branched) break;
+            // ---- vertex finished: unwind to the innermost vertex that still owes its transmit branch ----
+            if (sp == 0) {
+                done = true;
+                break;
+            }
+            sp -= 1;
+            size_t fi = ((size_t)p * pp.max_depth + sp) * 3;
+            float4 f0 = ds.frames[fi], f1 = ds.frames[fi + 1], f2 = ds.frames[fi + 2];
+            // restore the vertex into the continuation slot so the surface can be rebuilt
+            float4 r0 = ps.ray[rbase];
+            ps.ray[rbase] = make_float4(r0.x, r0.y, r0.z, f0.x);
+            ps.ray[rbase + 1] = make_float4(f0.y, f0.z, kInf, 0.0f);
+            ps.hit[rbase] = make_float4(0.0f, f0.w, f1.x, f1.y);
+            ps.hit[rbase + 1] = make_float4(f1.z, 0.0f, 0.0f, 0.0f);
+            depth = __float_as_int(f1.w);
+            T = V3{f2.x, f2.y, f2.z};
+            stage = total + 1;  // transmit branch
+            surface_ready = false;
+            have_vertex = true;
+        }
+        ps.rng[p] = rng.state;
+        ps.L[p] = make_float4(L.x, L.y, L.z, 1.0f);
+        ps.beta[p] = make_float4(T.x, T.y, T.z, __int_as_float((depth << 8) | flags));
+        ds.stage[p] = (stage & 0xffff) | (sp << 16);
+        ds.ld_acc[p] = make_float4(ld_acc.x, ld_acc.y, ld_acc.z, 0.0f);
+    }
+
     __shared__ BlockAppend sh;
     block_append(sh, qout, p, emit_cont, emit_mis, emit_shadow, emit_cont || emit_mis || emit_shadow);
 }
