@@ -63,7 +63,8 @@ typedef struct PbrtHit {
     float t;
     float b0, b1, b2;
     int32_t prim_id;
-    int32_t pad[3];
+    int32_t instance_id; /* TransformedPrimitive that was entered (caller's order), -1 = none */
+    int32_t pad[2];
 } PbrtHit;
 
 /* The material files under src/materials/ are empty stubs; the three materials are pbrt-v3's on the reference's
@@ -87,6 +88,17 @@ typedef struct PbrtLight {
     int32_t n_samples; /* src/core/light.rs:76 */
     int32_t pad;
 } PbrtLight;
+
+/* src/core/primitive.rs:105-123 TransformedPrimitive with a static transform: one instance of the
+ * object-space aggregate. Row-major 4x4, last row (0,0,0,1); to_object = inverse of to_world
+ * (the reference keeps both, src/core/transform.rs:195-198). material >= 0 overrides the
+ * triangles' own materials for this instance. Instanced primitives cannot be area lights. */
+typedef struct PbrtInstance {
+    float to_world[16];
+    float to_object[16];
+    int32_t material;
+    int32_t pad[3];
+} PbrtInstance;
 
 /* src/cameras/perspective.rs:19-32: the two matrices the ray generator applies. Row-major. */
 typedef struct PbrtCamera {
@@ -140,6 +152,15 @@ const char* pbrt_hip_last_error(const PbrtHipContext* ctx);
 int pbrt_hip_bvh_build(const float* positions, int32_t n_verts, const int32_t* indices, int32_t n_tris,
                        int32_t max_prims_in_node, int32_t split_method, PbrtLinearBVHNode** nodes_out,
                        int32_t* n_nodes_out, int32_t** prim_order_out);
+/* Same builder over caller-supplied primitive bounds (n x 3 floats min, n x 3 floats max), e.g. the
+ * world bounds of instances for the top-level aggregate. */
+int pbrt_hip_bvh_build_boxes(const float* bounds_min, const float* bounds_max, int32_t n, int32_t max_prims_in_node,
+                             int32_t split_method, PbrtLinearBVHNode** nodes_out, int32_t* n_nodes_out,
+                             int32_t** prim_order_out);
+/* TransformedPrimitive::world_bound (src/core/primitive.rs:126-134, src/core/transform.rs:568-607):
+ * the 8 transformed corners of the object aggregate's bounds, per instance. Host only. */
+int pbrt_hip_instance_bounds(const float object_min[3], const float object_max[3], const PbrtInstance* instances,
+                             int32_t n_instances, float* bounds_min, float* bounds_max);
 void pbrt_hip_free(void* p);
 
 /* ---- scene: Scene::new (src/core/scene.rs:18-34) over GeometricPrimitive triangles
@@ -152,6 +173,16 @@ int pbrt_hip_scene_create(PbrtHipContext* ctx, const float* positions, int32_t n
                           int32_t n_materials, const int32_t* tri_light, const PbrtLight* lights, int32_t n_lights,
                           const PbrtLinearBVHNode* nodes, int32_t n_nodes, const int32_t* prim_order,
                           PbrtHipScene** out);
+/* Two-level scene (BASELINE config 5): `n_instances` TransformedPrimitives of ONE object-space
+ * triangle aggregate. blas_* = BVHAccel over the triangles (object space); tlas_* = BVHAccel over the
+ * instances' world bounds, tlas_order[slot] = instance index. Only infinite lights are accepted. */
+int pbrt_hip_scene_create_instanced(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
+                                    const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
+                                    const PbrtMaterial* materials, int32_t n_materials, const PbrtLight* lights,
+                                    int32_t n_lights, const PbrtLinearBVHNode* blas_nodes, int32_t n_blas_nodes,
+                                    const int32_t* blas_order, const PbrtInstance* instances, int32_t n_instances,
+                                    const PbrtLinearBVHNode* tlas_nodes, int32_t n_tlas_nodes,
+                                    const int32_t* tlas_order, PbrtHipScene** out);
 void pbrt_hip_scene_destroy(PbrtHipScene* scene);
 
 /* ---- batch Primitive::intersect / intersect_p (src/core/primitive.rs:17-30 via
@@ -172,9 +203,10 @@ int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* total_ms, uint
 /* Instrumentation for the roofline accounting: when enabled, traversal launches
  * run an instrumented variant that counts the box tests (src/accelerators/bvh.rs:841-842) and
  * triangle tests (src/shapes/triangle.rs:74) the reference's loops perform for the same rays.
- * counters = {rays, node_tests, prim_tests}. Slower; never enabled in a timed region. */
+ * counters = {rays, node_tests, prim_tests, instance_tests (src/core/primitive.rs:136 calls)}.
+ * Slower; never enabled in a timed region. */
 int pbrt_hip_set_counting(PbrtHipContext* ctx, int enable);
-int pbrt_hip_get_counters(PbrtHipContext* ctx, int reset, uint64_t counters[3]);
+int pbrt_hip_get_counters(PbrtHipContext* ctx, int reset, uint64_t counters[4]);
 
 /* ---- Integrator::render (src/core/integrator.rs:29-42, 399-480) for this GPU's tile set ----
  * film_xyzw: width*height*4 floats {xyz[3], filter_weight_sum} = the first 16 bytes of the

@@ -36,6 +36,12 @@ def lib():
         L.orc_scene_create.restype = vp
         L.orc_scene_create.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
+        L.orc_scene_create_instanced.restype = vp
+        L.orc_scene_create_instanced.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, ctypes.c_int, vp,
+                                                 ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_uint32]
+        L.orc_scene_num_blas_nodes.argtypes = [vp]
+        L.orc_scene_get_blas.argtypes = [vp, vp, vp]
         L.orc_scene_destroy.argtypes = [vp]
         L.orc_scene_num_nodes.argtypes = [vp]
         L.orc_scene_get_nodes.argtypes = [vp, vp]
@@ -91,7 +97,7 @@ def _lights_flat(lights):
 
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"), ("prim_id", "<i4"),
-                      ("pad", "<i4", 3)])
+                      ("instance_id", "<i4"), ("pad", "<i4", 2)])
 NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"), ("n_primitives", "<u2"),
                        ("axis", "u1"), ("pad", "u1")])
 
@@ -101,6 +107,9 @@ class OracleScene:
 
     def __init__(self, scene, max_prims_in_node=4, split_method=0, quirks=0, normals=None, uvs=None):
         L = lib()
+        if "instances" in scene:
+            self._init_instanced(scene, max_prims_in_node, split_method, quirks)
+            return
         self._keep = dict(
             positions=_f32(scene["positions"]), indices=np.ascontiguousarray(scene["indices"], dtype=np.int32),
             tri_material=np.ascontiguousarray(scene["tri_material"], dtype=np.int32),
@@ -114,6 +123,30 @@ class OracleScene:
                                     _p(k["normals"]), _p(k["uvs"]), _p(k["tri_material"]), _p(k["materials"]),
                                     len(k["materials"]), _p(k["tri_light"]), _p(k["lights"]), len(k["lights"]),
                                     max_prims_in_node, split_method, quirks)
+
+    def _init_instanced(self, scene, max_prims_in_node, split_method, quirks):
+        """Config 5: TransformedPrimitive instances of one base mesh (scene["instances"] = (n,2,4,4) float32
+        {to_world, to_object}, scene["instance_material"] = (n,) int32)."""
+        L = lib()
+        self._keep = dict(
+            positions=_f32(scene["positions"]), indices=np.ascontiguousarray(scene["indices"], dtype=np.int32),
+            instances=_f32(scene["instances"]).reshape(-1, 32),
+            instance_material=np.ascontiguousarray(scene["instance_material"], dtype=np.int32),
+            materials=_materials_flat(scene["materials"]), lights=_lights_flat(scene["lights"]))
+        k = self._keep
+        self.n_tris = k["indices"].shape[0]
+        self.n_instances = k["instances"].shape[0]
+        self.h = L.orc_scene_create_instanced(_p(k["positions"]), k["positions"].shape[0], _p(k["indices"]), self.n_tris,
+                                              _p(k["instances"]), _p(k["instance_material"]), self.n_instances,
+                                              _p(k["materials"]), len(k["materials"]), _p(k["lights"]),
+                                              len(k["lights"]), max_prims_in_node, split_method, quirks)
+
+    def blas(self):
+        n = lib().orc_scene_num_blas_nodes(self.h)
+        nodes = np.zeros(n, dtype=NODE_DTYPE)
+        order = np.zeros(self.n_tris, dtype=np.int32)
+        lib().orc_scene_get_blas(self.h, _p(nodes), _p(order))
+        return nodes, order
 
     def close(self):
         if self.h:
@@ -133,34 +166,43 @@ class OracleScene:
         return out
 
     def prim_order(self):
-        out = np.zeros(self.n_tris, dtype=np.int32)
+        out = np.zeros(getattr(self, "n_instances", self.n_tris), dtype=np.int32)
         lib().orc_scene_get_prim_order(self.h, _p(out))
         return out
 
     def intersect(self, rays, n_threads=8):
         rays = np.ascontiguousarray(rays)
         out = np.zeros(len(rays), dtype=HIT_DTYPE)
-        ctr = np.zeros(3, dtype=np.uint64)
+        ctr = np.zeros(4, dtype=np.uint64)
         lib().orc_intersect(self.h, _p(rays), len(rays), _p(out), _p(ctr), n_threads)
-        return out, dict(rays=int(ctr[0]), node_tests=int(ctr[1]), prim_tests=int(ctr[2]))
+        return out, self._ctr(ctr)
 
     def intersect_p(self, rays, n_threads=8):
         rays = np.ascontiguousarray(rays)
         out = np.zeros(len(rays), dtype=np.uint8)
-        ctr = np.zeros(3, dtype=np.uint64)
+        ctr = np.zeros(4, dtype=np.uint64)
         lib().orc_intersect_p(self.h, _p(rays), len(rays), _p(out), _p(ctr), n_threads)
-        return out, dict(rays=int(ctr[0]), node_tests=int(ctr[1]), prim_tests=int(ctr[2]))
+        return out, self._ctr(ctr)
+
+    def _ctr(self, ctr):
+        d = dict(rays=int(ctr[0]), node_tests=int(ctr[1]), prim_tests=int(ctr[2]))
+        if hasattr(self, "n_instances"):
+            d["inst_tests"] = int(ctr[3])
+        return d
 
     def render(self, cam36, width, height, spp, integrator=0, max_depth=5, rr_threshold=1.0, light_strategy=1,
                seed=0, bounds=None, n_threads=8):
         x0, y0, x1, y1 = bounds if bounds is not None else (0, 0, width, height)
         film = np.zeros((height, width, 4), dtype=np.float32)
-        stats = np.zeros(5, dtype=np.uint64)
+        stats = np.zeros(6, dtype=np.uint64)
         cam36 = _f32(cam36)
         lib().orc_render(self.h, _p(cam36), integrator, max_depth, rr_threshold, light_strategy, spp, seed, width,
                          height, x0, y0, x1, y1, n_threads, _p(film), _p(stats))
-        return film, dict(rays=int(stats[0]), node_tests=int(stats[1]), prim_tests=int(stats[2]),
-                          camera_samples=int(stats[3]), seconds=float(stats[4]) * 1e-9)
+        st = dict(rays=int(stats[0]), node_tests=int(stats[1]), prim_tests=int(stats[2]),
+                  camera_samples=int(stats[3]), seconds=float(stats[4]) * 1e-9)
+        if hasattr(self, "n_instances"):
+            st["inst_tests"] = int(stats[5])
+        return film, st
 
 
 def film_to_rgb(film):

@@ -23,18 +23,24 @@
 #pragma once
 #include <algorithm>
 
-#include "o_shapes.h"
+#include "o_transform.h"
 
 namespace oracle {
 
 struct TraversalCounters {
-    uint64_t rays = 0, node_tests = 0, prim_tests = 0;
+    uint64_t rays = 0, node_tests = 0, prim_tests = 0, inst_tests = 0;
     void add(const TraversalCounters& o) {
         rays += o.rays;
         node_tests += o.node_tests;
         prim_tests += o.prim_tests;
+        inst_tests += o.inst_tests;
     }
 };
+// Counters of the calling thread (set by Scene::intersect / intersect_p; nested aggregates add to them).
+inline TraversalCounters*& tl_counters() {
+    static thread_local TraversalCounters* c = nullptr;
+    return c;
+}
 
 // src/core/primitive.rs:17-30
 struct Primitive {
@@ -105,7 +111,9 @@ inline int partition_in_place(T* a, int n, Pred pred) {
     }
 }
 
-struct BVHAccel {
+struct BVHAccel : Primitive {
+    bool counts_rays = true;       // false for a BLAS entered through a TransformedPrimitive
+    bool leaves_are_instances = false;
     int max_prims_in_node;
     SplitMethod split_method;
     uint32_t quirks;
@@ -279,12 +287,14 @@ struct BVHAccel {
         return my_offset;
     }
 
-    Bounds3f world_bound() const { return nodes.empty() ? Bounds3f() : nodes[0].bounds; }
+    Bounds3f world_bound() const override { return nodes.empty() ? Bounds3f() : nodes[0].bounds; }
+    bool intersect(const Ray& ray, SurfaceInteraction* si) const override { return intersect(ray, si, tl_counters()); }
+    bool intersect_p(const Ray& ray) const override { return intersect_p(ray, tl_counters()); }
 
     // bvh.rs:828-879
-    bool intersect(const Ray& ray, SurfaceInteraction* si, TraversalCounters* ctr = nullptr) const {
+    bool intersect(const Ray& ray, SurfaceInteraction* si, TraversalCounters* ctr) const {
         if (nodes.empty()) return false;
-        if (ctr) ctr->rays++;
+        if (ctr && counts_rays) ctr->rays++;
         bool hit = false;
         Vector3f inv_dir(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
         int dir_is_neg[3] = {inv_dir.x < 0.0f ? 1 : 0, inv_dir.y < 0.0f ? 1 : 0, inv_dir.z < 0.0f ? 1 : 0};
@@ -296,7 +306,7 @@ struct BVHAccel {
             if (bounds_intersect_p(node.bounds, ray, inv_dir, dir_is_neg, quirks)) {
                 if (node.n_primitives > 0) {
                     for (int i = 0; i < node.n_primitives; ++i) {
-                        if (ctr) ctr->prim_tests++;
+                        if (ctr) (leaves_are_instances ? ctr->inst_tests : ctr->prim_tests)++;
                         if (primitives[node.primitive_or_second_child_offset + i]->intersect(ray, si)) hit = true;
                     }
                     if (to_visit_offset == 0) break;
@@ -319,9 +329,9 @@ struct BVHAccel {
     }
 
     // bvh.rs:881-932
-    bool intersect_p(const Ray& ray, TraversalCounters* ctr = nullptr) const {
+    bool intersect_p(const Ray& ray, TraversalCounters* ctr) const {
         if (nodes.empty()) return false;
-        if (ctr) ctr->rays++;
+        if (ctr && counts_rays) ctr->rays++;
         Vector3f inv_dir(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
         int dir_is_neg[3] = {inv_dir.x < 0.0f ? 1 : 0, inv_dir.y < 0.0f ? 1 : 0, inv_dir.z < 0.0f ? 1 : 0};
         int to_visit_offset = 0, current = 0;
@@ -332,7 +342,7 @@ struct BVHAccel {
             if (bounds_intersect_p(node.bounds, ray, inv_dir, dir_is_neg, quirks)) {
                 if (node.n_primitives > 0) {
                     for (int i = 0; i < node.n_primitives; ++i) {
-                        if (ctr) ctr->prim_tests++;
+                        if (ctr) (leaves_are_instances ? ctr->inst_tests : ctr->prim_tests)++;
                         if (primitives[node.primitive_or_second_child_offset + i]->intersect_p(ray)) return true;
                     }
                     if (to_visit_offset == 0) break;
@@ -353,6 +363,36 @@ struct BVHAccel {
         }
         return false;
     }
+};
+
+// src/core/primitive.rs:105-177 TransformedPrimitive with a static transform (AnimatedTransform's
+// interpolate(time) is the identity on it). D6 disposition: intended pbrt-v3 — the hit is transformed
+// back to world space whenever the transform is not the identity (primitive.rs:145 tests the opposite).
+struct TransformedPrimitive : Primitive {
+    std::shared_ptr<Primitive> primitive;
+    Matrix4 to_world, to_object;
+    int instance_id;
+    bool identity;
+    TransformedPrimitive(const std::shared_ptr<Primitive>& p, const Matrix4& tw, const Matrix4& to, int id)
+        : primitive(p), to_world(tw), to_object(to), instance_id(id) {
+        identity = true;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
+                if (tw.m[i][j] != (i == j ? 1.0f : 0.0f)) identity = false;  // transform.rs:222-240
+    }
+    // primitive.rs:126-134 (motion_bounds of a static transform = Transform * Bounds3f)
+    Bounds3f world_bound() const override { return xform_bounds(to_world, primitive->world_bound()); }
+    // primitive.rs:136-149
+    bool intersect(const Ray& r, SurfaceInteraction* si) const override {
+        Ray ray = xform_ray(to_object, r);
+        if (!primitive->intersect(ray, si)) return false;
+        r.t_max = ray.t_max;
+        if (!identity) *si = xform_si(to_world, to_object, *si);
+        si->instance_id = instance_id;
+        return true;
+    }
+    // primitive.rs:151-159
+    bool intersect_p(const Ray& r) const override { return primitive->intersect_p(xform_ray(to_object, r)); }
 };
 
 }  // namespace oracle

@@ -169,7 +169,12 @@ struct Scene {
     std::vector<MaterialDesc> materials;
     // per caller-order primitive: material / area light ids (GeometricPrimitive fields)
     std::vector<int> prim_material, prim_light;
+    std::vector<int> instance_material;  // per instance: material of every primitive inside it, or -1 = the primitive's own
     uint32_t quirks = 0;
+    int material_of(const SurfaceInteraction& si) const {
+        if (si.instance_id >= 0 && instance_material[si.instance_id] >= 0) return instance_material[si.instance_id];
+        return prim_material[si.prim_id];
+    }
     void finish() {
         world_bound = aggregate->world_bound();
         for (auto& l : lights) {
@@ -178,9 +183,13 @@ struct Scene {
         }
     }
     bool intersect(const Ray& ray, SurfaceInteraction* isect, TraversalCounters* ctr) const {
-        return aggregate->intersect(ray, isect, ctr);
+        tl_counters() = ctr;
+        return aggregate->intersect(ray, isect);
     }
-    bool intersect_p(const Ray& ray, TraversalCounters* ctr) const { return aggregate->intersect_p(ray, ctr); }
+    bool intersect_p(const Ray& ray, TraversalCounters* ctr) const {
+        tl_counters() = ctr;
+        return aggregate->intersect_p(ray);
+    }
 };
 inline void InfiniteAreaLight::pre_process(const Scene& scene) {
     scene.world_bound.bounding_sphere(&world_center, &world_radius);
@@ -192,7 +201,8 @@ inline bool VisibilityTester::un_occluded(const Scene& scene, TraversalCounters*
 
 // interaction.rs:387-395
 inline Spectrum surface_le(const Scene& scene, const SurfaceInteraction& si, const Vector3f& w) {
-    int lid = si.prim_id >= 0 ? scene.prim_light[si.prim_id] : -1;
+    // instanced primitives carry no area lights (pbrt-v3: "area lights not supported with object instancing")
+    int lid = (si.prim_id >= 0 && si.instance_id < 0) ? scene.prim_light[si.prim_id] : -1;
     if (lid >= 0) return scene.lights[lid]->l(si, w);
     return Spectrum(0.0f);
 }
@@ -262,7 +272,8 @@ inline Spectrum estimate_direct(const SurfaceInteraction& it, const BSDF& bsdf, 
             Spectrum li2(0.0f);
             if (found) {
                 // D26: Le only if the hit primitive's area light is this light
-                if (light_isect.prim_id >= 0 && scene.prim_light[light_isect.prim_id] == light_id)
+                if (light_isect.prim_id >= 0 && light_isect.instance_id < 0 &&
+                    scene.prim_light[light_isect.prim_id] == light_id)
                     li2 = surface_le(scene, light_isect, -wi);
             } else {
                 li2 = light.le(ray);
@@ -349,7 +360,7 @@ struct PathIntegrator : Integrator {
                 }
             }
             if (!found || bounces >= max_depth) break;
-            const MaterialDesc& mat = scene.materials[scene.prim_material[isect.prim_id]];
+            const MaterialDesc& mat = scene.materials[scene.material_of(isect)];
             std::shared_ptr<BSDF> bsdf = compute_scattering_functions(mat, isect, MODE_RADIANCE, true, scene.quirks);
             if (!bsdf) {
                 ray = isect.spawn_ray(ray.d);
@@ -405,7 +416,7 @@ struct DirectLightingIntegrator : Integrator {
             for (auto& light : scene.lights) l += light->le(ray);
             return l;
         }
-        const MaterialDesc& mat = scene.materials[scene.prim_material[isect.prim_id]];
+        const MaterialDesc& mat = scene.materials[scene.material_of(isect)];
         std::shared_ptr<BSDF> bsdf = compute_scattering_functions(mat, isect, MODE_RADIANCE, false, scene.quirks);
         if (!bsdf) return li(isect.spawn_ray(ray.d), scene, rc, depth);
         Vector3f wo = isect.wo;
@@ -442,44 +453,6 @@ struct DirectLightingIntegrator : Integrator {
 // Camera — cameras/perspective.rs. The 4x4 matrices are supplied by the caller (the host side
 // computes Transform::perspective / look_at, transform.rs:510-566); the oracle applies them.
 // ---------------------------------------------------------------------------------
-struct Matrix4 {
-    Float m[4][4];
-};
-// transform.rs:351-370
-inline Point3f xform_point(const Matrix4& t, const Point3f& p) {
-    Float x = p.x, y = p.y, z = p.z;
-    Float xp = t.m[0][0] * x + t.m[0][1] * y + t.m[0][2] * z + t.m[0][3];
-    Float yp = t.m[1][0] * x + t.m[1][1] * y + t.m[1][2] * z + t.m[1][3];
-    Float zp = t.m[2][0] * x + t.m[2][1] * y + t.m[2][2] * z + t.m[2][3];
-    Float wp = t.m[3][0] * x + t.m[3][1] * y + t.m[3][2] * z + t.m[3][3];
-    if (wp == 1.0f) return Point3f(xp, yp, zp);
-    return Point3f(xp, yp, zp) / wp;
-}
-// transform.rs:372-385
-inline Vector3f xform_vector(const Matrix4& t, const Vector3f& v) {
-    Float x = v.x, y = v.y, z = v.z;
-    return Vector3f(t.m[0][0] * x + t.m[0][1] * y + t.m[0][2] * z, t.m[1][0] * x + t.m[1][1] * y + t.m[1][2] * z,
-                    t.m[2][0] * x + t.m[2][1] * y + t.m[2][2] * z);
-}
-// geometry.rs:898-935 (point with absolute error) + :865-881 (ray through a transform)
-inline Ray xform_ray(const Matrix4& t, const Ray& r) {
-    Float x = r.o.x, y = r.o.y, z = r.o.z;
-    Point3f o = xform_point(t, r.o);
-    Float x_abs = std::fabs(t.m[0][0] * x) + std::fabs(t.m[0][1] * y) + std::fabs(t.m[0][2] * z) + std::fabs(t.m[0][3]);
-    Float y_abs = std::fabs(t.m[1][0] * x) + std::fabs(t.m[1][1] * y) + std::fabs(t.m[1][2] * z) + std::fabs(t.m[1][3]);
-    Float z_abs = std::fabs(t.m[2][0] * x) + std::fabs(t.m[2][1] * y) + std::fabs(t.m[2][2] * z) + std::fabs(t.m[2][3]);
-    Vector3f o_error = Vector3f(x_abs, y_abs, z_abs) * gamma(3.0f);
-    Vector3f d = xform_vector(t, r.d);
-    Float length_squared = d.length_squared();
-    Float t_max = r.t_max;
-    if (length_squared > 0.0f) {
-        Float dt = d.abs().dot(o_error) / length_squared;
-        o += d * dt;
-        t_max -= dt;
-    }
-    return Ray(o, d, t_max, r.time);
-}
-
 struct PerspectiveCamera {
     Matrix4 camera_to_world, raster_to_camera;
     Float lens_radius = 0.0f, focal_distance = 1e6f;

@@ -56,6 +56,7 @@ struct SurfaceInteraction : BaseInteraction {
     Vector3f dpdu, dpdv;
     Normal3f dndu, dndv;
     ShadingGeom shading;
+    int instance_id = -1;  // TransformedPrimitive that was entered (primitive.rs:136-159), -1 = none
     int prim_id = -1;  // stands for `primitive: Option<PrimitiveDt>` (set by the aggregate; see D-note at primitive.rs:71)
     int face_index = 0;
     SurfaceInteraction() {}

@@ -13,6 +13,8 @@ namespace {
 struct OracleScene {
     Scene scene;
     std::shared_ptr<TriangleMesh> mesh;
+    std::shared_ptr<BVHAccel> blas;  // instanced scenes: the shared object-space aggregate
+    std::vector<Matrix4> to_object;  // per instance
 };
 
 struct OrcHit {  // same 32-byte layout as PbrtHit (include/pbrt_hip.h)
@@ -92,6 +94,69 @@ void* orc_scene_create(const float* positions, int n_verts, const int32_t* indic
     sc.finish();
     return os;
 }
+// Instanced scene (config 5): one base mesh in object space inside a BVHAccel (BLAS), n_inst
+// TransformedPrimitives of it (primitive.rs:105-177) inside a top-level BVHAccel.
+// instances: n_inst x 32 floats {to_world[16], to_object[16]} row-major; inst_material[i] = material of instance i.
+void* orc_scene_create_instanced(const float* positions, int n_verts, const int32_t* indices, int n_tris,
+                                 const float* instances, const int32_t* inst_material, int n_inst,
+                                 const float* materials, int n_mat, const float* lights, int n_light,
+                                 int max_prims_in_node, int split_method, uint32_t quirks) {
+    OracleScene* os = new OracleScene();
+    auto mesh = std::make_shared<TriangleMesh>();
+    mesh->n_vertices = n_verts;
+    mesh->n_triangles = n_tris;
+    mesh->p.resize(n_verts);
+    for (int i = 0; i < n_verts; ++i) mesh->p[i] = Point3f(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]);
+    mesh->vertex_indices.assign(indices, indices + 3 * (size_t)n_tris);
+    os->mesh = mesh;
+    Scene& sc = os->scene;
+    sc.quirks = quirks;
+    for (int i = 0; i < n_mat; ++i) {
+        const float* m = materials + 8 * i;
+        MaterialDesc d;
+        d.type = (int)m[0];
+        d.kd = Spectrum(m[1], m[2], m[3]);
+        d.kt = Spectrum(m[4], m[5], m[6]);
+        d.eta = m[7];
+        sc.materials.push_back(d);
+    }
+    for (int i = 0; i < n_light; ++i) {
+        const float* l = lights + 8 * i;
+        if ((int)l[0] != 1) continue;  // instanced primitives cannot be area lights
+        sc.lights.push_back(std::make_shared<InfiniteAreaLight>(Spectrum(l[1], l[2], l[3]), (int)l[6]));
+    }
+    std::vector<std::shared_ptr<Primitive>> prims(n_tris);
+    sc.prim_material.assign(n_tris, 0);
+    sc.prim_light.assign(n_tris, -1);
+    for (int i = 0; i < n_tris; ++i)
+        prims[i] = std::make_shared<GeometricPrimitive>(std::make_shared<Triangle>(mesh, i, false, quirks), 0, -1, i);
+    os->blas = std::make_shared<BVHAccel>(prims, max_prims_in_node, (SplitMethod)split_method, quirks);
+    os->blas->counts_rays = false;
+    std::vector<std::shared_ptr<Primitive>> insts(n_inst);
+    sc.instance_material.resize(n_inst);
+    os->to_object.resize(n_inst);
+    for (int i = 0; i < n_inst; ++i) {
+        Matrix4 tw, to;
+        std::memcpy(tw.m, instances + 32 * (size_t)i, 64);
+        std::memcpy(to.m, instances + 32 * (size_t)i + 16, 64);
+        os->to_object[i] = to;
+        insts[i] = std::make_shared<TransformedPrimitive>(os->blas, tw, to, i);
+        sc.instance_material[i] = inst_material ? inst_material[i] : -1;
+    }
+    sc.aggregate = std::make_shared<BVHAccel>(insts, max_prims_in_node, (SplitMethod)split_method, quirks);
+    sc.aggregate->leaves_are_instances = true;
+    sc.finish();
+    return os;
+}
+int orc_scene_num_blas_nodes(void* h) {
+    OracleScene* os = (OracleScene*)h;
+    return os->blas ? (int)os->blas->nodes.size() : 0;
+}
+void orc_scene_get_blas(void* h, void* nodes_out, int32_t* order_out) {
+    OracleScene* os = (OracleScene*)h;
+    std::memcpy(nodes_out, os->blas->nodes.data(), os->blas->nodes.size() * sizeof(LinearBVHNode));
+    std::memcpy(order_out, os->blas->ordered_prims.data(), os->blas->ordered_prims.size() * sizeof(int32_t));
+}
 void orc_scene_destroy(void* h) { delete (OracleScene*)h; }
 int orc_scene_num_nodes(void* h) { return (int)((OracleScene*)h)->scene.aggregate->nodes.size(); }
 void orc_scene_get_nodes(void* h, void* out) {
@@ -115,13 +180,15 @@ void orc_intersect(void* h, const float* rays, int64_t n, void* out_hits, uint64
             // re-run the winning triangle's test to report its barycentrics (the SurfaceInteraction
             // does not keep them)
             SurfaceInteraction si;
-            OrcHit hit = {FLOAT_INF, 0, 0, 0, -1, {0, 0, 0}};
+            OrcHit hit = {FLOAT_INF, 0, 0, 0, -1, {-1, 0, 0}};
             if (sc.intersect(ray, &si, &tc[tid])) {
                 hit.t = ray.t_max;
                 hit.prim_id = si.prim_id;
+                hit.pad[0] = si.instance_id;
                 const TriangleMesh& m = *((OracleScene*)h)->mesh;
                 const int32_t* v = &m.vertex_indices[3 * (size_t)si.prim_id];
                 Ray r0(Point3f(r[0], r[1], r[2]), Vector3f(r[3], r[4], r[5]), r[6], r[7]);
+                if (si.instance_id >= 0) r0 = xform_ray(((OracleScene*)h)->to_object[si.instance_id], r0);
                 TriHit th = triangle_intersect_test(m.p[v[0]], m.p[v[1]], m.p[v[2]], r0, sc.quirks);
                 hit.b0 = th.b0;
                 hit.b1 = th.b1;
@@ -136,6 +203,7 @@ void orc_intersect(void* h, const float* rays, int64_t n, void* out_hits, uint64
         counters[0] = s.rays;
         counters[1] = s.node_tests;
         counters[2] = s.prim_tests;
+        counters[3] = s.inst_tests;
     }
 }
 void orc_intersect_p(void* h, const float* rays, int64_t n, uint8_t* out, uint64_t* counters, int n_threads) {
@@ -154,12 +222,13 @@ void orc_intersect_p(void* h, const float* rays, int64_t n, uint8_t* out, uint64
         counters[0] = s.rays;
         counters[1] = s.node_tests;
         counters[2] = s.prim_tests;
+        counters[3] = s.inst_tests;
     }
 }
 
 // camera: 36 floats {camera_to_world[16] row-major, raster_to_camera[16], lens_radius, focal_distance, shutter_open, shutter_close}
 // integrator: 0 = path, 1 = direct lighting. light_strategy: path {0 uniform, 1 power}; direct {0 all, 1 one}
-// stats: {rays, node_tests, prim_tests, camera_samples, nanoseconds}
+// stats: {rays, node_tests, prim_tests, camera_samples, nanoseconds, inst_tests}
 void orc_render(void* h, const float* cam, int integrator, int max_depth, float rr_threshold, int light_strategy,
                 int spp, uint64_t seed, int width, int height, int x0, int y0, int x1, int y1, int n_threads,
                 float* film_out, uint64_t* stats) {
@@ -196,6 +265,7 @@ void orc_render(void* h, const float* cam, int integrator, int max_depth, float 
         stats[2] = st.ctr.prim_tests;
         stats[3] = st.camera_samples;
         stats[4] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+        stats[5] = st.ctr.inst_tests;
     }
 }
 

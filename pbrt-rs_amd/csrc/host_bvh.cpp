@@ -182,6 +182,39 @@ struct Builder {
 
 }  // namespace
 
+static int build_from_boxes(std::vector<float>& lo, std::vector<float>& hi, int32_t n, int32_t max_prims_in_node,
+                            int32_t split_method, PbrtLinearBVHNode** nodes_out, int32_t* n_nodes_out,
+                            int32_t** prim_order_out) {
+    std::vector<float> ctr(3 * (size_t)n);
+    for (size_t i = 0; i < 3 * (size_t)n; ++i) ctr[i] = lo[i] * 0.5f + hi[i] * 0.5f;  // bvh.rs:38
+    Builder bl;
+    bl.lo = lo.data();
+    bl.hi = hi.data();
+    bl.ctr = ctr.data();
+    bl.perm.resize(n);
+    for (int32_t i = 0; i < n; ++i) bl.perm[i] = i;
+    bl.max_prims = std::min(max_prims_in_node, 255);  // bvh.rs:222
+    bl.method = split_method;
+    bl.out.reserve(2 * (size_t)n);
+    bl.order.reserve(n);
+    bl.build(0, n);
+
+    size_t nn = bl.out.size();
+    PbrtLinearBVHNode* nodes = (PbrtLinearBVHNode*)std::malloc(nn * sizeof(PbrtLinearBVHNode));
+    int32_t* order = (int32_t*)std::malloc((size_t)n * sizeof(int32_t));
+    if (!nodes || !order) {
+        std::free(nodes);
+        std::free(order);
+        return PBRT_HIP_ERR_OOM;
+    }
+    std::memcpy(nodes, bl.out.data(), nn * sizeof(PbrtLinearBVHNode));
+    std::memcpy(order, bl.order.data(), (size_t)n * sizeof(int32_t));
+    *nodes_out = nodes;
+    *n_nodes_out = (int32_t)nn;
+    *prim_order_out = order;
+    return PBRT_HIP_OK;
+}
+
 extern "C" int pbrt_hip_bvh_build(const float* positions, int32_t n_verts, const int32_t* indices, int32_t n_tris,
                                   int32_t max_prims_in_node, int32_t split_method, PbrtLinearBVHNode** nodes_out,
                                   int32_t* n_nodes_out, int32_t** prim_order_out) {
@@ -195,7 +228,7 @@ extern "C" int pbrt_hip_bvh_build(const float* positions, int32_t n_verts, const
     for (int64_t i = 0; i < 3 * (int64_t)n_tris; ++i)
         if (indices[i] < 0 || indices[i] >= n_verts) return PBRT_HIP_ERR_INVALID;
 
-    std::vector<float> lo(3 * (size_t)n_tris), hi(3 * (size_t)n_tris), ctr(3 * (size_t)n_tris);
+    std::vector<float> lo(3 * (size_t)n_tris), hi(3 * (size_t)n_tris);
     for (int32_t t = 0; t < n_tris; ++t) {
         // Triangle::world_bound, src/shapes/triangle.rs:175-180
         const float* a = positions + 3 * (size_t)indices[3 * (size_t)t];
@@ -208,34 +241,51 @@ extern "C" int pbrt_hip_bvh_build(const float* positions, int32_t n_verts, const
             mx = mx > c[k] ? mx : c[k];
             lo[3 * (size_t)t + k] = mn;
             hi[3 * (size_t)t + k] = mx;
-            ctr[3 * (size_t)t + k] = mn * 0.5f + mx * 0.5f;  // bvh.rs:38
         }
     }
-    Builder bl;
-    bl.lo = lo.data();
-    bl.hi = hi.data();
-    bl.ctr = ctr.data();
-    bl.perm.resize(n_tris);
-    for (int32_t i = 0; i < n_tris; ++i) bl.perm[i] = i;
-    bl.max_prims = std::min(max_prims_in_node, 255);  // bvh.rs:222
-    bl.method = split_method;
-    bl.out.reserve(2 * (size_t)n_tris);
-    bl.order.reserve(n_tris);
-    bl.build(0, n_tris);
+    return build_from_boxes(lo, hi, n_tris, max_prims_in_node, split_method, nodes_out, n_nodes_out, prim_order_out);
+}
 
-    size_t nn = bl.out.size();
-    PbrtLinearBVHNode* nodes = (PbrtLinearBVHNode*)std::malloc(nn * sizeof(PbrtLinearBVHNode));
-    int32_t* order = (int32_t*)std::malloc((size_t)n_tris * sizeof(int32_t));
-    if (!nodes || !order) {
-        std::free(nodes);
-        std::free(order);
-        return PBRT_HIP_ERR_OOM;
+extern "C" int pbrt_hip_bvh_build_boxes(const float* bounds_min, const float* bounds_max, int32_t n,
+                                        int32_t max_prims_in_node, int32_t split_method, PbrtLinearBVHNode** nodes_out,
+                                        int32_t* n_nodes_out, int32_t** prim_order_out) {
+    if (!nodes_out || !n_nodes_out || !prim_order_out) return PBRT_HIP_ERR_INVALID;
+    *nodes_out = nullptr;
+    *prim_order_out = nullptr;
+    *n_nodes_out = 0;
+    if (n < 0 || (n > 0 && (!bounds_min || !bounds_max))) return PBRT_HIP_ERR_INVALID;
+    if (split_method != 0 && split_method != 2 && split_method != 3) return PBRT_HIP_ERR_INVALID;
+    if (n == 0) return PBRT_HIP_OK;
+    std::vector<float> lo(bounds_min, bounds_min + 3 * (size_t)n), hi(bounds_max, bounds_max + 3 * (size_t)n);
+    return build_from_boxes(lo, hi, n, max_prims_in_node, split_method, nodes_out, n_nodes_out, prim_order_out);
+}
+
+// Transform * Bounds3f (src/core/transform.rs:568-607): union of the 8 transformed corners
+extern "C" int pbrt_hip_instance_bounds(const float object_min[3], const float object_max[3],
+                                        const PbrtInstance* instances, int32_t n_instances, float* bounds_min,
+                                        float* bounds_max) {
+    if (!object_min || !object_max || n_instances < 0 || (n_instances > 0 && (!instances || !bounds_min || !bounds_max)))
+        return PBRT_HIP_ERR_INVALID;
+    for (int32_t i = 0; i < n_instances; ++i) {
+        const float* m = instances[i].to_world;
+        float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int c = 0; c < 8; ++c) {
+            float x = (c & 1) ? object_max[0] : object_min[0];
+            float y = (c & 2) ? object_max[1] : object_min[1];
+            float z = (c & 4) ? object_max[2] : object_min[2];
+            float p[3];
+            for (int r = 0; r < 3; ++r) p[r] = m[4 * r] * x + m[4 * r + 1] * y + m[4 * r + 2] * z + m[4 * r + 3];
+            float wp = m[12] * x + m[13] * y + m[14] * z + m[15];
+            if (wp != 1.0f)
+                for (int r = 0; r < 3; ++r) p[r] = p[r] / wp;
+            for (int r = 0; r < 3; ++r) {
+                mn[r] = p[r] < mn[r] ? p[r] : mn[r];
+                mx[r] = p[r] > mx[r] ? p[r] : mx[r];
+            }
+        }
+        std::memcpy(bounds_min + 3 * (size_t)i, mn, 12);
+        std::memcpy(bounds_max + 3 * (size_t)i, mx, 12);
     }
-    std::memcpy(nodes, bl.out.data(), nn * sizeof(PbrtLinearBVHNode));
-    std::memcpy(order, bl.order.data(), (size_t)n_tris * sizeof(int32_t));
-    *nodes_out = nodes;
-    *n_nodes_out = (int32_t)nn;
-    *prim_order_out = order;
     return PBRT_HIP_OK;
 }
 

@@ -57,9 +57,9 @@ extern "C" int pbrt_hip_context_create(int device_id, PbrtHipContext** out) {
     ctx->n_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_counters, 3 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_work_counter, sizeof(unsigned int)) != hipSuccess ||
-        hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMemset(ctx->d_counters, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
         g_create_error = "stream / event creation failed";
         delete ctx;
         return PBRT_HIP_ERR_DEVICE;
@@ -109,18 +109,18 @@ extern "C" int pbrt_hip_set_counting(PbrtHipContext* ctx, int enable) {
     return PBRT_HIP_OK;
 }
 
-extern "C" int pbrt_hip_get_counters(PbrtHipContext* ctx, int reset, uint64_t counters[3]) {
+extern "C" int pbrt_hip_get_counters(PbrtHipContext* ctx, int reset, uint64_t counters[4]) {
     if (!ctx || !counters) return PBRT_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long h[3] = {0, 0, 0};
+    unsigned long long h[4] = {0, 0, 0, 0};
     HIP_TRY(ctx, hipMemcpy(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     counters[0] = h[2];
     counters[1] = h[0];
     counters[2] = h[1];
+    counters[3] = h[3];
     if (reset) {
         HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, sizeof(h)));
-        ctx->counted_rays = 0;
     }
     return PBRT_HIP_OK;
 }
@@ -171,11 +171,115 @@ static float host_det_sin(float x) {
     return (ki == 0) ? sr : (ki == 1) ? cr : (ki == 2) ? -sr : -cr;
 }
 
+// Validates one reference-order LinearBVHNode array and converts it to the device records
+// (trace.h): interior nodes get indices base + 0.. in DFS order, leaves are encoded with count_bits.
+struct TreeLayout {
+    std::vector<float> inodes;   // 16 floats per interior node
+    int n_interior = 0, count_bits = 0;
+    int32_t root_ref = 0;
+};
+static const char* convert_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, int32_t n_prims, int32_t base,
+                                TreeLayout* out) {
+    std::vector<int32_t> interior_index(n_nodes, -1);
+    int n_interior = 0, max_count = 1;
+    int64_t leaf_prims = 0;
+    for (int32_t i = 0; i < n_nodes; ++i) {
+        const PbrtLinearBVHNode& nd = nodes[i];
+        if (nd.n_primitives > 0) {
+            if (nd.offset < 0 || (int64_t)nd.offset + nd.n_primitives > n_prims) return "leaf range outside the primitive list";
+            max_count = std::max<int>(max_count, nd.n_primitives);
+            leaf_prims += nd.n_primitives;
+        } else {
+            if (nd.axis > 2) return "interior node axis > 2";
+            if (nd.offset <= i + 1 || nd.offset >= n_nodes || i + 1 >= n_nodes) return "second-child offset out of range";
+            interior_index[i] = n_interior++;
+        }
+    }
+    if (leaf_prims != n_prims) return "leaves do not cover the primitive list exactly once";
+    if (n_interior != (n_nodes - 1) / 2 || (n_nodes & 1) == 0) return "node array is not a full binary tree";
+    int count_bits = 0;
+    while ((1 << count_bits) < max_count) ++count_bits;
+    if (((int64_t)n_prims << count_bits) >= (1ll << 31)) return "scene too large for 31-bit leaf references";
+    auto child_ref = [&](int32_t node) -> int32_t {
+        const PbrtLinearBVHNode& nd = nodes[node];
+        if (nd.n_primitives > 0) return ~(int32_t)(((uint32_t)nd.offset << count_bits) | (uint32_t)(nd.n_primitives - 1));
+        return base + interior_index[node];
+    };
+    out->inodes.assign((size_t)n_interior * 16, 0.0f);
+    for (int32_t i = 0; i < n_nodes; ++i) {
+        if (interior_index[i] < 0) continue;
+        const PbrtLinearBVHNode& c0 = nodes[i + 1];
+        const PbrtLinearBVHNode& c1 = nodes[nodes[i].offset];
+        float* r = &out->inodes[(size_t)interior_index[i] * 16];
+        r[0] = c0.bounds_min[0]; r[1] = c0.bounds_min[1]; r[2] = c0.bounds_min[2];
+        r[3] = c0.bounds_max[0]; r[4] = c0.bounds_max[1]; r[5] = c0.bounds_max[2];
+        r[6] = c1.bounds_min[0]; r[7] = c1.bounds_min[1]; r[8] = c1.bounds_min[2];
+        r[9] = c1.bounds_max[0]; r[10] = c1.bounds_max[1]; r[11] = c1.bounds_max[2];
+        int32_t refs[4] = {child_ref(i + 1), child_ref(nodes[i].offset), (int32_t)nodes[i].axis, 0};
+        std::memcpy(r + 12, refs, 16);
+    }
+    out->n_interior = n_interior;
+    out->count_bits = count_bits;
+    out->root_ref = child_ref(0);
+    return nullptr;
+}
+
+struct InstancingArgs {
+    const PbrtInstance* instances = nullptr;
+    int32_t n_instances = 0;
+    const PbrtLinearBVHNode* tlas_nodes = nullptr;
+    int32_t n_tlas_nodes = 0;
+    const int32_t* tlas_order = nullptr;
+};
+
+static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_t n_verts, const int32_t* indices,
+                             int32_t n_tris, const int32_t* tri_material, const PbrtMaterial* materials,
+                             int32_t n_materials, const int32_t* tri_light, const PbrtLight* lights, int32_t n_lights,
+                             const PbrtLinearBVHNode* nodes, int32_t n_nodes, const int32_t* prim_order,
+                             const InstancingArgs& ia, PbrtHipScene** out);
+
 extern "C" int pbrt_hip_scene_create(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
                                      const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
                                      const PbrtMaterial* materials, int32_t n_materials, const int32_t* tri_light,
                                      const PbrtLight* lights, int32_t n_lights, const PbrtLinearBVHNode* nodes,
                                      int32_t n_nodes, const int32_t* prim_order, PbrtHipScene** out) {
+    return scene_create_impl(ctx, positions, n_verts, indices, n_tris, tri_material, materials, n_materials, tri_light,
+                             lights, n_lights, nodes, n_nodes, prim_order, InstancingArgs(), out);
+}
+
+extern "C" int pbrt_hip_scene_create_instanced(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
+                                               const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
+                                               const PbrtMaterial* materials, int32_t n_materials,
+                                               const PbrtLight* lights, int32_t n_lights,
+                                               const PbrtLinearBVHNode* blas_nodes, int32_t n_blas_nodes,
+                                               const int32_t* blas_order, const PbrtInstance* instances,
+                                               int32_t n_instances, const PbrtLinearBVHNode* tlas_nodes,
+                                               int32_t n_tlas_nodes, const int32_t* tlas_order, PbrtHipScene** out) {
+    if (!ctx || !out) return PBRT_HIP_ERR_INVALID;
+    if (!instances || n_instances <= 0 || !tlas_nodes || n_tlas_nodes <= 0 || !tlas_order) {
+        ctx->last_error = "instanced scene needs instances and a top-level node array";
+        return PBRT_HIP_ERR_INVALID;
+    }
+    for (int32_t i = 0; i < n_lights; ++i)
+        if (lights[i].type != PBRT_LIGHT_INFINITE) {
+            ctx->last_error = "instanced primitives cannot be area lights: only infinite lights are accepted";
+            return PBRT_HIP_ERR_INVALID;
+        }
+    InstancingArgs ia;
+    ia.instances = instances;
+    ia.n_instances = n_instances;
+    ia.tlas_nodes = tlas_nodes;
+    ia.n_tlas_nodes = n_tlas_nodes;
+    ia.tlas_order = tlas_order;
+    return scene_create_impl(ctx, positions, n_verts, indices, n_tris, tri_material, materials, n_materials, nullptr,
+                             lights, n_lights, blas_nodes, n_blas_nodes, blas_order, ia, out);
+}
+
+static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_t n_verts, const int32_t* indices,
+                             int32_t n_tris, const int32_t* tri_material, const PbrtMaterial* materials,
+                             int32_t n_materials, const int32_t* tri_light, const PbrtLight* lights, int32_t n_lights,
+                             const PbrtLinearBVHNode* nodes, int32_t n_nodes, const int32_t* prim_order,
+                             const InstancingArgs& ia, PbrtHipScene** out) {
     if (!ctx || !out) return PBRT_HIP_ERR_INVALID;
     *out = nullptr;
     auto fail = [&](const char* msg) {
@@ -198,32 +302,27 @@ extern "C" int pbrt_hip_scene_create(PbrtHipContext* ctx, const float* positions
             return fail("area light triangle out of range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-    // ---- validate the tree and number interior nodes in DFS order ----
-    std::vector<int32_t> interior_index(n_nodes, -1);
-    int n_interior = 0, max_count = 1;
-    int64_t leaf_prims = 0;
-    for (int32_t i = 0; i < n_nodes; ++i) {
-        const PbrtLinearBVHNode& nd = nodes[i];
-        if (nd.n_primitives > 0) {
-            if (nd.offset < 0 || (int64_t)nd.offset + nd.n_primitives > n_tris) return fail("leaf range outside the primitive list");
-            max_count = std::max<int>(max_count, nd.n_primitives);
-            leaf_prims += nd.n_primitives;
-        } else {
-            if (nd.axis > 2) return fail("interior node axis > 2");
-            if (nd.offset <= i + 1 || nd.offset >= n_nodes || i + 1 >= n_nodes) return fail("second-child offset out of range");
-            interior_index[i] = n_interior++;
+    // ---- validate the tree(s) and lay out the interior records ----
+    // single level: one tree over the triangles. Two levels (instancing): top-level tree over the
+    // instances first, then the object-level tree over the triangles, in one record array.
+    const bool instanced = ia.n_instances > 0;
+    TreeLayout top, obj;
+    if (instanced) {
+        for (int32_t i = 0; i < ia.n_instances; ++i) {
+            if (ia.tlas_order[i] < 0 || ia.tlas_order[i] >= ia.n_instances) return fail("tlas_order entry out of range");
+            const float* m = ia.instances[i].to_world;
+            const float* mi = ia.instances[i].to_object;
+            if (m[12] != 0.0f || m[13] != 0.0f || m[14] != 0.0f || m[15] != 1.0f || mi[12] != 0.0f || mi[13] != 0.0f ||
+                mi[14] != 0.0f || mi[15] != 1.0f)
+                return fail("instance transforms must be affine (last row 0 0 0 1)");
+            if (ia.instances[i].material >= n_materials) return fail("instance material out of range");
         }
+        if (const char* e = convert_tree(ia.tlas_nodes, ia.n_tlas_nodes, ia.n_instances, 0, &top)) return fail(e);
+        if (const char* e = convert_tree(nodes, n_nodes, n_tris, top.n_interior, &obj)) return fail(e);
+    } else {
+        if (const char* e = convert_tree(nodes, n_nodes, n_tris, 0, &top)) return fail(e);
     }
-    if (leaf_prims != n_tris) return fail("leaves do not cover the primitive list exactly once");
-    if (n_interior != (n_nodes - 1) / 2 || (n_nodes & 1) == 0) return fail("node array is not a full binary tree");
-    int count_bits = 0;
-    while ((1 << count_bits) < max_count) ++count_bits;
-    if (((int64_t)n_tris << count_bits) >= (1ll << 31)) return fail("scene too large for 31-bit leaf references");
-    auto child_ref = [&](int32_t node) -> int32_t {
-        const PbrtLinearBVHNode& nd = nodes[node];
-        if (nd.n_primitives > 0) return ~(int32_t)(((uint32_t)nd.offset << count_bits) | (uint32_t)(nd.n_primitives - 1));
-        return interior_index[node];
-    };
+    const int n_interior = top.n_interior + obj.n_interior;
 
     PbrtHipScene* s = new PbrtHipScene();
     s->ctx = ctx;
@@ -233,19 +332,9 @@ extern "C" int pbrt_hip_scene_create(PbrtHipContext* ctx, const float* positions
     bool ok = true;
 
     // ---- interior records: both children's boxes + references + axis (64 B) ----
-    std::vector<float> inodes((size_t)std::max(1, n_interior) * 16, 0.0f);
-    for (int32_t i = 0; i < n_nodes; ++i) {
-        if (interior_index[i] < 0) continue;
-        const PbrtLinearBVHNode& c0 = nodes[i + 1];
-        const PbrtLinearBVHNode& c1 = nodes[nodes[i].offset];
-        float* r = &inodes[(size_t)interior_index[i] * 16];
-        r[0] = c0.bounds_min[0]; r[1] = c0.bounds_min[1]; r[2] = c0.bounds_min[2];
-        r[3] = c0.bounds_max[0]; r[4] = c0.bounds_max[1]; r[5] = c0.bounds_max[2];
-        r[6] = c1.bounds_min[0]; r[7] = c1.bounds_min[1]; r[8] = c1.bounds_min[2];
-        r[9] = c1.bounds_max[0]; r[10] = c1.bounds_max[1]; r[11] = c1.bounds_max[2];
-        int32_t refs[4] = {child_ref(i + 1), child_ref(nodes[i].offset), (int32_t)nodes[i].axis, 0};
-        std::memcpy(r + 12, refs, 16);
-    }
+    std::vector<float> inodes(top.inodes);
+    inodes.insert(inodes.end(), obj.inodes.begin(), obj.inodes.end());
+    if (inodes.empty()) inodes.assign(16, 0.0f);
     // ---- triangles in leaf order (48 B) ----
     std::vector<float> tris((size_t)n_tris * 12);
     std::vector<int32_t> prim_slot(n_tris, -1);
@@ -275,8 +364,8 @@ extern "C" int pbrt_hip_scene_create(PbrtHipContext* ctx, const float* positions
     float world_center[3], world_radius;
     {
         // Bounds3::bounding_sphere of the root bounds (infinite.rs:135-139)
-        const float* mn = nodes[0].bounds_min;
-        const float* mx = nodes[0].bounds_max;
+        const float* mn = (ia.n_instances > 0 ? ia.tlas_nodes[0] : nodes[0]).bounds_min;
+        const float* mx = (ia.n_instances > 0 ? ia.tlas_nodes[0] : nodes[0]).bounds_max;
         float dx[3];
         for (int k = 0; k < 3; ++k) {
             world_center[k] = (mn[k] + mx[k]) / 2.0f;
@@ -326,11 +415,38 @@ extern "C" int pbrt_hip_scene_create(PbrtHipContext* ctx, const float* positions
     std::memset(&d, 0, sizeof(d));
     d.bvh.inodes = (const float4*)dev_upload(s, inodes.data(), inodes.size(), &ok);
     d.bvh.tris = (const float4*)dev_upload(s, tris.data(), tris.size(), &ok);
-    std::memcpy(d.bvh.root_min, nodes[0].bounds_min, 12);
-    std::memcpy(d.bvh.root_max, nodes[0].bounds_max, 12);
-    d.bvh.root_ref = child_ref(0);
-    d.bvh.count_bits = count_bits;
+    const PbrtLinearBVHNode& root = instanced ? ia.tlas_nodes[0] : nodes[0];
+    std::memcpy(d.bvh.root_min, root.bounds_min, 12);
+    std::memcpy(d.bvh.root_max, root.bounds_max, 12);
+    d.bvh.root_ref = top.root_ref;
+    d.bvh.count_bits = top.count_bits;
     d.bvh.n_slots = n_tris;
+    d.bvh.instanced = instanced ? 1 : 0;
+    if (instanced) {
+        std::memcpy(d.bvh.blas_root_min, nodes[0].bounds_min, 12);
+        std::memcpy(d.bvh.blas_root_max, nodes[0].bounds_max, 12);
+        d.bvh.blas_root_ref = obj.root_ref;
+        d.bvh.blas_count_bits = obj.count_bits;
+        // instance records in top-level leaf order: to_object rows 0-2, to_world rows 0-2, (material, id)
+        std::vector<float> inst((size_t)ia.n_instances * 28, 0.0f);
+        std::vector<int32_t> slot_inst(ia.n_instances);
+        std::vector<char> seen(ia.n_instances, 0);
+        for (int32_t slot = 0; slot < ia.n_instances; ++slot) {
+            int32_t id = ia.tlas_order[slot];
+            if (seen[id]) ok = false;
+            seen[id] = 1;
+            slot_inst[slot] = id;
+            float* r = &inst[(size_t)slot * 28];
+            std::memcpy(r, ia.instances[id].to_object, 48);
+            std::memcpy(r + 12, ia.instances[id].to_world, 48);
+            int32_t meta[4] = {ia.instances[id].material, id, 0, 0};
+            std::memcpy(r + 24, meta, 16);
+        }
+        if (!ok) ctx->last_error = "tlas_order is not a permutation";
+        d.bvh.instances = (const float4*)dev_upload(s, inst.data(), inst.size(), &ok);
+        d.slot_instance = dev_upload(s, slot_inst.data(), slot_inst.size(), &ok);
+        s->n_instances = ia.n_instances;
+    }
     // spill slab for the deepest 40 stack entries of every resident lane of the traversal grid
     s->spill_lanes = ctx->n_cus * 2048;
     {
@@ -414,74 +530,42 @@ extern "C" void pbrt_hip_scene_destroy(PbrtHipScene* s) {
 // ------------------------------------------------------------------------------------
 // batch intersect
 // ------------------------------------------------------------------------------------
-// Instrumented variant: one ray per lane to completion (traverse<.., COUNT = true>)
-template <bool ANY>
-__global__ void __launch_bounds__(kTraceBlock) k_intersect_batch_count(DevBVH bvh, const int* __restrict__ slot_prim,
-                                                                         const PbrtRay* __restrict__ rays, int64_t n,
-                                                                         PbrtHit* __restrict__ out_hits,
-                                                                         uint8_t* __restrict__ out_flags,
-                                                                         unsigned long long* counters) {
-    __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
-    const int lane_slot = blockIdx.x * kTraceBlock + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * kTraceBlock;
-    for (int64_t i = lane_slot; i < n; i += stride) {
-        const float4* rp = reinterpret_cast<const float4*>(rays + i);
-        float4 a = rp[0], b = rp[1];
-        TravRay r{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
-        TravHit h;
-        uint32_t n_node = 0, n_prim = 0;
-        bool found = traverse<ANY, true>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim);
-        count_flush(counters, n_node, n_prim);
-        if (ANY) {
-            out_flags[i] = found ? 1 : 0;
-        } else {
-            float4 o0 = make_float4(found ? h.t : kInf, h.b0, h.b1, h.b2);
-            int prim = found ? slot_prim[h.slot] : -1;
-            float4 o1 = make_float4(__int_as_float(prim), 0.0f, 0.0f, 0.0f);
-            float4* op = reinterpret_cast<float4*>(out_hits + i);
-            op[0] = o0;
-            op[1] = o1;
-        }
-    }
-}
-
-// Production variant: persistent threads (trace_persistent.h)
+// Persistent-threads traversal (trace_persistent.h) over a caller-supplied ray batch
 template <bool ANY>
 struct BatchRayIO {
     const int* __restrict__ slot_prim;
+    const int* __restrict__ slot_instance;
     const PbrtRay* __restrict__ rays;
     uint32_t count;
     PbrtHit* __restrict__ out_hits;
     uint8_t* __restrict__ out_flags;
     PB_DEV uint32_t n() const { return count; }
-    PB_DEV void load(uint32_t i, TravRay* r, bool* any) const {
+    PB_DEV bool load(uint32_t i, TravRay* r, bool* any) const {
         const float4* rp = reinterpret_cast<const float4*>(rays + i);
         float4 a = rp[0], b = rp[1];
         *r = TravRay{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
         *any = ANY;
+        return true;
     }
-    PB_DEV void store(uint32_t i, bool any, bool found, float t, float b0, float b1, float b2, int slot) const {
+    PB_DEV void store(uint32_t i, bool any, bool found, float t, float b0, float b1, float b2, int slot, int inst) const {
         if (ANY) {
             out_flags[i] = found ? 1 : 0;
         } else {
             float4 o0 = make_float4(found ? t : kInf, found ? b0 : 0.0f, found ? b1 : 0.0f, found ? b2 : 0.0f);
             int prim = found ? slot_prim[slot] : -1;
+            int instance = (found && inst >= 0) ? slot_instance[inst] : -1;
             float4* op = reinterpret_cast<float4*>(out_hits + i);
             op[0] = o0;
-            op[1] = make_float4(__int_as_float(prim), 0.0f, 0.0f, 0.0f);
+            op[1] = make_float4(__int_as_float(prim), __int_as_float(instance), 0.0f, 0.0f);
         }
     }
 };
-template <bool ANY>
-__global__ void __launch_bounds__(kTraceBlock) k_intersect_batch(DevBVH bvh, BatchRayIO<ANY> io, unsigned int* work_counter) {
+template <bool ANY, bool COUNT, bool INST>
+__global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? 4 : PB_TRACE_WAVES)
+    k_intersect_batch(DevBVH bvh, BatchRayIO<ANY> io, unsigned int* work_counter, unsigned long long* counters) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
-    trace_persistent(bvh, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x);
-}
-
-static int trace_grid(PbrtHipScene* s, int64_t n) {
-    int64_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
-    int64_t cap = s->spill_lanes / kTraceBlock;
-    return (int)std::max<int64_t>(1, std::min(blocks, cap));
+    trace_persistent<BatchRayIO<ANY>, COUNT, INST>(bvh, io, work_counter, lds_stack + threadIdx.x,
+                                                   blockIdx.x * kTraceBlock + threadIdx.x, counters);
 }
 
 // persistent kernels: enough blocks to fill every CU (LDS: 160 KiB / (kStackLds * 2 KiB) blocks of 256, at most 8)
@@ -496,18 +580,29 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
     if (n == 0) return PBRT_HIP_OK;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_work_counter, 0, sizeof(unsigned int), ctx->stream));
     if (ctx->time_trace) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    if (ctx->count_traversal) {
-        hipLaunchKernelGGL((k_intersect_batch_count<ANY>), dim3(trace_grid(s, n)), dim3(kTraceBlock), 0, ctx->stream,
-                           s->d.bvh, s->d.slot_prim, d_rays, n, d_hits, d_flags, ctx->d_counters);
-        ctx->counted_rays += (uint64_t)n;
-    } else {
-        if (n >= (1ll << 32) - kChunk * 4096ll) {
-            ctx->last_error = "batch too large for one launch (split it below 2^32 rays)";
-            return PBRT_HIP_ERR_INVALID;
+    if (n >= (1ll << 32) - kChunk * 8192ll) {
+        ctx->last_error = "batch too large for one launch (split it below 2^32 rays)";
+        return PBRT_HIP_ERR_INVALID;
+    }
+    {
+        BatchRayIO<ANY> io{s->d.slot_prim, s->d.slot_instance, d_rays, (uint32_t)n, d_hits, d_flags};
+        dim3 grid(persistent_grid(s)), block(kTraceBlock);
+        const bool inst = s->d.bvh.instanced != 0;
+        if (ctx->count_traversal) {
+            if (inst)
+                hipLaunchKernelGGL((k_intersect_batch<ANY, true, true>), grid, block, 0, ctx->stream, s->d.bvh, io,
+                                   ctx->d_work_counter, ctx->d_counters);
+            else
+                hipLaunchKernelGGL((k_intersect_batch<ANY, true, false>), grid, block, 0, ctx->stream, s->d.bvh, io,
+                                   ctx->d_work_counter, ctx->d_counters);
+        } else {
+            if (inst)
+                hipLaunchKernelGGL((k_intersect_batch<ANY, false, true>), grid, block, 0, ctx->stream, s->d.bvh, io,
+                                   ctx->d_work_counter, ctx->d_counters);
+            else
+                hipLaunchKernelGGL((k_intersect_batch<ANY, false, false>), grid, block, 0, ctx->stream, s->d.bvh, io,
+                                   ctx->d_work_counter, ctx->d_counters);
         }
-        BatchRayIO<ANY> io{s->d.slot_prim, d_rays, (uint32_t)n, d_hits, d_flags};
-        hipLaunchKernelGGL((k_intersect_batch<ANY>), dim3(persistent_grid(s)), dim3(kTraceBlock), 0, ctx->stream, s->d.bvh,
-                           io, ctx->d_work_counter);
     }
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->time_trace) {
@@ -815,13 +910,24 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             if (n_trace > 0) {
                 RENDER_TRY(hipMemsetAsync(ctx->d_work_counter, 0, sizeof(unsigned int), st));
                 RENDER_TRY(hipEventRecord(e_t0, st));
-                if (ctx->count_traversal) {
-                    hipLaunchKernelGGL(k_trace_count, dim3(trace_grid(s, n_trace)), dim3(kTraceBlock), 0, st, s->d.bvh,
-                                       ps, q[cur].trace, n_trace, ctx->d_counters);
-                    ctx->counted_rays += n_trace;
-                } else {
-                    hipLaunchKernelGGL(k_trace, dim3(persistent_grid(s)), dim3(kTraceBlock), 0, st, s->d.bvh, ps,
-                                       q[cur].trace, n_trace, ctx->d_work_counter);
+                {
+                    dim3 grid(persistent_grid(s)), block(kTraceBlock);
+                    const bool inst = s->d.bvh.instanced != 0;
+                    if (ctx->count_traversal) {
+                        if (inst)
+                            hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, st, s->d.bvh, ps, q[cur].trace,
+                                               n_trace, ctx->d_work_counter, ctx->d_counters);
+                        else
+                            hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, st, s->d.bvh, ps, q[cur].trace,
+                                               n_trace, ctx->d_work_counter, ctx->d_counters);
+                    } else {
+                        if (inst)
+                            hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, st, s->d.bvh, ps, q[cur].trace,
+                                               n_trace, ctx->d_work_counter, ctx->d_counters);
+                        else
+                            hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, st, s->d.bvh, ps, q[cur].trace,
+                                               n_trace, ctx->d_work_counter, ctx->d_counters);
+                    }
                 }
                 RENDER_TRY(hipGetLastError());
                 RENDER_TRY(hipEventRecord(e_t1, st));

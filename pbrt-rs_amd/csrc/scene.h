@@ -59,6 +59,7 @@ struct DevDistribution1D {
 struct DevSceneData {
     DevBVH bvh;
     const int* slot_prim;       // leaf slot -> caller's triangle index
+    const int* slot_instance;   // top-level leaf slot -> caller's instance index (instanced scenes)
     const DevMaterial* materials;
     const DevLight* lights;
     int n_lights;
@@ -78,7 +79,7 @@ struct PbrtHipScene {
     PbrtHipContext* ctx = nullptr;
     pb::DevSceneData d;          // device pointers inside
     std::vector<void*> allocs;   // everything to hipFree
-    int n_tris = 0, n_nodes = 0, n_interior = 0;
+    int n_tris = 0, n_nodes = 0, n_interior = 0, n_instances = 0;
     int spill_lanes = 0;
     std::vector<pb::DevLight> h_lights;
     std::vector<int> light_samples;  // max(1, n_samples) per light (light.rs:76)

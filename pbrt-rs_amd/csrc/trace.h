@@ -16,6 +16,7 @@
 //   * triangles in leaf order, 48 B each: {v0.xyz v1.x | v1.yz v2.xy | v2.z prim_id material light}.
 //   * traversal stack: STACK_LDS entries per lane in LDS ([entry][lane], conflict-free),
 //     deeper entries spill to a per-lane global slab.
+// The traversal loop itself is in trace_persistent.h.
 #pragma once
 #include "dev_math.h"
 
@@ -30,6 +31,13 @@ struct DevBVH {
     int n_slots;
     uint2* __restrict__ spill;  // [entry][global lane] overflow stack
     int spill_stride;           // number of lanes the slab was sized for
+    // two-level scenes (TransformedPrimitive instances of one object-space aggregate): the fields
+    // above describe the top level (leaves = instance slots); these describe the object level.
+    int instanced;
+    const float4* __restrict__ instances;  // 7 x float4 per instance slot: to_object rows 0-2, to_world rows 0-2, (material, id, -, -)
+    int blas_root_ref;
+    int blas_count_bits;
+    float blas_root_min[3], blas_root_max[3];
 };
 
 #ifndef PB_STACK_LDS
@@ -150,147 +158,19 @@ PB_DEV void load_tri(const float4* __restrict__ tris, int slot, V3* p0, V3* p1, 
     *flags = __float_as_int(c.w);
 }
 
-// One ray per lane. `lds_stack` points at this lane's column: entry e lives at lds_stack[e * kTraceBlock].
-// ANY = true: BVHAccel::intersect_p (returns on the first triangle hit).
-// COUNT = true: instrumented variant that also returns the number of box tests (bvh.rs:841-842)
-// and triangle tests (triangle.rs:74) the REFERENCE's loop performs for this ray: the reference
-// pushes the far child untested and tests it when popped, so here a far child whose box already
-// failed is still pushed (entry distance +inf) and counted when popped; entries never popped
-// (any-hit early exit) are not counted. These counts feed the algorithmic-byte roofline.
-template <bool ANY, bool COUNT = false>
-PB_DEV bool traverse(const DevBVH& bvh, const TravRay& r, TravHit* hit, uint2* lds_stack, int spill_lane,
-                     uint32_t* n_node = nullptr, uint32_t* n_prim = nullptr) {
-    float tmax = r.tmax;
-    hit->t = tmax;
-    hit->slot = -1;
-    hit->b0 = hit->b1 = hit->b2 = 0.0f;
-    const float idx = 1.0f / r.dx, idy = 1.0f / r.dy, idz = 1.0f / r.dz;  // bvh.rs:831
-    const bool nx = idx < 0.0f, ny = idy < 0.0f, nz = idz < 0.0f;       // bvh.rs:832-836
-    const TriRayConst trc = tri_ray_setup(r);
-    float e;
-    if (COUNT) *n_node += 1;
-    if (!slab_test(nx ? bvh.root_max[0] : bvh.root_min[0], nx ? bvh.root_min[0] : bvh.root_max[0],
-                   ny ? bvh.root_max[1] : bvh.root_min[1], ny ? bvh.root_min[1] : bvh.root_max[1],
-                   nz ? bvh.root_max[2] : bvh.root_min[2], nz ? bvh.root_min[2] : bvh.root_max[2], r, idx, idy, idz,
-                   tmax, &e))
-        return false;
-    const int count_mask = (1 << bvh.count_bits) - 1;
-    int sp = 0;
-    int cur = bvh.root_ref;
-    bool found = false;
-    bool running = true;
-    while (running) {
-        // ---- interior nodes ----
-        while (running && cur >= 0) {
-            const float4* nd = bvh.inodes + 4 * (size_t)cur;
-            float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-            // child 0 box: min (q0.x q0.y q0.z) max (q0.w q1.x q1.y); child 1: min (q1.z q1.w q2.x) max (q2.y q2.z q2.w)
-            float e0, e1;
-            bool h0 = slab_test(nx ? q0.w : q0.x, nx ? q0.x : q0.w, ny ? q1.x : q0.y, ny ? q0.y : q1.x,
-                                nz ? q1.y : q0.z, nz ? q0.z : q1.y, r, idx, idy, idz, tmax, &e0);
-            bool h1 = slab_test(nx ? q2.y : q1.z, nx ? q1.z : q2.y, ny ? q2.z : q1.w, ny ? q1.w : q2.z,
-                                nz ? q2.w : q2.x, nz ? q2.x : q2.w, r, idx, idy, idz, tmax, &e1);
-            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y), axis = __float_as_int(q3.z);
-            // bvh.rs:857-865: if dir_is_neg[axis] visit the second child first
-            bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
-            int near_c = neg ? c1 : c0, far_c = neg ? c0 : c1;
-            bool near_h = neg ? h1 : h0, far_h = neg ? h0 : h1;
-            float far_e = neg ? e0 : e1;
-            if (COUNT) {
-                *n_node += 1;                 // the near child is tested as soon as it is visited
-                if (!near_h) *n_node += 1;    // near missed: the far child is popped and tested next
-                if (!far_h) far_e = kInf;
-            }
-            if (near_h) {
-                cur = near_c;
-                if (far_h || COUNT) {
-                    uint2 ent = make_uint2((uint32_t)far_c, __float_as_uint(far_e));
-                    if (sp < kStackLds)
-                        lds_stack[sp * kTraceBlock] = ent;
-                    else
-                        bvh.spill[(size_t)(sp - kStackLds) * bvh.spill_stride + spill_lane] = ent;
-                    ++sp;
-                }
-            } else if (far_h) {
-                cur = far_c;
-            } else {
-                // pop: skip entries whose entry distance no longer beats the shrunk t_max
-                for (;;) {
-                    if (sp == 0) {
-                        running = false;
-                        break;
-                    }
-                    --sp;
-                    uint2 ent = (sp < kStackLds) ? lds_stack[sp * kTraceBlock]
-                                                 : bvh.spill[(size_t)(sp - kStackLds) * bvh.spill_stride + spill_lane];
-                    if (COUNT) *n_node += 1;
-                    if (__uint_as_float(ent.y) < tmax) {
-                        cur = (int)ent.x;
-                        break;
-                    }
-                }
-            }
-        }
-        if (!running) break;
-        // ---- leaf ----
-        {
-            int ref = ~cur;
-            int n = (ref & count_mask) + 1;
-            int first = ref >> bvh.count_bits;
-            for (int i = 0; i < n; ++i) {
-                V3 p0, p1, p2;
-                int flags;
-                load_tri(bvh.tris, first + i, &p0, &p1, &p2, &flags);
-                float b0, b1, b2, t;
-                if (COUNT) *n_prim += 1;
-                if (triangle_test(p0, p1, p2, r, trc, tmax, &b0, &b1, &b2, &t)) {
-                    if (ANY) return true;
-                    if (!(flags & kTriDegenerate)) {
-                        tmax = t;  // primitive.rs:70
-                        hit->t = t;
-                        hit->b0 = b0;
-                        hit->b1 = b1;
-                        hit->b2 = b2;
-                        hit->slot = first + i;
-                        found = true;
-                    }
-                }
-            }
-            for (;;) {
-                if (sp == 0) {
-                    running = false;
-                    break;
-                }
-                --sp;
-                uint2 ent = (sp < kStackLds) ? lds_stack[sp * kTraceBlock]
-                                             : bvh.spill[(size_t)(sp - kStackLds) * bvh.spill_stride + spill_lane];
-                if (COUNT) *n_node += 1;
-                if (__uint_as_float(ent.y) < tmax) {
-                    cur = (int)ent.x;
-                    break;
-                }
-            }
-        }
-    }
-    return found;
-}
-
-// wave-reduce the instrumented counts, one atomic pair per wave
-PB_DEV void count_flush(unsigned long long* counters, uint32_t n_node, uint32_t n_prim, uint32_t n_rays = 1) {
-    // inactive lanes contribute 0 to __shfl_xor? No: they return their own stale register, so reduce
-    // with ballot-guarded values instead: every active lane adds through LDS-free wave atomics.
-    unsigned long long m = __ballot(1);
+// wave-reduce the instrumented counts (all 64 lanes active), one atomic set per wave
+PB_DEV void count_flush(unsigned long long* counters, uint32_t n_node, uint32_t n_prim, uint32_t n_rays, uint32_t n_inst) {
     for (int o = 32; o > 0; o >>= 1) {
-        uint32_t a = __shfl_xor(n_node, o, 64), b = __shfl_xor(n_prim, o, 64), c = __shfl_xor(n_rays, o, 64);
-        bool peer_active = (m >> ((threadIdx.x & 63) ^ o)) & 1ull;
-        n_node += peer_active ? a : 0u;
-        n_prim += peer_active ? b : 0u;
-        n_rays += peer_active ? c : 0u;
+        n_node += __shfl_xor(n_node, o, 64);
+        n_prim += __shfl_xor(n_prim, o, 64);
+        n_rays += __shfl_xor(n_rays, o, 64);
+        n_inst += __shfl_xor(n_inst, o, 64);
     }
-    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
+    if ((threadIdx.x & 63) == 0) {
         atomicAdd(&counters[0], (unsigned long long)n_node);
         atomicAdd(&counters[1], (unsigned long long)n_prim);
         atomicAdd(&counters[2], (unsigned long long)n_rays);
+        atomicAdd(&counters[3], (unsigned long long)n_inst);
     }
 }
 

@@ -1,7 +1,10 @@
 // trace_persistent.h — persistent-threads traversal with per-lane ray replacement.
 //
-// Same arithmetic and visiting order as traverse() in trace.h (BVHAccel::intersect / intersect_p,
-// src/accelerators/bvh.rs:828-932); what changes is how rays are scheduled onto the 64 lanes of a
+// Same arithmetic and visiting order as BVHAccel::intersect / intersect_p
+// (src/accelerators/bvh.rs:828-932) with Bounds3f::intersect_p (src/core/geometry.rs:709-751) and
+// Triangle::intersect_test (src/shapes/triangle.rs:74-158); with INST also TransformedPrimitive
+// (src/core/primitive.rs:136-159): a top-level BVHAccel whose leaves hold instances of one
+// object-space BVHAccel. What is MI355X-specific is how rays are scheduled onto the 64 lanes of a
 // wavefront. Ray lengths in an incoherent batch are heavy-tailed, so a wave that traces 64 rays
 // to completion idles most lanes (measured: ~9 % VALU lane utilisation). Here
 //   * a wave owns a contiguous chunk of the ray queue (one atomicAdd per kChunk rays),
@@ -11,6 +14,12 @@
 //     that reached a leaf wait and the leaf (<= max_prims triangles) is processed for all of them
 //     together (while-while with postponed leaves).
 // Traversal state lives in registers, the stack in LDS ([entry][lane]) with a global spill slab.
+//
+// COUNT = true is the instrumented variant: it also counts the box tests (bvh.rs:841-842),
+// triangle tests (triangle.rs:74) and instance entries (primitive.rs:136) that the REFERENCE's
+// loops perform for the same rays. The reference pushes the far child untested and tests it when
+// popped, so a far child whose box already failed is still pushed (entry distance +inf) and
+// counted when popped; entries never popped (any-hit early exit) are not counted.
 #pragma once
 #include "trace.h"
 
@@ -30,7 +39,7 @@ constexpr int kRefillThresh = PB_REFILL_THRESH;     // refill when at least this
 constexpr int kInteriorThresh = PB_INTERIOR_THRESH; // keep stepping interior nodes while at least this many lanes do
 
 struct LaneState {
-    TravRay r;
+    TravRay r;  // the ray being traversed (object-space inside an instance)
     float idx, idy, idz;
     TriRayConst trc;
     float tmax;
@@ -39,6 +48,15 @@ struct LaneState {
     int cur, sp;
     uint32_t index;  // queue position of this lane's ray
     bool nx, ny, nz, any, has_work;
+};
+// two-level state (INST)
+struct InstState {
+    float wox, woy, woz, wdx, wdy, wdz;  // world-space ray
+    float tmax_world;
+    int leaf_first, leaf_cnt, leaf_next;  // instance leaf being processed
+    int cur_inst, hit_inst;               // instance slots
+    int base_sp;                          // stack height when the instance was entered
+    bool in_instance, hit_here;
 };
 
 PB_DEV void stack_push(const DevBVH& bvh, uint2* lds_stack, int spill_lane, int& sp, int node, float entry) {
@@ -49,34 +67,137 @@ PB_DEV void stack_push(const DevBVH& bvh, uint2* lds_stack, int spill_lane, int&
         bvh.spill[(size_t)(sp - kStackLds) * bvh.spill_stride + spill_lane] = ent;
     ++sp;
 }
-// pop entries until one still beats t_max; returns false when the stack is empty (ray finished)
-PB_DEV bool stack_pop(const DevBVH& bvh, uint2* lds_stack, int spill_lane, int& sp, float tmax, int& cur) {
-    for (;;) {
-        if (sp == 0) return false;
-        --sp;
-        uint2 ent = (sp < kStackLds) ? lds_stack[sp * kTraceBlock]
-                                     : bvh.spill[(size_t)(sp - kStackLds) * bvh.spill_stride + spill_lane];
-        if (__uint_as_float(ent.y) < tmax) {
-            cur = (int)ent.x;
-            return true;
-        }
-    }
+PB_DEV uint2 stack_read(const DevBVH& bvh, const uint2* lds_stack, int spill_lane, int sp) {
+    return (sp < kStackLds) ? lds_stack[sp * kTraceBlock]
+                            : bvh.spill[(size_t)(sp - kStackLds) * bvh.spill_stride + spill_lane];
 }
 
-// IO policy: n(), load(i, &ray, &any), store(i, any, found, t, b0, b1, b2, slot)
-template <class IO>
+PB_DEV void ray_constants(LaneState& s) {
+    s.idx = 1.0f / s.r.dx;  // bvh.rs:831
+    s.idy = 1.0f / s.r.dy;
+    s.idz = 1.0f / s.r.dz;
+    s.nx = s.idx < 0.0f;    // bvh.rs:832-836
+    s.ny = s.idy < 0.0f;
+    s.nz = s.idz < 0.0f;
+    s.trc = tri_ray_setup(s.r);
+}
+PB_DEV bool root_box_test(const LaneState& s, const float* mn, const float* mx) {
+    float e;
+    return slab_test(s.nx ? mx[0] : mn[0], s.nx ? mn[0] : mx[0], s.ny ? mx[1] : mn[1], s.ny ? mn[1] : mx[1],
+                     s.nz ? mx[2] : mn[2], s.nz ? mn[2] : mx[2], s.r, s.idx, s.idy, s.idz, s.tmax, &e);
+}
+
+// IO policy: n(), load(i, &ray, &any) -> bool real ray, store(i, any, found, t, b0, b1, b2, slot, instance)
+template <class IO, bool COUNT, bool INST>
 PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __restrict__ work_counter,
-                             uint2* lds_stack, int spill_lane) {
+                             uint2* lds_stack, int spill_lane, unsigned long long* counters) {
     const uint32_t n = io.n();
     const int lane = threadIdx.x & 63;
     const int count_mask = (1 << bvh.count_bits) - 1;
+    const int tri_count_mask = INST ? ((1 << bvh.blas_count_bits) - 1) : count_mask;
+    const int tri_count_bits = INST ? bvh.blas_count_bits : bvh.count_bits;
     LaneState s;
+    InstState w;
     s.has_work = false;
     s.cur = 0;
     s.sp = 0;
     s.any = false;
+    w.in_instance = false;
+    w.hit_here = false;
+    w.base_sp = 0;
+    w.hit_inst = -1;
+    w.cur_inst = -1;
+    w.leaf_first = w.leaf_cnt = w.leaf_next = 0;
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
+    uint32_t n_node = 0, n_prim = 0, n_inst = 0, n_rays = 0;
+
+    auto finish = [&](bool found) {
+        io.store(s.index, s.any, found, s.tmax, s.b0, s.b1, s.b2, s.hit_slot, INST ? w.hit_inst : -1);
+        s.has_work = false;
+    };
+    // TransformedPrimitive::intersect, first half (primitive.rs:136-139): world ray -> object space
+    // (geometry.rs:865-881, 898-935), then the object aggregate's root box. Returns false if it misses.
+    auto enter_instance = [&](int slot) -> bool {
+        const float4* m = bvh.instances + 7 * (size_t)slot;
+        float4 r0 = m[0], r1 = m[1], r2 = m[2];
+        float x = w.wox, y = w.woy, z = w.woz;
+        float ox = r0.x * x + r0.y * y + r0.z * z + r0.w;
+        float oy = r1.x * x + r1.y * y + r1.z * z + r1.w;
+        float oz = r2.x * x + r2.y * y + r2.z * z + r2.w;
+        float xa = __builtin_fabsf(r0.x * x) + __builtin_fabsf(r0.y * y) + __builtin_fabsf(r0.z * z) + __builtin_fabsf(r0.w);
+        float ya = __builtin_fabsf(r1.x * x) + __builtin_fabsf(r1.y * y) + __builtin_fabsf(r1.z * z) + __builtin_fabsf(r1.w);
+        float za = __builtin_fabsf(r2.x * x) + __builtin_fabsf(r2.y * y) + __builtin_fabsf(r2.z * z) + __builtin_fabsf(r2.w);
+        float ex = xa * kGamma3, ey = ya * kGamma3, ez = za * kGamma3;
+        float dx = r0.x * w.wdx + r0.y * w.wdy + r0.z * w.wdz;
+        float dy = r1.x * w.wdx + r1.y * w.wdy + r1.z * w.wdz;
+        float dz = r2.x * w.wdx + r2.y * w.wdy + r2.z * w.wdz;
+        float l2 = dx * dx + dy * dy + dz * dz;
+        float tmax = w.tmax_world;
+        if (l2 > 0.0f) {
+            float dt = (__builtin_fabsf(dx) * ex + __builtin_fabsf(dy) * ey + __builtin_fabsf(dz) * ez) / l2;
+            ox = ox + dx * dt;
+            oy = oy + dy * dt;
+            oz = oz + dz * dt;
+            tmax -= dt;
+        }
+        s.r = TravRay{ox, oy, oz, dx, dy, dz, tmax};
+        s.tmax = tmax;
+        ray_constants(s);
+        w.in_instance = true;
+        w.hit_here = false;
+        w.cur_inst = slot;
+        w.base_sp = s.sp;
+        if (COUNT) {
+            n_inst += 1;
+            n_node += 1;  // the object aggregate tests its root box (bvh.rs:841-842)
+        }
+        if (!root_box_test(s, bvh.blas_root_min, bvh.blas_root_max)) return false;
+        s.cur = bvh.blas_root_ref;
+        return true;
+    };
+    // second half (primitive.rs:140-143): r.t_max = ray.t_max on a hit; back to the world ray
+    auto exit_instance = [&]() {
+        if (w.hit_here) w.tmax_world = s.tmax;
+        s.r = TravRay{w.wox, w.woy, w.woz, w.wdx, w.wdy, w.wdz, w.tmax_world};
+        s.tmax = w.tmax_world;
+        ray_constants(s);
+        w.in_instance = false;
+    };
+    // After a node / leaf is done: find the next node to visit. Returns false when the ray is finished.
+    auto advance = [&]() -> bool {
+        for (;;) {
+            if (INST && w.in_instance) {
+                if (s.sp > w.base_sp) {
+                    --s.sp;
+                    uint2 ent = stack_read(bvh, lds_stack, spill_lane, s.sp);
+                    if (COUNT) n_node += 1;
+                    if (__uint_as_float(ent.y) < s.tmax) {
+                        s.cur = (int)ent.x;
+                        return true;
+                    }
+                    continue;
+                }
+                exit_instance();
+                // remaining instances of the top-level leaf (bvh.rs:844-850)
+                while (w.leaf_next < w.leaf_cnt) {
+                    int slot = w.leaf_first + w.leaf_next;
+                    w.leaf_next += 1;
+                    if (enter_instance(slot)) return true;
+                    exit_instance();
+                }
+                continue;
+            }
+            if (s.sp == 0) return false;
+            --s.sp;
+            uint2 ent = stack_read(bvh, lds_stack, spill_lane, s.sp);
+            if (COUNT) n_node += 1;
+            if (__uint_as_float(ent.y) < s.tmax) {
+                s.cur = (int)ent.x;
+                return true;
+            }
+        }
+    };
 
     for (;;) {
         // ---------------- refill idle lanes ----------------
@@ -99,28 +220,34 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
             chunk_next += ((uint32_t)n_idle < avail) ? (uint32_t)n_idle : avail;
             if (take) {
                 s.index = my;
-                io.load(my, &s.r, &s.any);
+                bool real = io.load(my, &s.r, &s.any);
                 s.tmax = s.r.tmax;
-                s.idx = 1.0f / s.r.dx;  // bvh.rs:831
-                s.idy = 1.0f / s.r.dy;
-                s.idz = 1.0f / s.r.dz;
-                s.nx = s.idx < 0.0f;    // bvh.rs:832-836
-                s.ny = s.idy < 0.0f;
-                s.nz = s.idz < 0.0f;
-                s.trc = tri_ray_setup(s.r);
                 s.hit_slot = -1;
                 s.b0 = s.b1 = s.b2 = 0.0f;
                 s.sp = 0;
-                s.cur = bvh.root_ref;
                 s.has_work = true;
-                float e;
-                bool root_hit = slab_test(s.nx ? bvh.root_max[0] : bvh.root_min[0], s.nx ? bvh.root_min[0] : bvh.root_max[0],
-                                          s.ny ? bvh.root_max[1] : bvh.root_min[1], s.ny ? bvh.root_min[1] : bvh.root_max[1],
-                                          s.nz ? bvh.root_max[2] : bvh.root_min[2], s.nz ? bvh.root_min[2] : bvh.root_max[2],
-                                          s.r, s.idx, s.idy, s.idz, s.tmax, &e);
-                if (!root_hit) {
-                    io.store(s.index, s.any, false, s.tmax, 0.0f, 0.0f, 0.0f, -1);
-                    s.has_work = false;
+                if (INST) {
+                    w.wox = s.r.ox;
+                    w.woy = s.r.oy;
+                    w.woz = s.r.oz;
+                    w.wdx = s.r.dx;
+                    w.wdy = s.r.dy;
+                    w.wdz = s.r.dz;
+                    w.tmax_world = s.r.tmax;
+                    w.in_instance = false;
+                    w.hit_inst = -1;
+                    w.leaf_cnt = w.leaf_next = 0;
+                }
+                if (!real) {
+                    finish(false);  // placeholder of a path outside pixel_bounds: not a ray of the frame
+                } else {
+                    ray_constants(s);
+                    s.cur = bvh.root_ref;
+                    if (COUNT) {
+                        n_rays += 1;
+                        n_node += 1;
+                    }
+                    if (!root_box_test(s, bvh.root_min, bvh.root_max)) finish(false);
                 }
             }
         }
@@ -129,7 +256,7 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
             continue;
         }
 
-        // ---------------- interior nodes ----------------
+        // ---------------- interior nodes (both levels) ----------------
         for (;;) {
             bool interior = s.has_work && s.cur >= 0;
             unsigned long long im = __ballot(interior);
@@ -155,52 +282,77 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
                 int near_c = neg ? c1 : c0, far_c = neg ? c0 : c1;
                 bool near_h = neg ? h1 : h0, far_h = neg ? h0 : h1;
                 float far_e = neg ? e0 : e1;
+                if (COUNT) {
+                    n_node += 1;               // the near child is tested as soon as it is visited
+                    if (!near_h) n_node += 1;  // near missed: the far child is popped and tested next
+                    if (!far_h) far_e = kInf;
+                }
                 if (near_h) {
                     s.cur = near_c;
-                    if (far_h) stack_push(bvh, lds_stack, spill_lane, s.sp, far_c, far_e);
+                    if (far_h || COUNT) stack_push(bvh, lds_stack, spill_lane, s.sp, far_c, far_e);
                 } else if (far_h) {
                     s.cur = far_c;
-                } else if (!stack_pop(bvh, lds_stack, spill_lane, s.sp, s.tmax, s.cur)) {
-                    io.store(s.index, s.any, s.hit_slot >= 0, s.tmax, s.b0, s.b1, s.b2, s.hit_slot);
-                    s.has_work = false;
+                } else if (!advance()) {
+                    finish(s.hit_slot >= 0);
                 }
             }
         }
 
         // ---------------- leaves ----------------
         if (s.has_work && s.cur < 0) {
-            int ref = ~s.cur;
-            int cnt = (ref & count_mask) + 1;
-            int first = ref >> bvh.count_bits;
-            bool done = false;
-            for (int i = 0; i < cnt; ++i) {
-                V3 p0, p1, p2;
-                int flags;
-                load_tri(bvh.tris, first + i, &p0, &p1, &p2, &flags);
-                float b0, b1, b2, t;
-                if (triangle_test(p0, p1, p2, s.r, s.trc, s.tmax, &b0, &b1, &b2, &t)) {
-                    if (s.any) {
-                        done = true;
-                        break;
-                    }
-                    if (!(flags & kTriDegenerate)) {
-                        s.tmax = t;  // primitive.rs:70
-                        s.b0 = b0;
-                        s.b1 = b1;
-                        s.b2 = b2;
-                        s.hit_slot = first + i;
+            if (INST && !w.in_instance) {
+                // top-level leaf: TransformedPrimitives in leaf order (bvh.rs:844-850)
+                int ref = ~s.cur;
+                w.leaf_cnt = (ref & count_mask) + 1;
+                w.leaf_first = ref >> bvh.count_bits;
+                w.leaf_next = 0;
+                bool entered = false;
+                while (w.leaf_next < w.leaf_cnt && !entered) {
+                    int slot = w.leaf_first + w.leaf_next;
+                    w.leaf_next += 1;
+                    entered = enter_instance(slot);
+                    if (!entered) exit_instance();
+                }
+                if (!entered && !advance()) finish(s.hit_slot >= 0);
+            } else {
+                int ref = ~s.cur;
+                int cnt = (ref & tri_count_mask) + 1;
+                int first = ref >> tri_count_bits;
+                bool done = false;
+                for (int i = 0; i < cnt; ++i) {
+                    V3 p0, p1, p2;
+                    int flags;
+                    load_tri(bvh.tris, first + i, &p0, &p1, &p2, &flags);
+                    float b0, b1, b2, t;
+                    if (COUNT) n_prim += 1;
+                    if (triangle_test(p0, p1, p2, s.r, s.trc, s.tmax, &b0, &b1, &b2, &t)) {
+                        if (s.any) {
+                            done = true;
+                            break;
+                        }
+                        if (!(flags & kTriDegenerate)) {
+                            s.tmax = t;  // primitive.rs:70
+                            s.b0 = b0;
+                            s.b1 = b1;
+                            s.b2 = b2;
+                            s.hit_slot = first + i;
+                            if (INST) {
+                                w.hit_here = true;
+                                w.hit_inst = w.cur_inst;
+                            }
+                        }
                     }
                 }
-            }
-            if (done) {
-                io.store(s.index, true, true, s.tmax, 0.0f, 0.0f, 0.0f, first);
-                s.has_work = false;
-            } else if (!stack_pop(bvh, lds_stack, spill_lane, s.sp, s.tmax, s.cur)) {
-                io.store(s.index, s.any, s.hit_slot >= 0, s.tmax, s.b0, s.b1, s.b2, s.hit_slot);
-                s.has_work = false;
+                if (done) {
+                    s.hit_slot = first;
+                    finish(true);
+                } else if (!advance()) {
+                    finish(s.hit_slot >= 0);
+                }
             }
         }
     }
+    if (COUNT) count_flush(counters, n_node, n_prim, n_rays, n_inst);
 }
 
 }  // namespace pb

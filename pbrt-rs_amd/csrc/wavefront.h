@@ -208,54 +208,23 @@ __global__ void k_generate(PathState ps, Queues q, PassParams pp, DevCamera cam,
     q.shade[p] = p;
 }
 
-// ---- trace: every pending ray of the wavefront ----
-// Instrumented variant (COUNT): one ray per lane to completion, counts the reference's box / triangle tests.
-__global__ void __launch_bounds__(kTraceBlock) k_trace_count(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue,
-                                                               uint32_t n, unsigned long long* counters) {
-    __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
-    const int lane_slot = blockIdx.x * kTraceBlock + threadIdx.x;
-    const uint32_t stride = gridDim.x * kTraceBlock;
-    for (uint32_t i = lane_slot; i < n; i += stride) {
-        uint32_t e = queue[i];
-        uint32_t p = e >> 2, slot = e & 3u;
-        size_t ri = ((size_t)p * 3 + slot) * 2;
-        float4 a = ps.ray[ri], b = ps.ray[ri + 1];
-        TravRay r{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
-        TravHit h;
-        bool any = slot == RS_SHADOW;
-        uint32_t n_node = 0, n_prim = 0;
-        // t_max < 0 marks the placeholder ray of a path outside pixel_bounds (k_generate): not a ray of the frame
-        bool real = !(r.tmax < 0.0f);
-        bool found = false;
-        h.t = r.tmax; h.b0 = h.b1 = h.b2 = 0.0f; h.slot = -1;
-        if (real)
-            found = any ? traverse<true, true>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim)
-                        : traverse<false, true>(bvh, r, &h, lds_stack + threadIdx.x, lane_slot, &n_node, &n_prim);
-        count_flush(counters, n_node, n_prim, real ? 1u : 0u);
-        if (any) {
-            ps.hit[ri] = make_float4(found ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
-        } else {
-            ps.hit[ri] = make_float4(h.t, h.b0, h.b1, h.b2);
-            ps.hit[ri + 1] = make_float4(__int_as_float(found ? h.slot : -1), 0.0f, 0.0f, 0.0f);
-        }
-    }
-}
-
-// Production variant: persistent threads, per-lane ray replacement (trace_persistent.h)
+// ---- trace: every pending ray of the wavefront (trace_persistent.h) ----
 struct WavefrontRayIO {
     PathState ps;
     const uint32_t* __restrict__ queue;
     uint32_t count;
     PB_DEV uint32_t n() const { return count; }
-    PB_DEV void load(uint32_t i, TravRay* r, bool* any) const {
+    PB_DEV bool load(uint32_t i, TravRay* r, bool* any) const {
         uint32_t e = queue[i];
         uint32_t p = e >> 2, slot = e & 3u;
         size_t ri = ((size_t)p * 3 + slot) * 2;
         float4 a = ps.ray[ri], b = ps.ray[ri + 1];
         *r = TravRay{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
         *any = slot == RS_SHADOW;
+        // t_max < 0 marks the placeholder ray of a path outside pixel_bounds (k_generate): not a ray of the frame
+        return !(b.z < 0.0f);
     }
-    PB_DEV void store(uint32_t i, bool any, bool found, float t, float b0, float b1, float b2, int slot) const {
+    PB_DEV void store(uint32_t i, bool any, bool found, float t, float b0, float b1, float b2, int slot, int inst) const {
         uint32_t e = queue[i];
         uint32_t p = e >> 2, rs = e & 3u;
         size_t ri = ((size_t)p * 3 + rs) * 2;
@@ -263,19 +232,21 @@ struct WavefrontRayIO {
             ps.hit[ri] = make_float4(found ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
         } else {
             ps.hit[ri] = make_float4(t, b0, b1, b2);
-            ps.hit[ri + 1] = make_float4(__int_as_float(found ? slot : -1), 0.0f, 0.0f, 0.0f);
+            ps.hit[ri + 1] = make_float4(__int_as_float(found ? slot : -1), __int_as_float(inst), 0.0f, 0.0f);
         }
     }
 };
 #ifndef PB_TRACE_WAVES
 #define PB_TRACE_WAVES 6
 #endif
-__global__ void __launch_bounds__(kTraceBlock, PB_TRACE_WAVES) k_trace(DevBVH bvh, PathState ps,
-                                                                         const uint32_t* __restrict__ queue, uint32_t n,
-                                                                         unsigned int* work_counter) {
+template <bool COUNT, bool INST>
+__global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? 4 : PB_TRACE_WAVES)
+    k_trace(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
+            unsigned long long* counters) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
     WavefrontRayIO io{ps, queue, n};
-    trace_persistent(bvh, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x);
+    trace_persistent<WavefrontRayIO, COUNT, INST>(bvh, io, work_counter, lds_stack + threadIdx.x,
+                                                  blockIdx.x * kTraceBlock + threadIdx.x, counters);
 }
 
 // ---- shading helpers ----
@@ -319,6 +290,54 @@ PB_DEV Surf make_surface(const DevBVH& bvh, int slot, float b0, float b1, float 
     s.dpdu = dpdu;
     s.wo = -ray_d;
     return s;
+}
+// Transform::operator()(SurfaceInteraction) of pbrt-v3 (transform.rs:620-627 is a TODO in the reference, D6):
+// object-space hit -> world space through the instance's matrices (primitive.rs:145-147).
+PB_DEV void instance_to_world(const DevBVH& bvh, int inst_slot, Surf* s) {
+    const float4* m = bvh.instances + 7 * (size_t)inst_slot;
+    float4 o0 = m[0], o1 = m[1], o2 = m[2];  // to_object rows (= inverse of to_world)
+    float4 w0 = m[3], w1 = m[4], w2 = m[5];  // to_world rows
+    V3 p = s->p, pe = s->p_error;
+    // point with incoming absolute error (geometry.rs:936-1000)
+    float xp = w0.x * p.x + w0.y * p.y + w0.z * p.z + w0.w;
+    float yp = w1.x * p.x + w1.y * p.y + w1.z * p.z + w1.w;
+    float zp = w2.x * p.x + w2.y * p.y + w2.z * p.z + w2.w;
+    const float g3 = kGamma3;
+    V3 err;
+    err.x = (g3 + 1.0f) * (__builtin_fabsf(w0.x * pe.x) + __builtin_fabsf(w0.y * pe.y) + __builtin_fabsf(w0.z * pe.z)) +
+            g3 * (__builtin_fabsf(w0.x * p.x) + __builtin_fabsf(w0.y * p.y) + __builtin_fabsf(w0.z * p.z) + __builtin_fabsf(w0.w));
+    err.y = (g3 + 1.0f) * (__builtin_fabsf(w1.x * pe.x) + __builtin_fabsf(w1.y * pe.y) + __builtin_fabsf(w1.z * pe.z)) +
+            g3 * (__builtin_fabsf(w1.x * p.x) + __builtin_fabsf(w1.y * p.y) + __builtin_fabsf(w1.z * p.z) + __builtin_fabsf(w1.w));
+    err.z = (g3 + 1.0f) * (__builtin_fabsf(w2.x * pe.x) + __builtin_fabsf(w2.y * pe.y) + __builtin_fabsf(w2.z * pe.z)) +
+            g3 * (__builtin_fabsf(w2.x * p.x) + __builtin_fabsf(w2.y * p.y) + __builtin_fabsf(w2.z * p.z) + __builtin_fabsf(w2.w));
+    s->p = V3{xp, yp, zp};
+    s->p_error = err;
+    // normal: (M^-1)^T n (transform.rs:387-403, intended form), then normalised
+    V3 n = s->n;
+    s->n = normalize(V3{o0.x * n.x + o1.x * n.y + o2.x * n.z, o0.y * n.x + o1.y * n.y + o2.y * n.z,
+                        o0.z * n.x + o1.z * n.y + o2.z * n.z});
+    V3 wo = s->wo, du = s->dpdu;
+    s->wo = normalize(V3{w0.x * wo.x + w0.y * wo.y + w0.z * wo.z, w1.x * wo.x + w1.y * wo.y + w1.z * wo.z,
+                         w2.x * wo.x + w2.y * wo.y + w2.z * wo.z});
+    s->dpdu = V3{w0.x * du.x + w0.y * du.y + w0.z * du.z, w1.x * du.x + w1.y * du.y + w1.z * du.z,
+                 w2.x * du.x + w2.y * du.y + w2.z * du.z};
+    int mat = __float_as_int(m[6].x);
+    if (mat >= 0) s->material = mat;
+    s->light = -1;  // instanced primitives carry no area lights
+}
+// Hit record -> world-space surface. `rd` is the world-space ray direction.
+PB_DEV Surf surface_from_hit(const DevBVH& bvh, int slot, int inst_slot, float b0, float b1, float b2, V3 rd) {
+    if (bvh.instanced && inst_slot >= 0) {
+        const float4* m = bvh.instances + 7 * (size_t)inst_slot;
+        float4 r0 = m[0], r1 = m[1], r2 = m[2];
+        // the object-space ray direction TransformedPrimitive::intersect traced (geometry.rs:872)
+        V3 d_obj = V3{r0.x * rd.x + r0.y * rd.y + r0.z * rd.z, r1.x * rd.x + r1.y * rd.y + r1.z * rd.z,
+                      r2.x * rd.x + r2.y * rd.y + r2.z * rd.z};
+        Surf s = make_surface(bvh, slot, b0, b1, b2, d_obj);
+        instance_to_world(bvh, inst_slot, &s);
+        return s;
+    }
+    return make_surface(bvh, slot, b0, b1, b2, rd);
 }
 PB_DEV V3 tri_geometric_normal(const DevBVH& bvh, int slot) {
     V3 p0, p1, p2;
@@ -718,10 +737,11 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
             float4 r0 = ps.ray[rbase], r1 = ps.ray[rbase + 1];
             V3 rd = V3{r0.w, r1.x, r1.y};
             float4 h0 = ps.hit[rbase];
-            int hslot = __float_as_int(ps.hit[rbase + 1].x);
+            float4 h1 = ps.hit[rbase + 1];
+            int hslot = __float_as_int(h1.x);
             bool found = hslot >= 0;
             Surf sf;
-            if (found) sf = make_surface(sc.bvh, hslot, h0.y, h0.z, h0.w, rd);
+            if (found) sf = surface_from_hit(sc.bvh, hslot, __float_as_int(h1.y), h0.y, h0.z, h0.w, rd);
             // path.rs:80-88
             if (bounces == 0 || (flags & PF_SPECULAR_BOUNCE)) {
                 if (found) {
@@ -746,7 +766,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
                     Frame fr = make_frame(sf);
                     V3 kd = V3{mat.kd[0], mat.kd[1], mat.kd[2]};
                     V3 kt = V3{mat.kt[0], mat.kt[1], mat.kt[2]};
-                    V3 wo = sf.wo;
+                    V3 wo = -rd;  // path.rs:122 `let wo = -ray.d` (estimate_direct uses isect.wo = sf.wo)
                     bool has_lobe;  // which BxDFs the material adds: pbrt-v3 rules (matte / mirror / glass)
                     if (mat.type == PBRT_MAT_GLASS) has_lobe = !(is_black(kd) && is_black(kt));
                     else has_lobe = !is_black(kd);
@@ -901,9 +921,9 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
         auto load_surface = [&]() {
             float4 r0 = ps.ray[rbase], r1 = ps.ray[rbase + 1];
             rd = V3{r0.w, r1.x, r1.y};
-            float4 h0 = ps.hit[rbase];
-            int hslot = __float_as_int(ps.hit[rbase + 1].x);
-            sf = make_surface(sc.bvh, hslot, h0.y, h0.z, h0.w, rd);
+            float4 h0 = ps.hit[rbase], h1 = ps.hit[rbase + 1];
+            int hslot = __float_as_int(h1.x);
+            sf = surface_from_hit(sc.bvh, hslot, __float_as_int(h1.y), h0.y, h0.z, h0.w, rd);
             mat = sc.materials[sf.material];
             fr = make_frame(sf);
             kd = V3{mat.kd[0], mat.kd[1], mat.kd[2]};
@@ -995,8 +1015,9 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
                         size_t fi = ((size_t)p * pp.max_depth + sp) * 3;
                         float4 h0 = ps.hit[rbase];
                         ds.frames[fi] = make_float4(rd.x, rd.y, rd.z, h0.y);
-                        ds.frames[fi + 1] = make_float4(h0.z, h0.w, ps.hit[rbase + 1].x, __int_as_float(depth));
-                        ds.frames[fi + 2] = make_float4(T.x, T.y, T.z, 0.0f);
+                        float4 h1 = ps.hit[rbase + 1];
+                        ds.frames[fi + 1] = make_float4(h0.z, h0.w, h1.x, __int_as_float(depth));
+                        ds.frames[fi + 2] = make_float4(T.x, T.y, T.z, h1.y);
                         sp += 1;
                     }
                     T = mulv(T, f * (ad / pdf));
@@ -1022,7 +1043,7 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
             ps.ray[rbase] = make_float4(r0.x, r0.y, r0.z, f0.x);
             ps.ray[rbase + 1] = make_float4(f0.y, f0.z, kInf, 0.0f);
             ps.hit[rbase] = make_float4(0.0f, f0.w, f1.x, f1.y);
-            ps.hit[rbase + 1] = make_float4(f1.z, 0.0f, 0.0f, 0.0f);
+            ps.hit[rbase + 1] = make_float4(f1.z, f2.w, 0.0f, 0.0f);
             depth = __float_as_int(f1.w);
             T = V3{f2.x, f2.y, f2.z};
             stage = total + 1;  // transmit branch

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 from . import scenes
-from .scenes import (CAMERA_DTYPE, HIT_DTYPE, LIGHT_DTYPE, MATERIAL_DTYPE, NODE_DTYPE, RAY_DTYPE)
+from .scenes import (CAMERA_DTYPE, HIT_DTYPE, INSTANCE_DTYPE, LIGHT_DTYPE, MATERIAL_DTYPE, NODE_DTYPE, RAY_DTYPE)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpbrt_hip.so")
@@ -23,7 +23,8 @@ INTEGRATOR_PATH, INTEGRATOR_DIRECT = 0, 1
 
 EXPORTS = [
     "pbrt_hip_context_create", "pbrt_hip_context_destroy", "pbrt_hip_last_error", "pbrt_hip_bvh_build",
-    "pbrt_hip_free", "pbrt_hip_scene_create", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
+    "pbrt_hip_free", "pbrt_hip_bvh_build_boxes", "pbrt_hip_instance_bounds", "pbrt_hip_scene_create",
+    "pbrt_hip_scene_create_instanced", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
     "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
     "pbrt_hip_tile_partition",
@@ -71,6 +72,11 @@ def lib():
         L.pbrt_hip_free.restype = None
         L.pbrt_hip_scene_create.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp,
                                             ctypes.POINTER(vp)]
+        L.pbrt_hip_bvh_build_boxes.argtypes = [vp, vp, i32, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(i32),
+                                               ctypes.POINTER(vp)]
+        L.pbrt_hip_instance_bounds.argtypes = [vp, vp, vp, i32, vp, vp]
+        L.pbrt_hip_scene_create_instanced.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, vp, i32,
+                                                      vp, i32, vp, ctypes.POINTER(vp)]
         L.pbrt_hip_scene_destroy.argtypes = [vp]
         L.pbrt_hip_scene_destroy.restype = None
         for name in ("pbrt_hip_intersect", "pbrt_hip_intersect_p", "pbrt_hip_intersect_device",
@@ -80,7 +86,7 @@ def lib():
         L.pbrt_hip_trace_timing.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_uint64)]
         L.pbrt_hip_set_counting.argtypes = [vp, ctypes.c_int]
-        L.pbrt_hip_get_counters.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64 * 3)]
+        L.pbrt_hip_get_counters.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64 * 4)]
         L.pbrt_hip_render.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
         L.pbrt_hip_render_device.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
         L.pbrt_hip_tile_partition.argtypes = [i32, i32, i32, i32, i32, i32, vp, i32, ctypes.POINTER(i32)]
@@ -122,9 +128,12 @@ class Context:
         self.check(lib().pbrt_hip_set_counting(self.h, int(enable)), "set_counting")
 
     def counters(self, reset=False):
-        c = (ctypes.c_uint64 * 3)()
+        c = (ctypes.c_uint64 * 4)()
         self.check(lib().pbrt_hip_get_counters(self.h, int(reset), ctypes.byref(c)), "get_counters")
-        return dict(rays=int(c[0]), node_tests=int(c[1]), prim_tests=int(c[2]))
+        d = dict(rays=int(c[0]), node_tests=int(c[1]), prim_tests=int(c[2]))
+        if c[3]:
+            d["inst_tests"] = int(c[3])
+        return d
 
     def close(self):
         if self.h:
@@ -151,20 +160,74 @@ def bvh_build(positions, indices, max_prims_in_node=4, split_method=SPLIT_SAH):
     n = n_nodes.value
     if n == 0:
         return np.zeros(0, dtype=NODE_DTYPE), np.zeros(0, dtype=np.int32)
+    return _take_tree(nodes_p, n, order_p, indices.shape[0])
+
+
+def _take_tree(nodes_p, n_nodes, order_p, n_prims):
+    L = lib()
     try:
-        nodes = np.frombuffer(ctypes.string_at(nodes_p, n * NODE_DTYPE.itemsize), dtype=NODE_DTYPE).copy()
-        order = np.frombuffer(ctypes.string_at(order_p, indices.shape[0] * 4), dtype=np.int32).copy()
+        nodes = np.frombuffer(ctypes.string_at(nodes_p, n_nodes * NODE_DTYPE.itemsize), dtype=NODE_DTYPE).copy()
+        order = np.frombuffer(ctypes.string_at(order_p, n_prims * 4), dtype=np.int32).copy()
     finally:
         L.pbrt_hip_free(nodes_p)
         L.pbrt_hip_free(order_p)
     return nodes, order
 
 
+def bvh_build_boxes(bounds_min, bounds_max, max_prims_in_node=4, split_method=SPLIT_SAH):
+    """BVHAccel::new over caller-supplied primitive bounds (e.g. instance world bounds). Host only."""
+    lo = np.ascontiguousarray(bounds_min, dtype=np.float32)
+    hi = np.ascontiguousarray(bounds_max, dtype=np.float32)
+    nodes_p, order_p, n_nodes = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int32()
+    rc = lib().pbrt_hip_bvh_build_boxes(_p(lo), _p(hi), lo.shape[0], max_prims_in_node, split_method,
+                                        ctypes.byref(nodes_p), ctypes.byref(n_nodes), ctypes.byref(order_p))
+    if rc != 0:
+        raise PbrtHipError(f"pbrt_hip_bvh_build_boxes failed ({rc})")
+    if n_nodes.value == 0:
+        return np.zeros(0, dtype=NODE_DTYPE), np.zeros(0, dtype=np.int32)
+    return _take_tree(nodes_p, n_nodes.value, order_p, lo.shape[0])
+
+
+def make_instances(scene):
+    """scene["instances"] (n,2,4,4) + scene["instance_material"] -> PbrtInstance array."""
+    m = np.ascontiguousarray(scene["instances"], dtype=np.float32)
+    inst = np.zeros(m.shape[0], dtype=INSTANCE_DTYPE)
+    inst["to_world"] = m[:, 0].reshape(-1, 16)
+    inst["to_object"] = m[:, 1].reshape(-1, 16)
+    inst["material"] = scene["instance_material"]
+    return inst
+
+
+def instance_bounds(object_min, object_max, instances):
+    """TransformedPrimitive::world_bound per instance. Host only."""
+    n = len(instances)
+    lo, hi = np.zeros((n, 3), dtype=np.float32), np.zeros((n, 3), dtype=np.float32)
+    omin, omax = np.ascontiguousarray(object_min, dtype=np.float32), np.ascontiguousarray(object_max, dtype=np.float32)
+    rc = lib().pbrt_hip_instance_bounds(_p(omin), _p(omax), _p(instances), n, _p(lo), _p(hi))
+    if rc != 0:
+        raise PbrtHipError(f"pbrt_hip_instance_bounds failed ({rc})")
+    return lo, hi
+
+
+def build_two_level(scene, max_prims_in_node=4, split_method=SPLIT_SAH):
+    """Host BVH builds for an instanced scene: object-level tree over the triangles, top-level tree over
+    the instances' world bounds. Returns (blas_nodes, blas_order, instances, tlas_nodes, tlas_order)."""
+    blas_nodes, blas_order = bvh_build(scene["positions"], scene["indices"], max_prims_in_node, split_method)
+    inst = make_instances(scene)
+    lo, hi = instance_bounds(blas_nodes[0]["bmin"], blas_nodes[0]["bmax"], inst)
+    tlas_nodes, tlas_order = bvh_build_boxes(lo, hi, max_prims_in_node, split_method)
+    return blas_nodes, blas_order, inst, tlas_nodes, tlas_order
+
+
 class Scene:
-    """Scene::new: triangles as GeometricPrimitives in a BVHAccel, resident in HBM."""
+    """Scene::new: triangles as GeometricPrimitives in a BVHAccel, resident in HBM.
+    With scene["instances"]: TransformedPrimitive instances of the triangle aggregate (two levels)."""
 
     def __init__(self, ctx, scene, max_prims_in_node=4, split_method=SPLIT_SAH, bvh=None):
         self.ctx = ctx
+        if "instances" in scene:
+            self._init_instanced(scene, max_prims_in_node, split_method, bvh)
+            return
         self.positions = np.ascontiguousarray(scene["positions"], dtype=np.float32)
         self.indices = np.ascontiguousarray(scene["indices"], dtype=np.int32)
         tri_material = np.ascontiguousarray(scene["tri_material"], dtype=np.int32)
@@ -180,6 +243,24 @@ class Scene:
                                          _p(tri_light), _p(lights) if len(lights) else None, len(lights),
                                          _p(self.nodes), len(self.nodes), _p(self.prim_order), ctypes.byref(h))
         ctx.check(rc, "pbrt_hip_scene_create")
+        self.h = h
+
+    def _init_instanced(self, scene, max_prims_in_node, split_method, bvh):
+        self.positions = np.ascontiguousarray(scene["positions"], dtype=np.float32)
+        self.indices = np.ascontiguousarray(scene["indices"], dtype=np.int32)
+        tri_material = np.ascontiguousarray(scene["tri_material"], dtype=np.int32)
+        materials = np.ascontiguousarray(scene["materials"], dtype=MATERIAL_DTYPE)
+        lights = np.ascontiguousarray(scene["lights"], dtype=LIGHT_DTYPE)
+        if bvh is None:
+            bvh = build_two_level(scene, max_prims_in_node, split_method)
+        self.nodes, self.prim_order, self.instances, self.tlas_nodes, self.tlas_order = bvh
+        h = ctypes.c_void_p()
+        rc = lib().pbrt_hip_scene_create_instanced(
+            self.ctx.h, _p(self.positions), self.positions.shape[0], _p(self.indices), self.indices.shape[0],
+            _p(tri_material), _p(materials), len(materials), _p(lights) if len(lights) else None, len(lights),
+            _p(self.nodes), len(self.nodes), _p(self.prim_order), _p(self.instances), len(self.instances),
+            _p(self.tlas_nodes), len(self.tlas_nodes), _p(self.tlas_order), ctypes.byref(h))
+        self.ctx.check(rc, "pbrt_hip_scene_create_instanced")
         self.h = h
 
     def intersect(self, rays):

@@ -17,7 +17,8 @@ CAMERA_DTYPE = np.dtype([("camera_to_world", "<f4", 16), ("raster_to_camera", "<
                          ("shutter_open", "<f4"), ("shutter_close", "<f4")])
 RAY_DTYPE = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("t_max", "<f4"), ("time", "<f4")])
 HIT_DTYPE = np.dtype([("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"), ("prim_id", "<i4"),
-                      ("pad", "<i4", 3)])
+                      ("instance_id", "<i4"), ("pad", "<i4", 2)])
+INSTANCE_DTYPE = np.dtype([("to_world", "<f4", 16), ("to_object", "<f4", 16), ("material", "<i4"), ("pad", "<i4", 3)])
 NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"), ("n_primitives", "<u2"),
                        ("axis", "u1"), ("pad", "u1")])
 assert MATERIAL_DTYPE.itemsize == 32 and LIGHT_DTYPE.itemsize == 32
@@ -186,6 +187,49 @@ def mixed_materials_scene(n_tris=20000, seq=7):
                       (LIGHT_DIFFUSE_AREA, (20.0, 18.0, 15.0), n_tris + 1, 1, 1)])
     return dict(positions=positions, indices=indices, tri_material=tri_material, materials=materials,
                 tri_light=tri_light, lights=lights)
+
+
+def _random_rigid(u):
+    """Rotation (uniform quaternion from 3 uniforms, Shoemake) + translation from 3 more; float64 4x4."""
+    u1, u2, u3 = u[0], u[1], u[2]
+    q = np.array([np.sqrt(1 - u1) * np.sin(2 * np.pi * u2), np.sqrt(1 - u1) * np.cos(2 * np.pi * u2),
+                  np.sqrt(u1) * np.sin(2 * np.pi * u3), np.sqrt(u1) * np.cos(2 * np.pi * u3)])
+    x, y, z, w = q
+    r = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    m = np.eye(4)
+    m[:3, :3] = r
+    return m
+
+
+def instanced_scene(n_base_tris=10_000, n_instances=1000, seq_mesh=2, seq_xf=3, extent=4.0, base_extent=0.3,
+                    tri_size=0.02, env_L=(1.0, 1.0, 1.0)):
+    """Config 5: a base cloud of triangles (object space) x rigid instances placed in [-extent, extent]^3;
+    material of instance i = i % 3 -> matte / mirror / glass(eta 1.5); one constant env light.
+    scene["instances"]: (n, 2, 4, 4) float32 {to_world, to_object} (the inverse is computed in float64)."""
+    base = random_triangles(n_base_tris, seq=seq_mesh, extent=base_extent, size=tri_size, env_L=env_L)
+    u = pcg32_float(seq_xf, n_instances * 6).astype(np.float64).reshape(n_instances, 6)
+    inst = np.zeros((n_instances, 2, 4, 4), dtype=np.float32)
+    for i in range(n_instances):
+        m = _random_rigid(u[i, :3])
+        m[:3, 3] = (u[i, 3:] * 2 - 1) * extent
+        inst[i, 0] = m.astype(np.float32)
+        inst[i, 1] = np.linalg.inv(m).astype(np.float32)
+    inst[:, :, 3, :] = (0, 0, 0, 1)
+    materials = _materials([
+        (MAT_MATTE, (0.5, 0.5, 0.5), (0, 0, 0), 1.0),
+        (MAT_MIRROR, (0.9, 0.9, 0.9), (0, 0, 0), 1.0),
+        (MAT_GLASS, (1.0, 1.0, 1.0), (1.0, 1.0, 1.0), 1.5),
+    ])
+    return dict(positions=base["positions"], indices=base["indices"], materials=materials,
+                instances=inst, instance_material=(np.arange(n_instances) % 3).astype(np.int32),
+                lights=_lights([(LIGHT_INFINITE, env_L, -1, 0, 1)]),
+                tri_material=base["tri_material"], tri_light=base["tri_light"])
+
+
+def instanced_camera(width, height, extent=4.0):
+    return perspective_camera((0.0, 0.0, 3.2 * extent), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 40.0, width, height)
 
 
 def furnace_scene(rho=0.5, Le=1.0):

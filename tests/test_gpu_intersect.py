@@ -120,3 +120,35 @@ def test_instrumented_counts_match_reference_loops(hip_ctx):
     assert c_any == ctr_p
     gsc.close()
     osc.close()
+
+
+def test_instanced_scene_parity(hip_ctx):
+    """Two-level traversal (TransformedPrimitive instances, src/core/primitive.rs:136-159) vs the oracle:
+    bit-exact hits incl. the instance id, any-hit flags, and the reference-loop counters."""
+    sc = scenes.instanced_scene(3000, 60, extent=1.5)
+    osc = oracle.OracleScene(sc)
+    gsc = pbrt_hip.Scene(hip_ctx, sc)
+    assert gsc.tlas_nodes.tobytes() == osc.nodes().tobytes() and np.array_equal(gsc.tlas_order, osc.prim_order())
+    bn, bo = osc.blas()
+    assert gsc.nodes.tobytes() == bn.tobytes() and np.array_equal(gsc.prim_order, bo)
+    rays = _scene_rays(sc, 80_000, 31, 2.5)
+    cpu, ctr = osc.intersect(rays)
+    cpu_p, ctr_p = osc.intersect_p(rays)
+    gpu = gsc.intersect(rays)
+    _assert_hits_equal(gpu, cpu)
+    assert np.array_equal(gpu["instance_id"], cpu["instance_id"])
+    assert (cpu["instance_id"] >= 0).sum() > 5000
+    assert np.array_equal(gsc.intersect_p(rays), cpu_p)
+    hip_ctx.set_counting(True)
+    try:
+        hip_ctx.counters(reset=True)
+        g2 = gsc.intersect(rays)
+        c0 = hip_ctx.counters(reset=True)
+        gsc.intersect_p(rays)
+        c1 = hip_ctx.counters(reset=True)
+    finally:
+        hip_ctx.set_counting(False)
+    _assert_hits_equal(g2, cpu)
+    assert c0 == ctr and c1 == ctr_p
+    gsc.close()
+    osc.close()

@@ -148,3 +148,15 @@ def test_direct_lighting_env_and_crop(hip_ctx):
     assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
     gsc.close()
     osc.close()
+
+
+@pytest.mark.parametrize("integrator,max_depth", [(0, 8), (1, 4)])
+def test_instanced_scene_render(hip_ctx, integrator, max_depth):
+    """Config-5 style scene (instances, matte / mirror / glass by instance) through both integrators."""
+    w, h = 80, 56
+    sc = scenes.instanced_scene(2000, 40, extent=1.5)
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, scenes.instanced_camera(w, h, 1.5), w, h, 6,
+                                              integrator=integrator, max_depth=max_depth,
+                                              light_strategy=1 if integrator == 0 else 0, seed=23)
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
