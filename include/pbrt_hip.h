@@ -147,7 +147,7 @@ const char* pbrt_hip_last_error(const PbrtHipContext* ctx);
 
 /* ---- host side: BVHAccel::new (src/accelerators/bvh.rs:216-271) ----
  * Builds the flat DFS node array and the leaf order over world-space triangles
- * (split_method: 0 SAH, 2 Middle, 3 EqualCounts, numbering of bvh.rs:200-205).
+ * (split_method: 0 SAH, 1 HLBVH, 2 Middle, 3 EqualCounts: the order of bvh.rs:200-205).
  * Outputs are allocated by the library; release with pbrt_hip_free. */
 int pbrt_hip_bvh_build(const float* positions, int32_t n_verts, const int32_t* indices, int32_t n_tris,
                        int32_t max_prims_in_node, int32_t split_method, PbrtLinearBVHNode** nodes_out,

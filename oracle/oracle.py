@@ -36,6 +36,10 @@ def lib():
         L.orc_scene_create.restype = vp
         L.orc_scene_create.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
+        L.orc_scene_create_with_spheres.restype = vp
+        L.orc_scene_create_with_spheres.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp,
+                                                    vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_uint32]
         L.orc_scene_create_instanced.restype = vp
         L.orc_scene_create_instanced.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, ctypes.c_int, vp,
                                                  ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -119,10 +123,14 @@ class OracleScene:
             normals=None if normals is None else _f32(normals), uvs=None if uvs is None else _f32(uvs))
         k = self._keep
         self.n_tris = k["indices"].shape[0]
-        self.h = L.orc_scene_create(_p(k["positions"]), k["positions"].shape[0], _p(k["indices"]), self.n_tris,
-                                    _p(k["normals"]), _p(k["uvs"]), _p(k["tri_material"]), _p(k["materials"]),
-                                    len(k["materials"]), _p(k["tri_light"]), _p(k["lights"]), len(k["lights"]),
-                                    max_prims_in_node, split_method, quirks)
+        spheres = scene.get("spheres")
+        k["spheres"] = None if spheres is None else _f32(spheres).reshape(-1, 8)
+        n_spheres = 0 if spheres is None else k["spheres"].shape[0]
+        self.n_prims = self.n_tris + n_spheres
+        self.h = L.orc_scene_create_with_spheres(
+            _p(k["positions"]), k["positions"].shape[0], _p(k["indices"]), self.n_tris, _p(k["normals"]), _p(k["uvs"]),
+            _p(k["tri_material"]), _p(k["materials"]), len(k["materials"]), _p(k["tri_light"]), _p(k["lights"]),
+            len(k["lights"]), _p(k["spheres"]), n_spheres, max_prims_in_node, split_method, quirks)
 
     def _init_instanced(self, scene, max_prims_in_node, split_method, quirks):
         """Config 5: TransformedPrimitive instances of one base mesh (scene["instances"] = (n,2,4,4) float32
@@ -166,7 +174,7 @@ class OracleScene:
         return out
 
     def prim_order(self):
-        out = np.zeros(getattr(self, "n_instances", self.n_tris), dtype=np.int32)
+        out = np.zeros(getattr(self, "n_instances", getattr(self, "n_prims", self.n_tris)), dtype=np.int32)
         lib().orc_scene_get_prim_order(self.h, _p(out))
         return out
 

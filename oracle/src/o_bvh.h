@@ -16,7 +16,11 @@
 // partition predicate compares the un-truncated float bucket with `<` (bvh.rs:424-431), which
 // is off by one against the cost loop and sends nothing left when the best bucket is 0 —
 // intended pbrt-v3 `int b <= min_cost_split_bucket`.
-// HLBVH (bvh.rs:475-772) is not restated yet (D20: as written it cannot run).
+//   src/accelerators/bvh.rs:137-197   left_shift3 / encode_morton3 / radix_sort
+//   src/accelerators/bvh.rs:475-772   hlbvh_build, emit_lbvh, build_upper_sah
+// HLBVH dispositions (D20): treelet `start` advances, ordered_prims is sized up front, treelets are
+// emitted in order (the reference's parallel fetch_add makes leaf offsets run-dependent); upper-SAH bucket
+// index and partition predicate as pbrt-v3 (D18/D45 analogues at bvh.rs:711-715, 752-767).
 //
 // Instrumentation: per-ray counters of box tests (bvh.rs:841-842) and triangle tests
 // (triangle.rs:74) feed the algorithmic-byte roofline.
@@ -138,7 +142,8 @@ struct BVHAccel : Primitive {
         }
         int total_nodes = 0;
         ordered_prims.reserve(prim_bounds.size());
-        int root = recursive_build(info, 0, (int)info.size(), &total_nodes);
+        int root = (sm == SPLIT_HLBVH) ? hlbvh_build(info, &total_nodes)
+                                       : recursive_build(info, 0, (int)info.size(), &total_nodes);
         nodes.resize(total_nodes);
         int offset = 0;
         flatten(root, &offset);
@@ -265,6 +270,174 @@ struct BVHAccel : Primitive {
         arena[index].split_axis = dim;
         arena[index].n_primitives = 0;
         return index;
+    }
+
+    // ---- HLBVH (bvh.rs:475-772) ----
+    struct MortonPrimitive {
+        int primitive_index;
+        uint32_t morton_code;
+    };
+    // bvh.rs:137-156
+    static uint32_t left_shift3(uint32_t x) {
+        if (x == (1u << 10)) x -= 1;
+        x = (x | (x << 16)) & 0x30000ffu;
+        x = (x | (x << 8)) & 0x300f00fu;
+        x = (x | (x << 4)) & 0x30c30c3u;
+        x = (x | (x << 2)) & 0x9249249u;
+        return x;
+    }
+    static uint32_t encode_morton3(const Vector3f& v) {
+        return (left_shift3((uint32_t)v.z) << 2) | (left_shift3((uint32_t)v.y) << 1) | left_shift3((uint32_t)v.x);
+    }
+    // bvh.rs:158-197: LSD radix sort, 6 bits x 5 passes
+    static void radix_sort(std::vector<MortonPrimitive>& v) {
+        std::vector<MortonPrimitive> tmp(v.size());
+        const int bits_per_pass = 6, n_bits = 30, n_passes = n_bits / bits_per_pass;
+        for (int pass = 0; pass < n_passes; ++pass) {
+            int low_bit = pass * bits_per_pass;
+            std::vector<MortonPrimitive>& in = (pass & 1) ? tmp : v;
+            std::vector<MortonPrimitive>& out = (pass & 1) ? v : tmp;
+            const int n_buckets = 1 << bits_per_pass, bit_mask = n_buckets - 1;
+            int bucket_count[64] = {0}, out_index[64];
+            for (const MortonPrimitive& mp : in) bucket_count[(mp.morton_code >> low_bit) & bit_mask]++;
+            out_index[0] = 0;
+            for (int i = 1; i < n_buckets; ++i) out_index[i] = out_index[i - 1] + bucket_count[i - 1];
+            for (const MortonPrimitive& mp : in) out[out_index[(mp.morton_code >> low_bit) & bit_mask]++] = mp;
+        }
+        if (n_passes & 1) std::swap(v, tmp);
+    }
+    // bvh.rs:570-676: nodes of the treelet are appended to the arena; returns the treelet's root
+    int emit_lbvh(const std::vector<BVHPrimitiveInfo>& info, const MortonPrimitive* mp, int n_primitives, int* total_nodes,
+                  int bit_index) {
+        if (bit_index == -1 || n_primitives < max_prims_in_node) {
+            *total_nodes += 1;
+            int index = (int)arena.size();
+            arena.emplace_back();
+            Bounds3f bounds;
+            int first = (int)ordered_prims.size();
+            for (int i = 0; i < n_primitives; ++i) {
+                ordered_prims.push_back(mp[i].primitive_index);
+                bounds = bounds.union_(info[mp[i].primitive_index].bounds);
+            }
+            arena[index].first_prim_offset = first;
+            arena[index].n_primitives = n_primitives;
+            arena[index].bounds = bounds;
+            return index;
+        }
+        uint32_t mask = 1u << bit_index;
+        if ((mp[0].morton_code & mask) == (mp[n_primitives - 1].morton_code & mask))
+            return emit_lbvh(info, mp, n_primitives, total_nodes, bit_index - 1);
+        int search_start = 0, search_end = n_primitives - 1;
+        while (search_start + 1 != search_end) {
+            int mid = (search_start + search_end) / 2;
+            if ((mp[search_start].morton_code & mask) == (mp[mid].morton_code & mask))
+                search_start = mid;
+            else
+                search_end = mid;
+        }
+        int split_offset = search_end;
+        *total_nodes += 1;
+        int index = (int)arena.size();
+        arena.emplace_back();
+        int c0 = emit_lbvh(info, mp, split_offset, total_nodes, bit_index - 1);
+        int c1 = emit_lbvh(info, mp + split_offset, n_primitives - split_offset, total_nodes, bit_index - 1);
+        arena[index].children[0] = c0;
+        arena[index].children[1] = c1;
+        arena[index].bounds = arena[c0].bounds.union_(arena[c1].bounds);
+        arena[index].split_axis = bit_index % 3;
+        arena[index].n_primitives = 0;
+        return index;
+    }
+    // bvh.rs:678-772
+    int build_upper_sah(std::vector<int>& roots, int start, int end, int* total_nodes) {
+        int n_nodes = end - start;
+        if (n_nodes == 1) return roots[start];
+        *total_nodes += 1;
+        int index = (int)arena.size();
+        arena.emplace_back();
+        Bounds3f bounds, centroid_bounds;
+        for (int i = start; i < end; ++i) bounds = bounds.union_(arena[roots[i]].bounds);
+        for (int i = start; i < end; ++i) {
+            Point3f centroid = (arena[roots[i]].bounds.min + arena[roots[i]].bounds.max) * 0.5f;
+            centroid_bounds = centroid_bounds.union_(centroid);
+        }
+        int dim = centroid_bounds.maximum_extent();
+        const int n_buckets = 12;
+        auto bucket_of = [&](int root) {
+            Float centroid = (arena[root].bounds.min[dim] + arena[root].bounds.max[dim]) * 0.5f;
+            int b = (int)((Float)n_buckets *
+                          ((centroid - centroid_bounds.min[dim]) / (centroid_bounds.max[dim] - centroid_bounds.min[dim])));
+            if (b == n_buckets) b = n_buckets - 1;
+            return b;
+        };
+        int mid = start;
+        if (centroid_bounds.max[dim] != centroid_bounds.min[dim]) {
+            struct Bucket {
+                int count = 0;
+                Bounds3f bounds;
+            } buckets[n_buckets];
+            for (int i = start; i < end; ++i) {
+                int b = bucket_of(roots[i]);
+                buckets[b].count += 1;
+                buckets[b].bounds = buckets[b].bounds.union_(arena[roots[i]].bounds);
+            }
+            Float cost[n_buckets - 1];
+            for (int i = 0; i < n_buckets - 1; ++i) {
+                Bounds3f b0, b1;
+                int count0 = 0, count1 = 0;
+                for (int j = 0; j <= i; ++j) {
+                    b0 = b0.union_(buckets[j].bounds);
+                    count0 += buckets[j].count;
+                }
+                for (int j = i + 1; j < n_buckets; ++j) {
+                    b1 = b1.union_(buckets[j].bounds);
+                    count1 += buckets[j].count;
+                }
+                cost[i] = 0.125f + ((Float)count0 * b0.surface_area() + (Float)count1 * b1.surface_area()) /
+                                       bounds.surface_area();
+            }
+            Float min_cost = FLOAT_MAX;
+            int min_cost_split_bucket = 0;
+            for (int i = 0; i < n_buckets - 1; ++i)
+                if (cost[i] < min_cost) {
+                    min_cost = cost[i];
+                    min_cost_split_bucket = i;
+                }
+            mid = start + partition_in_place(&roots[start], end - start,
+                                             [&](int root) { return bucket_of(root) <= min_cost_split_bucket; });
+        }
+        // pbrt-v3 asserts mid != start && mid != end; coincident treelet centroids fall back to the median
+        if (mid == start || mid == end) mid = (start + end) / 2;
+        int c0 = build_upper_sah(roots, start, mid, total_nodes);
+        int c1 = build_upper_sah(roots, mid, end, total_nodes);
+        arena[index].children[0] = c0;
+        arena[index].children[1] = c1;
+        arena[index].bounds = arena[c0].bounds.union_(arena[c1].bounds);
+        arena[index].split_axis = dim;
+        arena[index].n_primitives = 0;
+        return index;
+    }
+    // bvh.rs:475-568
+    int hlbvh_build(const std::vector<BVHPrimitiveInfo>& info, int* total_nodes) {
+        Bounds3f bounds;
+        for (const BVHPrimitiveInfo& pi : info) bounds = bounds.union_(pi.centroid);
+        std::vector<MortonPrimitive> morton_prims(info.size());
+        const int morton_bits = 10, morton_scale = 1 << morton_bits;
+        for (size_t i = 0; i < info.size(); ++i) {
+            morton_prims[i].primitive_index = info[i].primitive_number;
+            Vector3f o = bounds.offset(info[i].centroid);
+            morton_prims[i].morton_code = encode_morton3(o * (Float)morton_scale);
+        }
+        radix_sort(morton_prims);
+        std::vector<int> roots;
+        const uint32_t mask = 0x3ffc0000u;  // top 12 of the 30 bits
+        for (size_t start = 0, end = 1; end <= morton_prims.size(); ++end) {
+            if (end == morton_prims.size() || (morton_prims[start].morton_code & mask) != (morton_prims[end].morton_code & mask)) {
+                roots.push_back(emit_lbvh(info, &morton_prims[start], (int)(end - start), total_nodes, 29 - 12));
+                start = end;
+            }
+        }
+        return build_upper_sah(roots, 0, (int)roots.size(), total_nodes);
     }
 
     // bvh.rs:774-811

@@ -6,6 +6,7 @@
 #include <chrono>
 
 #include "o_render.h"
+#include "o_sphere.h"
 
 using namespace oracle;
 
@@ -41,10 +42,26 @@ extern "C" {
 
 // materials: n_mat x 8 floats {type, kd.r, kd.g, kd.b, kt.r, kt.g, kt.b, eta}
 // lights:    n_light x 8 floats {type(0 = diffuse area, 1 = infinite), L.r, L.g, L.b, tri, two_sided, n_samples, 0}
+void* orc_scene_create_with_spheres(const float* positions, int n_verts, const int32_t* indices, int n_tris,
+                                    const float* normals, const float* uvs, const int32_t* tri_material,
+                                    const float* materials, int n_mat, const int32_t* tri_light, const float* lights,
+                                    int n_light, const float* spheres, int n_spheres, int max_prims_in_node,
+                                    int split_method, uint32_t quirks);
 void* orc_scene_create(const float* positions, int n_verts, const int32_t* indices, int n_tris,
                        const float* normals, const float* uvs, const int32_t* tri_material,
                        const float* materials, int n_mat, const int32_t* tri_light, const float* lights,
                        int n_light, int max_prims_in_node, int split_method, uint32_t quirks) {
+    return orc_scene_create_with_spheres(positions, n_verts, indices, n_tris, normals, uvs, tri_material, materials,
+                                         n_mat, tri_light, lights, n_light, nullptr, 0, max_prims_in_node, split_method,
+                                         quirks);
+}
+// spheres: n_spheres x 8 floats {cx, cy, cz, radius, material, light (-1 = none), 0, 0}; sphere i is
+// primitive n_tris + i (config 1: src/shapes/sphere.rs). A light's `tri` field may name a sphere primitive.
+void* orc_scene_create_with_spheres(const float* positions, int n_verts, const int32_t* indices, int n_tris,
+                                    const float* normals, const float* uvs, const int32_t* tri_material,
+                                    const float* materials, int n_mat, const int32_t* tri_light, const float* lights,
+                                    int n_light, const float* spheres, int n_spheres, int max_prims_in_node,
+                                    int split_method, uint32_t quirks) {
     OracleScene* os = new OracleScene();
     auto mesh = std::make_shared<TriangleMesh>();
     mesh->n_vertices = n_verts;
@@ -72,8 +89,13 @@ void* orc_scene_create(const float* positions, int n_verts, const int32_t* indic
         d.eta = m[7];
         sc.materials.push_back(d);
     }
-    std::vector<std::shared_ptr<Shape>> shapes(n_tris);
+    const int n_prims = n_tris + n_spheres;
+    std::vector<std::shared_ptr<Shape>> shapes(n_prims);
     for (int i = 0; i < n_tris; ++i) shapes[i] = std::make_shared<Triangle>(mesh, i, false, quirks);
+    for (int i = 0; i < n_spheres; ++i) {
+        const float* sp = spheres + 8 * i;
+        shapes[n_tris + i] = Sphere::at(Point3f(sp[0], sp[1], sp[2]), sp[3]);
+    }
     for (int i = 0; i < n_light; ++i) {
         const float* l = lights + 8 * i;
         Spectrum L(l[1], l[2], l[3]);
@@ -82,12 +104,17 @@ void* orc_scene_create(const float* positions, int n_verts, const int32_t* indic
         else
             sc.lights.push_back(std::make_shared<InfiniteAreaLight>(L, (int)l[6]));
     }
-    std::vector<std::shared_ptr<Primitive>> prims(n_tris);
-    sc.prim_material.resize(n_tris);
-    sc.prim_light.resize(n_tris);
-    for (int i = 0; i < n_tris; ++i) {
-        sc.prim_material[i] = tri_material ? tri_material[i] : 0;
-        sc.prim_light[i] = tri_light ? tri_light[i] : -1;
+    std::vector<std::shared_ptr<Primitive>> prims(n_prims);
+    sc.prim_material.resize(n_prims);
+    sc.prim_light.resize(n_prims);
+    for (int i = 0; i < n_prims; ++i) {
+        if (i < n_tris) {
+            sc.prim_material[i] = tri_material ? tri_material[i] : 0;
+            sc.prim_light[i] = tri_light ? tri_light[i] : -1;
+        } else {
+            sc.prim_material[i] = (int)spheres[8 * (i - n_tris) + 4];
+            sc.prim_light[i] = (int)spheres[8 * (i - n_tris) + 5];
+        }
         prims[i] = std::make_shared<GeometricPrimitive>(shapes[i], sc.prim_material[i], sc.prim_light[i], i);
     }
     sc.aggregate = std::make_shared<BVHAccel>(prims, max_prims_in_node, (SplitMethod)split_method, quirks);
@@ -186,6 +213,10 @@ void orc_intersect(void* h, const float* rays, int64_t n, void* out_hits, uint64
                 hit.prim_id = si.prim_id;
                 hit.pad[0] = si.instance_id;
                 const TriangleMesh& m = *((OracleScene*)h)->mesh;
+                if (si.prim_id >= m.n_triangles) {  // a sphere: no barycentrics
+                    out[i] = hit;
+                    continue;
+                }
                 const int32_t* v = &m.vertex_indices[3 * (size_t)si.prim_id];
                 Ray r0(Point3f(r[0], r[1], r[2]), Vector3f(r[3], r[4], r[5]), r[6], r[7]);
                 if (si.instance_id >= 0) r0 = xform_ray(((OracleScene*)h)->to_object[si.instance_id], r0);

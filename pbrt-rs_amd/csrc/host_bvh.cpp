@@ -180,6 +180,221 @@ struct Builder {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// HLBVH (src/accelerators/bvh.rs:475-772): Morton codes of the centroids (:137-156, :490-502), LSD
+// radix sort 6 bits x 5 passes (:158-197), one LBVH treelet per distinct top-12-bit prefix
+// (:509-528, emit_lbvh :570-676), SAH over the treelet roots (:678-772), DFS flattening (:774-811).
+// Dispositions (SURVEY.md D20 and the D18/D45 analogues in build_upper_sah): treelet ranges advance,
+// treelets are emitted in order so leaf offsets are deterministic, bucket = floor(12 * offset),
+// partition keeps buckets <= best; coincident treelet centroids fall back to the median.
+// ---------------------------------------------------------------------------------------------
+struct HlbvhBuilder {
+    struct Node {
+        Box box;
+        int child[2] = {-1, -1};
+        int axis = 0, first = 0, count = 0;
+    };
+    const float* lo;
+    const float* hi;
+    const float* ctr;
+    int max_prims;
+    std::vector<Node> pool;
+    std::vector<int32_t> order;
+    std::vector<uint32_t> code;
+    std::vector<int32_t> prim;  // primitive index, sorted by Morton code
+
+    static uint32_t spread3(uint32_t x) {
+        if (x == (1u << 10)) x -= 1;
+        x = (x | (x << 16)) & 0x30000ffu;
+        x = (x | (x << 8)) & 0x300f00fu;
+        x = (x | (x << 4)) & 0x30c30c3u;
+        x = (x | (x << 2)) & 0x9249249u;
+        return x;
+    }
+    void sort_by_code() {
+        size_t n = code.size();
+        std::vector<uint32_t> code2(n);
+        std::vector<int32_t> prim2(n);
+        for (int pass = 0; pass < 5; ++pass) {
+            int shift = 6 * pass;
+            size_t start[65] = {0};
+            for (size_t i = 0; i < n; ++i) start[((code[i] >> shift) & 63u) + 1]++;
+            for (int b = 0; b < 64; ++b) start[b + 1] += start[b];
+            for (size_t i = 0; i < n; ++i) {
+                size_t dst = start[(code[i] >> shift) & 63u]++;
+                code2[dst] = code[i];
+                prim2[dst] = prim[i];
+            }
+            code.swap(code2);
+            prim.swap(prim2);
+        }
+    }
+    int emit(size_t begin, int n, int bit) {
+        if (bit == -1 || n < max_prims) {
+            int self = (int)pool.size();
+            pool.emplace_back();
+            Node& nd = pool.back();
+            nd.box.reset();
+            nd.first = (int)order.size();
+            nd.count = n;
+            for (int i = 0; i < n; ++i) {
+                int32_t p = prim[begin + i];
+                order.push_back(p);
+                nd.box.grow(lo + 3 * (size_t)p, hi + 3 * (size_t)p);
+            }
+            return self;
+        }
+        uint32_t mask = 1u << bit;
+        if ((code[begin] & mask) == (code[begin + n - 1] & mask)) return emit(begin, n, bit - 1);
+        int a = 0, b = n - 1;  // last index with the first element's bit / first index with the other
+        while (a + 1 != b) {
+            int m = (a + b) / 2;
+            if ((code[begin + a] & mask) == (code[begin + m] & mask)) a = m;
+            else b = m;
+        }
+        int self = (int)pool.size();
+        pool.emplace_back();
+        int c0 = emit(begin, b, bit - 1);
+        int c1 = emit(begin + b, n - b, bit - 1);
+        Node& nd = pool[self];
+        nd.child[0] = c0;
+        nd.child[1] = c1;
+        nd.box.reset();
+        nd.box.grow(pool[c0].box);
+        nd.box.grow(pool[c1].box);
+        nd.axis = bit % 3;
+        return self;
+    }
+    int upper(std::vector<int>& roots, int start, int end) {
+        if (end - start == 1) return roots[start];
+        int self = (int)pool.size();
+        pool.emplace_back();
+        Box b, cb;
+        b.reset();
+        cb.reset();
+        for (int i = start; i < end; ++i) b.grow(pool[roots[i]].box);
+        for (int i = start; i < end; ++i) {
+            const Box& r = pool[roots[i]].box;
+            float c[3];
+            for (int k = 0; k < 3; ++k) c[k] = (r.mn[k] + r.mx[k]) * 0.5f;
+            cb.grow(c, c);
+        }
+        int dim = cb.widest();
+        const int NB = 12;
+        auto bucket = [&](int root) {
+            const Box& r = pool[root].box;
+            float c = (r.mn[dim] + r.mx[dim]) * 0.5f;
+            int k = (int)((float)NB * ((c - cb.mn[dim]) / (cb.mx[dim] - cb.mn[dim])));
+            return k == NB ? NB - 1 : k;
+        };
+        int mid = start;
+        if (cb.mx[dim] != cb.mn[dim]) {
+            int count[NB] = {0};
+            Box bb[NB];
+            for (int k = 0; k < NB; ++k) bb[k].reset();
+            for (int i = start; i < end; ++i) {
+                int k = bucket(roots[i]);
+                count[k]++;
+                bb[k].grow(pool[roots[i]].box);
+            }
+            float best_cost = FLT_MAX, area = b.area();
+            int best = 0;
+            for (int s = 0; s < NB - 1; ++s) {
+                Box b0, b1;
+                b0.reset();
+                b1.reset();
+                int c0 = 0, c1 = 0;
+                for (int j = 0; j <= s; ++j) {
+                    b0.grow(bb[j]);
+                    c0 += count[j];
+                }
+                for (int j = s + 1; j < NB; ++j) {
+                    b1.grow(bb[j]);
+                    c1 += count[j];
+                }
+                float cost = 0.125f + ((float)c0 * b0.area() + (float)c1 * b1.area()) / area;
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best = s;
+                }
+            }
+            int i = start, j = end;  // two-pointer partition on `bucket <= best`
+            for (;;) {
+                while (i < j && bucket(roots[i]) <= best) ++i;
+                if (i == j) break;
+                --j;
+                while (i < j && !(bucket(roots[j]) <= best)) --j;
+                if (i == j) break;
+                std::swap(roots[i], roots[j]);
+                ++i;
+            }
+            mid = i;
+        }
+        if (mid == start || mid == end) mid = (start + end) / 2;
+        int c0 = upper(roots, start, mid);
+        int c1 = upper(roots, mid, end);
+        Node& nd = pool[self];
+        nd.child[0] = c0;
+        nd.child[1] = c1;
+        nd.box.reset();
+        nd.box.grow(pool[c0].box);
+        nd.box.grow(pool[c1].box);
+        nd.axis = dim;
+        return self;
+    }
+    int flatten(int node, std::vector<PbrtLinearBVHNode>& out) {
+        int self = (int)out.size();
+        out.emplace_back();
+        const Node& nd = pool[node];
+        PbrtLinearBVHNode ln;
+        std::memcpy(ln.bounds_min, nd.box.mn, 12);
+        std::memcpy(ln.bounds_max, nd.box.mx, 12);
+        ln.pad = 0;
+        if (nd.count > 0) {
+            ln.offset = nd.first;
+            ln.n_primitives = (uint16_t)nd.count;
+            ln.axis = 0;
+            out[self] = ln;
+        } else {
+            ln.n_primitives = 0;
+            ln.axis = (uint8_t)nd.axis;
+            ln.offset = 0;
+            out[self] = ln;
+            flatten(nd.child[0], out);
+            out[self].offset = flatten(nd.child[1], out);
+        }
+        return self;
+    }
+    void run(int32_t n, std::vector<PbrtLinearBVHNode>& out) {
+        Box cb;
+        cb.reset();
+        for (int32_t i = 0; i < n; ++i) cb.grow(ctr + 3 * (size_t)i, ctr + 3 * (size_t)i);
+        code.resize(n);
+        prim.resize(n);
+        for (int32_t i = 0; i < n; ++i) {
+            uint32_t q[3];
+            for (int k = 0; k < 3; ++k) {
+                float o = ctr[3 * (size_t)i + k] - cb.mn[k];
+                if (cb.mx[k] > cb.mn[k]) o /= cb.mx[k] - cb.mn[k];
+                q[k] = (uint32_t)(o * 1024.0f);
+            }
+            code[i] = (spread3(q[2]) << 2) | (spread3(q[1]) << 1) | spread3(q[0]);
+            prim[i] = i;
+        }
+        sort_by_code();
+        std::vector<int> roots;
+        const uint32_t prefix = 0x3ffc0000u;
+        for (size_t start = 0, end = 1; end <= (size_t)n; ++end)
+            if (end == (size_t)n || (code[start] & prefix) != (code[end] & prefix)) {
+                roots.push_back(emit(start, (int)(end - start), 29 - 12));
+                start = end;
+            }
+        int root = upper(roots, 0, (int)roots.size());
+        out.reserve(pool.size());
+        flatten(root, out);
+    }
+};
+
 }  // namespace
 
 static int build_from_boxes(std::vector<float>& lo, std::vector<float>& hi, int32_t n, int32_t max_prims_in_node,
@@ -188,16 +403,28 @@ static int build_from_boxes(std::vector<float>& lo, std::vector<float>& hi, int3
     std::vector<float> ctr(3 * (size_t)n);
     for (size_t i = 0; i < 3 * (size_t)n; ++i) ctr[i] = lo[i] * 0.5f + hi[i] * 0.5f;  // bvh.rs:38
     Builder bl;
-    bl.lo = lo.data();
-    bl.hi = hi.data();
-    bl.ctr = ctr.data();
-    bl.perm.resize(n);
-    for (int32_t i = 0; i < n; ++i) bl.perm[i] = i;
-    bl.max_prims = std::min(max_prims_in_node, 255);  // bvh.rs:222
-    bl.method = split_method;
-    bl.out.reserve(2 * (size_t)n);
-    bl.order.reserve(n);
-    bl.build(0, n);
+    if (split_method == 1) {  // HLBVH
+        HlbvhBuilder hb;
+        hb.lo = lo.data();
+        hb.hi = hi.data();
+        hb.ctr = ctr.data();
+        hb.max_prims = std::min(max_prims_in_node, 255);
+        hb.order.reserve(n);
+        hb.pool.reserve(2 * (size_t)n);
+        hb.run(n, bl.out);
+        bl.order.swap(hb.order);
+    } else {
+        bl.lo = lo.data();
+        bl.hi = hi.data();
+        bl.ctr = ctr.data();
+        bl.perm.resize(n);
+        for (int32_t i = 0; i < n; ++i) bl.perm[i] = i;
+        bl.max_prims = std::min(max_prims_in_node, 255);  // bvh.rs:222
+        bl.method = split_method;
+        bl.out.reserve(2 * (size_t)n);
+        bl.order.reserve(n);
+        bl.build(0, n);
+    }
 
     size_t nn = bl.out.size();
     PbrtLinearBVHNode* nodes = (PbrtLinearBVHNode*)std::malloc(nn * sizeof(PbrtLinearBVHNode));
@@ -223,7 +450,7 @@ extern "C" int pbrt_hip_bvh_build(const float* positions, int32_t n_verts, const
     *prim_order_out = nullptr;
     *n_nodes_out = 0;
     if (n_tris < 0 || n_verts < 0 || (n_tris > 0 && (!positions || !indices))) return PBRT_HIP_ERR_INVALID;
-    if (split_method != 0 && split_method != 2 && split_method != 3) return PBRT_HIP_ERR_INVALID;
+    if (split_method < 0 || split_method > 3) return PBRT_HIP_ERR_INVALID;
     if (n_tris == 0) return PBRT_HIP_OK;  // bvh.rs:228-230: empty aggregate, no nodes
     for (int64_t i = 0; i < 3 * (int64_t)n_tris; ++i)
         if (indices[i] < 0 || indices[i] >= n_verts) return PBRT_HIP_ERR_INVALID;
@@ -254,7 +481,7 @@ extern "C" int pbrt_hip_bvh_build_boxes(const float* bounds_min, const float* bo
     *prim_order_out = nullptr;
     *n_nodes_out = 0;
     if (n < 0 || (n > 0 && (!bounds_min || !bounds_max))) return PBRT_HIP_ERR_INVALID;
-    if (split_method != 0 && split_method != 2 && split_method != 3) return PBRT_HIP_ERR_INVALID;
+    if (split_method < 0 || split_method > 3) return PBRT_HIP_ERR_INVALID;
     if (n == 0) return PBRT_HIP_OK;
     std::vector<float> lo(bounds_min, bounds_min + 3 * (size_t)n), hi(bounds_max, bounds_max + 3 * (size_t)n);
     return build_from_boxes(lo, hi, n, max_prims_in_node, split_method, nodes_out, n_nodes_out, prim_order_out);

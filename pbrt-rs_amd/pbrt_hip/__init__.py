@@ -18,7 +18,7 @@ from .scenes import (CAMERA_DTYPE, HIT_DTYPE, INSTANCE_DTYPE, LIGHT_DTYPE, MATER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpbrt_hip.so")
 
-SPLIT_SAH, SPLIT_MIDDLE, SPLIT_EQUAL_COUNTS = 0, 2, 3
+SPLIT_SAH, SPLIT_HLBVH, SPLIT_MIDDLE, SPLIT_EQUAL_COUNTS = 0, 1, 2, 3
 INTEGRATOR_PATH, INTEGRATOR_DIRECT = 0, 1
 
 EXPORTS = [

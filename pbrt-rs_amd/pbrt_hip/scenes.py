@@ -232,6 +232,25 @@ def instanced_camera(width, height, extent=4.0):
     return perspective_camera((0.0, 0.0, 3.2 * extent), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 40.0, width, height)
 
 
+def sphere_scene():
+    """Config 1 (CPU oracle only): unit matte sphere (rho 0.5) at the origin under a one-sided 2x2 quad
+    area light at y = 3 (Le = 10, facing down). scene["spheres"]: (n, 8) {c.xyz, radius, material, light, 0, 0}."""
+    quad = np.array([[-1, 3, -1], [1, 3, -1], [1, 3, 1], [-1, 3, 1]], dtype=np.float32)
+    return dict(
+        positions=quad,
+        indices=np.array([[0, 1, 2], [0, 2, 3]], dtype=np.int32),
+        tri_material=np.zeros(2, dtype=np.int32),
+        materials=_materials([(MAT_MATTE, (0.5, 0.5, 0.5), (0, 0, 0), 1.0)]),
+        tri_light=np.array([0, 1], dtype=np.int32),
+        lights=_lights([(LIGHT_DIFFUSE_AREA, (10.0, 10.0, 10.0), 0, 0, 1), (LIGHT_DIFFUSE_AREA, (10.0, 10.0, 10.0), 1, 0, 1)]),
+        spheres=np.array([[0, 0, 0, 1.0, 0, -1, 0, 0]], dtype=np.float32),
+    )
+
+
+def sphere_camera(width, height):
+    return perspective_camera((0.0, 1.0, 5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 45.0, width, height)
+
+
 def furnace_scene(rho=0.5, Le=1.0):
     """White-furnace check: a closed matte cube (rho) lit only by a constant env light cannot be
     reached by it, so use the open form: a single matte quad under a constant environment.

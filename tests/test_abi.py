@@ -42,7 +42,8 @@ def test_product_does_not_touch_the_oracle():
     assert "oracle" not in out
 
 
-@pytest.mark.parametrize("split", [pbrt_hip.SPLIT_SAH, pbrt_hip.SPLIT_MIDDLE, pbrt_hip.SPLIT_EQUAL_COUNTS])
+@pytest.mark.parametrize("split", [pbrt_hip.SPLIT_SAH, pbrt_hip.SPLIT_HLBVH, pbrt_hip.SPLIT_MIDDLE,
+                                   pbrt_hip.SPLIT_EQUAL_COUNTS])
 @pytest.mark.parametrize("max_prims", [1, 4, 255])
 def test_host_bvh_build_equals_oracle(split, max_prims):
     """BVHAccel::new on the host (csrc/host_bvh.cpp) vs the oracle's restatement: identical node array and leaf order."""
@@ -54,11 +55,23 @@ def test_host_bvh_build_equals_oracle(split, max_prims):
         # structural invariants of the flat layout (bvh.rs:774-811)
         leaf = nodes["n_primitives"] > 0
         assert leaf.sum() == (len(nodes) + 1) // 2
+        assert np.all(nodes["offset"][~leaf] > np.nonzero(~leaf)[0] + 1)   # second child after the first subtree
         assert nodes["n_primitives"].sum() == len(sc["indices"])
         assert sorted(order.tolist()) == list(range(len(sc["indices"])))
         # (leaves may exceed max_prims only when all centroids coincide, bvh.rs:312-326: e.g. the two
         # triangles of an axis-aligned quad have the same bounds, hence the same centroid)
         osc.close()
+
+
+def test_two_level_build_equals_oracle():
+    """Object-level tree + TransformedPrimitive world bounds + top-level tree vs the oracle."""
+    sc = scenes.instanced_scene(1500, 37, extent=1.2)
+    blas_nodes, blas_order, inst, tlas_nodes, tlas_order = pbrt_hip.build_two_level(sc)
+    osc = oracle.OracleScene(sc)
+    bn, bo = osc.blas()
+    assert blas_nodes.tobytes() == bn.tobytes() and np.array_equal(blas_order, bo)
+    assert tlas_nodes.tobytes() == osc.nodes().tobytes() and np.array_equal(tlas_order, osc.prim_order())
+    osc.close()
 
 
 def test_bvh_build_edge_cases():

@@ -152,3 +152,18 @@ def test_instanced_scene_parity(hip_ctx):
     assert c0 == ctr and c1 == ctr_p
     gsc.close()
     osc.close()
+
+
+@pytest.mark.parametrize("split", [pbrt_hip.SPLIT_HLBVH, pbrt_hip.SPLIT_MIDDLE, pbrt_hip.SPLIT_EQUAL_COUNTS])
+def test_other_split_methods(hip_ctx, split):
+    """Trees from the other BVHAccel split methods (bvh.rs:200-205), max 16 primitives per leaf."""
+    sc = scenes.random_triangles(20_000, seq=8, size=0.05)
+    osc = oracle.OracleScene(sc, 16, split)
+    gsc = pbrt_hip.Scene(hip_ctx, sc, 16, split)
+    assert gsc.nodes.tobytes() == osc.nodes().tobytes()
+    rays = _scene_rays(sc, 40_000, 12, 1.5)
+    cpu, _ = osc.intersect(rays)
+    _assert_hits_equal(gsc.intersect(rays), cpu)
+    assert np.array_equal(gsc.intersect_p(rays), osc.intersect_p(rays)[0])
+    gsc.close()
+    osc.close()

@@ -98,3 +98,55 @@ def test_quirk_d2_leaves_hits_unchanged_but_visits_more_nodes():
     assert cb["node_tests"] > ca["node_tests"]
     a.close()
     b.close()
+
+
+def test_sphere_intersection_matches_closed_form():
+    """Sphere::intersect (src/shapes/sphere.rs:38-92, EFloat quadratic) against the float64 closed form."""
+    sc = scenes.sphere_scene()
+    sc = dict(sc, lights=sc["lights"][:0], tri_light=np.full(2, -1, dtype=np.int32))
+    osc = oracle.OracleScene(sc)
+    rays = scenes.random_rays(20_000, 6, origin_extent=3.0)
+    rays["o"][:, 1] = np.minimum(rays["o"][:, 1], 2.5)       # keep origins below the quad
+    hits, _ = osc.intersect(rays, n_threads=2)
+    o, d = rays["o"].astype(np.float64), rays["d"].astype(np.float64)
+    a = (d * d).sum(1)
+    b = 2 * (o * d).sum(1)
+    c = (o * o).sum(1) - 1.0
+    disc = b * b - 4 * a * c
+    with np.errstate(invalid="ignore"):
+        t0 = (-b - np.sqrt(disc)) / (2 * a)
+        t1 = (-b + np.sqrt(disc)) / (2 * a)
+    t_ref = np.where(t0 > 1e-4, t0, t1)
+    expect_hit = (disc > 1e-6) & (t_ref > 1e-4)
+    is_sphere = hits["prim_id"] == 2                      # primitive n_tris + 0
+    quad_first = (hits["prim_id"] >= 0) & ~is_sphere
+    clear = expect_hit & ~quad_first & (np.abs(disc) > 1e-3) & (np.abs(t_ref) > 1e-2)
+    assert is_sphere[clear].all()
+    assert np.allclose(hits["t"][clear & is_sphere], t_ref[clear & is_sphere], rtol=2e-5, atol=1e-5)
+    assert is_sphere.sum() > 1000
+    occl, _ = osc.intersect_p(rays, n_threads=2)
+    assert np.array_equal(occl.astype(bool), hits["prim_id"] >= 0)
+    osc.close()
+
+
+def test_config1_sphere_direct_lighting():
+    """BASELINE config 1: diffuse sphere + area light, DirectLighting (UniformSampleAll), 256x256x4 on the CPU."""
+    w = h = 256
+    osc = oracle.OracleScene(scenes.sphere_scene())
+    film, st = osc.render(_cam(scenes.sphere_camera(w, h)), w, h, 4, integrator=1, max_depth=5, light_strategy=0, seed=0)
+    rgb = oracle.film_to_rgb(film)
+    assert st["camera_samples"] == w * h * 4
+    # lit from straight above by a 2x2 emitter (Le 10) at height 3: the top of the sphere (n = +y, 2 above it)
+    # receives E = Le * integral of cos*cos/r^2 over the quad; radiance = rho/pi * E
+    xs = (np.arange(400) + 0.5) / 400 * 2 - 1
+    X, Z = np.meshgrid(xs, xs)
+    r2 = X * X + Z * Z + 4.0
+    E = 10.0 * np.sum((2.0 / np.sqrt(r2)) ** 2 / r2) * (2.0 / 400) ** 2
+    expect_top = 0.5 / np.pi * E
+    # the top of the silhouette: brightest rows of the image
+    # the brightest visible points are near the pole (the camera at y = 1 sees it at a grazing angle)
+    assert abs(np.percentile(rgb[..., 0], 99.9) - expect_top) / expect_top < 0.25
+    assert rgb[200:, :].max() == 0.0                       # below the sphere: black background
+    left, right = rgb[:, :128].mean(), rgb[:, 128:].mean()
+    assert abs(left - right) / (left + right) < 0.02       # symmetric scene
+    osc.close()
