@@ -948,6 +948,8 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                 RENDER_TRY(hipEventElapsedTime(&ms, e_t0, e_t1));
                 local.trace_ms += ms;
                 local.trace_launches += 1;
+                if (std::getenv("PBRT_HIP_TRACE_LOG"))
+                    std::fprintf(stderr, "[pbrt_hip] k_trace: %u rays %.3f ms (%.0f Mrays/s)\n", n_trace, ms, n_trace / ms * 1e-3);
                 ctx->trace_ms += ms;
                 ctx->trace_launches += 1;
             }
