@@ -81,11 +81,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU is visible (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run the RCCL path runs even with one rank
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     W, H = args.width, args.height
@@ -103,7 +106,7 @@ def main():
         _, st = scene.render(cam, W, H, spp_total, max_depth=args.max_depth, rr_threshold=1.0, light_strategy=1,
                              seed=0, tile_rank=rank, tile_world=world, spp_per_pass=args.spp_per_pass,
                              d_film_ptr=film.data_ptr())
-        if world > 1:
+        if use_dist:
             dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)  # the only collective: Film reduce over xGMI
         return st
 
@@ -124,7 +127,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     tt = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=f"cuda:{local_rank}")
-    if world > 1:
+    if use_dist:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
@@ -204,7 +207,7 @@ def main():
     barrier()
     scene.close()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -561,7 +561,7 @@ struct BatchRayIO {
     }
 };
 template <bool ANY, bool COUNT, bool INST>
-__global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? 4 : PB_TRACE_WAVES)
+__global__ void __launch_bounds__(kTraceBlock, COUNT ? 4 : (INST ? PB_INST_WAVES : PB_TRACE_WAVES))
     k_intersect_batch(DevBVH bvh, BatchRayIO<ANY> io, unsigned int* work_counter, unsigned long long* counters) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
     trace_persistent<BatchRayIO<ANY>, COUNT, INST>(bvh, io, work_counter, lds_stack + threadIdx.x,

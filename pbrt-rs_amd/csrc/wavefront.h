@@ -239,8 +239,11 @@ struct WavefrontRayIO {
 #ifndef PB_TRACE_WAVES
 #define PB_TRACE_WAVES 6
 #endif
+#ifndef PB_INST_WAVES
+#define PB_INST_WAVES 4
+#endif
 template <bool COUNT, bool INST>
-__global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? 4 : PB_TRACE_WAVES)
+__global__ void __launch_bounds__(kTraceBlock, COUNT ? 4 : (INST ? PB_INST_WAVES : PB_TRACE_WAVES))
     k_trace(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
             unsigned long long* counters) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];

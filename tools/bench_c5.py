@@ -4,6 +4,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pbrt-rs_amd"))
 import pbrt_hip
+if os.environ.get("PBRT_LIB"): pbrt_hip.LIB_PATH = os.environ["PBRT_LIB"]
 from pbrt_hip import scenes
 W, H, spp = int(os.environ.get("W", 3840)), int(os.environ.get("H", 2160)), int(os.environ.get("SPP", 4))
 t = time.time()
@@ -18,3 +19,10 @@ for it in range(2):
 rays = st["rays_closest"] + st["rays_shadow"]
 print(f"{W}x{H}x{spp}: total {st['total_ms']:.1f} ms trace {st['trace_ms']:.1f} ms ({st['trace_launches']} launches) "
       f"rays {rays/1e6:.1f}M -> {rays/st['total_ms']/1e3:.0f} Mrays/s")
+ctx.set_counting(True); ctx.counters(reset=True)
+film, st2 = scene.render(cam, W, H, spp, max_depth=16, seed=0)
+c = ctx.counters(reset=True); ctx.set_counting(False)
+rays = c["rays"]
+alg = 32*rays + 32*c["node_tests"] + 48*c["prim_tests"] + 112*c.get("inst_tests",0) + 16*st2["rays_closest"] + 4*st2["rays_shadow"]
+print(f"per ray: node {c['node_tests']/rays:.1f} tri {c['prim_tests']/rays:.2f} inst {c.get('inst_tests',0)/rays:.2f}; "
+      f"algorithmic {alg/rays:.0f} B/ray -> {alg/st['trace_ms']/1e6:.0f} GB/s ({alg/st['trace_ms']/1e6/8000:.2f} of 8 TB/s)")
