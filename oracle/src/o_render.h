@@ -560,10 +560,13 @@ inline void render(const Scene& scene, const PerspectiveCamera& camera, Integrat
             int tx = tile % ntx, ty = tile / ntx;
             int x0 = sx0 + tx * TILE_SIZE, x1 = std::min(x0 + TILE_SIZE, sx1);
             int y0 = sy0 + ty * TILE_SIZE, y1 = std::min(y0 + TILE_SIZE, sy1);
-            // get_film_tile (film.rs:93-109): tile pixel bounds = [ceil(min - 0.5 - r), floor(max - 0.5 + r))
-            // = [x0 - 1, x1) x [y0 - 1, y1) for r = 0.5, clipped to the film. The extra row/column
-            // only ever receives samples whose film offset is exactly 0.0 (add_sample's ceil).
-            FilmTile film_tile(film, std::max(x0 - 1, 0), std::max(y0 - 1, 0), std::min(x1, film.width), std::min(y1, film.height));
+            // get_film_tile (film.rs:93-109): tile pixel bounds = [ceil(min - 0.5 - r), floor(max - 0.5 + r) + 1)
+            // = [x0 - 1, x1 + 1) x [y0 - 1, y1 + 1) for r = 0.5, clipped to the film. The reference omits
+            // pbrt-v3's "+ (1,1)" on the upper corner (film.rs:100-102), which would drop the samples whose
+            // film position rounds up to the next pixel at a tile's last column / row — intended (D50).
+            // The extra rows / columns only receive samples whose film offset rounds to exactly 0.0 or 1.0.
+            FilmTile film_tile(film, std::max(x0 - 1, 0), std::max(y0 - 1, 0), std::min(x1 + 1, film.width),
+                               std::min(y1 + 1, film.height));
             for (int py = y0; py < y1; ++py)
                 for (int px = x0; px < x1; ++px) {
                     for (int s = 0; s < rp.spp; ++s) {

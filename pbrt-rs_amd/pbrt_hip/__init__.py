@@ -9,6 +9,7 @@ There is no CPU fallback: without the HIP library or without a GPU every compute
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -110,6 +111,7 @@ class Context:
         if rc != 0:
             raise PbrtHipError(f"pbrt_hip_context_create failed ({rc}): {L.pbrt_hip_last_error(None).decode()}")
         self.h = h
+        self._scenes = weakref.WeakSet()  # scenes are destroyed before their context
 
     def check(self, rc, what):
         if rc != 0:
@@ -137,6 +139,8 @@ class Context:
 
     def close(self):
         if self.h:
+            for sc in list(self._scenes):
+                sc.close()
             lib().pbrt_hip_context_destroy(self.h)
             self.h = None
 
@@ -244,6 +248,7 @@ class Scene:
                                          _p(self.nodes), len(self.nodes), _p(self.prim_order), ctypes.byref(h))
         ctx.check(rc, "pbrt_hip_scene_create")
         self.h = h
+        ctx._scenes.add(self)
 
     def _init_instanced(self, scene, max_prims_in_node, split_method, bvh):
         self.positions = np.ascontiguousarray(scene["positions"], dtype=np.float32)
@@ -262,6 +267,7 @@ class Scene:
             _p(self.tlas_nodes), len(self.tlas_nodes), _p(self.tlas_order), ctypes.byref(h))
         self.ctx.check(rc, "pbrt_hip_scene_create_instanced")
         self.h = h
+        self.ctx._scenes.add(self)
 
     def intersect(self, rays):
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
@@ -308,8 +314,9 @@ class Scene:
         return film, stats
 
     def close(self):
-        if self.h:
-            lib().pbrt_hip_scene_destroy(self.h)
+        if getattr(self, "h", None):
+            if self.ctx.h:
+                lib().pbrt_hip_scene_destroy(self.h)
             self.h = None
 
     def __del__(self):

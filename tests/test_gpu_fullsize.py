@@ -1,0 +1,109 @@
+"""Parity and size-independent properties at BASELINE.json's sizes:
+config 2 (Cornell 512x512x64 spp, depth 8) against the oracle in full; config 3 (1 M triangles,
+1920x1080) against the oracle on a 256x256 crop at 64 spp, plus properties that need no oracle at
+full resolution: determinism, tile-partition linearity, closest-hit / any-hit consistency, t_max
+monotonicity."""
+import numpy as np
+import pytest
+
+import oracle
+import pbrt_hip
+from pbrt_hip import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _rmse(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def test_config2_cornell_full(hip_ctx):
+    w = h = 512
+    sc, cam = scenes.cornell_box(), scenes.cornell_camera(512, 512)
+    osc = oracle.OracleScene(sc)
+    gsc = pbrt_hip.Scene(hip_ctx, sc)
+    kw = dict(max_depth=8, rr_threshold=1.0, light_strategy=1, seed=0)
+    film_c, st_c = osc.render(scenes.camera_dict_to_floats(cam), w, h, 64, n_threads=16, **kw)
+    film_g, st_g = gsc.render(cam, w, h, 64, **kw)
+    rgb_g, rgb_c = pbrt_hip.film_to_rgb(film_g), oracle.film_to_rgb(film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    assert np.all(np.abs(rgb_g - rgb_c) <= 1e-5 * np.maximum(1.0, np.abs(rgb_c)))   # last-bit float differences only
+    assert _rmse(rgb_g, rgb_c) <= 1e-5                      # north_star budget: 1e-4 (emitter pixels are ~17)
+    gsc.close()
+    osc.close()
+
+
+@pytest.fixture(scope="module")
+def config3(hip_ctx):
+    sc = scenes.random_triangles(1_000_000, seq=1)
+    gsc = pbrt_hip.Scene(hip_ctx, sc)
+    yield sc, gsc
+    gsc.close()
+
+
+def test_config3_crop_vs_oracle(hip_ctx, config3):
+    sc, gsc = config3
+    w, h = 1920, 1080
+    cam = scenes.random_triangles_camera(w, h)
+    bounds = (832, 412, 1088, 668)                          # 256x256 centre crop
+    osc = oracle.OracleScene(sc)
+    assert osc.nodes().tobytes() == gsc.nodes.tobytes()     # 1 M-triangle SAH tree: host builder == oracle
+    film_c, st_c = osc.render(scenes.camera_dict_to_floats(cam), w, h, 64, max_depth=5, seed=0, bounds=bounds,
+                              n_threads=16)
+    film_g, st_g = gsc.render(cam, w, h, 64, max_depth=5, seed=0, bounds=bounds)
+    osc.close()
+    crop = (slice(bounds[1], bounds[3]), slice(bounds[0], bounds[2]))
+    rgb_g, rgb_c = pbrt_hip.film_to_rgb(film_g[crop]), oracle.film_to_rgb(film_c[crop])
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    assert np.all(np.abs(rgb_g - rgb_c) <= 1e-5 * np.maximum(1.0, np.abs(rgb_c)))
+    assert _rmse(rgb_g, rgb_c) <= 1e-6
+    assert np.all(film_g[:bounds[1]] == 0)
+
+
+def test_config3_full_frame_properties(hip_ctx, config3):
+    sc, gsc = config3
+    w, h, spp = 1920, 1080, 4
+    cam = scenes.random_triangles_camera(w, h)
+    a, st_a = gsc.render(cam, w, h, spp, max_depth=5, seed=0)
+    b, st_b = gsc.render(cam, w, h, spp, max_depth=5, seed=0, spp_per_pass=3)
+    assert a.tobytes() == b.tobytes()                        # deterministic, independent of the pass split
+    assert st_a["rays_closest"] == st_b["rays_closest"] and st_a["rays_shadow"] == st_b["rays_shadow"]
+    # every pixel received its spp unit filter weights; a few also one from a neighbour whose film position
+    # x + u rounded to a whole pixel (add_sample's ceil / floor, film.rs:263-264)
+    assert np.all(a[..., 3] >= spp) and (a[..., 3] != spp).mean() < 1e-3
+    parts = [gsc.render(cam, w, h, spp, max_depth=5, seed=0, tile_rank=r, tile_world=4)[0] for r in range(4)]
+    owned = sum((p[..., 3] >= spp).astype(np.int32) for p in parts)
+    assert np.all(owned == 1)                                # the four ranks' tile sets partition the frame
+    total = sum(parts)
+    plain = a[..., 3] == spp
+    assert np.array_equal(total[plain], a[plain])            # and their films sum to it exactly
+    assert np.allclose(total, a, rtol=1e-6, atol=1e-6)       # (neighbour contributions: float atomics, any order)
+    c, _ = gsc.render(cam, w, h, spp, max_depth=5, seed=1)
+    assert c.tobytes() != a.tobytes()
+    rgb = pbrt_hip.film_to_rgb(a)
+    assert np.isfinite(rgb).all() and rgb.min() >= 0.0 and 0.3 < rgb.mean() < 1.0   # rho 0.5 cloud under L = 1
+
+
+def test_config3_ray_batch_properties(hip_ctx, config3):
+    sc, gsc = config3
+    rays = scenes.random_rays(4_000_000, 77, origin_extent=1.2)
+    hits = gsc.intersect(rays)
+    occl = gsc.intersect_p(rays)
+    found = hits["prim_id"] >= 0
+    assert np.array_equal(found, occl.astype(bool))          # closest-hit and any-hit agree on occlusion
+    assert found.mean() > 0.5
+    # t_max just beyond the hit keeps it; t_max short of it finds nothing (nothing lies before the closest hit)
+    sub = np.nonzero(found)[0][:500_000]
+    r2 = rays[sub].copy()
+    r2["t_max"] = np.nextafter(hits["t"][sub], np.float32(np.inf))
+    h2 = gsc.intersect(r2)
+    assert np.array_equal(h2["prim_id"], hits["prim_id"][sub]) and np.array_equal(h2["t"], hits["t"][sub])
+    r3 = rays[sub].copy()
+    r3["t_max"] = hits["t"][sub] * np.float32(0.999)
+    h3 = gsc.intersect(r3)
+    assert np.all(h3["prim_id"] < 0)
+    # barycentrics reconstruct the hit point on the ray
+    tri = sc["positions"][sc["indices"][hits["prim_id"][sub]]]
+    p = (hits["b0"][sub, None] * tri[:, 0] + hits["b1"][sub, None] * tri[:, 1] + hits["b2"][sub, None] * tri[:, 2])
+    q = rays["o"][sub] + hits["t"][sub, None] * rays["d"][sub]
+    assert np.abs(p - q).max() < 1e-4
