@@ -128,6 +128,12 @@ typedef struct PbrtRenderParams {
     int32_t tile_world;     /* 1 = all tiles */
     int32_t spp_per_pass;   /* 0 = library default; samples of one pixel traced concurrently */
     int32_t pad;
+    /* Reconstruction filter (src/core/filter.rs:10-15, src/filters/): radius in pixels and Film's 16x16
+     * table of filter.evaluate over the positive quadrant (src/core/film.rs:52-63; build it with
+     * pbrt_hip_filter_table). filter_table == NULL or radius 0 = the 0.5 box filter. With a wider filter
+     * the pixel bounds may reach outside the film by the sample bounds (pbrt_hip_sample_bounds). */
+    float filter_radius[2];
+    const float* filter_table;
 } PbrtRenderParams;
 
 typedef struct PbrtRenderStats {
@@ -224,6 +230,17 @@ int pbrt_hip_render_device(PbrtHipScene* scene, const PbrtCamera* camera, const 
  * to n_out; returns PBRT_HIP_ERR_INVALID if the capacity is too small (n_out then holds the need). */
 int pbrt_hip_tile_partition(int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t rank, int32_t world,
                             int32_t* origins_xy, int32_t capacity, int32_t* n_out);
+
+/* Reconstruction filters of src/filters/{boxf,gaussian,mitchell,sinc,triangle}.rs tabulated as Film::new
+ * does (src/core/film.rs:52-63). a, b: gaussian alpha / mitchell B, C / lanczos tau. Host only. */
+enum PbrtFilterType { PBRT_FILTER_BOX = 0, PBRT_FILTER_GAUSSIAN = 1, PBRT_FILTER_MITCHELL = 2, PBRT_FILTER_LANCZOS = 3,
+                      PBRT_FILTER_TRIANGLE = 4 };
+int pbrt_hip_filter_table(int32_t type, float radius_x, float radius_y, float a, float b, float table256[256]);
+/* Film::get_sample_bounds (src/core/film.rs:76-81) of the whole film: {x0, y0, x1, y1}. Host only. */
+int pbrt_hip_sample_bounds(int32_t width, int32_t height, float radius_x, float radius_y, int32_t bounds[4]);
+/* Image output: Film::write_image ends in a file writer that is todo!() in the reference
+ * (src/core/imageio.rs:3-5); this writes the RGB image as a little-endian PFM (top row first in memory). */
+int pbrt_hip_write_pfm(const char* path, const float* rgb, int32_t width, int32_t height);
 
 /* Film::write_image's per-pixel arithmetic (src/core/film.rs:153-178, without the file
  * writer, which is todo!() in the reference): rgb = max(0, xyz_to_rgb(xyz) / filter_weight_sum). Host. */

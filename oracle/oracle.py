@@ -54,6 +54,10 @@ def lib():
         L.orc_intersect_p.argtypes = [vp, vp, ctypes.c_int64, vp, vp, ctypes.c_int]
         L.orc_render.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_uint64] + [ctypes.c_int] * 7 + [vp, vp]
+        L.orc_render_filtered.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_uint64] + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_float, vp, vp, vp]
+        L.orc_filter_table.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]
+        L.orc_sample_bounds.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp]
         L.orc_triangle_test.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, vp]
         L.orc_bounds_intersect_p.argtypes = [vp, vp, ctypes.c_uint32]
         L.orc_bounds_intersect_p.restype = ctypes.c_int
@@ -199,18 +203,38 @@ class OracleScene:
         return d
 
     def render(self, cam36, width, height, spp, integrator=0, max_depth=5, rr_threshold=1.0, light_strategy=1,
-               seed=0, bounds=None, n_threads=8):
-        x0, y0, x1, y1 = bounds if bounds is not None else (0, 0, width, height)
+               seed=0, bounds=None, n_threads=8, filter=None):
+        """filter = (radius_x, radius_y, table[256]) or None for the 0.5 box; with a wider filter the default
+        bounds are Film::get_sample_bounds (pixels outside the film are sampled too)."""
         film = np.zeros((height, width, 4), dtype=np.float32)
         stats = np.zeros(6, dtype=np.uint64)
         cam36 = _f32(cam36)
-        lib().orc_render(self.h, _p(cam36), integrator, max_depth, rr_threshold, light_strategy, spp, seed, width,
-                         height, x0, y0, x1, y1, n_threads, _p(film), _p(stats))
+        rx, ry, table = (0.5, 0.5, None) if filter is None else filter
+        table = None if table is None else _f32(table)
+        x0, y0, x1, y1 = bounds if bounds is not None else sample_bounds(width, height, rx, ry)
+        lib().orc_render_filtered(self.h, _p(cam36), integrator, max_depth, rr_threshold, light_strategy, spp, seed,
+                                  width, height, x0, y0, x1, y1, n_threads, rx, ry, _p(table), _p(film), _p(stats))
         st = dict(rays=int(stats[0]), node_tests=int(stats[1]), prim_tests=int(stats[2]),
                   camera_samples=int(stats[3]), seconds=float(stats[4]) * 1e-9)
         if hasattr(self, "n_instances"):
             st["inst_tests"] = int(stats[5])
         return film, st
+
+
+FILTERS = dict(box=0, gaussian=1, mitchell=2, lanczos=3, triangle=4)
+
+
+def filter_table(kind, rx, ry, a=0.0, b=0.0):
+    """Film::new's 16x16 table of filter.evaluate (film.rs:52-63). a, b: gaussian alpha / mitchell B, C / lanczos tau."""
+    t = np.zeros(256, dtype=np.float32)
+    lib().orc_filter_table(FILTERS[kind], rx, ry, a, b, _p(t))
+    return t
+
+
+def sample_bounds(width, height, rx=0.5, ry=0.5):
+    out = np.zeros(4, dtype=np.int32)
+    lib().orc_sample_bounds(width, height, rx, ry, _p(out))
+    return tuple(int(v) for v in out)
 
 
 def film_to_rgb(film):

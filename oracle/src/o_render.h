@@ -491,7 +491,64 @@ struct Film {
     Film(int w, int h) : width(w), height(h), pixels((size_t)w * h * 4, 0.0f) {
         for (int i = 0; i < FILTER_TABLE_WIDTH * FILTER_TABLE_WIDTH; ++i) filter_table[i] = 1.0f;  // film.rs:52-63, boxf.rs:25-27
     }
+    // film.rs:76-81 (D42: intended): floor(min + 0.5 - r), ceil(max - 0.5 + r) over the whole film
+    void sample_bounds(int* x0, int* y0, int* x1, int* y1) const {
+        *x0 = (int)std::floor(0.0f + 0.5f - filter_radius_x);
+        *y0 = (int)std::floor(0.0f + 0.5f - filter_radius_y);
+        *x1 = (int)std::ceil((Float)width - 0.5f + filter_radius_x);
+        *y1 = (int)std::ceil((Float)height - 0.5f + filter_radius_y);
+    }
 };
+
+// Reconstruction filters: src/filters/{boxf,gaussian,mitchell,sinc,triangle}.rs; Film::new tabulates
+// filter.evaluate over the positive quadrant (film.rs:52-63).
+enum FilterType { FILTER_BOX = 0, FILTER_GAUSSIAN = 1, FILTER_MITCHELL = 2, FILTER_LANCZOS = 3, FILTER_TRIANGLE = 4 };
+inline Float filter_evaluate(int type, Float rx, Float ry, Float a, Float b, Float px, Float py) {
+    switch (type) {
+        case FILTER_GAUSSIAN: {  // gaussian.rs:17-39
+            Float exp_x = std::exp(-a * rx * rx), exp_y = std::exp(-a * ry * ry);
+            Float gx = fmaxr(std::exp(-a * px * px) - exp_x, 0.0f), gy = fmaxr(std::exp(-a * py * py) - exp_y, 0.0f);
+            return gx * gy;
+        }
+        case FILTER_MITCHELL: {  // mitchell.rs:24-47
+            auto m1d = [&](Float x) {
+                x = std::fabs(2.0f * x);
+                if (x > 1.0f)
+                    return ((-a - 6.0f * b) * x * x * x + (6.0f * a + 30.0f * b) * x * x + (-12.0f * a - 48.0f * b) * x +
+                            (8.0f * a + 24.0f * b)) * (1.0f / 6.0f);
+                return ((12.0f - 9.0f * a - 6.0f * b) * x * x * x + (-18.0f + 12.0f * a + 6.0f * b) * x * x + (6.0f - 2.0f * a)) *
+                       (1.0f / 6.0f);
+            };
+            return m1d(px * (1.0f / rx)) * m1d(py * (1.0f / ry));
+        }
+        case FILTER_LANCZOS: {  // sinc.rs:22-48
+            auto sinc = [](Float x) {
+                x = std::fabs(x);
+                if (x < 1e-5f) return 1.0f;
+                return std::sin(PI * x) / (PI * x);
+            };
+            auto wsinc = [&](Float x, Float radius) {
+                x = std::fabs(x);
+                if (x > radius) return 0.0f;
+                return sinc(x) * sinc(x / a);
+            };
+            return wsinc(px, rx) * wsinc(py, ry);
+        }
+        case FILTER_TRIANGLE:  // triangle.rs:21-27
+            return fmaxr(rx - std::fabs(px), 0.0f) * fmaxr(ry - std::fabs(py), 0.0f);
+        default:
+            return 1.0f;  // boxf.rs:25-27
+    }
+}
+inline void filter_table(int type, Float rx, Float ry, Float a, Float b, Float* table) {
+    const int n = Film::FILTER_TABLE_WIDTH;
+    int offset = 0;
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x) {
+            Float px = ((Float)x + 0.5f) * rx / (Float)n, py = ((Float)y + 0.5f) * ry / (Float)n;
+            table[offset++] = filter_evaluate(type, rx, ry, a, b, px, py);
+        }
+}
 struct FilmTilePixel {
     Spectrum contrib_sum;
     Float filter_weight_sum = 0.0f;
@@ -561,12 +618,12 @@ inline void render(const Scene& scene, const PerspectiveCamera& camera, Integrat
             int x0 = sx0 + tx * TILE_SIZE, x1 = std::min(x0 + TILE_SIZE, sx1);
             int y0 = sy0 + ty * TILE_SIZE, y1 = std::min(y0 + TILE_SIZE, sy1);
             // get_film_tile (film.rs:93-109): tile pixel bounds = [ceil(min - 0.5 - r), floor(max - 0.5 + r) + 1)
-            // = [x0 - 1, x1 + 1) x [y0 - 1, y1 + 1) for r = 0.5, clipped to the film. The reference omits
-            // pbrt-v3's "+ (1,1)" on the upper corner (film.rs:100-102), which would drop the samples whose
-            // film position rounds up to the next pixel at a tile's last column / row — intended (D50).
-            // The extra rows / columns only receive samples whose film offset rounds to exactly 0.0 or 1.0.
-            FilmTile film_tile(film, std::max(x0 - 1, 0), std::max(y0 - 1, 0), std::min(x1 + 1, film.width),
-                               std::min(y1 + 1, film.height));
+            // clipped to the film. The reference omits pbrt-v3's "+ (1,1)" on the upper corner
+            // (film.rs:100-102), which would drop the samples whose film position rounds up to the next
+            // pixel at a tile's last column / row — intended (D50).
+            int tx0 = (int)std::ceil((Float)x0 - 0.5f - film.filter_radius_x), ty0 = (int)std::ceil((Float)y0 - 0.5f - film.filter_radius_y);
+            int tx1 = (int)std::floor((Float)x1 - 0.5f + film.filter_radius_x) + 1, ty1 = (int)std::floor((Float)y1 - 0.5f + film.filter_radius_y) + 1;
+            FilmTile film_tile(film, std::max(tx0, 0), std::max(ty0, 0), std::min(tx1, film.width), std::min(ty1, film.height));
             for (int py = y0; py < y1; ++py)
                 for (int px = x0; px < x1; ++px) {
                     for (int s = 0; s < rp.spp; ++s) {

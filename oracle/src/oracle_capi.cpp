@@ -260,9 +260,21 @@ void orc_intersect_p(void* h, const float* rays, int64_t n, uint8_t* out, uint64
 // camera: 36 floats {camera_to_world[16] row-major, raster_to_camera[16], lens_radius, focal_distance, shutter_open, shutter_close}
 // integrator: 0 = path, 1 = direct lighting. light_strategy: path {0 uniform, 1 power}; direct {0 all, 1 one}
 // stats: {rays, node_tests, prim_tests, camera_samples, nanoseconds, inst_tests}
+void orc_render_filtered(void* h, const float* cam, int integrator, int max_depth, float rr_threshold,
+                         int light_strategy, int spp, uint64_t seed, int width, int height, int x0, int y0, int x1,
+                         int y1, int n_threads, float filter_rx, float filter_ry, const float* filter_table256,
+                         float* film_out, uint64_t* stats);
 void orc_render(void* h, const float* cam, int integrator, int max_depth, float rr_threshold, int light_strategy,
                 int spp, uint64_t seed, int width, int height, int x0, int y0, int x1, int y1, int n_threads,
                 float* film_out, uint64_t* stats) {
+    orc_render_filtered(h, cam, integrator, max_depth, rr_threshold, light_strategy, spp, seed, width, height, x0, y0,
+                        x1, y1, n_threads, 0.5f, 0.5f, nullptr, film_out, stats);
+}
+// filter_table256 = Film::filter_table (film.rs:52-63), nullptr = box
+void orc_render_filtered(void* h, const float* cam, int integrator, int max_depth, float rr_threshold,
+                         int light_strategy, int spp, uint64_t seed, int width, int height, int x0, int y0, int x1,
+                         int y1, int n_threads, float filter_rx, float filter_ry, const float* filter_table256,
+                         float* film_out, uint64_t* stats) {
     const Scene& sc = ((OracleScene*)h)->scene;
     PerspectiveCamera camera;
     std::memcpy(camera.camera_to_world.m, cam, 64);
@@ -272,6 +284,9 @@ void orc_render(void* h, const float* cam, int integrator, int max_depth, float 
     camera.shutter_open = cam[34];
     camera.shutter_close = cam[35];
     Film film(width, height);
+    film.filter_radius_x = filter_rx;
+    film.filter_radius_y = filter_ry;
+    if (filter_table256) std::memcpy(film.filter_table, filter_table256, sizeof(film.filter_table));
     RenderParams rp;
     rp.spp = spp;
     rp.seed = seed;
@@ -298,6 +313,18 @@ void orc_render(void* h, const float* cam, int integrator, int max_depth, float 
         stats[4] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
         stats[5] = st.ctr.inst_tests;
     }
+}
+
+void orc_filter_table(int type, float rx, float ry, float a, float b, float* table256) {
+    filter_table(type, rx, ry, a, b, table256);
+}
+void orc_sample_bounds(int width, int height, float rx, float ry, int32_t* out4) {
+    Film f(width, height);
+    f.filter_radius_x = rx;
+    f.filter_radius_y = ry;
+    int x0, y0, x1, y1;
+    f.sample_bounds(&x0, &y0, &x1, &y1);
+    out4[0] = x0; out4[1] = y0; out4[2] = x1; out4[3] = y1;
 }
 
 // ---- unit entry points for known-answer tests ----

@@ -660,6 +660,71 @@ extern "C" int pbrt_hip_intersect_p(PbrtHipScene* s, const PbrtRay* rays, int64_
     return intersect_host<true>(s, rays, n, out);
 }
 
+// Film::get_sample_bounds (film.rs:76-81, D42 intended) of the whole film
+extern "C" int pbrt_hip_sample_bounds(int32_t width, int32_t height, float rx, float ry, int32_t b[4]) {
+    if (!b || width <= 0 || height <= 0 || !(rx > 0.0f) || !(ry > 0.0f)) return PBRT_HIP_ERR_INVALID;
+    b[0] = (int32_t)std::floor(0.0f + 0.5f - rx);
+    b[1] = (int32_t)std::floor(0.0f + 0.5f - ry);
+    b[2] = (int32_t)std::ceil((float)width - 0.5f + rx);
+    b[3] = (int32_t)std::ceil((float)height - 0.5f + ry);
+    return PBRT_HIP_OK;
+}
+
+// Filter::evaluate of src/filters/*.rs tabulated as Film::new does (film.rs:52-63)
+extern "C" int pbrt_hip_filter_table(int32_t type, float rx, float ry, float a, float b, float table[256]) {
+    if (!table || !(rx > 0.0f) || !(ry > 0.0f) || type < 0 || type > 4) return PBRT_HIP_ERR_INVALID;
+    auto mitchell = [&](float x) {  // mitchell.rs:31-47
+        x = std::fabs(2.0f * x);
+        if (x > 1.0f)
+            return ((-a - 6.0f * b) * x * x * x + (6.0f * a + 30.0f * b) * x * x + (-12.0f * a - 48.0f * b) * x +
+                    (8.0f * a + 24.0f * b)) * (1.0f / 6.0f);
+        return ((12.0f - 9.0f * a - 6.0f * b) * x * x * x + (-18.0f + 12.0f * a + 6.0f * b) * x * x + (6.0f - 2.0f * a)) *
+               (1.0f / 6.0f);
+    };
+    auto sinc = [](float x) {  // sinc.rs:28-35
+        x = std::fabs(x);
+        return x < 1e-5f ? 1.0f : std::sin(kPi * x) / (kPi * x);
+    };
+    auto wsinc = [&](float x, float radius) {  // sinc.rs:37-45
+        x = std::fabs(x);
+        return x > radius ? 0.0f : sinc(x) * sinc(x / a);
+    };
+    int k = 0;
+    for (int y = 0; y < 16; ++y)
+        for (int x = 0; x < 16; ++x) {
+            float px = ((float)x + 0.5f) * rx / 16.0f, py = ((float)y + 0.5f) * ry / 16.0f, v = 1.0f;
+            switch (type) {
+                case PBRT_FILTER_GAUSSIAN: {  // gaussian.rs:17-39
+                    float ex = std::exp(-a * rx * rx), ey = std::exp(-a * ry * ry);
+                    float gx = std::exp(-a * px * px) - ex, gy = std::exp(-a * py * py) - ey;
+                    v = (gx > 0.0f ? gx : 0.0f) * (gy > 0.0f ? gy : 0.0f);
+                    break;
+                }
+                case PBRT_FILTER_MITCHELL: v = mitchell(px * (1.0f / rx)) * mitchell(py * (1.0f / ry)); break;
+                case PBRT_FILTER_LANCZOS: v = wsinc(px, rx) * wsinc(py, ry); break;
+                case PBRT_FILTER_TRIANGLE: {  // triangle.rs:21-27
+                    float tx = rx - std::fabs(px), ty = ry - std::fabs(py);
+                    v = (tx > 0.0f ? tx : 0.0f) * (ty > 0.0f ? ty : 0.0f);
+                    break;
+                }
+                default: v = 1.0f;  // boxf.rs:25-27
+            }
+            table[k++] = v;
+        }
+    return PBRT_HIP_OK;
+}
+
+extern "C" int pbrt_hip_write_pfm(const char* path, const float* rgb, int32_t width, int32_t height) {
+    if (!path || !rgb || width <= 0 || height <= 0) return PBRT_HIP_ERR_INVALID;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return PBRT_HIP_ERR_INVALID;
+    std::fprintf(f, "PF\n%d %d\n-1.0\n", width, height);  // negative scale = little endian
+    for (int32_t y = height - 1; y >= 0; --y)               // PFM stores the bottom row first
+        std::fwrite(rgb + (size_t)y * width * 3, sizeof(float), (size_t)width * 3, f);
+    bool ok = std::fclose(f) == 0;
+    return ok ? PBRT_HIP_OK : PBRT_HIP_ERR_INVALID;
+}
+
 extern "C" void pbrt_hip_film_to_rgb(const float* film, int64_t n_pixels, float* rgb) {
     for (int64_t i = 0; i < n_pixels; ++i) {
         const float* p = film + 4 * i;
@@ -753,8 +818,23 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         return PBRT_HIP_ERR_INVALID;
     };
     if (rp.width <= 0 || rp.height <= 0 || rp.spp <= 0) return invalid("width, height and spp must be positive");
-    if (rp.x0 < 0 || rp.y0 < 0 || rp.x1 > rp.width || rp.y1 > rp.height || rp.x0 > rp.x1 || rp.y0 > rp.y1)
-        return invalid("pixel bounds outside the film");
+    float frx = rp.filter_radius[0] > 0.0f ? rp.filter_radius[0] : 0.5f;
+    float fry = rp.filter_radius[1] > 0.0f ? rp.filter_radius[1] : 0.5f;
+    bool box = true;  // the 0.5 box filter: exact in-order accumulation (k_film_accumulate)
+    if (rp.filter_table) {
+        if (frx != 0.5f || fry != 0.5f) box = false;
+        for (int i = 0; i < 256; ++i)
+            if (rp.filter_table[i] != 1.0f) box = false;
+    } else {
+        frx = fry = 0.5f;
+    }
+    if (frx > 64.0f || fry > 64.0f) return invalid("filter radius too large");
+    {
+        int32_t sb[4];
+        pbrt_hip_sample_bounds(rp.width, rp.height, frx, fry, sb);
+        if (rp.x0 < sb[0] || rp.y0 < sb[1] || rp.x1 > sb[2] || rp.y1 > sb[3] || rp.x0 > rp.x1 || rp.y0 > rp.y1)
+            return invalid("pixel bounds outside the film's sample bounds");
+    }
     if (rp.integrator != PBRT_INTEGRATOR_PATH && rp.integrator != PBRT_INTEGRATOR_DIRECT)
         return invalid("integrator must be PBRT_INTEGRATOR_PATH or PBRT_INTEGRATOR_DIRECT");
     const bool direct = rp.integrator == PBRT_INTEGRATOR_DIRECT;
@@ -825,6 +905,11 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         ds.light_strategy = rp.light_strategy;
         if (prefix.back() >= 0xfff0) return invalid("too many light samples per vertex");
     }
+    float* d_filter = nullptr;
+    if (!box) {
+        d_filter = buf.alloc<float>(256, &ok);
+        if (ok) HIP_TRY(ctx, hipMemcpyAsync(d_filter, rp.filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, st));
+    }
     float4* accum = buf.alloc<float4>(n_pix, &ok);
     int2* d_origins = buf.alloc<int2>(origins.size(), &ok);
     if (!ok) return PBRT_HIP_ERR_OOM;
@@ -892,6 +977,9 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         pp.max_depth = rp.max_depth;
         pp.rr_threshold = rp.rr_threshold;
         pp.light_strategy = rp.light_strategy;
+        pp.filter_rx = frx;
+        pp.filter_ry = fry;
+        pp.filter_table = d_filter;
         uint32_t n_paths = (uint32_t)n_pix * pp.n_samples;
         int cur = 0;
         hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, st, ps, q[cur], pp, cam, tiles);
@@ -962,6 +1050,11 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             (void)first;
             first = false;
             cur = nxt;
+        }
+        if (!box) {
+            hipLaunchKernelGGL(k_film_splat, dim3((n_paths + 255) / 256), dim3(256), 0, st, ps, pp, tiles, d_film);
+            RENDER_TRY(hipGetLastError());
+            continue;
         }
         hipLaunchKernelGGL(k_film_accumulate, dim3((n_pix + 255) / 256), dim3(256), 0, st, ps, pp, tiles, accum, d_film);
         RENDER_TRY(hipGetLastError());

@@ -53,6 +53,8 @@ struct PassParams {
     int max_depth;
     float rr_threshold;
     int light_strategy;
+    float filter_rx, filter_ry;       // reconstruction filter radius
+    const float* filter_table;        // 16 x 16 table (device), nullptr = 0.5 box (exact in-order path)
 };
 
 struct Queues {
@@ -1105,6 +1107,42 @@ __global__ void k_film_accumulate(PathState ps, PassParams pp, TileList tiles, f
             }
     }
     accum[pix] = acc;
+}
+
+// General reconstruction filter: FilmTile::add_sample (film.rs:252-295) as a scatter. Each sample adds
+// L * weight * filter and the filter weight to every pixel of its footprint with float atomics (the
+// footprints of neighbouring samples, tiles and GPUs overlap); XYZ conversion is linear, so it is applied
+// per contribution instead of per tile (film.rs:111-123).
+__global__ void k_film_splat(PathState ps, PassParams pp, TileList tiles, float* d_film) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (uint32_t)pp.n_pix * pp.n_samples) return;
+    if (!(__float_as_int(ps.beta[p].w) & PF_VALID)) return;
+    float4 Lq = ps.L[p];
+    V3 L = V3{Lq.x, Lq.y, Lq.z};
+    float yv = 0.212671f * L.x + 0.715160f * L.y + 0.072169f * L.z;
+    if (__builtin_isnan(L.x) || __builtin_isnan(L.y) || __builtin_isnan(L.z) || yv < -1e-5f || __builtin_isinf(yv))
+        L = V3{0.0f, 0.0f, 0.0f};
+    float2 pf = ps.pfilm[p];
+    float dx = pf.x - 0.5f, dy = pf.y - 0.5f;
+    int px0 = max((int)__builtin_ceilf(dx - pp.filter_rx), 0), py0 = max((int)__builtin_ceilf(dy - pp.filter_ry), 0);
+    int px1 = min((int)__builtin_floorf(dx + pp.filter_rx) + 1, pp.width);
+    int py1 = min((int)__builtin_floorf(dy + pp.filter_ry) + 1, pp.height);
+    const float inv_rx = 1.0f / pp.filter_rx, inv_ry = 1.0f / pp.filter_ry;
+    for (int yy = py0; yy < py1; ++yy) {
+        float fy = __builtin_fabsf(((float)yy - dy) * inv_ry * 16.0f);
+        int ify = min(15, (int)__builtin_floorf(fy));
+        for (int xx = px0; xx < px1; ++xx) {
+            float fx = __builtin_fabsf(((float)xx - dx) * inv_rx * 16.0f);
+            int ifx = min(15, (int)__builtin_floorf(fx));
+            float fw = pp.filter_table[ify * 16 + ifx];
+            V3 c = L * 1.0f * fw;
+            float* fp = d_film + ((size_t)yy * pp.width + xx) * 4;
+            atomicAdd(fp + 0, 0.412453f * c.x + 0.357580f * c.y + 0.180423f * c.z);
+            atomicAdd(fp + 1, 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z);
+            atomicAdd(fp + 2, 0.019334f * c.x + 0.119193f * c.y + 0.950227f * c.z);
+            atomicAdd(fp + 3, fw);
+        }
+    }
 }
 
 // Film::merge_film_tile (film.rs:111-123): contrib_sum -> XYZ, accumulated into the film

@@ -28,7 +28,7 @@ EXPORTS = [
     "pbrt_hip_scene_create_instanced", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
     "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
-    "pbrt_hip_tile_partition",
+    "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm",
 ]
 
 
@@ -37,7 +37,8 @@ class RenderParams(ctypes.Structure):
                 ("light_strategy", ctypes.c_int32), ("spp", ctypes.c_int32), ("width", ctypes.c_int32),
                 ("height", ctypes.c_int32), ("x0", ctypes.c_int32), ("y0", ctypes.c_int32), ("x1", ctypes.c_int32),
                 ("y1", ctypes.c_int32), ("seed", ctypes.c_uint64), ("tile_rank", ctypes.c_int32),
-                ("tile_world", ctypes.c_int32), ("spp_per_pass", ctypes.c_int32), ("pad", ctypes.c_int32)]
+                ("tile_world", ctypes.c_int32), ("spp_per_pass", ctypes.c_int32), ("pad", ctypes.c_int32),
+                ("filter_radius", ctypes.c_float * 2), ("filter_table", ctypes.c_void_p)]
 
 
 class RenderStats(ctypes.Structure):
@@ -91,6 +92,9 @@ def lib():
         L.pbrt_hip_render.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
         L.pbrt_hip_render_device.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
         L.pbrt_hip_tile_partition.argtypes = [i32, i32, i32, i32, i32, i32, vp, i32, ctypes.POINTER(i32)]
+        L.pbrt_hip_filter_table.argtypes = [i32, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]
+        L.pbrt_hip_sample_bounds.argtypes = [i32, i32, ctypes.c_float, ctypes.c_float, vp]
+        L.pbrt_hip_write_pfm.argtypes = [ctypes.c_char_p, vp, i32, i32]
         L.pbrt_hip_film_to_rgb.argtypes = [vp, i64, vp]
         L.pbrt_hip_film_to_rgb.restype = None
         _lib = L
@@ -290,17 +294,24 @@ class Scene:
                                                          ctypes.c_void_p(d_out_ptr)), "pbrt_hip_intersect_p_device")
 
     def _params(self, width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
-                tile_rank, tile_world, spp_per_pass):
-        x0, y0, x1, y1 = bounds if bounds is not None else (0, 0, width, height)
+                tile_rank, tile_world, spp_per_pass, filter=None):
+        rx, ry, table = (0.5, 0.5, None) if filter is None else filter
+        if table is not None:
+            table = np.ascontiguousarray(table, dtype=np.float32)
+            self._filter_keep = table
+        x0, y0, x1, y1 = bounds if bounds is not None else sample_bounds(width, height, rx, ry)
         return RenderParams(integrator, max_depth, rr_threshold, light_strategy, spp, width, height, x0, y0, x1, y1,
-                            seed, tile_rank, tile_world, spp_per_pass, 0)
+                            seed, tile_rank, tile_world, spp_per_pass, 0, (ctypes.c_float * 2)(rx, ry),
+                            None if table is None else table.ctypes.data)
 
     def render(self, camera, width, height, spp, integrator=INTEGRATOR_PATH, max_depth=5, rr_threshold=1.0,
-               light_strategy=1, seed=0, bounds=None, tile_rank=0, tile_world=1, spp_per_pass=0, d_film_ptr=None):
-        """Integrator::render. Returns (film[h,w,4] or None when d_film_ptr is given, stats dict)."""
+               light_strategy=1, seed=0, bounds=None, tile_rank=0, tile_world=1, spp_per_pass=0, d_film_ptr=None,
+               filter=None):
+        """Integrator::render. Returns (film[h,w,4] or None when d_film_ptr is given, stats dict).
+        filter = (radius_x, radius_y, table256) from filter_table(), None = 0.5 box."""
         camera = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
         rp = self._params(width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
-                          tile_rank, tile_world, spp_per_pass)
+                          tile_rank, tile_world, spp_per_pass, filter)
         st = RenderStats()
         if d_film_ptr is None:
             film = np.zeros((height, width, 4), dtype=np.float32)
@@ -338,6 +349,33 @@ def tile_partition(bounds, rank, world):
     if rc != 0:
         raise PbrtHipError(f"pbrt_hip_tile_partition failed ({rc})")
     return out
+
+
+FILTERS = dict(box=0, gaussian=1, mitchell=2, lanczos=3, triangle=4)
+
+
+def filter_table(kind, rx, ry, a=0.0, b=0.0):
+    """(rx, ry, table256) for Scene.render(filter=...): Film::new's table of the named reconstruction filter."""
+    t = np.zeros(256, dtype=np.float32)
+    rc = lib().pbrt_hip_filter_table(FILTERS[kind], rx, ry, a, b, _p(t))
+    if rc != 0:
+        raise PbrtHipError(f"pbrt_hip_filter_table failed ({rc})")
+    return (float(rx), float(ry), t)
+
+
+def sample_bounds(width, height, rx=0.5, ry=0.5):
+    b = np.zeros(4, dtype=np.int32)
+    rc = lib().pbrt_hip_sample_bounds(width, height, rx, ry, _p(b))
+    if rc != 0:
+        raise PbrtHipError(f"pbrt_hip_sample_bounds failed ({rc})")
+    return tuple(int(v) for v in b)
+
+
+def write_pfm(path, rgb):
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    rc = lib().pbrt_hip_write_pfm(str(path).encode(), _p(rgb), rgb.shape[1], rgb.shape[0])
+    if rc != 0:
+        raise PbrtHipError(f"pbrt_hip_write_pfm failed ({rc})")
 
 
 def film_to_rgb(film):

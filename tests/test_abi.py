@@ -25,7 +25,7 @@ def test_header_symbols_exported():
 
 
 def test_struct_sizes_match_header():
-    assert ctypes.sizeof(pbrt_hip.RenderParams) == 72  # 11 x i32, pad to 8, u64 seed, 4 x i32
+    assert ctypes.sizeof(pbrt_hip.RenderParams) == 88  # 11 x i32, pad, u64 seed, 4 x i32, 2 x f32, pointer
     assert ctypes.sizeof(pbrt_hip.RenderStats) == 48
     assert scenes.CAMERA_DTYPE.itemsize == 144
 
@@ -114,3 +114,34 @@ def test_no_gpu_is_an_error_not_a_fallback():
     with pytest.raises(pbrt_hip.PbrtHipError) as e:
         pbrt_hip.Context(0)
     assert "no HIP device" in str(e.value) or "failed" in str(e.value)
+
+
+@pytest.mark.parametrize("kind,rx,ry,a,b", [("box", 0.5, 0.5, 0, 0), ("gaussian", 2.0, 2.0, 2.0, 0),
+                                            ("mitchell", 2.0, 2.0, 1 / 3, 1 / 3), ("lanczos", 4.0, 4.0, 3.0, 0),
+                                            ("triangle", 2.0, 1.5, 0, 0)])
+def test_filter_tables_and_sample_bounds(kind, rx, ry, a, b):
+    """Film::new's filter table (film.rs:52-63) and get_sample_bounds: host library == oracle restatement."""
+    _, _, t = pbrt_hip.filter_table(kind, rx, ry, a, b)
+    assert np.array_equal(t, oracle.filter_table(kind, rx, ry, a, b))
+    t = t.reshape(16, 16)
+    if kind == "box":
+        assert np.all(t == 1.0)
+    else:
+        assert t[0, 0] == t.max() and t[0, 0] > 0 and abs(t[15, 15]) < 0.05 * t[0, 0]
+        if kind in ("gaussian", "triangle"):
+            assert np.all(np.diff(t[0]) <= 0) and np.all(np.diff(t[:, 0]) <= 0) and t.min() >= 0
+    for w, h in ((64, 48), (1920, 1080)):
+        assert pbrt_hip.sample_bounds(w, h, rx, ry) == oracle.sample_bounds(w, h, rx, ry)
+    assert pbrt_hip.sample_bounds(64, 48) == (0, 0, 64, 48)
+    assert pbrt_hip.sample_bounds(64, 48, 2.0, 2.0) == (-2, -2, 66, 50)
+
+
+def test_write_pfm_roundtrip(tmp_path):
+    rgb = scenes.pcg32_float(3, 7 * 5 * 3).reshape(5, 7, 3)
+    path = tmp_path / "img.pfm"
+    pbrt_hip.write_pfm(path, rgb)
+    raw = open(path, "rb").read()
+    header, body = raw.split(b"-1.0\n", 1)
+    assert header == b"PF\n7 5\n"
+    back = np.frombuffer(body, dtype="<f4").reshape(5, 7, 3)[::-1]
+    assert np.array_equal(back, rgb)

@@ -160,3 +160,28 @@ def test_instanced_scene_render(hip_ctx, integrator, max_depth):
                                               light_strategy=1 if integrator == 0 else 0, seed=23)
     _compare(film_g, film_c)
     assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+
+
+@pytest.mark.parametrize("kind,rx,a,b", [("gaussian", 2.0, 2.0, 0.0), ("mitchell", 2.0, 1 / 3, 1 / 3), ("triangle", 1.5, 0, 0)])
+def test_reconstruction_filters(hip_ctx, kind, rx, a, b):
+    """Film with a wide reconstruction filter (src/filters/*.rs, FilmTile::add_sample film.rs:252-295): samples
+    outside the film (sample bounds) included. Both sides add the same terms; only the order of the float
+    additions differs (tile merges on the CPU, atomics on the GPU)."""
+    w, h = 72, 56
+    sc, cam = scenes.cornell_box(), scenes.cornell_camera(72, 56)
+    filt = pbrt_hip.filter_table(kind, rx, rx, a, b)
+    osc = oracle.OracleScene(sc)
+    gsc = pbrt_hip.Scene(hip_ctx, sc)
+    film_c, st_c = osc.render(scenes.camera_dict_to_floats(cam), w, h, 6, max_depth=5, seed=3, filter=filt)
+    film_g, st_g = gsc.render(cam, w, h, 6, max_depth=5, seed=3, filter=filt, spp_per_pass=4)
+    assert st_g["camera_samples"] == st_c["camera_samples"] == (w + 2 * int(np.ceil(rx - 0.5))) * (h + 2 * int(np.ceil(rx - 0.5))) * 6
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    assert np.allclose(film_g, film_c, rtol=2e-5, atol=2e-5)
+    rgb_g, rgb_c = pbrt_hip.film_to_rgb(film_g), oracle.film_to_rgb(film_c)
+    assert float(np.sqrt(np.mean((rgb_g.astype(np.float64) - rgb_c) ** 2))) <= 1e-5
+    # the two ranks' films still sum to the frame (footprints cross tile borders)
+    f0, _ = gsc.render(cam, w, h, 6, max_depth=5, seed=3, filter=filt, tile_rank=0, tile_world=2)
+    f1, _ = gsc.render(cam, w, h, 6, max_depth=5, seed=3, filter=filt, tile_rank=1, tile_world=2)
+    assert np.allclose(f0 + f1, film_c, rtol=2e-5, atol=2e-5)
+    gsc.close()
+    osc.close()
