@@ -110,7 +110,12 @@ typedef struct PbrtCamera {
     float shutter_close;
 } PbrtCamera;
 
-enum PbrtIntegratorKind { PBRT_INTEGRATOR_PATH = 0, PBRT_INTEGRATOR_DIRECT = 1 };
+enum PbrtIntegratorKind {
+    PBRT_INTEGRATOR_PATH = 0,    /* src/integrators/path.rs */
+    PBRT_INTEGRATOR_DIRECT = 1,  /* src/integrators/directlighting.rs */
+    PBRT_INTEGRATOR_WHITTED = 2, /* src/integrators/whitted.rs:47-98 */
+    PBRT_INTEGRATOR_AO = 3       /* src/integrators/ao.rs:55-104 (D51: the unoccluded directions contribute) */
+};
 
 /* Constructor arguments of PathIntegrator (src/integrators/path.rs:31-46) /
  * DirectLightingIntegrator (src/integrators/directlighting.rs:33-46) plus the sampler and film
@@ -119,7 +124,8 @@ typedef struct PbrtRenderParams {
     int32_t integrator;     /* PbrtIntegratorKind */
     int32_t max_depth;
     float rr_threshold;     /* path only */
-    int32_t light_strategy; /* path: 0 "uniform", 1 "power"; direct: 0 UniformSampleAll, 1 UniformSampleOne */
+    int32_t light_strategy; /* path: 0 "uniform", 1 "power"; direct: 0 UniformSampleAll, 1 UniformSampleOne;
+                             * ao: cos_sample (0 uniform hemisphere, 1 cosine-weighted) */
     int32_t spp;            /* RandomSampler samples per pixel */
     int32_t width, height;  /* film full_resolution */
     int32_t x0, y0, x1, y1; /* pixel_bounds [x0,x1) x [y0,y1) */
@@ -127,7 +133,7 @@ typedef struct PbrtRenderParams {
     int32_t tile_rank;      /* this GPU renders the 16x16 tiles whose index % tile_world == tile_rank */
     int32_t tile_world;     /* 1 = all tiles */
     int32_t spp_per_pass;   /* 0 = library default; samples of one pixel traced concurrently */
-    int32_t pad;
+    int32_t ao_samples;     /* AOIntegrator::n_samples (ao.rs:21); other integrators ignore it */
     /* Reconstruction filter (src/core/filter.rs:10-15, src/filters/): radius in pixels and Film's 16x16
      * table of filter.evaluate over the positive quadrant (src/core/film.rs:52-63; build it with
      * pbrt_hip_filter_table). filter_table == NULL or radius 0 = the 0.5 box filter. With a wider filter

@@ -203,8 +203,9 @@ class OracleScene:
         return d
 
     def render(self, cam36, width, height, spp, integrator=0, max_depth=5, rr_threshold=1.0, light_strategy=1,
-               seed=0, bounds=None, n_threads=8, filter=None):
-        """filter = (radius_x, radius_y, table[256]) or None for the 0.5 box; with a wider filter the default
+               seed=0, bounds=None, n_threads=8, filter=None, ao_samples=64, cos_sample=True):
+        """integrator: 0 path, 1 direct lighting, 2 Whitted, 3 ambient occlusion (ao_samples, cos_sample).
+        filter = (radius_x, radius_y, table[256]) or None for the 0.5 box; with a wider filter the default
         bounds are Film::get_sample_bounds (pixels outside the film are sampled too)."""
         film = np.zeros((height, width, 4), dtype=np.float32)
         stats = np.zeros(6, dtype=np.uint64)
@@ -212,6 +213,8 @@ class OracleScene:
         rx, ry, table = (0.5, 0.5, None) if filter is None else filter
         table = None if table is None else _f32(table)
         x0, y0, x1, y1 = bounds if bounds is not None else sample_bounds(width, height, rx, ry)
+        if integrator == 3:
+            max_depth, light_strategy = ao_samples, int(bool(cos_sample))
         lib().orc_render_filtered(self.h, _p(cam36), integrator, max_depth, rr_threshold, light_strategy, spp, seed,
                                   width, height, x0, y0, x1, y1, n_threads, rx, ry, _p(table), _p(film), _p(stats))
         st = dict(rays=int(stats[0]), node_tests=int(stats[1]), prim_tests=int(stats[2]),

@@ -449,6 +449,100 @@ struct DirectLightingIntegrator : Integrator {
     }
 };
 
+// integrators/whitted.rs:47-98. One Light::sample_li per light with BSDF::f over all lobes (no MIS, no
+// BSDF sampling), emission at every vertex, then the specular_reflect / specular_transmit recursion of
+// integrator.rs:294-392 shared with DirectLightingIntegrator.
+struct WhittedIntegrator : DirectLightingIntegrator {
+    WhittedIntegrator(int md) : DirectLightingIntegrator(UNIFORM_SAMPLE_ONE, md) {}
+    void pre_process(const Scene&) override {}
+    Spectrum li(Ray ray, const Scene& scene, RenderCtx& rc, int depth) const override {
+        Spectrum l(0.0f);
+        SurfaceInteraction isect;
+        if (!scene.intersect(ray, &isect, &rc.ctr)) {
+            for (auto& light : scene.lights) l += light->le(ray);  // whitted.rs:57-62
+            return l;
+        }
+        const Normal3f n = isect.shading.n;
+        Vector3f wo = isect.wo;
+        const MaterialDesc& mat = scene.materials[scene.material_of(isect)];
+        std::shared_ptr<BSDF> bsdf = compute_scattering_functions(mat, isect, MODE_RADIANCE, false, scene.quirks);
+        if (!bsdf) return li(isect.spawn_ray(ray.d), scene, rc, depth);  // whitted.rs:68-71
+        l += surface_le(scene, isect, wo);
+        for (auto& light : scene.lights) {  // whitted.rs:75-91
+            Vector3f wi;
+            Float pdf = 0.0f;
+            VisibilityTester visibility;
+            Spectrum li_ = light->sample_li(isect, rc.sampler.get_2d(), &wi, &pdf, &visibility);
+            if (li_.is_black() || pdf == 0.0f) continue;
+            Spectrum f = bsdf->f(wo, wi, BSDF_ALL);
+            if (!f.is_black() && visibility.un_occluded(scene, &rc.ctr)) l += f * li_ * wi.abs_dot(n) / pdf;
+        }
+        if (depth + 1 < max_depth) {
+            l += specular_bounce(ray, isect, *bsdf, scene, rc, depth, (uint8_t)(BSDF_REFLECTION | BSDF_SPECULAR));
+            l += specular_bounce(ray, isect, *bsdf, scene, rc, depth, (uint8_t)(BSDF_TRANSMISSION | BSDF_SPECULAR));
+        }
+        return l;
+    }
+};
+
+// src/core/sampling.rs:219-228
+inline Vector3f uniform_sample_hemisphere(const Point2f& u) {
+    Float z = u.x;
+    Float r = std::sqrt(fmaxr(1.0f - z * z, 0.0f));
+    Float phi = 2.0f * PI * u.y;
+    Float sp, cp;
+    det_sincos(phi, &sp, &cp);
+    return Vector3f(r * cp, r * sp, z);
+}
+inline Float uniform_hemisphere_pdf() { return INV_2_PI; }
+
+// integrators/ao.rs:55-104. n_samples hemisphere directions about the geometric normal at the first
+// surface that has a BSDF; each contributes cos / (pdf * n_samples) when its ray escapes.
+// D51 (intended): ao.rs:96 adds the term when scene.intersect_p(...) is TRUE, i.e. for the occluded
+// directions — the complement of ambient occlusion (pbrt-v3 ao.cpp:79 tests !IntersectP). The
+// unoccluded directions contribute here.
+// The 2D array of ao.rs:77-81 (Sampler::get_2d_array) is drawn from the sample's stream in index order.
+struct AOIntegrator : Integrator {
+    bool cos_sample;
+    int n_samples;
+    AOIntegrator(bool cs, int ns) : cos_sample(cs), n_samples(ns) {}
+    Spectrum li(Ray ray, const Scene& scene, RenderCtx& rc, int) const override {
+        Spectrum l(0.0f);
+        SurfaceInteraction isect;
+        for (;;) {
+            if (scene.intersect(ray, &isect, &rc.ctr)) {
+                const MaterialDesc& mat = scene.materials[scene.material_of(isect)];
+                std::shared_ptr<BSDF> bsdf = compute_scattering_functions(mat, isect, MODE_RADIANCE, true, scene.quirks);
+                if (!bsdf) {
+                    ray = isect.spawn_ray(ray.d);
+                    continue;
+                }
+                Normal3f n = isect.n.face_forward(-ray.d);
+                Vector3f s = isect.dpdu.normalize();
+                Vector3f t = isect.n.cross(s);
+                for (int i = 0; i < n_samples; ++i) {
+                    Point2f u = rc.sampler.get_2d();
+                    Vector3f wi;
+                    Float pdf;
+                    if (cos_sample) {
+                        wi = cosine_sample_hemisphere(u, scene.quirks);
+                        pdf = cosine_hemisphere_pdf(std::fabs(wi.z));
+                    } else {
+                        wi = uniform_sample_hemisphere(u);
+                        pdf = uniform_hemisphere_pdf();
+                    }
+                    wi = Vector3f(s.x * wi.x + t.x * wi.y + n.x * wi.z, s.y * wi.x + t.y * wi.y + n.y * wi.z,
+                                  s.z * wi.x + t.z * wi.y + n.z * wi.z);
+                    Ray shadow = isect.spawn_ray(wi);
+                    if (!scene.intersect_p(shadow, &rc.ctr)) l += Spectrum(wi.dot(n) / (pdf * (Float)n_samples));
+                }
+            }
+            break;
+        }
+        return l;
+    }
+};
+
 // ---------------------------------------------------------------------------------
 // Camera — cameras/perspective.rs. The 4x4 matrices are supplied by the caller (the host side
 // computes Transform::perspective / look_at, transform.rs:510-566); the oracle applies them.

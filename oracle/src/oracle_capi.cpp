@@ -258,7 +258,9 @@ void orc_intersect_p(void* h, const float* rays, int64_t n, uint8_t* out, uint64
 }
 
 // camera: 36 floats {camera_to_world[16] row-major, raster_to_camera[16], lens_radius, focal_distance, shutter_open, shutter_close}
-// integrator: 0 = path, 1 = direct lighting. light_strategy: path {0 uniform, 1 power}; direct {0 all, 1 one}
+// integrator: 0 = path, 1 = direct lighting, 2 = Whitted, 3 = ambient occlusion.
+// light_strategy: path {0 uniform, 1 power}; direct {0 all, 1 one}; AO {0 uniform hemisphere, 1 cosine};
+// for AO max_depth carries n_samples.
 // stats: {rays, node_tests, prim_tests, camera_samples, nanoseconds, inst_tests}
 void orc_render_filtered(void* h, const float* cam, int integrator, int max_depth, float rr_threshold,
                          int light_strategy, int spp, uint64_t seed, int width, int height, int x0, int y0, int x1,
@@ -299,8 +301,12 @@ void orc_render_filtered(void* h, const float* cam, int integrator, int max_dept
     std::unique_ptr<Integrator> integ;
     if (integrator == 0)
         integ.reset(new PathIntegrator(max_depth, rr_threshold, light_strategy == 0 ? "uniform" : "power"));
-    else
+    else if (integrator == 1)
         integ.reset(new DirectLightingIntegrator((LightStrategy)light_strategy, max_depth));
+    else if (integrator == 2)
+        integ.reset(new WhittedIntegrator(max_depth));
+    else
+        integ.reset(new AOIntegrator(light_strategy != 0, max_depth));  // AO: max_depth carries n_samples
     auto t0 = std::chrono::steady_clock::now();
     render(sc, camera, *integ, film, rp, &st);
     auto t1 = std::chrono::steady_clock::now();

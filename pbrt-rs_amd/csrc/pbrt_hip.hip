@@ -835,10 +835,13 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         if (rp.x0 < sb[0] || rp.y0 < sb[1] || rp.x1 > sb[2] || rp.y1 > sb[3] || rp.x0 > rp.x1 || rp.y0 > rp.y1)
             return invalid("pixel bounds outside the film's sample bounds");
     }
-    if (rp.integrator != PBRT_INTEGRATOR_PATH && rp.integrator != PBRT_INTEGRATOR_DIRECT)
-        return invalid("integrator must be PBRT_INTEGRATOR_PATH or PBRT_INTEGRATOR_DIRECT");
-    const bool direct = rp.integrator == PBRT_INTEGRATOR_DIRECT;
-    if (direct && rp.max_depth > 64) return invalid("direct lighting: max_depth > 64 (frame stack)");
+    if (rp.integrator < PBRT_INTEGRATOR_PATH || rp.integrator > PBRT_INTEGRATOR_AO)
+        return invalid("integrator must be a PbrtIntegratorKind");
+    // DirectLighting, Whitted and AO share the per-vertex stage machine of k_shade_direct
+    const bool direct = rp.integrator != PBRT_INTEGRATOR_PATH;
+    if (direct && rp.max_depth > 64) return invalid("direct lighting / Whitted: max_depth > 64 (frame stack)");
+    if (rp.integrator == PBRT_INTEGRATOR_AO && (rp.ao_samples < 1 || rp.ao_samples > 65535))
+        return invalid("ambient occlusion: ao_samples must be in [1, 65535]");
     if (rp.max_depth < 0 || rp.max_depth > 1 << 20) return invalid("bad max_depth");
     int world = rp.tile_world <= 0 ? 1 : rp.tile_world;
     int rank = rp.tile_rank;
@@ -903,6 +906,9 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         ds.ld_acc = buf.alloc<float4>(N, &ok);
         ds.frames = buf.alloc<float4>(N * (size_t)std::max(1, rp.max_depth) * 3, &ok);
         ds.light_strategy = rp.light_strategy;
+        ds.mode = rp.integrator;
+        ds.ao_samples = rp.ao_samples;
+        ds.ao_cos_sample = rp.light_strategy != 0;
         if (prefix.back() >= 0xfff0) return invalid("too many light samples per vertex");
     }
     float* d_filter = nullptr;

@@ -484,22 +484,15 @@ PB_DEV V3 surface_le(const ShadeConsts& sc, const Surf& sf, V3 w) {
     return V3{0.0f, 0.0f, 0.0f};
 }
 
-// estimate_direct (integrator.rs:136-266), first part: sample the light, evaluate the BSDF, sample the
-// BSDF, evaluate the light pdf. Writes the shadow ray (slot 2), the MIS ray (slot 1) and the pending
-// terms into the path state; returns PF_NEE_* flags for the rays that must be traced. `matte` = the
-// BSDF has a non-specular (Lambertian) lobe with reflectance kd; otherwise f == 0 and nothing is emitted.
-PB_DEV int estimate_direct_emit(const ShadeConsts& sc, const PathState& ps, uint32_t p, const Surf& sf, const Frame& fr,
-                                bool matte, V3 kd, int light_num, float ul0, float ul1, float us0, float us1,
-                                float pick_pdf, V3 beta) {
-    if (!matte) return 0;
-    V3 wo = sf.wo;
-    DevLight lt = sc.lights[light_num];
-    V3 Lc = V3{lt.L[0], lt.L[1], lt.L[2]};
-    // -- Light::sample_li --
+// Light::sample_li (light.rs:35-42): DiffuseAreaLight (diffuse.rs:60-81 with Triangle::sample / Shape::sample2)
+// or InfiniteAreaLight (infinite.rs:96-129). Outputs the visibility tester's far point (p1, error, normal).
+PB_DEV void light_sample_li(const ShadeConsts& sc, const Surf& sf, const DevLight& lt, float ul0, float ul1, V3* wi_o,
+                            float* pdf_o, V3* li_o, V3* p1_o, V3* p1_err_o, V3* p1_n_o) {
     V3 wi = V3{0.0f, 0.0f, 0.0f};
     float light_pdf = 0.0f;
     V3 li = V3{0.0f, 0.0f, 0.0f};
     V3 p1 = V3{0.0f, 0.0f, 0.0f}, p1_err = V3{0.0f, 0.0f, 0.0f}, p1_n = V3{0.0f, 0.0f, 0.0f};
+    V3 Lc = V3{lt.L[0], lt.L[1], lt.L[2]};
     if (lt.type == PBRT_LIGHT_DIFFUSE_AREA) {
         // Triangle::sample (triangle.rs:330-348) + Shape::sample2 (shape.rs:38-53)
         V3 q0, q1, q2;
@@ -549,6 +542,27 @@ PB_DEV int estimate_direct_emit(const ShadeConsts& sc, const PathState& ps, uint
             li = Lc;
         }
     }
+    *wi_o = wi;
+    *pdf_o = light_pdf;
+    *li_o = li;
+    *p1_o = p1;
+    *p1_err_o = p1_err;
+    *p1_n_o = p1_n;
+}
+
+// estimate_direct (integrator.rs:136-266), first part: sample the light, evaluate the BSDF, sample the
+// BSDF, evaluate the light pdf. Writes the shadow ray (slot 2), the MIS ray (slot 1) and the pending
+// terms into the path state; returns PF_NEE_* flags for the rays that must be traced. `matte` = the
+// BSDF has a non-specular (Lambertian) lobe with reflectance kd; otherwise f == 0 and nothing is emitted.
+PB_DEV int estimate_direct_emit(const ShadeConsts& sc, const PathState& ps, uint32_t p, const Surf& sf, const Frame& fr,
+                                bool matte, V3 kd, int light_num, float ul0, float ul1, float us0, float us1,
+                                float pick_pdf, V3 beta) {
+    if (!matte) return 0;
+    V3 wo = sf.wo;
+    DevLight lt = sc.lights[light_num];
+    V3 wi, li, p1, p1_err, p1_n;
+    float light_pdf;
+    light_sample_li(sc, sf, lt, ul0, ul1, &wi, &light_pdf, &li, &p1, &p1_err, &p1_n);
     int nee_flags = 0;
     V3 A = V3{0.0f, 0.0f, 0.0f};
     if (light_pdf > 0.0f && !is_black(li)) {
@@ -866,6 +880,9 @@ struct DirectState {
     float4* ld_acc;    // estimate_direct sum over the samples of the current light
     float4* frames;    // [p * max_depth * 3 + k*3 + {0,1,2}]: (ray.d xyz, b0) (b1, b2, slot, depth) (T rgb, -)
     int light_strategy;  // 0 UniformSampleAll, 1 UniformSampleOne
+    int mode;            // PBRT_INTEGRATOR_DIRECT, _WHITTED or _AO (the three share the vertex state machine)
+    int ao_samples;      // AOIntegrator::n_samples
+    int ao_cos_sample;   // AOIntegrator::cos_sample
 };
 
 __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState ps, DirectState ds, Queues qin,
@@ -887,8 +904,13 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
         float4 accq = ds.ld_acc[p];
         V3 ld_acc = V3{accq.x, accq.y, accq.z};
         size_t rbase = (size_t)p * 3 * 2;
-        const bool sample_all = ds.light_strategy == 0;
-        const int total = (sc.n_lights == 0) ? 0 : (sample_all ? sc.total_light_samples : 1);
+        const int mode = ds.mode;
+        const bool sample_all = mode == PBRT_INTEGRATOR_DIRECT && ds.light_strategy == 0;
+        // stages at a vertex: direct = light samples, Whitted = one per light (whitted.rs:75), AO = hemisphere samples
+        const int total = (mode == PBRT_INTEGRATOR_AO)        ? ds.ao_samples
+                          : (sc.n_lights == 0)                ? 0
+                          : (mode == PBRT_INTEGRATOR_WHITTED) ? sc.n_lights
+                                                              : (sample_all ? sc.total_light_samples : 1);
         Rng rng = path_rng(ps, pp, tiles, p);
         bool have_vertex = !(flags & PF_ALIVE);  // ALIVE: a continuation ray was traced, its hit is a new vertex
 
@@ -945,7 +967,8 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
                 if (hslot < 0) {
                     float4 r0 = ps.ray[rbase];
                     (void)r0;
-                    for (int k = 0; k < sc.n_infinite; ++k) {  // Σ light.le(ray): only infinite lights emit on a miss
+                    // Σ light.le(ray): only infinite lights emit on a miss (AO: nothing, ao.rs:66)
+                    for (int k = 0; k < sc.n_infinite && mode != PBRT_INTEGRATOR_AO; ++k) {
                         DevLight lt = sc.lights[sc.infinite_ids[k]];
                         L = L + mulv(T, V3{lt.L[0], lt.L[1], lt.L[2]});
                     }
@@ -960,10 +983,63 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
                         emit_cont = true;
                         break;
                     }
-                    L = L + mulv(T, surface_le(sc, sf, sf.wo));  // D28: + isect.Le(wo)
+                    if (mode != PBRT_INTEGRATOR_AO) L = L + mulv(T, surface_le(sc, sf, sf.wo));  // D28: + isect.Le(wo)
                     stage = 0;
                 }
                 have_vertex = true;
+            }
+            if (stage < total && mode == PBRT_INTEGRATOR_AO) {
+                // ---- one hemisphere sample of AOIntegrator::li (ao.rs:73-99; D51: unoccluded directions count) ----
+                if (!surface_ready) load_surface();
+                V3 n = dot(sf.n, -rd) < 0.0f ? -sf.n : sf.n;  // face_forward(isect.n, -ray.d), D46 intended
+                V3 s = normalize(sf.dpdu);
+                V3 t = cross(sf.n, s);
+                float u0 = rng_float(rng), u1 = rng_float(rng);
+                V3 wl;
+                float pdf;
+                if (ds.ao_cos_sample) {
+                    wl = cosine_sample_hemisphere(u0, u1);
+                    pdf = __builtin_fabsf(wl.z) * kInvPi;
+                } else {
+                    float r = __builtin_sqrtf(fmaxr(1.0f - u0 * u0, 0.0f));
+                    float sp_, cp_;
+                    det_sincos(2.0f * kPi * u1, &sp_, &cp_);
+                    wl = V3{r * cp_, r * sp_, u0};
+                    pdf = kInv2Pi;
+                }
+                V3 wi = V3{s.x * wl.x + t.x * wl.y + n.x * wl.z, s.y * wl.x + t.y * wl.y + n.y * wl.z,
+                           s.z * wl.x + t.z * wl.y + n.z * wl.z};
+                float a = dot(wi, n) / (pdf * (float)ds.ao_samples);
+                V3 o = offset_ray_origin(sf.p, sf.p_error, sf.n, wi);
+                store_ray(ps, p, RS_SHADOW, o, wi, kInf);
+                ps.nee_a[p] = make_float4(a, a, a, 1.0f);
+                flags |= PF_NEE_SHADOW;
+                emit_shadow = true;
+                stage += 1;
+                break;
+            }
+            if (stage < total && mode == PBRT_INTEGRATOR_WHITTED) {
+                // ---- one light of WhittedIntegrator::li's loop (whitted.rs:75-91) ----
+                if (!surface_ready) load_surface();
+                DevLight lt = sc.lights[stage];
+                float ul0 = rng_float(rng), ul1 = rng_float(rng);
+                stage += 1;
+                V3 wi, li, p1, p1_err, p1_n;
+                float pdf;
+                light_sample_li(sc, sf, lt, ul0, ul1, &wi, &pdf, &li, &p1, &p1_err, &p1_n);
+                if (is_black(li) || pdf == 0.0f) continue;
+                V3 f = V3{0.0f, 0.0f, 0.0f};
+                float spdf;
+                if (mat.type == PBRT_MAT_MATTE && !is_black(kd)) matte_f_pdf(fr, kd, sf.wo, wi, &f, &spdf);  // BSDF::f, all lobes
+                if (is_black(f)) continue;
+                V3 origin = offset_ray_origin(sf.p, sf.p_error, sf.n, p1 - sf.p);
+                V3 target = offset_ray_origin(p1, p1_err, p1_n, origin - p1);
+                store_ray(ps, p, RS_SHADOW, origin, target - origin, 1.0f - kShadowEpsilon);
+                V3 A = mulv(f, li) * absdot(wi, fr.ns) / pdf;
+                ps.nee_a[p] = make_float4(A.x, A.y, A.z, 1.0f);
+                flags |= PF_NEE_SHADOW;
+                emit_shadow = true;
+                break;
             }
             if (stage < total) {
                 // ---- one estimate_direct ----
@@ -995,7 +1071,7 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
             }
             // ---- specular branches (directlighting.rs:121-125), only while depth + 1 < max_depth ----
             bool branched = false;
-            if ((stage == total || stage == total + 1) && depth + 1 < pp.max_depth) {
+            if ((stage == total || stage == total + 1) && depth + 1 < pp.max_depth && mode != PBRT_INTEGRATOR_AO) {
                 if (!surface_ready) load_surface();
                 for (; stage <= total + 1 && !branched; ++stage) {
                     int which = (stage == total) ? 1 : 2;  // reflect first, then transmit

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpbrt_hip.so")
 
 SPLIT_SAH, SPLIT_HLBVH, SPLIT_MIDDLE, SPLIT_EQUAL_COUNTS = 0, 1, 2, 3
-INTEGRATOR_PATH, INTEGRATOR_DIRECT = 0, 1
+INTEGRATOR_PATH, INTEGRATOR_DIRECT, INTEGRATOR_WHITTED, INTEGRATOR_AO = 0, 1, 2, 3
 
 EXPORTS = [
     "pbrt_hip_context_create", "pbrt_hip_context_destroy", "pbrt_hip_last_error", "pbrt_hip_bvh_build",
@@ -37,7 +37,7 @@ class RenderParams(ctypes.Structure):
                 ("light_strategy", ctypes.c_int32), ("spp", ctypes.c_int32), ("width", ctypes.c_int32),
                 ("height", ctypes.c_int32), ("x0", ctypes.c_int32), ("y0", ctypes.c_int32), ("x1", ctypes.c_int32),
                 ("y1", ctypes.c_int32), ("seed", ctypes.c_uint64), ("tile_rank", ctypes.c_int32),
-                ("tile_world", ctypes.c_int32), ("spp_per_pass", ctypes.c_int32), ("pad", ctypes.c_int32),
+                ("tile_world", ctypes.c_int32), ("spp_per_pass", ctypes.c_int32), ("ao_samples", ctypes.c_int32),
                 ("filter_radius", ctypes.c_float * 2), ("filter_table", ctypes.c_void_p)]
 
 
@@ -294,24 +294,27 @@ class Scene:
                                                          ctypes.c_void_p(d_out_ptr)), "pbrt_hip_intersect_p_device")
 
     def _params(self, width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
-                tile_rank, tile_world, spp_per_pass, filter=None):
+                tile_rank, tile_world, spp_per_pass, filter=None, ao_samples=64):
         rx, ry, table = (0.5, 0.5, None) if filter is None else filter
         if table is not None:
             table = np.ascontiguousarray(table, dtype=np.float32)
             self._filter_keep = table
         x0, y0, x1, y1 = bounds if bounds is not None else sample_bounds(width, height, rx, ry)
         return RenderParams(integrator, max_depth, rr_threshold, light_strategy, spp, width, height, x0, y0, x1, y1,
-                            seed, tile_rank, tile_world, spp_per_pass, 0, (ctypes.c_float * 2)(rx, ry),
+                            seed, tile_rank, tile_world, spp_per_pass, ao_samples, (ctypes.c_float * 2)(rx, ry),
                             None if table is None else table.ctypes.data)
 
     def render(self, camera, width, height, spp, integrator=INTEGRATOR_PATH, max_depth=5, rr_threshold=1.0,
                light_strategy=1, seed=0, bounds=None, tile_rank=0, tile_world=1, spp_per_pass=0, d_film_ptr=None,
-               filter=None):
+               filter=None, ao_samples=64, cos_sample=True):
         """Integrator::render. Returns (film[h,w,4] or None when d_film_ptr is given, stats dict).
+        integrator: INTEGRATOR_PATH / _DIRECT / _WHITTED / _AO (ao_samples, cos_sample: AOIntegrator::new).
         filter = (radius_x, radius_y, table256) from filter_table(), None = 0.5 box."""
         camera = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
+        if integrator == INTEGRATOR_AO:
+            light_strategy = int(bool(cos_sample))
         rp = self._params(width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
-                          tile_rank, tile_world, spp_per_pass, filter)
+                          tile_rank, tile_world, spp_per_pass, filter, ao_samples)
         st = RenderStats()
         if d_film_ptr is None:
             film = np.zeros((height, width, 4), dtype=np.float32)

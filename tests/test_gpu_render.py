@@ -185,3 +185,48 @@ def test_reconstruction_filters(hip_ctx, kind, rx, a, b):
     assert np.allclose(f0 + f1, film_c, rtol=2e-5, atol=2e-5)
     gsc.close()
     osc.close()
+
+
+@pytest.mark.parametrize("scene_name,max_depth", [("cornell", 5), ("mixed", 1), ("mixed", 4), ("env", 3)])
+def test_whitted(hip_ctx, scene_name, max_depth):
+    """WhittedIntegrator::li (whitted.rs:47-98): one sample_li per light, no MIS, specular recursion."""
+    if scene_name == "cornell":
+        w, h, sc, cam = 64, 64, scenes.cornell_box(), scenes.cornell_camera(64, 64)
+    elif scene_name == "mixed":
+        w, h, sc, cam = 64, 48, scenes.mixed_materials_scene(), scenes.random_triangles_camera(64, 48)
+    else:
+        w, h, sc, cam = 72, 40, scenes.random_triangles(30_000, seq=2, size=0.04), scenes.random_triangles_camera(72, 40)
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, cam, w, h, 4, integrator=pbrt_hip.INTEGRATOR_WHITTED,
+                                              max_depth=max_depth, seed=29)
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+
+
+@pytest.mark.parametrize("cos_sample", [True, False])
+def test_ambient_occlusion(hip_ctx, cos_sample):
+    """AOIntegrator::li (ao.rs:55-104, D51 intended): n_samples any-hit rays per camera hit."""
+    w = h = 64
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, scenes.cornell_box(), scenes.cornell_camera(w, h), w, h, 3,
+                                              integrator=pbrt_hip.INTEGRATOR_AO, ao_samples=16, cos_sample=cos_sample,
+                                              seed=31)
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    assert st_g["rays_shadow"] % 16 == 0 and 0.9 * 16 * st_g["rays_closest"] < st_g["rays_shadow"] <= 16 * st_g["rays_closest"]
+    rgb = pbrt_hip.film_to_rgb(film_g)
+    assert 0.0 <= rgb.min() and rgb.max() <= (np.pi if cos_sample else 2 * np.pi) * 1.01 and 0.3 < rgb.mean() < 2.0
+
+
+def test_ambient_occlusion_instanced_passthrough(hip_ctx):
+    """AO over the instanced scene, samples split over several passes."""
+    w, h = 80, 56
+    sc = scenes.instanced_scene(2000, 40, extent=1.5)
+    osc = oracle.OracleScene(sc)
+    gsc = pbrt_hip.Scene(hip_ctx, sc)
+    cam = scenes.instanced_camera(w, h, 1.5)
+    kw = dict(integrator=pbrt_hip.INTEGRATOR_AO, ao_samples=5, cos_sample=True, seed=37)
+    film_c, st_c = osc.render(scenes.camera_dict_to_floats(cam), w, h, 4, **kw)
+    film_g, st_g = gsc.render(cam, w, h, 4, spp_per_pass=3, **kw)
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    gsc.close()
+    osc.close()

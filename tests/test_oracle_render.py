@@ -40,7 +40,8 @@ def test_area_light_irradiance_matches_closed_form():
     # a narrow camera looking at the floor point under the lamp, from the side so the lamp is not in view
     cam = scenes.perspective_camera((3, 1.0, 0), (0, 0, 0), (0, 1, 0), 0.5, w, h)
     expect = 0.6 / np.pi * 100.0 * (2 * s) ** 2 / 4.0
-    for integrator, kw in ((0, dict(max_depth=1, light_strategy=1)), (1, dict(max_depth=1, light_strategy=0))):
+    for integrator, kw in ((0, dict(max_depth=1, light_strategy=1)), (1, dict(max_depth=1, light_strategy=0)),
+                           (2, dict(max_depth=1))):      # path, direct lighting, Whitted
         film, _ = osc.render(_cam(cam), w, h, 512, integrator=integrator, seed=3, **kw)
         rgb = oracle.film_to_rgb(film)
         assert abs(rgb.mean() - expect) / expect < 0.03, (integrator, rgb.mean(), expect)
@@ -149,4 +150,49 @@ def test_config1_sphere_direct_lighting():
     assert rgb[200:, :].max() == 0.0                       # below the sphere: black background
     left, right = rgb[:, :128].mean(), rgb[:, 128:].mean()
     assert abs(left - right) / (left + right) < 0.02       # symmetric scene
+    osc.close()
+
+
+def test_whitted_furnace_and_emission():
+    """Whitted: one light sample per light without MIS still integrates rho * Le under a uniform environment;
+    in the Cornell box it adds the emitter's Le and equals direct lighting in expectation."""
+    w = h = 24
+    osc = oracle.OracleScene(scenes.furnace_scene(rho=0.5, Le=2.0))
+    cam = scenes.perspective_camera((0, 5, 0), (0, 0, 0.001), (0, 0, 1), 30.0, w, h)
+    film, _ = osc.render(_cam(cam), w, h, 256, integrator=2, max_depth=1, seed=1)
+    assert abs(oracle.film_to_rgb(film).mean() - 1.0) < 0.02
+    osc.close()
+    osc = oracle.OracleScene(scenes.cornell_box())
+    cam = _cam(scenes.cornell_camera(32, 32))
+    fw, _ = osc.render(cam, 32, 32, 64, integrator=2, max_depth=3, seed=5)
+    fd, _ = osc.render(cam, 32, 32, 64, integrator=1, max_depth=3, light_strategy=0, seed=6)
+    rw, rd = oracle.film_to_rgb(fw), oracle.film_to_rgb(fd)
+    assert rw.max() > 10.0 and abs(rw.mean() - rd.mean()) < 0.03 * rd.mean()
+    osc.close()
+
+
+def test_ambient_occlusion_closed_forms():
+    """AO (D51 intended): an open plane sees the whole hemisphere -> pi for both sampling modes; floor points at
+    the foot of a tall wall lose half of the cosine-weighted hemisphere -> pi / 2."""
+    w = h = 16
+    osc = oracle.OracleScene(scenes.furnace_scene())
+    cam = scenes.perspective_camera((0, 5, 0), (0, 0, 0.001), (0, 0, 1), 30.0, w, h)
+    for cos_sample in (True, False):
+        film, st = osc.render(_cam(cam), w, h, 8, integrator=3, ao_samples=32, cos_sample=cos_sample, seed=2)
+        rgb = oracle.film_to_rgb(film)
+        assert abs(rgb.mean() - np.pi) < (1e-4 if cos_sample else 0.05)
+        assert st["rays"] == w * h * 8 * 33
+    osc.close()
+    floor = np.array([[-10, 0, 0], [-10, 0, 10], [10, 0, 10], [10, 0, 0]], dtype=np.float32)
+    wall = np.array([[-10, 0, 0], [10, 0, 0], [10, 10, 0], [-10, 10, 0]], dtype=np.float32)
+    sc = dict(positions=np.concatenate([floor, wall]),
+              indices=np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7]], dtype=np.int32),
+              tri_material=np.zeros(4, dtype=np.int32),
+              materials=scenes._materials([(scenes.MAT_MATTE, (0.5, 0.5, 0.5), (0, 0, 0), 1.0)]),
+              tri_light=np.full(4, -1, dtype=np.int32), lights=scenes._lights([]))
+    osc = oracle.OracleScene(sc)
+    cam = scenes.perspective_camera((0, 3, 3), (0, 0, 0.002), (0, 1, 0), 0.02, w, h)   # floor points ~2 mm from the wall
+    for cos_sample in (True, False):
+        film, _ = osc.render(_cam(cam), w, h, 16, integrator=3, ao_samples=64, cos_sample=cos_sample, seed=4)
+        assert abs(oracle.film_to_rgb(film).mean() - np.pi / 2) < 0.03
     osc.close()
