@@ -169,6 +169,15 @@ int pbrt_hip_bvh_build(const float* positions, int32_t n_verts, const int32_t* i
 int pbrt_hip_bvh_build_boxes(const float* bounds_min, const float* bounds_max, int32_t n, int32_t max_prims_in_node,
                              int32_t split_method, PbrtLinearBVHNode** nodes_out, int32_t* n_nodes_out,
                              int32_t** prim_order_out);
+/* BVHAccel::new with SplitMethod::HLBVH built on the GPU (src/accelerators/bvh.rs:475-568: Morton codes
+ * :137-156 — the loop the reference marks "TODO parallel" at :489 — radix sort :158-197, treelets :509-528,
+ * emit_lbvh :570-676, build_upper_sah :678-772, flatten :774-811). Same outputs, byte for byte, as
+ * pbrt_hip_bvh_build(..., split_method = 1). build_ms (may be NULL): HIP-event time of the build with
+ * the mesh resident on the device (upload of the mesh and download of the tree excluded). */
+int pbrt_hip_bvh_build_hlbvh_device(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
+                                    const int32_t* indices, int32_t n_tris, int32_t max_prims_in_node,
+                                    PbrtLinearBVHNode** nodes_out, int32_t* n_nodes_out, int32_t** prim_order_out,
+                                    double* build_ms);
 /* TransformedPrimitive::world_bound (src/core/primitive.rs:126-134, src/core/transform.rs:568-607):
  * the 8 transformed corners of the object aggregate's bounds, per instance. Host only. */
 int pbrt_hip_instance_bounds(const float object_min[3], const float object_max[3], const PbrtInstance* instances,

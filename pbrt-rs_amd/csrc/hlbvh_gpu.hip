@@ -1,0 +1,562 @@
+// hlbvh_gpu.hip — BVHAccel::new with SplitMethod::HLBVH on the GPU.
+//
+// Reference: src/accelerators/bvh.rs — primitive bounds / centroids :26-41, Morton encode :137-156
+// (the loop the reference marks "TODO parallel", :489), radix sort :158-197, treelets :509-528,
+// emit_lbvh :570-676, build_upper_sah :678-772, flatten :774-811. The output (flat pre-order node array
+// + leaf order) is byte-identical to the host builder (host_bvh.cpp, split_method 1) and to the oracle.
+//
+// Device formulation (no recursion, no per-treelet serial loop):
+//   1. k_prim_bounds   one thread per triangle: bounds, centroid; centroid bounds by wave/block reduction and
+//                      one ordered-integer atomic per block.
+//   2. k_morton        30-bit Morton code of the centroid offset (10 bits per axis).
+//   3. rocprim radix_sort_pairs on bits [0, 30): any stable sort equals the reference's 5 x 6-bit LSD passes.
+//   4. k_treelet_*     one treelet per distinct top-12-bit prefix, in ascending order.
+//   5. k_level x 19    level-synchronous emit_lbvh: a work item is a (range, bit) pair; each thread skips the
+//                      bits on which its range does not split, then makes a leaf (bit == -1 or n < max_prims)
+//                      or an interior node and two items for the next level. Node ids and queue slots are
+//                      allocated with one atomic per wave.
+//   6. k_fit x 19      bottom-up by level: child-box unions and subtree sizes.
+//   7. k_local_index   pre-order index of every node inside its treelet from the subtree sizes (walk to the root).
+//   8. host            SAH over the <= 4096 treelet roots (host_bvh.cpp: hlbvh_upper_tree) -> global pre-order
+//                      offset of every treelet and the upper interior nodes. ~100 KB crosses PCIe.
+//   9. k_emit          LinearBVHNode records at (treelet offset + local index). The leaf order is the sorted
+//                      primitive list (the reference's ordered_prims_offset advances in DFS = Morton order).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdlib>
+#include <vector>
+
+#include "scene.h"
+
+namespace pb {
+void hlbvh_upper_tree(const float* boxes6, const int32_t* sizes, int32_t n, std::vector<int32_t>& treelet_offset,
+                      std::vector<int32_t>& upper_index, std::vector<PbrtLinearBVHNode>& upper_nodes,
+                      int32_t* n_nodes_total);
+}
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxTreelets = 4096;   // 12 Morton bits
+constexpr int kFirstBit = 29 - 12;   // bvh.rs:521
+constexpr int kLevels = kFirstBit + 2;  // bit 17 .. -1
+
+// monotone float <-> uint map for atomicMin / atomicMax
+__device__ inline uint32_t f2ord(float f) {
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ inline float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+__device__ inline float wave_min(float v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        float w = __shfl_xor(v, o);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+__device__ inline float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        float w = __shfl_xor(v, o);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+// One atomicAdd per wave: every lane of the wave must call this (want = false for lanes without a request).
+__device__ inline int wave_alloc(int* counter, bool want, int per_lane) {
+    unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return 0;
+    int lane = __lane_id();
+    int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, per_lane * __popcll(mask));
+    base = __shfl(base, leader);
+    return base + per_lane * __popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// Triangle::world_bound (triangle.rs:175-180), centroid = 0.5 * min + 0.5 * max (bvh.rs:38)
+__global__ void __launch_bounds__(kBlock) k_prim_bounds(const float* __restrict__ pos, const int* __restrict__ idx, int n,
+                                                        float* __restrict__ lo, float* __restrict__ hi,
+                                                        uint32_t* __restrict__ cb_ord) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    float cmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    if (i < n) {
+        const float* a = pos + 3 * (size_t)idx[3 * (size_t)i];
+        const float* b = pos + 3 * (size_t)idx[3 * (size_t)i + 1];
+        const float* c = pos + 3 * (size_t)idx[3 * (size_t)i + 2];
+        for (int k = 0; k < 3; ++k) {
+            float av = a[k], bv = b[k], cv = c[k];
+            float mn = av < bv ? av : bv;
+            float mx = av > bv ? av : bv;
+            mn = mn < cv ? mn : cv;
+            mx = mx > cv ? mx : cv;
+            lo[3 * (size_t)i + k] = mn;
+            hi[3 * (size_t)i + k] = mx;
+            float ctr = mn * 0.5f + mx * 0.5f;
+            cmn[k] = ctr;
+            cmx[k] = ctr;
+        }
+    }
+    __shared__ float sh[kBlock / 64][6];
+    int wave = threadIdx.x >> 6;
+    for (int k = 0; k < 3; ++k) {
+        float mn = wave_min(cmn[k]), mx = wave_max(cmx[k]);
+        if ((threadIdx.x & 63) == 0) {
+            sh[wave][k] = mn;
+            sh[wave][3 + k] = mx;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        int k = threadIdx.x;
+        float v = sh[0][k];
+        for (int w = 1; w < kBlock / 64; ++w) v = (k < 3) ? (sh[w][k] < v ? sh[w][k] : v) : (sh[w][k] > v ? sh[w][k] : v);
+        if (k < 3)
+            atomicMin(&cb_ord[k], f2ord(v));
+        else
+            atomicMax(&cb_ord[k], f2ord(v));
+    }
+}
+
+// left_shift3 / encode_morton3 (bvh.rs:137-156), offset of the centroid in the centroid bounds (bvh.rs:491-497)
+__device__ inline uint32_t spread3(uint32_t x) {
+    if (x == (1u << 10)) x -= 1;
+    x = (x | (x << 16)) & 0x30000ffu;
+    x = (x | (x << 8)) & 0x300f00fu;
+    x = (x | (x << 4)) & 0x30c30c3u;
+    x = (x | (x << 2)) & 0x9249249u;
+    return x;
+}
+__global__ void __launch_bounds__(kBlock) k_morton(const float* __restrict__ lo, const float* __restrict__ hi, int n,
+                                                   const uint32_t* __restrict__ cb_ord, uint32_t* __restrict__ code,
+                                                   int* __restrict__ prim) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+        float mn = ord2f(cb_ord[k]), mx = ord2f(cb_ord[3 + k]);
+        float ctr = lo[3 * (size_t)i + k] * 0.5f + hi[3 * (size_t)i + k] * 0.5f;
+        float o = ctr - mn;
+        if (mx > mn) o /= mx - mn;
+        q[k] = (uint32_t)(o * 1024.0f);
+    }
+    code[i] = (spread3(q[2]) << 2) | (spread3(q[1]) << 1) | spread3(q[0]);
+    prim[i] = i;
+}
+
+struct Item {
+    int begin, n;
+    int bit_treelet;  // (bit + 1) | treelet << 8
+    int parent;       // node id | which << 31; -1 = treelet root
+};
+
+// bvh.rs:509-528: a treelet starts wherever the top 12 Morton bits change
+__global__ void __launch_bounds__(kBlock) k_treelet_flags(const uint32_t* __restrict__ code, int n, int* __restrict__ first) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint32_t p = code[i] >> 18;
+    if (i == 0 || p != (code[i - 1] >> 18)) first[p] = i;
+}
+// single block: compact the present prefixes in ascending order into level-0 work items
+__global__ void __launch_bounds__(kBlock) k_treelet_compact(const int* __restrict__ first, int n, Item* __restrict__ items,
+                                                            int* __restrict__ level_count, int* __restrict__ n_treelets) {
+    __shared__ int sh_count[kBlock];
+    __shared__ int sh_start[kMaxTreelets + 1];
+    constexpr int per = kMaxTreelets / kBlock;
+    int t = threadIdx.x;
+    int cnt = 0;
+    for (int j = 0; j < per; ++j) cnt += first[t * per + j] >= 0;
+    sh_count[t] = cnt;
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        for (int j = 0; j < kBlock; ++j) {
+            int c = sh_count[j];
+            sh_count[j] = acc;
+            acc += c;
+        }
+        *n_treelets = acc;
+        level_count[0] = acc;
+        sh_start[acc] = n;
+    }
+    __syncthreads();
+    int at = sh_count[t];
+    for (int j = 0; j < per; ++j) {
+        int f = first[t * per + j];
+        if (f >= 0) sh_start[at++] = f;
+    }
+    __syncthreads();
+    at = sh_count[t];
+    for (int j = 0; j < per; ++j)
+        if (first[t * per + j] >= 0) {
+            Item it;
+            it.begin = sh_start[at];
+            it.n = sh_start[at + 1] - sh_start[at];
+            it.bit_treelet = (kFirstBit + 1) | (at << 8);
+            it.parent = -1;
+            items[at] = it;
+            ++at;
+        }
+}
+
+struct Nodes {
+    int4* info;     // (begin, n, parent | which << 31, (bit + 1) | treelet << 8); bit = split bit, -1.. for leaves unused
+    int* child;     // [2 * id + which], -1 = leaf
+    float* box;     // [6 * id]: min xyz, max xyz
+    int* size;      // subtree node count
+    int* local;     // pre-order index inside the treelet
+    int* treelet_root;
+};
+
+// emit_lbvh (bvh.rs:570-676), one level
+__global__ void __launch_bounds__(kBlock) k_level(const uint32_t* __restrict__ code, const int* __restrict__ prim,
+                                                  const float* __restrict__ lo, const float* __restrict__ hi,
+                                                  const Item* __restrict__ in, const int* __restrict__ count_in,
+                                                  Item* __restrict__ out, int* __restrict__ count_out, Nodes nd,
+                                                  int* __restrict__ node_count, int max_prims) {
+    const int count = *count_in;
+    const int stride = gridDim.x * kBlock;
+    // wave-uniform trip count: lanes past the end stay in the loop with valid = false
+    for (int base = blockIdx.x * kBlock + (threadIdx.x & ~63); base < count; base += stride) {
+        int i = base + (threadIdx.x & 63);
+        bool valid = i < count;
+        Item it = valid ? in[i] : Item{0, 0, 0, -1};
+        int begin = it.begin, n = it.n, bit = (it.bit_treelet & 0xff) - 1, treelet = it.bit_treelet >> 8;
+        int split = 0;
+        bool leaf = true;
+        if (valid) {
+            // ranges that do not split on this bit move on to the next one without a node (bvh.rs:607-620)
+            while (bit >= 0 && n >= max_prims) {
+                uint32_t mask = 1u << bit;
+                if ((code[begin] & mask) != (code[begin + n - 1] & mask)) break;
+                --bit;
+            }
+            leaf = (bit < 0) || (n < max_prims);
+            if (!leaf) {
+                // first index whose bit differs from the first element's (bvh.rs:622-639)
+                uint32_t mask = 1u << bit;
+                uint32_t b0 = code[begin] & mask;
+                int a = 0, b = n - 1;
+                while (a + 1 != b) {
+                    int m = (a + b) >> 1;
+                    if ((code[begin + m] & mask) == b0)
+                        a = m;
+                    else
+                        b = m;
+                }
+                split = b;
+            }
+        }
+        int id = wave_alloc(node_count, valid, 1);
+        int slot = wave_alloc(count_out, valid && !leaf, 2);
+        if (!valid) continue;
+        nd.info[id] = make_int4(begin, n, it.parent, (bit + 1) | (treelet << 8));
+        if (it.parent == -1)
+            nd.treelet_root[treelet] = id;
+        else
+            nd.child[2 * (size_t)(it.parent & 0x7fffffff) + ((unsigned)it.parent >> 31)] = id;
+        if (leaf) {
+            float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            for (int j = 0; j < n; ++j) {
+                size_t p = (size_t)prim[begin + j];
+                for (int k = 0; k < 3; ++k) {
+                    float l = lo[3 * p + k], h = hi[3 * p + k];
+                    mn[k] = l < mn[k] ? l : mn[k];
+                    mx[k] = h > mx[k] ? h : mx[k];
+                }
+            }
+            for (int k = 0; k < 3; ++k) {
+                nd.box[6 * (size_t)id + k] = mn[k];
+                nd.box[6 * (size_t)id + 3 + k] = mx[k];
+            }
+            nd.size[id] = 1;
+        } else {
+            Item c0{begin, split, bit | (treelet << 8), id};                       // (bit - 1) + 1
+            Item c1{begin + split, n - split, bit | (treelet << 8), (int)((unsigned)id | 0x80000000u)};
+            out[slot] = c0;
+            out[slot + 1] = c1;
+        }
+    }
+}
+
+// interior nodes of one level: bounds = union(child 0, child 1) in that order, subtree size
+__global__ void __launch_bounds__(kBlock) k_fit(Nodes nd, const int* __restrict__ level_start, int level) {
+    int id = level_start[level] + blockIdx.x * kBlock + threadIdx.x;
+    if (id >= level_start[level + 1]) return;
+    int c0 = nd.child[2 * (size_t)id], c1 = nd.child[2 * (size_t)id + 1];
+    if (c0 < 0) return;
+    for (int k = 0; k < 3; ++k) {
+        float mn = FLT_MAX, mx = -FLT_MAX;
+        float l0 = nd.box[6 * (size_t)c0 + k], h0 = nd.box[6 * (size_t)c0 + 3 + k];
+        float l1 = nd.box[6 * (size_t)c1 + k], h1 = nd.box[6 * (size_t)c1 + 3 + k];
+        mn = l0 < mn ? l0 : mn;
+        mn = l1 < mn ? l1 : mn;
+        mx = h0 > mx ? h0 : mx;
+        mx = h1 > mx ? h1 : mx;
+        nd.box[6 * (size_t)id + k] = mn;
+        nd.box[6 * (size_t)id + 3 + k] = mx;
+    }
+    nd.size[id] = 1 + nd.size[c0] + nd.size[c1];
+}
+
+// pre-order index inside the treelet: each step to the parent adds 1, plus the first sibling's subtree for a second child
+__global__ void __launch_bounds__(kBlock) k_local_index(Nodes nd, const int* __restrict__ node_count) {
+    int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id >= *node_count) return;
+    int local = 0;
+    int parent = nd.info[id].z;
+    while (parent != -1) {
+        int pid = parent & 0x7fffffff;
+        local += 1;
+        if ((unsigned)parent >> 31) local += nd.size[nd.child[2 * (size_t)pid]];
+        parent = nd.info[pid].z;
+    }
+    nd.local[id] = local;
+}
+
+struct RootSummary {
+    int n_treelets, n_nodes;
+    int level_start[kLevels + 1];
+    int size[kMaxTreelets];
+    float box[kMaxTreelets * 6];
+};
+__global__ void __launch_bounds__(kBlock) k_root_summary(Nodes nd, const int* __restrict__ n_treelets,
+                                                         const int* __restrict__ node_count,
+                                                         const int* __restrict__ level_start, RootSummary* out) {
+    int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t == 0) {
+        out->n_treelets = *n_treelets;
+        out->n_nodes = *node_count;
+        for (int l = 0; l <= kLevels; ++l) out->level_start[l] = level_start[l];
+    }
+    if (t >= *n_treelets) return;
+    int id = nd.treelet_root[t];
+    out->size[t] = nd.size[id];
+    for (int k = 0; k < 6; ++k) out->box[6 * t + k] = nd.box[6 * (size_t)id + k];
+}
+
+// flatten_bvh_tree (bvh.rs:774-811) for the treelet nodes
+__global__ void __launch_bounds__(kBlock) k_emit(Nodes nd, const int* __restrict__ node_count,
+                                                 const int* __restrict__ treelet_offset, PbrtLinearBVHNode* __restrict__ out) {
+    int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id >= *node_count) return;
+    int4 info = nd.info[id];
+    int base = treelet_offset[info.w >> 8];
+    PbrtLinearBVHNode ln;
+    for (int k = 0; k < 3; ++k) {
+        ln.bounds_min[k] = nd.box[6 * (size_t)id + k];
+        ln.bounds_max[k] = nd.box[6 * (size_t)id + 3 + k];
+    }
+    int c1 = nd.child[2 * (size_t)id + 1];
+    if (c1 < 0) {
+        ln.offset = info.x;  // leaves take the sorted primitive list in order
+        ln.n_primitives = (uint16_t)info.y;
+        ln.axis = 0;
+    } else {
+        ln.offset = base + nd.local[c1];
+        ln.n_primitives = 0;
+        ln.axis = (uint8_t)(((info.w & 0xff) - 1) % 3);
+    }
+    ln.pad = 0;
+    out[base + nd.local[id]] = ln;
+}
+__global__ void __launch_bounds__(kBlock) k_scatter_upper(const int* __restrict__ index, const PbrtLinearBVHNode* __restrict__ src,
+                                                          int n, PbrtLinearBVHNode* __restrict__ out) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[index[i]] = src[i];
+}
+
+struct DeviceArena {
+    std::vector<void*> ptrs;
+    bool ok = true;
+    hipError_t err = hipSuccess;
+    template <class T>
+    T* alloc(size_t n) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T));
+        if (e != hipSuccess) {
+            ok = false;
+            err = e;
+            return nullptr;
+        }
+        ptrs.push_back(p);
+        return (T*)p;
+    }
+    ~DeviceArena() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+};
+
+inline int blocks_for(size_t n) { return (int)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+#define HL_TRY(call)                                                   \
+    do {                                                               \
+        if (!pb::hip_ok(ctx, (call), #call)) return PBRT_HIP_ERR_DEVICE; \
+    } while (0)
+
+extern "C" int pbrt_hip_bvh_build_hlbvh_device(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
+                                               const int32_t* indices, int32_t n_tris, int32_t max_prims_in_node,
+                                               PbrtLinearBVHNode** nodes_out, int32_t* n_nodes_out,
+                                               int32_t** prim_order_out, double* build_ms) {
+    if (!ctx) return PBRT_HIP_ERR_INVALID;
+    auto invalid = [&](const char* m) {
+        ctx->last_error = m;
+        return PBRT_HIP_ERR_INVALID;
+    };
+    if (!nodes_out || !n_nodes_out || !prim_order_out) return invalid("null output pointer");
+    *nodes_out = nullptr;
+    *prim_order_out = nullptr;
+    *n_nodes_out = 0;
+    if (build_ms) *build_ms = 0.0;
+    if (n_tris < 0 || n_verts < 0 || (n_tris > 0 && (!positions || !indices))) return invalid("bad mesh arguments");
+    if (n_tris == 0) return PBRT_HIP_OK;  // bvh.rs:228-230
+    for (int64_t i = 0; i < 3 * (int64_t)n_tris; ++i)
+        if (indices[i] < 0 || indices[i] >= n_verts) return invalid("vertex index out of range");
+    const int n = n_tris;
+    const int max_prims = std::min(max_prims_in_node, 255);  // bvh.rs:222
+    HL_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+
+    DeviceArena mem;
+    float* d_pos = mem.alloc<float>(3 * (size_t)n_verts);
+    int* d_idx = mem.alloc<int>(3 * (size_t)n);
+    float* d_lo = mem.alloc<float>(3 * (size_t)n);
+    float* d_hi = mem.alloc<float>(3 * (size_t)n);
+    uint32_t* d_code[2] = {mem.alloc<uint32_t>(n), mem.alloc<uint32_t>(n)};
+    int* d_prim[2] = {mem.alloc<int>(n), mem.alloc<int>(n)};
+    Item* d_items[2] = {mem.alloc<Item>(std::max(n, kMaxTreelets)), mem.alloc<Item>(std::max(n, kMaxTreelets))};
+    // small state: centroid bounds [6], level counters [kLevels + 1], level starts [kLevels + 1], node counter, treelet count
+    constexpr int kSmall = 6 + 2 * (kLevels + 1) + 2;
+    uint32_t* d_small = mem.alloc<uint32_t>(kSmall);
+    int* d_first = mem.alloc<int>(kMaxTreelets);
+    const size_t cap = 2 * (size_t)n;  // leaves <= n, interior nodes < leaves
+    Nodes nd;
+    nd.info = mem.alloc<int4>(cap);
+    nd.child = mem.alloc<int>(2 * cap);
+    nd.box = mem.alloc<float>(6 * cap);
+    nd.size = mem.alloc<int>(cap);
+    nd.local = mem.alloc<int>(cap);
+    nd.treelet_root = mem.alloc<int>(kMaxTreelets);
+    int* d_treelet_offset = mem.alloc<int>(kMaxTreelets);
+    int* d_upper_index = mem.alloc<int>(kMaxTreelets);
+    PbrtLinearBVHNode* d_upper_nodes = mem.alloc<PbrtLinearBVHNode>(kMaxTreelets);
+    RootSummary* d_summary = mem.alloc<RootSummary>(1);
+    size_t sort_bytes = 0;
+    HL_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, d_code[0], d_code[1], d_prim[0], d_prim[1], (size_t)n, 0u, 30u, st));
+    void* d_sort_tmp = mem.alloc<char>(sort_bytes);
+    if (!mem.ok) {
+        ctx->last_error = std::string("hipMalloc: ") + hipGetErrorString(mem.err);
+        return PBRT_HIP_ERR_OOM;
+    }
+    uint32_t* d_cb = d_small;
+    int* d_level_count = (int*)d_small + 6;
+    int* d_level_start = d_level_count + (kLevels + 1);
+    int* d_node_count = d_level_start + (kLevels + 1);
+    int* d_n_treelets = d_node_count + 1;
+
+    HL_TRY(hipMemcpyAsync(d_pos, positions, 3 * (size_t)n_verts * sizeof(float), hipMemcpyHostToDevice, st));
+    HL_TRY(hipMemcpyAsync(d_idx, indices, 3 * (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+
+    hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;
+    HL_TRY(hipEventRecord(e0, st));
+    {
+        uint32_t init[kSmall] = {0};
+        init[0] = init[1] = init[2] = 0xffffffffu;  // running minima
+        HL_TRY(hipMemcpyAsync(d_small, init, sizeof(init), hipMemcpyHostToDevice, st));
+        HL_TRY(hipStreamSynchronize(st));  // `init` leaves scope
+    }
+    HL_TRY(hipMemsetAsync(d_first, 0xff, kMaxTreelets * sizeof(int), st));
+    HL_TRY(hipMemsetAsync(nd.child, 0xff, 2 * cap * sizeof(int), st));
+    hipLaunchKernelGGL(k_prim_bounds, dim3(blocks_for(n)), dim3(kBlock), 0, st, d_pos, d_idx, n, d_lo, d_hi, d_cb);
+    hipLaunchKernelGGL(k_morton, dim3(blocks_for(n)), dim3(kBlock), 0, st, d_lo, d_hi, n, d_cb, d_code[0], d_prim[0]);
+    HL_TRY(rocprim::radix_sort_pairs(d_sort_tmp, sort_bytes, d_code[0], d_code[1], d_prim[0], d_prim[1], (size_t)n, 0u, 30u, st));
+    const uint32_t* code = d_code[1];
+    const int* prim = d_prim[1];
+    hipLaunchKernelGGL(k_treelet_flags, dim3(blocks_for(n)), dim3(kBlock), 0, st, code, n, d_first);
+    hipLaunchKernelGGL(k_treelet_compact, dim3(1), dim3(kBlock), 0, st, d_first, n, d_items[0], d_level_count, d_n_treelets);
+    const int level_grid = std::max(1, std::min(blocks_for(n), 4 * std::max(1, ctx->n_cus)));
+    for (int l = 0; l < kLevels; ++l) {
+        HL_TRY(hipMemcpyAsync(d_level_start + l, d_node_count, sizeof(int), hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_level, dim3(level_grid), dim3(kBlock), 0, st, code, prim, d_lo, d_hi, d_items[l & 1],
+                           d_level_count + l, d_items[(l + 1) & 1], d_level_count + l + 1, nd, d_node_count, max_prims);
+    }
+    HL_TRY(hipMemcpyAsync(d_level_start + kLevels, d_node_count, sizeof(int), hipMemcpyDeviceToDevice, st));
+    // The level sizes are only known on the device: size every k_fit launch for the largest possible level.
+    // A level holds disjoint ranges, so at most n nodes.
+    for (int l = kLevels - 1; l >= 0; --l)
+        hipLaunchKernelGGL(k_fit, dim3(blocks_for(n)), dim3(kBlock), 0, st, nd, d_level_start, l);
+    hipLaunchKernelGGL(k_local_index, dim3(blocks_for(cap)), dim3(kBlock), 0, st, nd, d_node_count);
+    hipLaunchKernelGGL(k_root_summary, dim3(kMaxTreelets / kBlock), dim3(kBlock), 0, st, nd, d_n_treelets, d_node_count,
+                       d_level_start, d_summary);
+    HL_TRY(hipGetLastError());
+    std::vector<RootSummary> summary(1);
+    HL_TRY(hipMemcpyAsync(summary.data(), d_summary, sizeof(RootSummary), hipMemcpyDeviceToHost, st));
+    HL_TRY(hipStreamSynchronize(st));
+    const RootSummary& rs = summary[0];
+    if (rs.n_treelets < 1 || rs.n_treelets > kMaxTreelets || rs.n_nodes < rs.n_treelets || (size_t)rs.n_nodes > cap) {
+        ctx->last_error = "hlbvh: inconsistent treelet summary";
+        return PBRT_HIP_ERR_DEVICE;
+    }
+
+    // SAH over the treelet roots + global pre-order numbering (host, <= 4096 entries)
+    std::vector<int32_t> treelet_offset, upper_index;
+    std::vector<PbrtLinearBVHNode> upper_nodes;
+    int32_t n_nodes = 0;
+    pb::hlbvh_upper_tree(rs.box, rs.size, rs.n_treelets, treelet_offset, upper_index, upper_nodes, &n_nodes);
+    if ((size_t)n_nodes != (size_t)rs.n_nodes + upper_nodes.size()) {
+        ctx->last_error = "hlbvh: node count mismatch";
+        return PBRT_HIP_ERR_DEVICE;
+    }
+    PbrtLinearBVHNode* d_out = mem.alloc<PbrtLinearBVHNode>(n_nodes);
+    if (!mem.ok) {
+        ctx->last_error = std::string("hipMalloc: ") + hipGetErrorString(mem.err);
+        return PBRT_HIP_ERR_OOM;
+    }
+    HL_TRY(hipMemcpyAsync(d_treelet_offset, treelet_offset.data(), treelet_offset.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    if (!upper_nodes.empty()) {
+        HL_TRY(hipMemcpyAsync(d_upper_index, upper_index.data(), upper_index.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        HL_TRY(hipMemcpyAsync(d_upper_nodes, upper_nodes.data(), upper_nodes.size() * sizeof(PbrtLinearBVHNode),
+                              hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_scatter_upper, dim3(blocks_for(upper_nodes.size())), dim3(kBlock), 0, st, d_upper_index,
+                           d_upper_nodes, (int)upper_nodes.size(), d_out);
+    }
+    hipLaunchKernelGGL(k_emit, dim3(blocks_for(rs.n_nodes)), dim3(kBlock), 0, st, nd, d_node_count, d_treelet_offset, d_out);
+    HL_TRY(hipGetLastError());
+    HL_TRY(hipEventRecord(e1, st));
+
+    PbrtLinearBVHNode* nodes = (PbrtLinearBVHNode*)std::malloc((size_t)n_nodes * sizeof(PbrtLinearBVHNode));
+    int32_t* order = (int32_t*)std::malloc((size_t)n * sizeof(int32_t));
+    if (!nodes || !order) {
+        std::free(nodes);
+        std::free(order);
+        (void)hipStreamSynchronize(st);
+        return PBRT_HIP_ERR_OOM;
+    }
+    hipError_t ce = hipMemcpyAsync(nodes, d_out, (size_t)n_nodes * sizeof(PbrtLinearBVHNode), hipMemcpyDeviceToHost, st);
+    if (ce == hipSuccess) ce = hipMemcpyAsync(order, prim, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(st);
+    if (ce != hipSuccess) {
+        std::free(nodes);
+        std::free(order);
+        pb::hip_ok(ctx, ce, "hlbvh: copy back");
+        return PBRT_HIP_ERR_DEVICE;
+    }
+    if (build_ms) {
+        float ms = 0.0f;
+        HL_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *build_ms = ms;
+    }
+    *nodes_out = nodes;
+    *n_nodes_out = n_nodes;
+    *prim_order_out = order;
+    return PBRT_HIP_OK;
+}

@@ -397,6 +397,60 @@ struct HlbvhBuilder {
 
 }  // namespace
 
+// Upper levels of the HLBVH for the device builder (hlbvh_gpu.hip): the SAH tree over the treelet
+// roots (bvh.rs:678-772) and the pre-order numbering of bvh.rs:774-811, with every treelet standing in
+// for its `sizes[t]` nodes. boxes6 = {min xyz, max xyz} per treelet root.
+namespace pb {
+void hlbvh_upper_tree(const float* boxes6, const int32_t* sizes, int32_t n, std::vector<int32_t>& treelet_offset,
+                      std::vector<int32_t>& upper_index, std::vector<PbrtLinearBVHNode>& upper_nodes,
+                      int32_t* n_nodes_total) {
+    HlbvhBuilder hb;
+    hb.lo = hb.hi = hb.ctr = nullptr;
+    hb.max_prims = 0;
+    hb.pool.resize(n);
+    hb.pool.reserve(2 * (size_t)n);
+    std::vector<int> roots(n);
+    for (int32_t t = 0; t < n; ++t) {
+        std::memcpy(hb.pool[t].box.mn, boxes6 + 6 * (size_t)t, 12);
+        std::memcpy(hb.pool[t].box.mx, boxes6 + 6 * (size_t)t + 3, 12);
+        roots[t] = t;
+    }
+    int root = hb.upper(roots, 0, n);
+    treelet_offset.assign(n, 0);
+    upper_index.clear();
+    upper_nodes.clear();
+    int32_t next = 0;
+    // explicit stack: (node, slot of the parent's record waiting for its second-child offset or -1)
+    struct Item { int node; int parent_slot; };
+    std::vector<Item> stack;
+    stack.push_back({root, -1});
+    while (!stack.empty()) {
+        Item it = stack.back();
+        stack.pop_back();
+        if (it.parent_slot >= 0) upper_nodes[it.parent_slot].offset = next;  // this subtree is a second child
+        if (it.node < n) {
+            treelet_offset[it.node] = next;
+            next += sizes[it.node];
+            continue;
+        }
+        const HlbvhBuilder::Node& nd = hb.pool[it.node];
+        PbrtLinearBVHNode ln;
+        std::memcpy(ln.bounds_min, nd.box.mn, 12);
+        std::memcpy(ln.bounds_max, nd.box.mx, 12);
+        ln.offset = 0;
+        ln.n_primitives = 0;
+        ln.axis = (uint8_t)nd.axis;
+        ln.pad = 0;
+        upper_index.push_back(next++);
+        upper_nodes.push_back(ln);
+        int slot = (int)upper_nodes.size() - 1;
+        stack.push_back({nd.child[1], slot});   // popped after the whole first subtree
+        stack.push_back({nd.child[0], -1});
+    }
+    *n_nodes_total = next;
+}
+}  // namespace pb
+
 static int build_from_boxes(std::vector<float>& lo, std::vector<float>& hi, int32_t n, int32_t max_prims_in_node,
                             int32_t split_method, PbrtLinearBVHNode** nodes_out, int32_t* n_nodes_out,
                             int32_t** prim_order_out) {

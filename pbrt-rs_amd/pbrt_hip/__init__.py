@@ -28,7 +28,7 @@ EXPORTS = [
     "pbrt_hip_scene_create_instanced", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
     "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
-    "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm",
+    "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm",
 ]
 
 
@@ -70,6 +70,8 @@ def lib():
         L.pbrt_hip_last_error.restype = ctypes.c_char_p
         L.pbrt_hip_bvh_build.argtypes = [vp, i32, vp, i32, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(i32),
                                          ctypes.POINTER(vp)]
+        L.pbrt_hip_bvh_build_hlbvh_device.argtypes = [vp, vp, i32, vp, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(i32),
+                                                      ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_double)]
         L.pbrt_hip_free.argtypes = [vp]
         L.pbrt_hip_free.restype = None
         L.pbrt_hip_scene_create.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp,
@@ -169,6 +171,21 @@ def bvh_build(positions, indices, max_prims_in_node=4, split_method=SPLIT_SAH):
     if n == 0:
         return np.zeros(0, dtype=NODE_DTYPE), np.zeros(0, dtype=np.int32)
     return _take_tree(nodes_p, n, order_p, indices.shape[0])
+
+
+def bvh_build_hlbvh_device(ctx, positions, indices, max_prims_in_node=4):
+    """BVHAccel::new (HLBVH) on the GPU. Returns (nodes, prim_order, build_ms); equals bvh_build(..., SPLIT_HLBVH)."""
+    positions = np.ascontiguousarray(positions, dtype=np.float32)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    nodes_p, order_p, n_nodes, ms = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int32(), ctypes.c_double()
+    rc = lib().pbrt_hip_bvh_build_hlbvh_device(ctx.h, _p(positions), positions.shape[0], _p(indices), indices.shape[0],
+                                               max_prims_in_node, ctypes.byref(nodes_p), ctypes.byref(n_nodes),
+                                               ctypes.byref(order_p), ctypes.byref(ms))
+    ctx.check(rc, "pbrt_hip_bvh_build_hlbvh_device")
+    if n_nodes.value == 0:
+        return np.zeros(0, dtype=NODE_DTYPE), np.zeros(0, dtype=np.int32), 0.0
+    nodes, order = _take_tree(nodes_p, n_nodes.value, order_p, indices.shape[0])
+    return nodes, order, ms.value
 
 
 def _take_tree(nodes_p, n_nodes, order_p, n_prims):

@@ -167,3 +167,52 @@ def test_other_split_methods(hip_ctx, split):
     assert np.array_equal(gsc.intersect_p(rays), osc.intersect_p(rays)[0])
     gsc.close()
     osc.close()
+
+
+@pytest.mark.parametrize("n,max_prims,seq", [(1, 4, 1), (3, 4, 2), (1000, 4, 3), (50_000, 4, 4), (50_000, 1, 5),
+                                             (200_000, 8, 6), (20_000, 255, 7)])
+def test_gpu_hlbvh_build_equals_host_and_oracle(hip_ctx, n, max_prims, seq):
+    """GPU HLBVH (bvh.rs:475-568 + emit_lbvh / build_upper_sah / flatten): byte-identical to the host builder
+    and to the oracle's BVHAccel::new(HLBVH)."""
+    sc = scenes.random_triangles(n, seq=seq, size=0.05)
+    nodes_h, order_h = pbrt_hip.bvh_build(sc["positions"], sc["indices"], max_prims, pbrt_hip.SPLIT_HLBVH)
+    nodes_g, order_g, ms = pbrt_hip.bvh_build_hlbvh_device(hip_ctx, sc["positions"], sc["indices"], max_prims)
+    assert np.array_equal(order_g, order_h)
+    assert nodes_g.tobytes() == nodes_h.tobytes()
+    osc = oracle.OracleScene(sc, max_prims_in_node=max_prims, split_method=1)
+    assert osc.nodes().tobytes() == nodes_g.tobytes()
+    osc.close()
+
+
+def test_gpu_hlbvh_clustered_and_duplicate_centroids(hip_ctx):
+    """Few treelets (geometry in one corner), many identical Morton codes (bit == -1 leaves), Cornell box."""
+    sc = scenes.random_triangles(30_000, seq=9, size=0.02)
+    pos = sc["positions"].copy()
+    pos[: pos.shape[0] // 2] *= np.float32(1e-3)             # half of the mesh collapses into one Morton cell
+    nodes_h, order_h = pbrt_hip.bvh_build(pos, sc["indices"], 4, pbrt_hip.SPLIT_HLBVH)
+    nodes_g, order_g, _ = pbrt_hip.bvh_build_hlbvh_device(hip_ctx, pos, sc["indices"], 4)
+    assert np.array_equal(order_g, order_h) and nodes_g.tobytes() == nodes_h.tobytes()
+    dup = np.tile(sc["indices"][:7], (40, 1))                # 40 copies of 7 triangles: equal centroids
+    nodes_h, order_h = pbrt_hip.bvh_build(sc["positions"], dup, 4, pbrt_hip.SPLIT_HLBVH)
+    nodes_g, order_g, _ = pbrt_hip.bvh_build_hlbvh_device(hip_ctx, sc["positions"], dup, 4)
+    assert np.array_equal(order_g, order_h) and nodes_g.tobytes() == nodes_h.tobytes()
+    cb = scenes.cornell_box()
+    nodes_h, order_h = pbrt_hip.bvh_build(cb["positions"], cb["indices"], 4, pbrt_hip.SPLIT_HLBVH)
+    nodes_g, order_g, _ = pbrt_hip.bvh_build_hlbvh_device(hip_ctx, cb["positions"], cb["indices"], 4)
+    assert np.array_equal(order_g, order_h) and nodes_g.tobytes() == nodes_h.tobytes()
+
+
+def test_gpu_hlbvh_1m_triangles_and_trace(hip_ctx):
+    """Config-3 mesh: GPU-built tree == host tree, and a scene over it answers ray queries like the SAH scene."""
+    sc = scenes.random_triangles(1_000_000, seq=1)
+    nodes_h, order_h = pbrt_hip.bvh_build(sc["positions"], sc["indices"], 4, pbrt_hip.SPLIT_HLBVH)
+    nodes_g, order_g, ms = pbrt_hip.bvh_build_hlbvh_device(hip_ctx, sc["positions"], sc["indices"], 4)
+    assert np.array_equal(order_g, order_h) and nodes_g.tobytes() == nodes_h.tobytes()
+    assert 0.0 < ms < 200.0
+    rays = scenes.random_rays(200_000, 5, origin_extent=1.2)
+    g1 = pbrt_hip.Scene(hip_ctx, sc, bvh=(nodes_g, order_g))
+    g2 = pbrt_hip.Scene(hip_ctx, sc)
+    h1, h2 = g1.intersect(rays), g2.intersect(rays)
+    assert np.array_equal(h1["prim_id"], h2["prim_id"]) and np.array_equal(h1["t"], h2["t"])
+    g1.close()
+    g2.close()

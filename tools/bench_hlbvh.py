@@ -1,0 +1,27 @@
+"""BVH build time: GPU HLBVH (pbrt_hip_bvh_build_hlbvh_device) vs the host builders, config-3 style meshes.
+Usage: python tools/bench_hlbvh.py [n_tris ...]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pbrt-rs_amd"))
+import numpy as np
+import pbrt_hip
+from pbrt_hip import scenes
+
+sizes = [int(a) for a in sys.argv[1:]] or [1_000_000, 10_000_000]
+ctx = pbrt_hip.Context(0)
+for n in sizes:
+    sc = scenes.random_triangles(n, seq=1)
+    pbrt_hip.bvh_build_hlbvh_device(ctx, sc["positions"], sc["indices"], 4)          # warm up (module load, allocator)
+    t0 = time.time()
+    nodes_g, order_g, ms = pbrt_hip.bvh_build_hlbvh_device(ctx, sc["positions"], sc["indices"], 4)
+    wall_g = time.time() - t0
+    t0 = time.time()
+    nodes_h, order_h = pbrt_hip.bvh_build(sc["positions"], sc["indices"], 4, pbrt_hip.SPLIT_HLBVH)
+    wall_h = time.time() - t0
+    same = nodes_g.tobytes() == nodes_h.tobytes() and np.array_equal(order_g, order_h)
+    print(f"n_tris={n} nodes={len(nodes_g)} gpu_build_ms={ms:.3f} gpu_call_wall_ms={wall_g * 1e3:.1f} "
+          f"host_hlbvh_ms={wall_h * 1e3:.1f} identical={same} Mtris/s(device)={n / ms * 1e-3:.1f}", flush=True)
+ctx.close()
