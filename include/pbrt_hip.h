@@ -178,6 +178,14 @@ int pbrt_hip_bvh_build_hlbvh_device(PbrtHipContext* ctx, const float* positions,
                                     const int32_t* indices, int32_t n_tris, int32_t max_prims_in_node,
                                     PbrtLinearBVHNode** nodes_out, int32_t* n_nodes_out, int32_t** prim_order_out,
                                     double* build_ms);
+/* Scene::new (src/core/scene.rs:18-34) over BVHAccel::new(HLBVH) with the tree built AND re-laid out for
+ * the traversal kernels on the device: the mesh is uploaded once, nothing of the tree crosses PCIe. The
+ * scene is identical to pbrt_hip_scene_create over pbrt_hip_bvh_build(..., split_method = 1).
+ * build_ms / layout_ms (may be NULL): HIP-event times of the tree build and of the re-layout. */
+int pbrt_hip_scene_create_hlbvh(PbrtHipContext* ctx, const float* positions, int32_t n_verts, const int32_t* indices,
+                                int32_t n_tris, const int32_t* tri_material, const PbrtMaterial* materials,
+                                int32_t n_materials, const int32_t* tri_light, const PbrtLight* lights, int32_t n_lights,
+                                int32_t max_prims_in_node, PbrtHipScene** out, double* build_ms, double* layout_ms);
 /* TransformedPrimitive::world_bound (src/core/primitive.rs:126-134, src/core/transform.rs:568-607):
  * the 8 transformed corners of the object aggregate's bounds, per instance. Host only. */
 int pbrt_hip_instance_bounds(const float object_min[3], const float object_max[3], const PbrtInstance* instances,

@@ -26,6 +26,7 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <cfloat>
@@ -69,25 +70,13 @@ __device__ inline float wave_max(float v) {
     return v;
 }
 
-// One atomicAdd per wave: every lane of the wave must call this (want = false for lanes without a request).
-__device__ inline int wave_alloc(int* counter, bool want, int per_lane) {
-    unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return 0;
-    int lane = __lane_id();
-    int leader = __ffsll((long long)mask) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, per_lane * __popcll(mask));
-    base = __shfl(base, leader);
-    return base + per_lane * __popcll(mask & ((1ull << lane) - 1ull));
-}
-
 // Triangle::world_bound (triangle.rs:175-180), centroid = 0.5 * min + 0.5 * max (bvh.rs:38)
 __global__ void __launch_bounds__(kBlock) k_prim_bounds(const float* __restrict__ pos, const int* __restrict__ idx, int n,
                                                         float* __restrict__ lo, float* __restrict__ hi,
                                                         uint32_t* __restrict__ cb_ord) {
-    int i = blockIdx.x * kBlock + threadIdx.x;
     float cmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    if (i < n) {
+    // grid-stride: same-address atomics retire at ~100 per microsecond, so the grid is kept small
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const float* a = pos + 3 * (size_t)idx[3 * (size_t)i];
         const float* b = pos + 3 * (size_t)idx[3 * (size_t)i + 1];
         const float* c = pos + 3 * (size_t)idx[3 * (size_t)i + 2];
@@ -100,8 +89,8 @@ __global__ void __launch_bounds__(kBlock) k_prim_bounds(const float* __restrict_
             lo[3 * (size_t)i + k] = mn;
             hi[3 * (size_t)i + k] = mx;
             float ctr = mn * 0.5f + mx * 0.5f;
-            cmn[k] = ctr;
-            cmx[k] = ctr;
+            cmn[k] = ctr < cmn[k] ? ctr : cmn[k];
+            cmx[k] = ctr > cmx[k] ? ctr : cmx[k];
         }
     }
     __shared__ float sh[kBlock / 64][6];
@@ -215,17 +204,25 @@ struct Nodes {
     int* treelet_root;
 };
 
-// emit_lbvh (bvh.rs:570-676), one level
-__global__ void __launch_bounds__(kBlock) k_level(const uint32_t* __restrict__ code, const int* __restrict__ prim,
-                                                  const float* __restrict__ lo, const float* __restrict__ hi,
-                                                  const Item* __restrict__ in, const int* __restrict__ count_in,
-                                                  Item* __restrict__ out, int* __restrict__ count_out, Nodes nd,
-                                                  int* __restrict__ node_count, int max_prims) {
+// emit_lbvh (bvh.rs:570-676), one level. Every work item becomes exactly one node, so node ids need no
+// allocation: id = level_start[level] + item index. Queue slots for the two children of the interior nodes
+// are handed out with one atomic per block (wave ballots + an LDS prefix over the waves).
+constexpr int kLevelBlock = 1024;
+__global__ void __launch_bounds__(kLevelBlock) k_level(const uint32_t* __restrict__ code, const int* __restrict__ prim,
+                                                       const float* __restrict__ lo, const float* __restrict__ hi,
+                                                       const Item* __restrict__ in, const int* __restrict__ count_in,
+                                                       Item* __restrict__ out, int* __restrict__ count_out, Nodes nd,
+                                                       int* __restrict__ level_start, int max_prims) {
     const int count = *count_in;
-    const int stride = gridDim.x * kBlock;
-    // wave-uniform trip count: lanes past the end stay in the loop with valid = false
-    for (int base = blockIdx.x * kBlock + (threadIdx.x & ~63); base < count; base += stride) {
-        int i = base + (threadIdx.x & 63);
+    const int first_id = level_start[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) level_start[1] = first_id + count;
+    __shared__ int sh_wave[kLevelBlock / 64];
+    __shared__ int sh_base;
+    const int stride = gridDim.x * kLevelBlock;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // block-uniform trip count: threads past the end stay in the loop with valid = false
+    for (int base = blockIdx.x * kLevelBlock; base < count; base += stride) {
+        int i = base + threadIdx.x;
         bool valid = i < count;
         Item it = valid ? in[i] : Item{0, 0, 0, -1};
         int begin = it.begin, n = it.n, bit = (it.bit_treelet & 0xff) - 1, treelet = it.bit_treelet >> 8;
@@ -254,9 +251,23 @@ __global__ void __launch_bounds__(kBlock) k_level(const uint32_t* __restrict__ c
                 split = b;
             }
         }
-        int id = wave_alloc(node_count, valid, 1);
-        int slot = wave_alloc(count_out, valid && !leaf, 2);
+        unsigned long long mask = __ballot(valid && !leaf);
+        if (lane == 0) sh_wave[wave] = __popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int total = 0;
+            for (int w = 0; w < kLevelBlock / 64; ++w) {
+                int c = sh_wave[w];
+                sh_wave[w] = total;
+                total += c;
+            }
+            sh_base = total ? atomicAdd(count_out, 2 * total) : 0;
+        }
+        __syncthreads();
+        int slot = sh_base + 2 * (sh_wave[wave] + __popcll(mask & ((1ull << lane) - 1ull)));
+        __syncthreads();  // sh_wave / sh_base are rewritten by the next iteration
         if (!valid) continue;
+        int id = first_id + i;
         nd.info[id] = make_int4(begin, n, it.parent, (bit + 1) | (treelet << 8));
         if (it.parent == -1)
             nd.treelet_root[treelet] = id;
@@ -403,32 +414,13 @@ inline int blocks_for(size_t n) { return (int)((n + kBlock - 1) / kBlock); }
         if (!pb::hip_ok(ctx, (call), #call)) return PBRT_HIP_ERR_DEVICE; \
     } while (0)
 
-extern "C" int pbrt_hip_bvh_build_hlbvh_device(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
-                                               const int32_t* indices, int32_t n_tris, int32_t max_prims_in_node,
-                                               PbrtLinearBVHNode** nodes_out, int32_t* n_nodes_out,
-                                               int32_t** prim_order_out, double* build_ms) {
-    if (!ctx) return PBRT_HIP_ERR_INVALID;
-    auto invalid = [&](const char* m) {
-        ctx->last_error = m;
-        return PBRT_HIP_ERR_INVALID;
-    };
-    if (!nodes_out || !n_nodes_out || !prim_order_out) return invalid("null output pointer");
-    *nodes_out = nullptr;
-    *prim_order_out = nullptr;
-    *n_nodes_out = 0;
-    if (build_ms) *build_ms = 0.0;
-    if (n_tris < 0 || n_verts < 0 || (n_tris > 0 && (!positions || !indices))) return invalid("bad mesh arguments");
-    if (n_tris == 0) return PBRT_HIP_OK;  // bvh.rs:228-230
-    for (int64_t i = 0; i < 3 * (int64_t)n_tris; ++i)
-        if (indices[i] < 0 || indices[i] >= n_verts) return invalid("vertex index out of range");
-    const int n = n_tris;
-    const int max_prims = std::min(max_prims_in_node, 255);  // bvh.rs:222
-    HL_TRY(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+namespace {
 
-    DeviceArena mem;
-    float* d_pos = mem.alloc<float>(3 * (size_t)n_verts);
-    int* d_idx = mem.alloc<int>(3 * (size_t)n);
+// Steps 1-9 of the header comment over a mesh that is already on the device. Leaves the flat node array
+// (d_nodes, n_nodes) and the leaf order (d_order) in `mem`; ev0/ev1 of the context bracket the build.
+int hlbvh_build_core(PbrtHipContext* ctx, DeviceArena& mem, const float* d_pos, const int* d_idx, int n, int max_prims,
+                     PbrtLinearBVHNode** d_nodes_out, int32_t* n_nodes_out, const int** d_order_out) {
+    hipStream_t st = ctx->stream;
     float* d_lo = mem.alloc<float>(3 * (size_t)n);
     float* d_hi = mem.alloc<float>(3 * (size_t)n);
     uint32_t* d_code[2] = {mem.alloc<uint32_t>(n), mem.alloc<uint32_t>(n)};
@@ -460,36 +452,26 @@ extern "C" int pbrt_hip_bvh_build_hlbvh_device(PbrtHipContext* ctx, const float*
     uint32_t* d_cb = d_small;
     int* d_level_count = (int*)d_small + 6;
     int* d_level_start = d_level_count + (kLevels + 1);
-    int* d_node_count = d_level_start + (kLevels + 1);
-    int* d_n_treelets = d_node_count + 1;
+    int* d_n_treelets = d_level_start + (kLevels + 1);
 
-    HL_TRY(hipMemcpyAsync(d_pos, positions, 3 * (size_t)n_verts * sizeof(float), hipMemcpyHostToDevice, st));
-    HL_TRY(hipMemcpyAsync(d_idx, indices, 3 * (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
-
-    hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;
-    HL_TRY(hipEventRecord(e0, st));
-    {
-        uint32_t init[kSmall] = {0};
-        init[0] = init[1] = init[2] = 0xffffffffu;  // running minima
-        HL_TRY(hipMemcpyAsync(d_small, init, sizeof(init), hipMemcpyHostToDevice, st));
-        HL_TRY(hipStreamSynchronize(st));  // `init` leaves scope
-    }
+    HL_TRY(hipEventRecord(ctx->ev0, st));
+    HL_TRY(hipMemsetAsync(d_small, 0, kSmall * sizeof(uint32_t), st));
+    HL_TRY(hipMemsetAsync(d_small, 0xff, 3 * sizeof(uint32_t), st));  // running minima of the centroid bounds
     HL_TRY(hipMemsetAsync(d_first, 0xff, kMaxTreelets * sizeof(int), st));
     HL_TRY(hipMemsetAsync(nd.child, 0xff, 2 * cap * sizeof(int), st));
-    hipLaunchKernelGGL(k_prim_bounds, dim3(blocks_for(n)), dim3(kBlock), 0, st, d_pos, d_idx, n, d_lo, d_hi, d_cb);
+    hipLaunchKernelGGL(k_prim_bounds, dim3(std::min(blocks_for(n), 2 * std::max(1, ctx->n_cus))), dim3(kBlock), 0, st, d_pos,
+                       d_idx, n, d_lo, d_hi, d_cb);
     hipLaunchKernelGGL(k_morton, dim3(blocks_for(n)), dim3(kBlock), 0, st, d_lo, d_hi, n, d_cb, d_code[0], d_prim[0]);
     HL_TRY(rocprim::radix_sort_pairs(d_sort_tmp, sort_bytes, d_code[0], d_code[1], d_prim[0], d_prim[1], (size_t)n, 0u, 30u, st));
     const uint32_t* code = d_code[1];
     const int* prim = d_prim[1];
     hipLaunchKernelGGL(k_treelet_flags, dim3(blocks_for(n)), dim3(kBlock), 0, st, code, n, d_first);
     hipLaunchKernelGGL(k_treelet_compact, dim3(1), dim3(kBlock), 0, st, d_first, n, d_items[0], d_level_count, d_n_treelets);
-    const int level_grid = std::max(1, std::min(blocks_for(n), 4 * std::max(1, ctx->n_cus)));
-    for (int l = 0; l < kLevels; ++l) {
-        HL_TRY(hipMemcpyAsync(d_level_start + l, d_node_count, sizeof(int), hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_level, dim3(level_grid), dim3(kBlock), 0, st, code, prim, d_lo, d_hi, d_items[l & 1],
-                           d_level_count + l, d_items[(l + 1) & 1], d_level_count + l + 1, nd, d_node_count, max_prims);
-    }
-    HL_TRY(hipMemcpyAsync(d_level_start + kLevels, d_node_count, sizeof(int), hipMemcpyDeviceToDevice, st));
+    const int level_grid = std::max(1, std::min((n + kLevelBlock - 1) / kLevelBlock, 2 * std::max(1, ctx->n_cus)));
+    for (int l = 0; l < kLevels; ++l)  // k_level l also writes level_start[l + 1]; level_start[0] = 0 from the memset
+        hipLaunchKernelGGL(k_level, dim3(level_grid), dim3(kLevelBlock), 0, st, code, prim, d_lo, d_hi, d_items[l & 1],
+                           d_level_count + l, d_items[(l + 1) & 1], d_level_count + l + 1, nd, d_level_start + l, max_prims);
+    const int* d_node_count = d_level_start + kLevels;
     // The level sizes are only known on the device: size every k_fit launch for the largest possible level.
     // A level holds disjoint ranges, so at most n nodes.
     for (int l = kLevels - 1; l >= 0; --l)
@@ -531,18 +513,127 @@ extern "C" int pbrt_hip_bvh_build_hlbvh_device(PbrtHipContext* ctx, const float*
     }
     hipLaunchKernelGGL(k_emit, dim3(blocks_for(rs.n_nodes)), dim3(kBlock), 0, st, nd, d_node_count, d_treelet_offset, d_out);
     HL_TRY(hipGetLastError());
-    HL_TRY(hipEventRecord(e1, st));
+    HL_TRY(hipEventRecord(ctx->ev1, st));
+    HL_TRY(hipStreamSynchronize(st));  // the host vectors above feed async copies
+    *d_nodes_out = d_out;
+    *n_nodes_out = n_nodes;
+    *d_order_out = prim;
+    return PBRT_HIP_OK;
+}
 
+// ---- re-layout for the traversal kernel (what convert_tree and the triangle loop of pbrt_hip.hip do on the host) ----
+__global__ void __launch_bounds__(kBlock) k_mark_interior(const PbrtLinearBVHNode* __restrict__ nodes, int n_nodes,
+                                                          int* __restrict__ flag, int* __restrict__ max_count) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    int cnt = 0;
+    if (i < n_nodes) {
+        cnt = nodes[i].n_primitives;
+        flag[i] = cnt == 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt = max(cnt, __shfl_xor(cnt, o));
+    // the maximum saturates after a few blocks: read first so that nearly every wave skips the atomic
+    if ((threadIdx.x & 63) == 0 && cnt > *(volatile int*)max_count) atomicMax(max_count, cnt);
+}
+__device__ inline int child_ref(const PbrtLinearBVHNode* nodes, const int* interior_index, int node, int count_bits) {
+    PbrtLinearBVHNode nd = nodes[node];
+    if (nd.n_primitives > 0) return ~(int)(((uint32_t)nd.offset << count_bits) | (uint32_t)(nd.n_primitives - 1));
+    return interior_index[node];
+}
+__global__ void __launch_bounds__(kBlock) k_convert(const PbrtLinearBVHNode* __restrict__ nodes, int n_nodes,
+                                                    const int* __restrict__ interior_index, int count_bits,
+                                                    float4* __restrict__ inodes) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_nodes) return;
+    PbrtLinearBVHNode nd = nodes[i];
+    if (nd.n_primitives > 0) return;
+    PbrtLinearBVHNode c0 = nodes[i + 1], c1 = nodes[nd.offset];
+    float4* r = inodes + 4 * (size_t)interior_index[i];
+    r[0] = make_float4(c0.bounds_min[0], c0.bounds_min[1], c0.bounds_min[2], c0.bounds_max[0]);
+    r[1] = make_float4(c0.bounds_max[1], c0.bounds_max[2], c1.bounds_min[0], c1.bounds_min[1]);
+    r[2] = make_float4(c1.bounds_min[2], c1.bounds_max[0], c1.bounds_max[1], c1.bounds_max[2]);
+    r[3] = make_float4(__int_as_float(child_ref(nodes, interior_index, i + 1, count_bits)),
+                       __int_as_float(child_ref(nodes, interior_index, nd.offset, count_bits)), __int_as_float((int)nd.axis),
+                       __int_as_float(0));
+}
+__global__ void __launch_bounds__(kBlock) k_tri_records(const float* __restrict__ pos, const int* __restrict__ idx,
+                                                        const int* __restrict__ order, const int* __restrict__ tri_material,
+                                                        const int* __restrict__ tri_light, int n, float4* __restrict__ tris,
+                                                        int* __restrict__ prim_slot) {
+    int slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= n) return;
+    int prim = order[slot];
+    prim_slot[prim] = slot;
+    float a[3], b[3], c[3];
+    for (int k = 0; k < 3; ++k) {
+        a[k] = pos[3 * (size_t)idx[3 * (size_t)prim] + k];
+        b[k] = pos[3 * (size_t)idx[3 * (size_t)prim + 1] + k];
+        c[k] = pos[3 * (size_t)idx[3 * (size_t)prim + 2] + k];
+    }
+    int material = tri_material ? tri_material[prim] : 0;
+    int light = (tri_light ? tri_light[prim] + 1 : 0) | (pb::triangle_rejected_by_intersect(a, b, c) ? pb::kTriDegenerate : 0);
+    float4* t = tris + 3 * (size_t)slot;
+    t[0] = make_float4(a[0], a[1], a[2], b[0]);
+    t[1] = make_float4(b[1], b[2], c[0], c[1]);
+    t[2] = make_float4(c[2], __int_as_float(prim), __int_as_float(material), __int_as_float(light));
+}
+__global__ void __launch_bounds__(kBlock) k_light_slots(const int* __restrict__ light_prim, int n_lights,
+                                                        const int* __restrict__ prim_slot, int* __restrict__ light_slot) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_lights) light_slot[i] = light_prim[i] >= 0 ? prim_slot[light_prim[i]] : -1;
+}
+
+}  // namespace
+
+extern "C" int pbrt_hip_bvh_build_hlbvh_device(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
+                                               const int32_t* indices, int32_t n_tris, int32_t max_prims_in_node,
+                                               PbrtLinearBVHNode** nodes_out, int32_t* n_nodes_out,
+                                               int32_t** prim_order_out, double* build_ms) {
+    if (!ctx) return PBRT_HIP_ERR_INVALID;
+    auto invalid = [&](const char* m) {
+        ctx->last_error = m;
+        return PBRT_HIP_ERR_INVALID;
+    };
+    if (!nodes_out || !n_nodes_out || !prim_order_out) return invalid("null output pointer");
+    *nodes_out = nullptr;
+    *prim_order_out = nullptr;
+    *n_nodes_out = 0;
+    if (build_ms) *build_ms = 0.0;
+    if (n_tris < 0 || n_verts < 0 || (n_tris > 0 && (!positions || !indices))) return invalid("bad mesh arguments");
+    if (n_tris == 0) return PBRT_HIP_OK;  // bvh.rs:228-230
+    for (int64_t i = 0; i < 3 * (int64_t)n_tris; ++i)
+        if (indices[i] < 0 || indices[i] >= n_verts) return invalid("vertex index out of range");
+    const int n = n_tris;
+    HL_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DeviceArena mem;
+    float* d_pos = mem.alloc<float>(3 * (size_t)n_verts);
+    int* d_idx = mem.alloc<int>(3 * (size_t)n);
+    if (!mem.ok) {
+        ctx->last_error = std::string("hipMalloc: ") + hipGetErrorString(mem.err);
+        return PBRT_HIP_ERR_OOM;
+    }
+    HL_TRY(hipMemcpyAsync(d_pos, positions, 3 * (size_t)n_verts * sizeof(float), hipMemcpyHostToDevice, st));
+    HL_TRY(hipMemcpyAsync(d_idx, indices, 3 * (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    PbrtLinearBVHNode* d_out = nullptr;
+    const int* d_order = nullptr;
+    int32_t n_nodes = 0;
+    int rc = hlbvh_build_core(ctx, mem, d_pos, d_idx, n, std::min(max_prims_in_node, 255) /* bvh.rs:222 */, &d_out, &n_nodes,
+                              &d_order);
+    if (rc != PBRT_HIP_OK) return rc;
+    if (build_ms) {
+        float ms = 0.0f;
+        HL_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        *build_ms = ms;
+    }
     PbrtLinearBVHNode* nodes = (PbrtLinearBVHNode*)std::malloc((size_t)n_nodes * sizeof(PbrtLinearBVHNode));
     int32_t* order = (int32_t*)std::malloc((size_t)n * sizeof(int32_t));
     if (!nodes || !order) {
         std::free(nodes);
         std::free(order);
-        (void)hipStreamSynchronize(st);
         return PBRT_HIP_ERR_OOM;
     }
     hipError_t ce = hipMemcpyAsync(nodes, d_out, (size_t)n_nodes * sizeof(PbrtLinearBVHNode), hipMemcpyDeviceToHost, st);
-    if (ce == hipSuccess) ce = hipMemcpyAsync(order, prim, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (ce == hipSuccess) ce = hipMemcpyAsync(order, d_order, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st);
     if (ce == hipSuccess) ce = hipStreamSynchronize(st);
     if (ce != hipSuccess) {
         std::free(nodes);
@@ -550,13 +641,128 @@ extern "C" int pbrt_hip_bvh_build_hlbvh_device(PbrtHipContext* ctx, const float*
         pb::hip_ok(ctx, ce, "hlbvh: copy back");
         return PBRT_HIP_ERR_DEVICE;
     }
-    if (build_ms) {
-        float ms = 0.0f;
-        HL_TRY(hipEventElapsedTime(&ms, e0, e1));
-        *build_ms = ms;
-    }
     *nodes_out = nodes;
     *n_nodes_out = n_nodes;
     *prim_order_out = order;
     return PBRT_HIP_OK;
 }
+
+// Tree + triangle records + leaf order for a single-level scene, all produced on the device. Inputs are
+// validated by the caller (scene_create_impl's checks on indices / tri_material / tri_light / lights).
+namespace pb {
+int hlbvh_build_scene_tree(PbrtHipContext* ctx, const float* positions, int32_t n_verts, const int32_t* indices,
+                           int32_t n_tris, const int32_t* tri_material, const int32_t* tri_light, const PbrtLight* lights,
+                           int32_t n_lights, int32_t max_prims_in_node, DeviceTree* out) {
+    const int n = n_tris;
+    HL_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DeviceArena mem;
+    float* d_pos = mem.alloc<float>(3 * (size_t)n_verts);
+    int* d_idx = mem.alloc<int>(3 * (size_t)n);
+    int* d_mat = tri_material ? mem.alloc<int>(n) : nullptr;
+    int* d_tl = tri_light ? mem.alloc<int>(n) : nullptr;
+    int* d_prim_slot = mem.alloc<int>(n);
+    int* d_light_prim = mem.alloc<int>(std::max(1, n_lights));
+    int* d_light_slot = mem.alloc<int>(std::max(1, n_lights));
+    int* d_max_count = mem.alloc<int>(1);
+    if (!mem.ok) {
+        ctx->last_error = std::string("hipMalloc: ") + hipGetErrorString(mem.err);
+        return PBRT_HIP_ERR_OOM;
+    }
+    std::vector<int> light_prim(std::max(1, n_lights), -1);
+    for (int32_t i = 0; i < n_lights; ++i)
+        if (lights[i].type == PBRT_LIGHT_DIFFUSE_AREA) light_prim[i] = lights[i].prim;
+    HL_TRY(hipMemcpyAsync(d_pos, positions, 3 * (size_t)n_verts * sizeof(float), hipMemcpyHostToDevice, st));
+    HL_TRY(hipMemcpyAsync(d_idx, indices, 3 * (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    if (d_mat) HL_TRY(hipMemcpyAsync(d_mat, tri_material, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    if (d_tl) HL_TRY(hipMemcpyAsync(d_tl, tri_light, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    HL_TRY(hipMemcpyAsync(d_light_prim, light_prim.data(), light_prim.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HL_TRY(hipMemsetAsync(d_max_count, 0, sizeof(int), st));
+    PbrtLinearBVHNode* d_nodes = nullptr;
+    const int* d_order = nullptr;
+    int32_t n_nodes = 0;
+    int rc = hlbvh_build_core(ctx, mem, d_pos, d_idx, n, std::min(max_prims_in_node, 255), &d_nodes, &n_nodes, &d_order);
+    if (rc != PBRT_HIP_OK) return rc;
+    {
+        float ms = 0.0f;
+        HL_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        out->build_ms = ms;
+    }
+    // ---- re-layout ----
+    HL_TRY(hipEventRecord(ctx->ev0, st));
+    const int n_interior = (n_nodes - 1) / 2;
+    int* d_flag = mem.alloc<int>(n_nodes);
+    int* d_interior_index = mem.alloc<int>(n_nodes);
+    size_t scan_bytes = 0;
+    HL_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, d_flag, d_interior_index, 0, (size_t)n_nodes, rocprim::plus<int>(), st));
+    void* d_scan_tmp = mem.alloc<char>(scan_bytes);
+    // the three arrays the scene keeps
+    void *p_inodes = nullptr, *p_tris = nullptr, *p_slot_prim = nullptr;
+    auto release = [&]() {
+        (void)hipFree(p_inodes);
+        (void)hipFree(p_tris);
+        (void)hipFree(p_slot_prim);
+    };
+    if (!mem.ok || hipMalloc(&p_inodes, (size_t)std::max(1, n_interior) * 64) != hipSuccess ||
+        hipMalloc(&p_tris, (size_t)n * 48) != hipSuccess || hipMalloc(&p_slot_prim, (size_t)n * sizeof(int)) != hipSuccess) {
+        release();
+        ctx->last_error = "hipMalloc: scene tree";
+        return PBRT_HIP_ERR_OOM;
+    }
+    hipLaunchKernelGGL(k_mark_interior, dim3(blocks_for(n_nodes)), dim3(kBlock), 0, st, d_nodes, n_nodes, d_flag, d_max_count);
+    hipError_t e = rocprim::exclusive_scan(d_scan_tmp, scan_bytes, d_flag, d_interior_index, 0, (size_t)n_nodes,
+                                           rocprim::plus<int>(), st);
+    int max_count = 0;
+    PbrtLinearBVHNode root;
+    if (e == hipSuccess) e = hipMemcpyAsync(&max_count, d_max_count, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&root, d_nodes, sizeof(root), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        release();
+        pb::hip_ok(ctx, e, "hlbvh: re-layout");
+        return PBRT_HIP_ERR_DEVICE;
+    }
+    int count_bits = 0;
+    while ((1 << count_bits) < std::max(1, max_count)) ++count_bits;
+    if (((int64_t)n << count_bits) >= (1ll << 31)) {
+        release();
+        ctx->last_error = "scene too large for 31-bit leaf references";
+        return PBRT_HIP_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(k_convert, dim3(blocks_for(n_nodes)), dim3(kBlock), 0, st, d_nodes, n_nodes, d_interior_index, count_bits,
+                       (float4*)p_inodes);
+    hipLaunchKernelGGL(k_tri_records, dim3(blocks_for(n)), dim3(kBlock), 0, st, d_pos, d_idx, d_order, d_mat, d_tl, n,
+                       (float4*)p_tris, d_prim_slot);
+    hipLaunchKernelGGL(k_light_slots, dim3(blocks_for(std::max(1, n_lights))), dim3(kBlock), 0, st, d_light_prim, n_lights,
+                       d_prim_slot, d_light_slot);
+    out->light_slot.assign(std::max(1, n_lights), -1);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(p_slot_prim, d_order, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && n_lights > 0)
+        e = hipMemcpyAsync(out->light_slot.data(), d_light_slot, (size_t)n_lights * sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev1, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        release();
+        pb::hip_ok(ctx, e, "hlbvh: re-layout");
+        return PBRT_HIP_ERR_DEVICE;
+    }
+    {
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+        out->convert_ms = ms;
+    }
+    out->inodes = (float4*)p_inodes;
+    out->tris = (float4*)p_tris;
+    out->slot_prim = (int*)p_slot_prim;
+    std::memcpy(out->root_min, root.bounds_min, 12);
+    std::memcpy(out->root_max, root.bounds_max, 12);
+    out->n_nodes = n_nodes;
+    out->n_interior = n_interior;
+    out->count_bits = count_bits;
+    out->root_ref = root.n_primitives > 0
+                        ? ~(int32_t)(((uint32_t)root.offset << count_bits) | (uint32_t)(root.n_primitives - 1))
+                        : 0;
+    return PBRT_HIP_OK;
+}
+}  // namespace pb

@@ -236,7 +236,7 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
                              int32_t n_tris, const int32_t* tri_material, const PbrtMaterial* materials,
                              int32_t n_materials, const int32_t* tri_light, const PbrtLight* lights, int32_t n_lights,
                              const PbrtLinearBVHNode* nodes, int32_t n_nodes, const int32_t* prim_order,
-                             const InstancingArgs& ia, PbrtHipScene** out);
+                             const InstancingArgs& ia, PbrtHipScene** out, pb::DeviceTree* dt = nullptr);
 
 extern "C" int pbrt_hip_scene_create(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
                                      const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
@@ -245,6 +245,50 @@ extern "C" int pbrt_hip_scene_create(PbrtHipContext* ctx, const float* positions
                                      int32_t n_nodes, const int32_t* prim_order, PbrtHipScene** out) {
     return scene_create_impl(ctx, positions, n_verts, indices, n_tris, tri_material, materials, n_materials, tri_light,
                              lights, n_lights, nodes, n_nodes, prim_order, InstancingArgs(), out);
+}
+
+namespace pb {
+int hlbvh_build_scene_tree(PbrtHipContext* ctx, const float* positions, int32_t n_verts, const int32_t* indices,
+                           int32_t n_tris, const int32_t* tri_material, const int32_t* tri_light, const PbrtLight* lights,
+                           int32_t n_lights, int32_t max_prims_in_node, DeviceTree* out);
+}
+
+// Scene::new with BVHAccel::new(HLBVH) built and laid out on the device: only the mesh goes up.
+extern "C" int pbrt_hip_scene_create_hlbvh(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
+                                           const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
+                                           const PbrtMaterial* materials, int32_t n_materials, const int32_t* tri_light,
+                                           const PbrtLight* lights, int32_t n_lights, int32_t max_prims_in_node,
+                                           PbrtHipScene** out, double* build_ms, double* layout_ms) {
+    if (!ctx || !out) return PBRT_HIP_ERR_INVALID;
+    *out = nullptr;
+    auto fail = [&](const char* msg) {
+        ctx->last_error = msg;
+        return PBRT_HIP_ERR_INVALID;
+    };
+    // the checks scene_create_impl makes before it touches the device, needed here before the build
+    if (n_tris <= 0 || n_verts <= 0) return fail("empty scene: n_tris and n_verts must be > 0");
+    if (!positions || !indices) return fail("null geometry pointer");
+    if (n_materials <= 0 || !materials) return fail("at least one material is required");
+    if (n_lights < 0 || (n_lights > 0 && !lights)) return fail("bad light table");
+    for (int64_t i = 0; i < 3 * (int64_t)n_tris; ++i)
+        if (indices[i] < 0 || indices[i] >= n_verts) return fail("vertex index out of range");
+    for (int32_t i = 0; i < n_lights; ++i)
+        if (lights[i].type == PBRT_LIGHT_DIFFUSE_AREA && (lights[i].prim < 0 || lights[i].prim >= n_tris))
+            return fail("area light triangle out of range");
+    pb::DeviceTree dt;
+    int rc = pb::hlbvh_build_scene_tree(ctx, positions, n_verts, indices, n_tris, tri_material, tri_light, lights, n_lights,
+                                        max_prims_in_node, &dt);
+    if (rc != PBRT_HIP_OK) return rc;
+    if (build_ms) *build_ms = dt.build_ms;
+    if (layout_ms) *layout_ms = dt.convert_ms;
+    rc = scene_create_impl(ctx, positions, n_verts, indices, n_tris, tri_material, materials, n_materials, tri_light, lights,
+                           n_lights, nullptr, 0, nullptr, InstancingArgs(), out, &dt);
+    if (dt.inodes) {  // scene_create_impl failed before taking ownership
+        (void)hipFree(dt.inodes);
+        (void)hipFree(dt.tris);
+        (void)hipFree(dt.slot_prim);
+    }
+    return rc;
 }
 
 extern "C" int pbrt_hip_scene_create_instanced(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
@@ -279,21 +323,24 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
                              int32_t n_tris, const int32_t* tri_material, const PbrtMaterial* materials,
                              int32_t n_materials, const int32_t* tri_light, const PbrtLight* lights, int32_t n_lights,
                              const PbrtLinearBVHNode* nodes, int32_t n_nodes, const int32_t* prim_order,
-                             const InstancingArgs& ia, PbrtHipScene** out) {
+                             const InstancingArgs& ia, PbrtHipScene** out, pb::DeviceTree* dt) {
+    // dt != nullptr: the tree, the triangle records and the leaf order are already on the device
+    // (pbrt_hip_scene_create_hlbvh); nodes / prim_order are then unused.
     if (!ctx || !out) return PBRT_HIP_ERR_INVALID;
     *out = nullptr;
+    if (dt) n_nodes = dt->n_nodes;
     auto fail = [&](const char* msg) {
         ctx->last_error = msg;
         return PBRT_HIP_ERR_INVALID;
     };
     if (n_tris <= 0 || n_verts <= 0 || n_nodes <= 0) return fail("empty scene: n_tris, n_verts and n_nodes must be > 0");
-    if (!positions || !indices || !nodes || !prim_order) return fail("null geometry / BVH pointer");
+    if (!positions || !indices || (!dt && (!nodes || !prim_order))) return fail("null geometry / BVH pointer");
     if (n_materials <= 0 || !materials) return fail("at least one material is required");
     if (n_lights < 0 || (n_lights > 0 && !lights)) return fail("bad light table");
     for (int64_t i = 0; i < 3 * (int64_t)n_tris; ++i)
         if (indices[i] < 0 || indices[i] >= n_verts) return fail("vertex index out of range");
     for (int32_t i = 0; i < n_tris; ++i) {
-        if (prim_order[i] < 0 || prim_order[i] >= n_tris) return fail("prim_order entry out of range");
+        if (!dt && (prim_order[i] < 0 || prim_order[i] >= n_tris)) return fail("prim_order entry out of range");
         if (tri_material && (tri_material[i] < 0 || tri_material[i] >= n_materials)) return fail("tri_material out of range");
         if (tri_light && (tri_light[i] < -1 || tri_light[i] >= n_lights)) return fail("tri_light out of range");
     }
@@ -319,6 +366,10 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         }
         if (const char* e = convert_tree(ia.tlas_nodes, ia.n_tlas_nodes, ia.n_instances, 0, &top)) return fail(e);
         if (const char* e = convert_tree(nodes, n_nodes, n_tris, top.n_interior, &obj)) return fail(e);
+    } else if (dt) {
+        top.n_interior = dt->n_interior;
+        top.root_ref = dt->root_ref;
+        top.count_bits = dt->count_bits;
     } else {
         if (const char* e = convert_tree(nodes, n_nodes, n_tris, 0, &top)) return fail(e);
     }
@@ -336,9 +387,9 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     inodes.insert(inodes.end(), obj.inodes.begin(), obj.inodes.end());
     if (inodes.empty()) inodes.assign(16, 0.0f);
     // ---- triangles in leaf order (48 B) ----
-    std::vector<float> tris((size_t)n_tris * 12);
-    std::vector<int32_t> prim_slot(n_tris, -1);
-    for (int32_t slot = 0; slot < n_tris; ++slot) {
+    std::vector<float> tris(dt ? 0 : (size_t)n_tris * 12);
+    std::vector<int32_t> prim_slot(dt ? 0 : n_tris, -1);
+    for (int32_t slot = 0; slot < n_tris && !dt; ++slot) {
         int32_t prim = prim_order[slot];
         if (prim_slot[prim] != -1) {
             delete s;
@@ -364,8 +415,8 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     float world_center[3], world_radius;
     {
         // Bounds3::bounding_sphere of the root bounds (infinite.rs:135-139)
-        const float* mn = (ia.n_instances > 0 ? ia.tlas_nodes[0] : nodes[0]).bounds_min;
-        const float* mx = (ia.n_instances > 0 ? ia.tlas_nodes[0] : nodes[0]).bounds_max;
+        const float* mn = dt ? dt->root_min : (ia.n_instances > 0 ? ia.tlas_nodes[0] : nodes[0]).bounds_min;
+        const float* mx = dt ? dt->root_max : (ia.n_instances > 0 ? ia.tlas_nodes[0] : nodes[0]).bounds_max;
         float dx[3];
         for (int k = 0; k < 3; ++k) {
             world_center[k] = (mn[k] + mx[k]) / 2.0f;
@@ -386,7 +437,7 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         float scale;
         if (l.type == PBRT_LIGHT_DIFFUSE_AREA) {
             int32_t prim = lights[i].prim;
-            l.slot = prim_slot[prim];
+            l.slot = dt ? dt->light_slot[i] : prim_slot[prim];
             const float* a = positions + 3 * (size_t)indices[3 * (size_t)prim];
             const float* b = positions + 3 * (size_t)indices[3 * (size_t)prim + 1];
             const float* c = positions + 3 * (size_t)indices[3 * (size_t)prim + 2];
@@ -413,11 +464,24 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
 
     DevSceneData& d = s->d;
     std::memset(&d, 0, sizeof(d));
-    d.bvh.inodes = (const float4*)dev_upload(s, inodes.data(), inodes.size(), &ok);
-    d.bvh.tris = (const float4*)dev_upload(s, tris.data(), tris.size(), &ok);
-    const PbrtLinearBVHNode& root = instanced ? ia.tlas_nodes[0] : nodes[0];
-    std::memcpy(d.bvh.root_min, root.bounds_min, 12);
-    std::memcpy(d.bvh.root_max, root.bounds_max, 12);
+    if (dt) {
+        d.bvh.inodes = dt->inodes;
+        d.bvh.tris = dt->tris;
+        d.slot_prim = dt->slot_prim;
+        s->allocs.push_back(dt->inodes);
+        s->allocs.push_back(dt->tris);
+        s->allocs.push_back(dt->slot_prim);
+        dt->inodes = dt->tris = nullptr;  // owned by the scene from here on
+        dt->slot_prim = nullptr;
+        std::memcpy(d.bvh.root_min, dt->root_min, 12);
+        std::memcpy(d.bvh.root_max, dt->root_max, 12);
+    } else {
+        d.bvh.inodes = (const float4*)dev_upload(s, inodes.data(), inodes.size(), &ok);
+        d.bvh.tris = (const float4*)dev_upload(s, tris.data(), tris.size(), &ok);
+        const PbrtLinearBVHNode& root = instanced ? ia.tlas_nodes[0] : nodes[0];
+        std::memcpy(d.bvh.root_min, root.bounds_min, 12);
+        std::memcpy(d.bvh.root_max, root.bounds_max, 12);
+    }
     d.bvh.root_ref = top.root_ref;
     d.bvh.count_bits = top.count_bits;
     d.bvh.n_slots = n_tris;
@@ -456,7 +520,7 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         d.bvh.spill = (uint2*)p;
         d.bvh.spill_stride = s->spill_lanes;
     }
-    d.slot_prim = dev_upload(s, prim_order, n_tris, &ok);
+    if (!dt) d.slot_prim = dev_upload(s, prim_order, n_tris, &ok);
     d.materials = dev_upload(s, dm.data(), dm.size(), &ok);
     d.lights = dev_upload(s, dl.data(), dl.size(), &ok);
     d.n_lights = n_lights;

@@ -106,11 +106,24 @@ inline T* dev_upload(PbrtHipScene* s, const T* src, size_t n, bool* ok) {
     return (T*)p;
 }
 
-// Host evaluation of "Triangle::intersect returns false" (triangle.rs:197-216) with the default
+// A single-level scene tree built and re-laid out on the device (hlbvh_gpu.hip): the scene takes
+// ownership of the three device arrays.
+struct DeviceTree {
+    float4* inodes = nullptr;   // 64-B child-pair records
+    float4* tris = nullptr;     // 48-B triangles in leaf order
+    int* slot_prim = nullptr;   // leaf slot -> caller's triangle index
+    float root_min[3], root_max[3];
+    int root_ref = 0, count_bits = 0, n_interior = 0, n_nodes = 0;
+    std::vector<int32_t> light_slot;  // per light: leaf slot of an area light's triangle, -1 otherwise
+    double build_ms = 0.0;            // tree build; convert_ms: re-layout into the traversal format
+    double convert_ms = 0.0;
+};
+
+// Evaluation of "Triangle::intersect returns false" (triangle.rs:197-216) with the default
 // uv set (triangle.rs:66-70): degenerate uv frame or dpdu x dpdv == 0, and a zero geometric
 // normal. Ray independent, so it is a per-triangle flag. Same float operation order as the kernel
 // side (this file is compiled with -ffp-contract=off).
-inline bool triangle_rejected_by_intersect(const float* a, const float* b, const float* c) {
+__host__ __device__ inline bool triangle_rejected_by_intersect(const float* a, const float* b, const float* c) {
     const float uv[3][2] = {{0.0f, 0.0f}, {1.0f, 0.0f}, {1.0f, 1.0f}};
     float duv02[2] = {uv[0][0] - uv[2][0], uv[0][1] - uv[2][1]};
     float duv12[2] = {uv[1][0] - uv[2][0], uv[1][1] - uv[2][1]};
@@ -120,7 +133,7 @@ inline bool triangle_rejected_by_intersect(const float* a, const float* b, const
         dp12[k] = b[k] - c[k];
     }
     float determinant = duv02[0] * duv12[1] - duv02[1] * duv12[0];
-    bool degenerate_uv = std::fabs(determinant) < 1e-8f;
+    bool degenerate_uv = __builtin_fabsf(determinant) < 1e-8f;
     float dpdu[3] = {0, 0, 0}, dpdv[3] = {0, 0, 0};
     if (!degenerate_uv) {
         float inv_det = 1.0f / determinant;

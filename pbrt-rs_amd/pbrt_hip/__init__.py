@@ -28,7 +28,7 @@ EXPORTS = [
     "pbrt_hip_scene_create_instanced", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
     "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
-    "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm",
+    "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm",
 ]
 
 
@@ -72,6 +72,8 @@ def lib():
                                          ctypes.POINTER(vp)]
         L.pbrt_hip_bvh_build_hlbvh_device.argtypes = [vp, vp, i32, vp, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(i32),
                                                       ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_double)]
+        L.pbrt_hip_scene_create_hlbvh.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, i32, ctypes.POINTER(vp),
+                                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.pbrt_hip_free.argtypes = [vp]
         L.pbrt_hip_free.restype = None
         L.pbrt_hip_scene_create.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp,
@@ -248,10 +250,15 @@ class Scene:
     """Scene::new: triangles as GeometricPrimitives in a BVHAccel, resident in HBM.
     With scene["instances"]: TransformedPrimitive instances of the triangle aggregate (two levels)."""
 
-    def __init__(self, ctx, scene, max_prims_in_node=4, split_method=SPLIT_SAH, bvh=None):
+    def __init__(self, ctx, scene, max_prims_in_node=4, split_method=SPLIT_SAH, bvh=None, device_build=False):
+        """device_build=True: BVHAccel::new(HLBVH) built and laid out on the GPU (pbrt_hip_scene_create_hlbvh);
+        self.build_ms / self.layout_ms then hold the HIP-event times and self.nodes is None."""
         self.ctx = ctx
         if "instances" in scene:
             self._init_instanced(scene, max_prims_in_node, split_method, bvh)
+            return
+        if device_build:
+            self._init_device_build(scene, max_prims_in_node)
             return
         self.positions = np.ascontiguousarray(scene["positions"], dtype=np.float32)
         self.indices = np.ascontiguousarray(scene["indices"], dtype=np.int32)
@@ -270,6 +277,24 @@ class Scene:
         ctx.check(rc, "pbrt_hip_scene_create")
         self.h = h
         ctx._scenes.add(self)
+
+    def _init_device_build(self, scene, max_prims_in_node):
+        self.positions = np.ascontiguousarray(scene["positions"], dtype=np.float32)
+        self.indices = np.ascontiguousarray(scene["indices"], dtype=np.int32)
+        tri_material = np.ascontiguousarray(scene["tri_material"], dtype=np.int32)
+        materials = np.ascontiguousarray(scene["materials"], dtype=MATERIAL_DTYPE)
+        tri_light = np.ascontiguousarray(scene["tri_light"], dtype=np.int32)
+        lights = np.ascontiguousarray(scene["lights"], dtype=LIGHT_DTYPE)
+        self.nodes = self.prim_order = None
+        h, b_ms, l_ms = ctypes.c_void_p(), ctypes.c_double(), ctypes.c_double()
+        rc = lib().pbrt_hip_scene_create_hlbvh(self.ctx.h, _p(self.positions), self.positions.shape[0], _p(self.indices),
+                                               self.indices.shape[0], _p(tri_material), _p(materials), len(materials),
+                                               _p(tri_light), _p(lights) if len(lights) else None, len(lights),
+                                               max_prims_in_node, ctypes.byref(h), ctypes.byref(b_ms), ctypes.byref(l_ms))
+        self.ctx.check(rc, "pbrt_hip_scene_create_hlbvh")
+        self.h = h
+        self.build_ms, self.layout_ms = b_ms.value, l_ms.value
+        self.ctx._scenes.add(self)
 
     def _init_instanced(self, scene, max_prims_in_node, split_method, bvh):
         self.positions = np.ascontiguousarray(scene["positions"], dtype=np.float32)

@@ -216,3 +216,36 @@ def test_gpu_hlbvh_1m_triangles_and_trace(hip_ctx):
     assert np.array_equal(h1["prim_id"], h2["prim_id"]) and np.array_equal(h1["t"], h2["t"])
     g1.close()
     g2.close()
+
+
+@pytest.mark.parametrize("which", ["cloud", "cornell", "mixed"])
+def test_scene_create_hlbvh_on_device(hip_ctx, which):
+    """pbrt_hip_scene_create_hlbvh: tree built and re-laid out on the device == the scene over the host HLBVH
+    tree: same hits bit for bit, same reference-loop test counts, same rendered film (area-light slots included)."""
+    if which == "cloud":
+        sc, cam, w, h = scenes.random_triangles(120_000, seq=11, size=0.03), scenes.random_triangles_camera(64, 48), 64, 48
+    elif which == "cornell":
+        sc, cam, w, h = scenes.cornell_box(), scenes.cornell_camera(48, 48), 48, 48
+    else:
+        sc, cam, w, h = scenes.mixed_materials_scene(), scenes.random_triangles_camera(64, 48), 64, 48
+    g_dev = pbrt_hip.Scene(hip_ctx, sc, device_build=True)
+    g_host = pbrt_hip.Scene(hip_ctx, sc, split_method=pbrt_hip.SPLIT_HLBVH)
+    assert g_dev.build_ms > 0.0 and g_dev.layout_ms > 0.0
+    rays = scenes.random_rays(100_000, 21, origin_extent=1.2)
+    hip_ctx.set_counting(True)
+    try:
+        res = []
+        for g in (g_dev, g_host):
+            hip_ctx.counters(reset=True)
+            hits = g.intersect(rays)
+            occl = g.intersect_p(rays)
+            res.append((hits, occl, hip_ctx.counters(reset=True)))
+    finally:
+        hip_ctx.set_counting(False)
+    assert res[0][0].tobytes() == res[1][0].tobytes() and np.array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2]
+    f_dev, st_dev = g_dev.render(cam, w, h, 4, max_depth=5, seed=3)
+    f_host, st_host = g_host.render(cam, w, h, 4, max_depth=5, seed=3)
+    assert f_dev.tobytes() == f_host.tobytes() and st_dev["rays_shadow"] == st_host["rays_shadow"]
+    g_dev.close()
+    g_host.close()

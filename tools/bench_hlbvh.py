@@ -24,4 +24,17 @@ for n in sizes:
     same = nodes_g.tobytes() == nodes_h.tobytes() and np.array_equal(order_g, order_h)
     print(f"n_tris={n} nodes={len(nodes_g)} gpu_build_ms={ms:.3f} gpu_call_wall_ms={wall_g * 1e3:.1f} "
           f"host_hlbvh_ms={wall_h * 1e3:.1f} identical={same} Mtris/s(device)={n / ms * 1e-3:.1f}", flush=True)
+    # whole scene setup: mesh in host memory -> scene ready to trace
+    t0 = time.time()
+    g = pbrt_hip.Scene(ctx, sc, device_build=True)
+    wall_dev = time.time() - t0
+    b_ms, l_ms = g.build_ms, g.layout_ms
+    g.close()
+    t0 = time.time()
+    g = pbrt_hip.Scene(ctx, sc, bvh=(nodes_h, order_h))
+    wall_create = time.time() - t0
+    g.close()
+    print(f"n_tris={n} scene_setup: device_build wall_ms={wall_dev * 1e3:.1f} (build {b_ms:.3f} + layout {l_ms:.3f} on device) "
+          f"| host path wall_ms={(wall_h + wall_create) * 1e3:.1f} (build {wall_h * 1e3:.1f} + create {wall_create * 1e3:.1f})",
+          flush=True)
 ctx.close()
