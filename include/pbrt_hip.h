@@ -78,15 +78,28 @@ typedef struct PbrtMaterial {
 } PbrtMaterial;
 
 /* src/lights/diffuse.rs:19-27 DiffuseAreaLight on one triangle; src/lights/infinite.rs:23-31
- * InfiniteAreaLight with a constant (1x1) map. */
-enum PbrtLightType { PBRT_LIGHT_DIFFUSE_AREA = 0, PBRT_LIGHT_INFINITE = 1 };
+ * InfiniteAreaLight with a constant (1x1) map; the delta lights src/lights/point.rs:17-40,
+ * src/lights/spot.rs:18-64 and src/lights/distant.rs:18-47. The caller passes what the reference's
+ * constructors compute: p_light = light_to_world * (0,0,0), cos_total_width / cos_falloff_start =
+ * cos(radians(..)), the upper 3x3 of world_to_light (spot.rs:50-51), w_light = normalize(light_to_world * w). */
+enum PbrtLightType {
+    PBRT_LIGHT_DIFFUSE_AREA = 0,
+    PBRT_LIGHT_INFINITE = 1,
+    PBRT_LIGHT_POINT = 2,
+    PBRT_LIGHT_SPOT = 3,
+    PBRT_LIGHT_DISTANT = 4
+};
 typedef struct PbrtLight {
     int32_t type;
-    float L[3];
+    float L[3];        /* area / infinite / distant: radiance L; point / spot: intensity I */
     int32_t prim;      /* area light: triangle index (caller's order) */
     int32_t two_sided; /* src/lights/diffuse.rs:25 */
-    int32_t n_samples; /* src/core/light.rs:76 */
+    int32_t n_samples; /* src/core/light.rs:76 (delta lights: 1) */
     int32_t pad;
+    float pos[3];      /* point / spot: p_light (world); distant: w_light (world, unit length) */
+    float cos_total_width, cos_falloff_start; /* spot */
+    float world_to_light[9];                  /* spot: rows of the upper 3x3, row-major */
+    int32_t pad2[2];
 } PbrtLight;
 
 /* src/core/primitive.rs:105-123 TransformedPrimitive with a static transform: one instance of the

@@ -95,12 +95,19 @@ def _materials_flat(materials):
 
 
 def _lights_flat(lights):
-    l = np.zeros((len(lights), 8), dtype=np.float32)
+    """24 floats per light: type, L rgb, prim, two_sided, n_samples, 0, pos xyz, cos_total_width,
+    cos_falloff_start, world_to_light 3x3, 0, 0 (the field order of PbrtLight)."""
+    l = np.zeros((len(lights), 24), dtype=np.float32)
     l[:, 0] = lights["type"]
     l[:, 1:4] = lights["L"]
     l[:, 4] = lights["prim"]
     l[:, 5] = lights["two_sided"]
     l[:, 6] = lights["n_samples"]
+    if lights.dtype.names and "pos" in lights.dtype.names:
+        l[:, 8:11] = lights["pos"]
+        l[:, 11] = lights["cos_total_width"]
+        l[:, 12] = lights["cos_falloff_start"]
+        l[:, 13:22] = lights["world_to_light"]
     return l
 
 

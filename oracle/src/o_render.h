@@ -160,6 +160,89 @@ struct InfiniteAreaLight : Light {
     }
 };
 
+// lights/point.rs:17-63. p_light = light_to_world * (0,0,0) is computed by the caller (point.rs:27).
+struct PointLight : Light {
+    Point3f p_light;
+    Spectrum i;
+    PointLight(const Point3f& p, const Spectrum& i_) : Light(LIGHT_DELTA_POSITION, 1), p_light(p), i(i_) {}
+    // point.rs:47-63
+    Spectrum sample_li(const BaseInteraction& ref, const Point2f&, Vector3f* wi, Float* pdf,
+                       VisibilityTester* vis) const override {
+        *wi = (p_light - ref.p).normalize();
+        *pdf = 1.0f;
+        vis->p0 = ref;
+        vis->p1 = BaseInteraction();
+        vis->p1.p = p_light;
+        vis->p1.time = ref.time;
+        return i / (p_light - ref.p).length_squared();
+    }
+    Spectrum power() const override { return i * (4.0f * PI); }  // point.rs:65-67
+    Float pdf_li(const BaseInteraction&, const Vector3f&) const override { return 0.0f; }
+};
+
+// lights/spot.rs:18-92. cos_total_width / cos_falloff_start = cos(radians(..)) (spot.rs:38-39) and the
+// upper 3x3 of world_to_light come from the caller.
+// D52 (intended): falloff() reads wl.z of the un-normalised world_to_light * w (spot.rs:50-51); pbrt-v3
+// normalises wl first (spot.cpp:64), which matters when light_to_world carries a scale.
+struct SpotLight : Light {
+    Point3f p_light;
+    Spectrum i;
+    Float cos_total_width, cos_falloff_start;
+    Float w2l[9];
+    SpotLight(const Point3f& p, const Spectrum& i_, Float ctw, Float cfs, const Float* m)
+        : Light(LIGHT_DELTA_POSITION, 1), p_light(p), i(i_), cos_total_width(ctw), cos_falloff_start(cfs) {
+        for (int k = 0; k < 9; ++k) w2l[k] = m[k];
+    }
+    // spot.rs:49-62
+    Float falloff(const Vector3f& w) const {
+        Vector3f wl(w2l[0] * w.x + w2l[1] * w.y + w2l[2] * w.z, w2l[3] * w.x + w2l[4] * w.y + w2l[5] * w.z,
+                    w2l[6] * w.x + w2l[7] * w.y + w2l[8] * w.z);
+        wl = wl.normalize();
+        Float cos_theta = wl.z;
+        if (cos_theta < cos_total_width) return 0.0f;
+        if (cos_theta >= cos_falloff_start) return 1.0f;
+        Float delta = (cos_theta - cos_total_width) / (cos_falloff_start - cos_total_width);
+        return (delta * delta) * (delta * delta);
+    }
+    // spot.rs:70-88
+    Spectrum sample_li(const BaseInteraction& ref, const Point2f&, Vector3f* wi, Float* pdf,
+                       VisibilityTester* vis) const override {
+        *wi = (p_light - ref.p).normalize();
+        *pdf = 1.0f;
+        vis->p0 = ref;
+        vis->p1 = BaseInteraction();
+        vis->p1.p = p_light;
+        vis->p1.time = ref.time;
+        return i * falloff(-*wi) / (p_light - ref.p).length_squared();
+    }
+    // spot.rs:90-92
+    Spectrum power() const override { return i * (2.0f * PI * (1.0f - 0.5f * (cos_falloff_start + cos_total_width))); }
+    Float pdf_li(const BaseInteraction&, const Vector3f&) const override { return 0.0f; }
+};
+
+// lights/distant.rs:18-87. w_light = normalize(light_to_world * w) comes from the caller (distant.rs:30).
+struct DistantLight : Light {
+    Spectrum l_emit;
+    Vector3f w_light;
+    Point3f world_center;
+    Float world_radius = 0.0f;
+    DistantLight(const Spectrum& l, const Vector3f& w) : Light(LIGHT_DELTA_DIRECTION, 1), l_emit(l), w_light(w) {}
+    // distant.rs:54-74
+    Spectrum sample_li(const BaseInteraction& ref, const Point2f&, Vector3f* wi, Float* pdf,
+                       VisibilityTester* vis) const override {
+        *wi = w_light;
+        *pdf = 1.0f;
+        vis->p0 = ref;
+        vis->p1 = BaseInteraction();
+        vis->p1.p = ref.p + w_light * (2.0f * world_radius);
+        vis->p1.time = ref.time;
+        return l_emit;
+    }
+    Spectrum power() const override { return l_emit * (PI * world_radius * world_radius); }  // distant.rs:76-78
+    void pre_process(const Scene& scene) override;                                            // distant.rs:80-84
+    Float pdf_li(const BaseInteraction&, const Vector3f&) const override { return 0.0f; }
+};
+
 // scene.rs:11-46
 struct Scene {
     std::vector<std::shared_ptr<Light>> lights;
@@ -192,6 +275,9 @@ struct Scene {
     }
 };
 inline void InfiniteAreaLight::pre_process(const Scene& scene) {
+    scene.world_bound.bounding_sphere(&world_center, &world_radius);
+}
+inline void DistantLight::pre_process(const Scene& scene) {
     scene.world_bound.bounding_sphere(&world_center, &world_radius);
 }
 // light.rs:126-135 (D31: intended negation)

@@ -38,10 +38,23 @@ void parallel_chunks(int64_t n, int n_threads, F f) {
 }
 }  // namespace
 
+static const int kLightStride = 24;
+static std::shared_ptr<Light> make_non_area_light(const float* l) {
+    Spectrum L(l[1], l[2], l[3]);
+    switch ((int)l[0]) {
+        case 2: return std::make_shared<PointLight>(Point3f(l[8], l[9], l[10]), L);
+        case 3: return std::make_shared<SpotLight>(Point3f(l[8], l[9], l[10]), L, l[11], l[12], l + 13);
+        case 4: return std::make_shared<DistantLight>(L, Vector3f(l[8], l[9], l[10]));
+        default: return std::make_shared<InfiniteAreaLight>(L, (int)l[6]);
+    }
+}
+
 extern "C" {
 
 // materials: n_mat x 8 floats {type, kd.r, kd.g, kd.b, kt.r, kt.g, kt.b, eta}
-// lights:    n_light x 8 floats {type(0 = diffuse area, 1 = infinite), L.r, L.g, L.b, tri, two_sided, n_samples, 0}
+// lights:    n_light x 24 floats in PbrtLight's field order {type (0 diffuse area, 1 infinite, 2 point, 3 spot,
+//            4 distant), L rgb, tri, two_sided, n_samples, 0, pos xyz, cos_total_width, cos_falloff_start,
+//            world_to_light 3x3, 0, 0}
 void* orc_scene_create_with_spheres(const float* positions, int n_verts, const int32_t* indices, int n_tris,
                                     const float* normals, const float* uvs, const int32_t* tri_material,
                                     const float* materials, int n_mat, const int32_t* tri_light, const float* lights,
@@ -97,12 +110,12 @@ void* orc_scene_create_with_spheres(const float* positions, int n_verts, const i
         shapes[n_tris + i] = Sphere::at(Point3f(sp[0], sp[1], sp[2]), sp[3]);
     }
     for (int i = 0; i < n_light; ++i) {
-        const float* l = lights + 8 * i;
-        Spectrum L(l[1], l[2], l[3]);
+        const float* l = lights + kLightStride * i;
         if ((int)l[0] == 0)
-            sc.lights.push_back(std::make_shared<DiffuseAreaLight>(L, (int)l[6], shapes[(int)l[4]], l[5] != 0.0f));
+            sc.lights.push_back(std::make_shared<DiffuseAreaLight>(Spectrum(l[1], l[2], l[3]), (int)l[6], shapes[(int)l[4]],
+                                                                   l[5] != 0.0f));
         else
-            sc.lights.push_back(std::make_shared<InfiniteAreaLight>(L, (int)l[6]));
+            sc.lights.push_back(make_non_area_light(l));
     }
     std::vector<std::shared_ptr<Primitive>> prims(n_prims);
     sc.prim_material.resize(n_prims);
@@ -148,9 +161,9 @@ void* orc_scene_create_instanced(const float* positions, int n_verts, const int3
         sc.materials.push_back(d);
     }
     for (int i = 0; i < n_light; ++i) {
-        const float* l = lights + 8 * i;
-        if ((int)l[0] != 1) continue;  // instanced primitives cannot be area lights
-        sc.lights.push_back(std::make_shared<InfiniteAreaLight>(Spectrum(l[1], l[2], l[3]), (int)l[6]));
+        const float* l = lights + kLightStride * i;
+        if ((int)l[0] == 0) continue;  // instanced primitives cannot be area lights
+        sc.lights.push_back(make_non_area_light(l));
     }
     std::vector<std::shared_ptr<Primitive>> prims(n_tris);
     sc.prim_material.assign(n_tris, 0);

@@ -305,8 +305,8 @@ extern "C" int pbrt_hip_scene_create_instanced(PbrtHipContext* ctx, const float*
         return PBRT_HIP_ERR_INVALID;
     }
     for (int32_t i = 0; i < n_lights; ++i)
-        if (lights[i].type != PBRT_LIGHT_INFINITE) {
-            ctx->last_error = "instanced primitives cannot be area lights: only infinite lights are accepted";
+        if (lights[i].type == PBRT_LIGHT_DIFFUSE_AREA) {
+            ctx->last_error = "instanced primitives cannot be area lights: only infinite and delta lights are accepted";
             return PBRT_HIP_ERR_INVALID;
         }
     InstancingArgs ia;
@@ -344,9 +344,11 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         if (tri_material && (tri_material[i] < 0 || tri_material[i] >= n_materials)) return fail("tri_material out of range");
         if (tri_light && (tri_light[i] < -1 || tri_light[i] >= n_lights)) return fail("tri_light out of range");
     }
-    for (int32_t i = 0; i < n_lights; ++i)
+    for (int32_t i = 0; i < n_lights; ++i) {
+        if (lights[i].type < PBRT_LIGHT_DIFFUSE_AREA || lights[i].type > PBRT_LIGHT_DISTANT) return fail("unknown light type");
         if (lights[i].type == PBRT_LIGHT_DIFFUSE_AREA && (lights[i].prim < 0 || lights[i].prim >= n_tris))
             return fail("area light triangle out of range");
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     // ---- validate the tree(s) and lay out the interior records ----
@@ -435,6 +437,11 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         l.slot = -1;
         l.area = 0.0f;
         float scale;
+        std::memcpy(l.pos, lights[i].pos, 12);
+        l.cos_total_width = lights[i].cos_total_width;
+        l.cos_falloff_start = lights[i].cos_falloff_start;
+        std::memcpy(l.w2l, lights[i].world_to_light, 36);
+        l.delta = (l.type == PBRT_LIGHT_POINT || l.type == PBRT_LIGHT_SPOT || l.type == PBRT_LIGHT_DISTANT) ? 1 : 0;
         if (l.type == PBRT_LIGHT_DIFFUSE_AREA) {
             int32_t prim = lights[i].prim;
             l.slot = dt ? dt->light_slot[i] : prim_slot[prim];
@@ -443,6 +450,12 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
             const float* c = positions + 3 * (size_t)indices[3 * (size_t)prim + 2];
             l.area = tri_area(a, b, c);
             scale = (l.two_sided ? 2.0f : 1.0f) * l.area * kPi;  // diffuse.rs:83-85
+        } else if (l.type == PBRT_LIGHT_POINT) {
+            scale = 4.0f * kPi;  // point.rs:65-67
+        } else if (l.type == PBRT_LIGHT_SPOT) {
+            scale = 2.0f * kPi * (1.0f - 0.5f * (l.cos_falloff_start + l.cos_total_width));  // spot.rs:90-92
+        } else if (l.type == PBRT_LIGHT_DISTANT) {
+            scale = kPi * world_radius * world_radius;  // distant.rs:76-78
         } else {
             infinite_ids.push_back(i);
             scale = kPi * world_radius * world_radius;  // infinite.rs:131-133

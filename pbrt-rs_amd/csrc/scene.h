@@ -41,6 +41,11 @@ struct DevLight {
     int two_sided;
     float area;     // Triangle::area (triangle.rs:323-328)
     float power_y;  // Light::power().y_value() for the power distribution
+    // delta lights (lights/point.rs, spot.rs, distant.rs): p_light or w_light, spot cone, world_to_light 3x3
+    float pos[3];
+    float cos_total_width, cos_falloff_start;
+    float w2l[9];
+    int delta;      // is_delta_light (light.rs:28-31): no BSDF-sampling half, no MIS weight
 };
 struct DevMaterial {
     int type;

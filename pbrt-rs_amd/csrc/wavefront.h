@@ -522,6 +522,38 @@ PB_DEV void light_sample_li(const ShadeConsts& sc, const Surf& sf, const DevLigh
             wi = normalize(p1 - sf.p);
             if (lt.two_sided || dot(p1_n, -wi) > 0.0f) li = Lc;
         }
+    } else if (lt.type == PBRT_LIGHT_POINT || lt.type == PBRT_LIGHT_SPOT) {
+        // PointLight::sample_li (point.rs:47-63), SpotLight::sample_li (spot.rs:70-88)
+        p1 = V3{lt.pos[0], lt.pos[1], lt.pos[2]};
+        V3 dv = p1 - sf.p;
+        wi = normalize(dv);
+        light_pdf = 1.0f;
+        float d2 = len2(dv);
+        if (lt.type == PBRT_LIGHT_POINT) {
+            li = Lc / d2;
+        } else {
+            // SpotLight::falloff (spot.rs:49-62; D52: wl normalised)
+            V3 w = -wi;
+            V3 wl = V3{lt.w2l[0] * w.x + lt.w2l[1] * w.y + lt.w2l[2] * w.z, lt.w2l[3] * w.x + lt.w2l[4] * w.y + lt.w2l[5] * w.z,
+                       lt.w2l[6] * w.x + lt.w2l[7] * w.y + lt.w2l[8] * w.z};
+            wl = normalize(wl);
+            float cos_theta = wl.z, fall;
+            if (cos_theta < lt.cos_total_width) {
+                fall = 0.0f;
+            } else if (cos_theta >= lt.cos_falloff_start) {
+                fall = 1.0f;
+            } else {
+                float delta = (cos_theta - lt.cos_total_width) / (lt.cos_falloff_start - lt.cos_total_width);
+                fall = (delta * delta) * (delta * delta);
+            }
+            li = Lc * fall / d2;
+        }
+    } else if (lt.type == PBRT_LIGHT_DISTANT) {
+        // DistantLight::sample_li (distant.rs:54-74)
+        wi = V3{lt.pos[0], lt.pos[1], lt.pos[2]};
+        light_pdf = 1.0f;
+        p1 = sf.p + wi * (2.0f * sc.world_radius);
+        li = Lc;
     } else {
         // InfiniteAreaLight::sample_li (infinite.rs:96-129)
         float pdf1, pdf0;
@@ -576,17 +608,22 @@ PB_DEV int estimate_direct_emit(const ShadeConsts& sc, const PathState& ps, uint
             V3 target = offset_ray_origin(p1, p1_err, p1_n, origin - p1);
             V3 d = target - origin;
             store_ray(ps, p, RS_SHADOW, origin, d, 1.0f - kShadowEpsilon);
-            float weight = power_heuristic1(light_pdf, scattering_pdf);
-            A = mulv(li, f) * weight / light_pdf;
+            if (lt.delta) {
+                A = mulv(li, f) / light_pdf;  // integrator.rs:196-198: no MIS weight for a delta light
+            } else {
+                float weight = power_heuristic1(light_pdf, scattering_pdf);
+                A = mulv(li, f) * weight / light_pdf;
+            }
             nee_flags |= PF_NEE_SHADOW;
         }
     }
-    // -- BSDF sampling half (both light types are non-delta) --
+    // -- BSDF sampling half, only for non-delta lights (integrator.rs:207) --
     V3 wi2;
     float spdf = 0.0f;
-    bool ok;
+    bool ok = false;
+    V3 f2 = V3{0.0f, 0.0f, 0.0f};
     // scattering_pdf keeps the light-half value if wo.z == 0 (then it is 0 as well)
-    V3 f2 = matte_sample_f(fr, kd, wo, us0, us1, &wi2, &spdf, &ok);
+    if (!lt.delta) f2 = matte_sample_f(fr, kd, wo, us0, us1, &wi2, &spdf, &ok);
     if (ok) f2 = f2 * absdot(wi2, fr.ns);
     if (ok && !is_black(f2) && spdf > 0.0f) {
         float lpdf;

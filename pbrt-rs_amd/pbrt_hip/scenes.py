@@ -11,7 +11,8 @@ import numpy as np
 
 MATERIAL_DTYPE = np.dtype([("type", "<i4"), ("kd", "<f4", 3), ("kt", "<f4", 3), ("eta", "<f4")])
 LIGHT_DTYPE = np.dtype([("type", "<i4"), ("L", "<f4", 3), ("prim", "<i4"), ("two_sided", "<i4"),
-                        ("n_samples", "<i4"), ("pad", "<i4")])
+                        ("n_samples", "<i4"), ("pad", "<i4"), ("pos", "<f4", 3), ("cos_total_width", "<f4"),
+                        ("cos_falloff_start", "<f4"), ("world_to_light", "<f4", 9), ("pad2", "<i4", 2)])
 CAMERA_DTYPE = np.dtype([("camera_to_world", "<f4", 16), ("raster_to_camera", "<f4", 16),
                          ("lens_radius", "<f4"), ("focal_distance", "<f4"),
                          ("shutter_open", "<f4"), ("shutter_close", "<f4")])
@@ -21,11 +22,11 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"),
 INSTANCE_DTYPE = np.dtype([("to_world", "<f4", 16), ("to_object", "<f4", 16), ("material", "<i4"), ("pad", "<i4", 3)])
 NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"), ("n_primitives", "<u2"),
                        ("axis", "u1"), ("pad", "u1")])
-assert MATERIAL_DTYPE.itemsize == 32 and LIGHT_DTYPE.itemsize == 32
+assert MATERIAL_DTYPE.itemsize == 32 and LIGHT_DTYPE.itemsize == 96
 assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 32 and NODE_DTYPE.itemsize == 32
 
 MAT_NONE, MAT_MATTE, MAT_MIRROR, MAT_GLASS = 0, 1, 2, 3
-LIGHT_DIFFUSE_AREA, LIGHT_INFINITE = 0, 1
+LIGHT_DIFFUSE_AREA, LIGHT_INFINITE, LIGHT_POINT, LIGHT_SPOT, LIGHT_DISTANT = 0, 1, 2, 3, 4
 
 _PCG32_MULT = np.uint64(0x5851F42D4C957F2D)
 _PCG32_DEFAULT_STATE = np.uint64(0x853C49E6748FEA9B)
@@ -69,9 +70,45 @@ def _materials(rows):
 
 
 def _lights(rows):
+    """rows: (type, L, prim, two_sided, n_samples) tuples or ready LIGHT_DTYPE records (point_light() ...)."""
     l = np.zeros(len(rows), dtype=LIGHT_DTYPE)
-    for i, (t, L, prim, two_sided, ns) in enumerate(rows):
-        l[i] = (t, L, prim, two_sided, ns, 0)
+    for i, row in enumerate(rows):
+        if isinstance(row, np.void) or (isinstance(row, np.ndarray) and row.dtype == LIGHT_DTYPE):
+            l[i] = row
+            continue
+        t, L, prim, two_sided, ns = row
+        l[i]["type"], l[i]["L"], l[i]["prim"], l[i]["two_sided"], l[i]["n_samples"] = t, L, prim, two_sided, ns
+    return l
+
+
+def point_light(p_light, intensity):
+    """PointLight::new (lights/point.rs:26-40) with light_to_world = translate(p_light)."""
+    l = np.zeros((), dtype=LIGHT_DTYPE)
+    l["type"], l["L"], l["prim"], l["n_samples"], l["pos"] = LIGHT_POINT, intensity, -1, 1, p_light
+    return l
+
+
+def spot_light(p_from, p_to, intensity, total_width=30.0, falloff_start=25.0):
+    """SpotLight::new (lights/spot.rs:29-47); light_to_world = the scene-file form (api.cpp: look from `from`
+    down +z towards `to`): rotation with z = normalize(to - from), then translate(from)."""
+    p_from, p_to = np.asarray(p_from, dtype=np.float64), np.asarray(p_to, dtype=np.float64)
+    z = (p_to - p_from) / np.linalg.norm(p_to - p_from)
+    x = np.cross(z, [1.0, 0.0, 0.0]) if abs(z[0]) < 0.9 else np.cross(z, [0.0, 1.0, 0.0])
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    l = np.zeros((), dtype=LIGHT_DTYPE)
+    l["type"], l["L"], l["prim"], l["n_samples"], l["pos"] = LIGHT_SPOT, intensity, -1, 1, p_from
+    l["cos_total_width"] = np.cos(np.radians(total_width))
+    l["cos_falloff_start"] = np.cos(np.radians(falloff_start))
+    l["world_to_light"] = np.stack([x, y, z]).reshape(9)       # rows = light axes in world space (rigid: inverse = transpose)
+    return l
+
+
+def distant_light(w_from_surface_to_light, radiance):
+    """DistantLight::new (lights/distant.rs:29-46): w_light = normalize(light_to_world * w)."""
+    w = np.asarray(w_from_surface_to_light, dtype=np.float64)
+    l = np.zeros((), dtype=LIGHT_DTYPE)
+    l["type"], l["L"], l["prim"], l["n_samples"], l["pos"] = LIGHT_DISTANT, radiance, -1, 1, w / np.linalg.norm(w)
     return l
 
 
@@ -136,6 +173,23 @@ def cornell_box():
     )
     assert scene["indices"].shape[0] == 36
     return scene
+
+
+def with_lights(scene, extra, keep_existing=True):
+    """Copy of `scene` with the LIGHT_DTYPE records `extra` appended to (or replacing) its light table."""
+    out = dict(scene)
+    old = scene["lights"] if keep_existing else scene["lights"][:0]
+    out["lights"] = np.concatenate([old, _lights(list(extra))]) if len(extra) else old.copy()
+    if not keep_existing:
+        out["tri_light"] = np.full_like(scene["tri_light"], -1)
+    return out
+
+
+def cornell_delta_lights():
+    """Point, spot and distant lights placed inside the Cornell box (intensities sized to its 555-unit scale)."""
+    return [point_light((278.0, 450.0, 279.0), (4.0e5, 3.5e5, 3.0e5)),
+            spot_light((100.0, 500.0, 100.0), (300.0, 0.0, 300.0), (9.0e5, 9.0e5, 6.0e5), 35.0, 20.0),
+            distant_light((0.3, 1.0, -0.8), (1.5, 1.5, 2.0))]
 
 
 def cornell_camera(width, height):

@@ -230,3 +230,38 @@ def test_ambient_occlusion_instanced_passthrough(hip_ctx):
     assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
     gsc.close()
     osc.close()
+
+
+@pytest.mark.parametrize("integrator,kw", [(0, dict(max_depth=5, light_strategy=0)), (0, dict(max_depth=5, light_strategy=1)),
+                                           (1, dict(max_depth=3, light_strategy=0)), (1, dict(max_depth=3, light_strategy=1)),
+                                           (2, dict(max_depth=3))])
+@pytest.mark.parametrize("keep_area", [True, False])
+def test_delta_lights(hip_ctx, integrator, kw, keep_area):
+    """Point / spot / distant lights (lights/point.rs, spot.rs, distant.rs): is_delta_light skips MIS and the
+    BSDF-sampling half of estimate_direct (integrator.rs:196-207); mixed with the area light for the power
+    distribution."""
+    w = h = 64
+    sc = scenes.with_lights(scenes.cornell_box(), scenes.cornell_delta_lights(), keep_existing=keep_area)
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, scenes.cornell_camera(w, h), w, h, 4, integrator=integrator,
+                                              seed=41, **kw)
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    assert pbrt_hip.film_to_rgb(film_g).mean() > 0.05
+
+
+def test_delta_lights_specular_and_instances(hip_ctx):
+    """Delta lights over mirror / glass (mixed scene) and over the instanced scene."""
+    w, h = 64, 48
+    extra = [scenes.point_light((0.2, 0.9, -0.4), (3.0, 3.0, 3.0)), scenes.distant_light((0.0, 1.0, 0.2), (0.8, 0.8, 0.8)),
+             scenes.spot_light((1.5, 1.5, 1.5), (0.0, 0.0, 0.0), (20.0, 18.0, 15.0), 40.0, 30.0)]
+    sc = scenes.with_lights(scenes.mixed_materials_scene(), extra)
+    for integrator, kw in ((0, dict(max_depth=6, light_strategy=1)), (2, dict(max_depth=4))):
+        film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, scenes.random_triangles_camera(w, h), w, h, 4,
+                                                  integrator=integrator, seed=43, **kw)
+        _compare(film_g, film_c)
+        assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    sc = scenes.with_lights(scenes.instanced_scene(2000, 40, extent=1.5), extra)
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, scenes.instanced_camera(80, 56, 1.5), 80, 56, 4, integrator=0,
+                                              max_depth=6, light_strategy=1, seed=47)
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]

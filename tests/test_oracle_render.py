@@ -196,3 +196,42 @@ def test_ambient_occlusion_closed_forms():
         film, _ = osc.render(_cam(cam), w, h, 16, integrator=3, ao_samples=64, cos_sample=cos_sample, seed=4)
         assert abs(oracle.film_to_rgb(film).mean() - np.pi / 2) < 0.03
     osc.close()
+
+
+def test_delta_lights_closed_forms():
+    """Point / spot / distant light over a Lambertian floor: L = rho/pi * E with E = I cos / d^2 (point, and spot
+    inside its full-intensity cone), 0 outside the spot cone, L_d * cos for the distant light; all three
+    integrators agree exactly in expectation because a delta light has no variance."""
+    w = h = 8
+    rho = 0.6
+    floor = dict(positions=np.array([[-50, 0, -50], [-50, 0, 50], [50, 0, 50], [50, 0, -50]], dtype=np.float32),
+                 indices=np.array([[0, 1, 2], [0, 2, 3]], dtype=np.int32), tri_material=np.zeros(2, dtype=np.int32),
+                 materials=scenes._materials([(scenes.MAT_MATTE, (rho, rho, rho), (0, 0, 0), 1.0)]),
+                 tri_light=np.full(2, -1, dtype=np.int32), lights=scenes._lights([]))
+    cam = scenes.perspective_camera((3, 1.0, 0), (0, 0, 0), (0, 1, 0), 0.5, w, h)   # looks at the origin
+    cases = [
+        (scenes.point_light((0.0, 2.0, 0.0), (10.0, 10.0, 10.0)), rho / np.pi * 10.0 / 4.0),
+        (scenes.point_light((2.0, 2.0, 0.0), (10.0, 10.0, 10.0)), rho / np.pi * 10.0 * np.cos(np.pi / 4) / 8.0),
+        (scenes.spot_light((0.0, 2.0, 0.0), (0.0, 0.0, 0.0), (10.0, 10.0, 10.0), 30.0, 20.0), rho / np.pi * 10.0 / 4.0),
+        (scenes.spot_light((0.0, 2.0, 0.0), (5.0, 0.0, 0.0), (10.0, 10.0, 10.0), 30.0, 20.0), 0.0),   # cone misses the origin
+        (scenes.distant_light((0.0, 1.0, 0.0), (2.0, 2.0, 2.0)), rho / np.pi * 2.0),
+        (scenes.distant_light((1.0, 1.0, 0.0), (2.0, 2.0, 2.0)), rho / np.pi * 2.0 * np.cos(np.pi / 4)),
+    ]
+    for light, expect in cases:
+        osc = oracle.OracleScene(scenes.with_lights(floor, [light]))
+        for integrator, kw in ((0, dict(max_depth=1, light_strategy=1)), (1, dict(max_depth=1, light_strategy=0)),
+                               (2, dict(max_depth=1))):
+            film, _ = osc.render(_cam(cam), w, h, 4, integrator=integrator, seed=3, **kw)
+            rgb = oracle.film_to_rgb(film)
+            assert abs(rgb.mean() - expect) <= 2e-3 * max(expect, 1e-3), (light["type"], integrator, rgb.mean(), expect)
+        osc.close()
+    # spot falloff between the two cones: delta^4 with delta = (cos t - cos total) / (cos start - cos total)
+    ang = np.radians(25.0)
+    target = (2.0 * np.tan(ang), 0.0, 0.0)                       # the origin sits 25 degrees off the spot axis
+    osc = oracle.OracleScene(scenes.with_lights(floor, [scenes.spot_light((0.0, 2.0, 0.0), target, (10.0,) * 3, 30.0, 20.0)]))
+    cam = scenes.perspective_camera((3, 1.0, 0), (0, 0, 0), (0, 1, 0), 0.01, w, h)   # delta^4 is steep: tiny footprint
+    film, _ = osc.render(_cam(cam), w, h, 4, integrator=1, max_depth=1, light_strategy=0, seed=3)
+    delta = (np.cos(ang) - np.cos(np.radians(30.0))) / (np.cos(np.radians(20.0)) - np.cos(np.radians(30.0)))
+    expect = rho / np.pi * 10.0 * delta ** 4 / 4.0
+    assert abs(oracle.film_to_rgb(film).mean() - expect) < 0.02 * expect
+    osc.close()
