@@ -55,7 +55,7 @@ def lib():
         L.orc_render.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_uint64] + [ctypes.c_int] * 7 + [vp, vp]
         L.orc_render_filtered.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int,
-                                          ctypes.c_uint64] + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_float, vp, vp, vp]
+                                          ctypes.c_uint64] + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
         L.orc_filter_table.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]
         L.orc_sample_bounds.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp]
         L.orc_triangle_test.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, vp]
@@ -210,8 +210,10 @@ class OracleScene:
         return d
 
     def render(self, cam36, width, height, spp, integrator=0, max_depth=5, rr_threshold=1.0, light_strategy=1,
-               seed=0, bounds=None, n_threads=8, filter=None, ao_samples=64, cos_sample=True):
+               seed=0, bounds=None, n_threads=8, filter=None, ao_samples=64, cos_sample=True, sampler=None):
         """integrator: 0 path, 1 direct lighting, 2 Whitted, 3 ambient occlusion (ao_samples, cos_sample).
+        sampler: None (random) or ("stratified", nx, ny, jitter, n_dims) / ("zerotwo", n_dims); spp then becomes
+        nx * ny / the next power of two.
         filter = (radius_x, radius_y, table[256]) or None for the 0.5 box; with a wider filter the default
         bounds are Film::get_sample_bounds (pixels outside the film are sampled too)."""
         film = np.zeros((height, width, 4), dtype=np.float32)
@@ -223,12 +225,24 @@ class OracleScene:
         if integrator == 3:
             max_depth, light_strategy = ao_samples, int(bool(cos_sample))
         lib().orc_render_filtered(self.h, _p(cam36), integrator, max_depth, rr_threshold, light_strategy, spp, seed,
-                                  width, height, x0, y0, x1, y1, n_threads, rx, ry, _p(table), _p(film), _p(stats))
+                                  width, height, x0, y0, x1, y1, n_threads, rx, ry, _p(table), _p(sampler_spec(sampler)),
+                                  _p(film), _p(stats))
         st = dict(rays=int(stats[0]), node_tests=int(stats[1]), prim_tests=int(stats[2]),
                   camera_samples=int(stats[3]), seconds=float(stats[4]) * 1e-9)
         if hasattr(self, "n_instances"):
             st["inst_tests"] = int(stats[5])
         return film, st
+
+
+def sampler_spec(sampler):
+    """("stratified", nx, ny, jitter, n_dims) / ("zerotwo", n_dims) / None -> int32[5] or None."""
+    if sampler is None:
+        return None
+    if sampler[0] == "stratified":
+        return np.array([1, sampler[1], sampler[2], int(bool(sampler[3])), sampler[4]], dtype=np.int32)
+    if sampler[0] == "zerotwo":
+        return np.array([2, 1, 1, 1, sampler[1]], dtype=np.int32)
+    raise ValueError(sampler)
 
 
 FILTERS = dict(box=0, gaussian=1, mitchell=2, lanczos=3, triangle=4)

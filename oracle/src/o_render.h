@@ -400,6 +400,22 @@ inline Spectrum uniform_sample_all_lights(const SurfaceInteraction& it, const BS
     for (size_t j = 0; j < scene.lights.size(); ++j) {
         const Light& light = *scene.lights[j];
         int n_samples = n_light_samples[j];
+        if (rc.sampler.tabulated()) {
+            // integrator.rs:55-89: the two requested arrays, or ONE get_2d pair once they have run out
+            const Point2f* u_light_array = rc.sampler.get_2d_array(n_samples);
+            const Point2f* u_scattering_array = rc.sampler.get_2d_array(n_samples);
+            if (!u_light_array || !u_scattering_array) {
+                Point2f u_light = rc.sampler.get_2d();
+                Point2f u_scattering = rc.sampler.get_2d();
+                l += estimate_direct(it, bsdf, u_scattering, light, (int)j, u_light, scene, rc);
+            } else {
+                Spectrum ld(0.0f);
+                for (int k = 0; k < n_samples; ++k)
+                    ld += estimate_direct(it, bsdf, u_scattering_array[k], light, (int)j, u_light_array[k], scene, rc);
+                l += ld / (Float)n_samples;
+            }
+            continue;
+        }
         Spectrum ld(0.0f);
         for (int k = 0; k < n_samples; ++k) {
             Point2f u_light = rc.sampler.get_2d();
@@ -415,6 +431,8 @@ inline Spectrum uniform_sample_all_lights(const SurfaceInteraction& it, const BS
 struct Integrator {
     virtual ~Integrator() {}
     virtual void pre_process(const Scene&) {}
+    // the sample-array requests an integrator makes of the sampler in its constructor / pre_process
+    virtual void request_samples(const Scene&, SamplerSpec&) {}
     virtual Spectrum li(Ray ray, const Scene& scene, RenderCtx& rc, int depth) const = 0;
 };
 
@@ -494,6 +512,17 @@ struct DirectLightingIntegrator : Integrator {
         if (strategy == UNIFORM_SAMPLE_ALL)
             for (auto& l : scene.lights) n_light_samples.push_back(l->n_samples);
     }
+    // directlighting.rs:58-76: round_count, then two arrays per light for each of max_depth vertices
+    void request_samples(const Scene& scene, SamplerSpec& spec) override {
+        if (strategy != UNIFORM_SAMPLE_ALL) return;
+        n_light_samples.clear();
+        for (auto& l : scene.lights) n_light_samples.push_back(spec.round_count(l->n_samples));
+        for (int i = 0; i < max_depth; ++i)
+            for (size_t j = 0; j < scene.lights.size(); ++j) {
+                spec.arrays_2d.push_back(n_light_samples[j]);
+                spec.arrays_2d.push_back(n_light_samples[j]);
+            }
+    }
     // directlighting.rs:79-127
     Spectrum li(Ray ray, const Scene& scene, RenderCtx& rc, int depth) const override {
         Spectrum l(0.0f);
@@ -541,6 +570,7 @@ struct DirectLightingIntegrator : Integrator {
 struct WhittedIntegrator : DirectLightingIntegrator {
     WhittedIntegrator(int md) : DirectLightingIntegrator(UNIFORM_SAMPLE_ONE, md) {}
     void pre_process(const Scene&) override {}
+    void request_samples(const Scene&, SamplerSpec&) override {}
     Spectrum li(Ray ray, const Scene& scene, RenderCtx& rc, int depth) const override {
         Spectrum l(0.0f);
         SurfaceInteraction isect;
@@ -592,6 +622,11 @@ struct AOIntegrator : Integrator {
     bool cos_sample;
     int n_samples;
     AOIntegrator(bool cs, int ns) : cos_sample(cs), n_samples(ns) {}
+    // ao.rs:36-37
+    void request_samples(const Scene&, SamplerSpec& spec) override {
+        n_samples = spec.round_count(n_samples);
+        spec.arrays_2d.push_back(n_samples);
+    }
     Spectrum li(Ray ray, const Scene& scene, RenderCtx& rc, int) const override {
         Spectrum l(0.0f);
         SurfaceInteraction isect;
@@ -606,8 +641,9 @@ struct AOIntegrator : Integrator {
                 Normal3f n = isect.n.face_forward(-ray.d);
                 Vector3f s = isect.dpdu.normalize();
                 Vector3f t = isect.n.cross(s);
+                const Point2f* u_array = rc.sampler.get_2d_array(n_samples);  // ao.rs:77-81
                 for (int i = 0; i < n_samples; ++i) {
-                    Point2f u = rc.sampler.get_2d();
+                    Point2f u = u_array ? u_array[i] : rc.sampler.get_2d();
                     Vector3f wi;
                     Float pdf;
                     if (cos_sample) {
@@ -770,6 +806,7 @@ struct RenderParams {
     // rectangle of pixels to render [x0,x1) x [y0,y1) (pixel_bounds of SamplerIntegrator)
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     int n_threads = 1;
+    SamplerSpec sampler;
 };
 struct RenderStats {
     TraversalCounters ctr;
@@ -779,8 +816,12 @@ struct RenderStats {
 
 // integrator.rs:399-480 — 16x16 tiles, one task per tile (parallel.rs:4-21 -> std::thread pool).
 inline void render(const Scene& scene, const PerspectiveCamera& camera, Integrator& integrator, Film& film,
-                   const RenderParams& rp, RenderStats* stats) {
+                   const RenderParams& rp_in, RenderStats* stats) {
+    RenderParams rp = rp_in;
     integrator.pre_process(scene);
+    rp.sampler.arrays_2d.clear();
+    integrator.request_samples(scene, rp.sampler);
+    rp.spp = (int)rp.sampler.samples_per_pixel(rp.spp);
     const int TILE_SIZE = 16;
     // get_sample_bounds with a 0.5 box filter = the pixel rectangle itself (film.rs:76-81, D42)
     int sx0 = rp.x0, sy0 = rp.y0, sx1 = rp.x1, sy1 = rp.y1;
@@ -791,6 +832,7 @@ inline void render(const Scene& scene, const PerspectiveCamera& camera, Integrat
     std::vector<RenderStats> tstats(n_threads);
     auto worker = [&](int tid) {
         RenderCtx rc;
+        rc.sampler.spec = &rp.sampler;
         for (;;) {
             int tile = next_tile.fetch_add(1);
             if (tile >= ntx * nty) break;
@@ -806,6 +848,7 @@ inline void render(const Scene& scene, const PerspectiveCamera& camera, Integrat
             FilmTile film_tile(film, std::max(tx0, 0), std::max(ty0, 0), std::min(tx1, film.width), std::min(ty1, film.height));
             for (int py = y0; py < y1; ++py)
                 for (int px = x0; px < x1; ++px) {
+                    rc.sampler.start_pixel(rp.seed, (int64_t)py * film.width + px, rp.spp);
                     for (int s = 0; s < rp.spp; ++s) {
                         rc.sampler.start_sample(rp.seed, (int64_t)py * film.width + px, rp.spp, s);
                         CameraSample cs = rc.sampler.get_camera_sample(px, py);

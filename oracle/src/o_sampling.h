@@ -7,6 +7,10 @@
 //   src/core/rng.rs:5-98              RNG (PCG32): set_sequence, uniform_u32, uniform_float
 //   src/core/sampler.rs:15-33         Sampler::get_1d/get_2d/get_camera_sample (2D, 1D, 2D)
 //   src/samplers/random.rs:12-56      RandomSampler
+//   src/core/sampler.rs:252-318       PixelSampler (per-pixel tables for the first n dimensions, RNG beyond)
+//   src/samplers/stratified.rs:13-112 StratifiedSampler::start_pixel; src/core/sampling.rs:11-66, 280-287
+//   src/samplers/zerotwosequence.rs   ZeroTwoSequenceSampler; src/core/lowdiscrepancy.rs:416-505 (gray-code
+//                                     van der Corput / Sobol' (0,2) points, scrambles, shuffles)
 //   src/core/sampling.rs:62-154       Distribution1D (find_interval predicate `cdf[i] < u` as written)
 //   src/core/sampling.rs:168-213      Distribution2D
 //   src/core/sampling.rs:258-313      concentric_sample_disk, uniform_sample_triangle,
@@ -17,6 +21,7 @@
 // intended (signed clamp). Distribution2D::pdf casts before multiplying (sampling.rs:201-210) —
 // intended `(p*count) as int`.
 #pragma once
+#include <algorithm>
 #include <vector>
 
 #include "o_math.h"
@@ -47,6 +52,14 @@ struct RNG {
         uint32_t rot = (uint32_t)(old_state >> 59);
         return (xor_shifted >> rot) | (xor_shifted << ((~rot + 1) & 31));
     }
+    // rng.rs:37-45
+    uint32_t uniform_u32_bounded(uint32_t b) {
+        uint32_t threshold = (~b + 1u) % b;
+        for (;;) {
+            uint32_t r = uniform_u32();
+            if (r >= threshold) return r % b;
+        }
+    }
     // rng.rs:46-48
     Float uniform_float() { return fminr(ONE_MINUS_EPSILON, (Float)uniform_u32() * 2.3283064365386963e-10f); }
 };
@@ -60,23 +73,199 @@ struct CameraSample {
     Point2f p_film, p_lens;
     Float time;
 };
+// sampling.rs:11-17
+inline void stratified_sample_1d(Float* samples, int n_samples, RNG& rng, bool jitter) {
+    Float inv_n_samples = 1.0f / (Float)n_samples;
+    for (int i = 0; i < n_samples; ++i) {
+        Float delta = jitter ? rng.uniform_float() : 0.5f;
+        samples[i] = fminr(ONE_MINUS_EPSILON, ((Float)i + delta) * inv_n_samples);
+    }
+}
+// sampling.rs:19-41
+inline void stratified_sample_2d(Point2f* samples, int nx, int ny, RNG& rng, bool jitter) {
+    Float dx = 1.0f / (Float)nx, dy = 1.0f / (Float)ny;
+    int i = 0;
+    for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x) {
+            Float jx = 0.5f, jy = 0.5f;
+            if (jitter) {
+                jx = rng.uniform_float();
+                jy = rng.uniform_float();
+            }
+            samples[i].x = fminr(ONE_MINUS_EPSILON, ((Float)x + jx) * dx);
+            samples[i].y = fminr(ONE_MINUS_EPSILON, ((Float)y + jy) * dy);
+            ++i;
+        }
+}
+// sampling.rs:280-287: blocks of n_dimensions values are swapped
+template <class T>
+inline void shuffle(T* samp, int count, int n_dimensions, RNG& rng) {
+    for (int i = 0; i < count; ++i) {
+        int other = i + (int)rng.uniform_u32_bounded((uint32_t)(count - i));
+        for (int j = 0; j < n_dimensions; ++j) std::swap(samp[n_dimensions * i + j], samp[n_dimensions * other + j]);
+    }
+}
+// sampling.rs:44-66 for Point2f samples (n_dim = 2)
+inline void latin_hyper_cube_2d(Point2f* samples, int n_samples, RNG& rng) {
+    Float inv_n_samples = 1.0f / (Float)n_samples;
+    for (int i = 0; i < n_samples; ++i)
+        for (int j = 0; j < 2; ++j) {
+            Float sj = ((Float)i + rng.uniform_float()) * inv_n_samples;
+            (j == 0 ? samples[i].x : samples[i].y) = fminr(ONE_MINUS_EPSILON, sj);
+        }
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < n_samples; ++j) {
+            int other = j + (int)rng.uniform_u32_bounded((uint32_t)(n_samples - j));
+            if (i == 0)
+                std::swap(samples[j].x, samples[other].x);
+            else
+                std::swap(samples[j].y, samples[other].y);
+        }
+}
+// lowdiscrepancy.rs:416-434 gray_code_sample / gray_code_sample_2d, :436-505 van_der_corput / sobol_2d.
+// D54 (intended): van_der_corput shuffles the block at `i * n_pixel_samples` (lowdiscrepancy.rs:452), which is
+// out of range for i >= 1 when one sample per pixel sample is asked for; pbrt-v3 (and sobol_2d, :496) use
+// `i * n_samples_per_pixel_sample`.
+inline int count_trailing_zeros(uint32_t v) { return __builtin_ctz(v); }
+static const uint32_t C_SOBOL_1[32] = {
+    0x80000000u, 0xc0000000u, 0xa0000000u, 0xf0000000u, 0x88000000u, 0xcc000000u, 0xaa000000u, 0xff000000u,
+    0x80800000u, 0xc0c00000u, 0xa0a00000u, 0xf0f00000u, 0x88880000u, 0xcccc0000u, 0xaaaa0000u, 0xffff0000u,
+    0x80008000u, 0xc000c000u, 0xa000a000u, 0xf000f000u, 0x88008800u, 0xcc00cc00u, 0xaa00aa00u, 0xff00ff00u,
+    0x80808080u, 0xc0c0c0c0u, 0xa0a0a0a0u, 0xf0f0f0f0u, 0x88888888u, 0xccccccccu, 0xaaaaaaaau, 0xffffffffu};
+inline uint32_t c_van_der_corput(int i) { return 0x80000000u >> i; }  // the identity generator matrix
+inline void van_der_corput(int n_per_pixel_sample, int n_pixel_samples, Float* samples, RNG& rng) {
+    uint32_t scramble = rng.uniform_u32();
+    int total = n_per_pixel_sample * n_pixel_samples;
+    uint32_t v = scramble;
+    for (int i = 0; i < total; ++i) {
+        samples[i] = fminr(ONE_MINUS_EPSILON, (Float)v * 2.3283064365386963e-10f);
+        v ^= c_van_der_corput(count_trailing_zeros((uint32_t)i + 1u));
+    }
+    for (int i = 0; i < n_pixel_samples; ++i) shuffle(samples + i * n_per_pixel_sample, n_per_pixel_sample, 1, rng);
+    shuffle(samples, n_pixel_samples, n_per_pixel_sample, rng);
+}
+inline void sobol_2d(int n_per_pixel_sample, int n_pixel_samples, Point2f* samples, RNG& rng) {
+    uint32_t s0 = rng.uniform_u32(), s1 = rng.uniform_u32();
+    int total = n_per_pixel_sample * n_pixel_samples;
+    uint32_t v0 = s0, v1 = s1;
+    for (int i = 0; i < total; ++i) {
+        samples[i].x = fminr(ONE_MINUS_EPSILON, (Float)v0 * 2.3283064365386963e-10f);
+        samples[i].y = fminr(ONE_MINUS_EPSILON, (Float)v1 * 2.3283064365386963e-10f);
+        int tz = count_trailing_zeros((uint32_t)i + 1u);
+        v0 ^= c_van_der_corput(tz);
+        v1 ^= C_SOBOL_1[tz];
+    }
+    for (int i = 0; i < n_pixel_samples; ++i) shuffle(samples + i * n_per_pixel_sample, n_per_pixel_sample, 1, rng);
+    shuffle(samples, n_pixel_samples, n_per_pixel_sample, rng);
+}
+// pbrt.rs:185-194
+inline int64_t round_up_pow2(int64_t v) {
+    v -= 1;
+    v |= v >> 1;
+    v |= v >> 2;
+    v |= v >> 4;
+    v |= v >> 8;
+    v |= v >> 16;
+    v |= v >> 32;
+    return v + 1;
+}
+
+enum SamplerKind { SAMPLER_RANDOM = 0, SAMPLER_STRATIFIED = 1, SAMPLER_ZEROTWO = 2 };
+// What the sampler constructors and the integrators' request_2d_array calls fix before rendering starts.
+struct SamplerSpec {
+    int kind = SAMPLER_RANDOM;
+    int nx = 1, ny = 1;       // StratifiedSampler::new x_pixel_samples, y_pixel_samples
+    bool jitter = true;
+    int n_dims = 4;           // n_sampled_dimensions
+    std::vector<int> arrays_2d;  // Sampler::request_2d_array sizes in request order (sampler.rs:41-46)
+    // samples per pixel the sampler actually takes (stratified.rs:30-33, zerotwosequence.rs:20)
+    int64_t samples_per_pixel(int64_t requested) const {
+        if (kind == SAMPLER_STRATIFIED) return (int64_t)nx * ny;
+        if (kind == SAMPLER_ZEROTWO) return round_up_pow2(requested);
+        return requested;
+    }
+    // Sampler::round_count (sampler.rs:48-50, zerotwosequence.rs:62-64)
+    int round_count(int n) const { return kind == SAMPLER_ZEROTWO ? (int)round_up_pow2(n) : n; }
+};
+
+// RandomSampler, and PixelSampler (sampler.rs:252-318) with the StratifiedSampler / ZeroTwoSequenceSampler
+// start_pixel tables. Streams (the reference consumes one tile stream serially, which no parallel renderer can
+// reproduce): start_pixel draws from the pixel's own stream, seed ^ (2^62 | pixel_index); the draws past the
+// tabulated dimensions come from the (pixel, sample) stream of the random sampler.
 struct Sampler {
     RNG rng;
     int64_t samples_per_pixel;
     uint64_t n_draws = 0;  // instrumentation
+    const SamplerSpec* spec = nullptr;
+    std::vector<std::vector<Float>> samples_1d;      // [dimension][pixel sample]
+    std::vector<std::vector<Point2f>> samples_2d;
+    std::vector<std::vector<Point2f>> sample_array_2d;  // [array][pixel sample * n + k]
+    int current_1d_dimension = 0, current_2d_dimension = 0, array_2d_offset = 0;
+    int64_t current_pixel_sample_index = 0;
     Sampler() : samples_per_pixel(1) {}
+    bool tabulated() const { return spec && spec->kind != SAMPLER_RANDOM; }
+    // StratifiedSampler::start_pixel (stratified.rs:44-104), ZeroTwoSequenceSampler::start_pixel
+    // (zerotwosequence.rs:28-60); 1D arrays are never requested on this path.
+    void start_pixel(uint64_t seed, int64_t pixel_index, int64_t spp) {
+        samples_per_pixel = spp;
+        if (!tabulated()) return;
+        RNG prng;
+        prng.set_sequence(seed ^ (0x4000000000000000ULL | (uint64_t)pixel_index));
+        const int n = (int)spp;
+        samples_1d.assign(spec->n_dims, std::vector<Float>(n));
+        samples_2d.assign(spec->n_dims, std::vector<Point2f>(n));
+        sample_array_2d.resize(spec->arrays_2d.size());
+        for (size_t i = 0; i < sample_array_2d.size(); ++i) sample_array_2d[i].assign((size_t)spec->arrays_2d[i] * n, Point2f());
+        if (spec->kind == SAMPLER_STRATIFIED) {
+            for (auto& d : samples_1d) {
+                stratified_sample_1d(d.data(), n, prng, spec->jitter);
+                shuffle(d.data(), n, 1, prng);
+            }
+            for (auto& d : samples_2d) {
+                stratified_sample_2d(d.data(), spec->nx, spec->ny, prng, spec->jitter);
+                shuffle(d.data(), n, 1, prng);
+            }
+            for (size_t i = 0; i < sample_array_2d.size(); ++i)
+                for (int j = 0; j < n; ++j) {
+                    int count = spec->arrays_2d[i];
+                    latin_hyper_cube_2d(sample_array_2d[i].data() + (size_t)j * count, count, prng);
+                }
+        } else {
+            for (auto& d : samples_1d) van_der_corput(1, n, d.data(), prng);
+            for (auto& d : samples_2d) sobol_2d(1, n, d.data(), prng);
+            for (size_t i = 0; i < sample_array_2d.size(); ++i) sobol_2d(spec->arrays_2d[i], n, sample_array_2d[i].data(), prng);
+        }
+    }
     void start_sample(uint64_t seed, int64_t pixel_index, int64_t spp, int64_t s) {
         samples_per_pixel = spp;
         rng.set_sequence(seed ^ (uint64_t)(pixel_index * spp + s));
+        current_1d_dimension = current_2d_dimension = array_2d_offset = 0;
+        current_pixel_sample_index = s;
     }
+    // sampler.rs:284-292
     Float get_1d() {
         ++n_draws;
+        if (tabulated() && current_1d_dimension < spec->n_dims)
+            return samples_1d[current_1d_dimension++][current_pixel_sample_index];
         return rng.uniform_float();
     }
+    // sampler.rs:294-302
     Point2f get_2d() {
-        Float a = get_1d();
-        Float b = get_1d();
+        if (tabulated() && current_2d_dimension < spec->n_dims) {
+            n_draws += 2;
+            return samples_2d[current_2d_dimension++][current_pixel_sample_index];
+        }
+        n_draws += 2;
+        Float a = rng.uniform_float();
+        Float b = rng.uniform_float();
         return Point2f(a, b);
+    }
+    // sampler.rs:64-75: the next requested array, or null when all have been handed out. The random sampler
+    // keeps its on-demand draws (its arrays are plain uniform numbers, random.rs:29-42), so it returns null.
+    const Point2f* get_2d_array(int n) {
+        if (!tabulated() || array_2d_offset == (int)sample_array_2d.size()) return nullptr;
+        const std::vector<Point2f>& a = sample_array_2d[array_2d_offset++];
+        return a.data() + (size_t)current_pixel_sample_index * n;
     }
     // sampler.rs:27-33
     CameraSample get_camera_sample(int px, int py) {

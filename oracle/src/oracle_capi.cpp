@@ -278,18 +278,20 @@ void orc_intersect_p(void* h, const float* rays, int64_t n, uint8_t* out, uint64
 void orc_render_filtered(void* h, const float* cam, int integrator, int max_depth, float rr_threshold,
                          int light_strategy, int spp, uint64_t seed, int width, int height, int x0, int y0, int x1,
                          int y1, int n_threads, float filter_rx, float filter_ry, const float* filter_table256,
-                         float* film_out, uint64_t* stats);
+                         const int32_t* sampler5, float* film_out, uint64_t* stats);
 void orc_render(void* h, const float* cam, int integrator, int max_depth, float rr_threshold, int light_strategy,
                 int spp, uint64_t seed, int width, int height, int x0, int y0, int x1, int y1, int n_threads,
                 float* film_out, uint64_t* stats) {
     orc_render_filtered(h, cam, integrator, max_depth, rr_threshold, light_strategy, spp, seed, width, height, x0, y0,
-                        x1, y1, n_threads, 0.5f, 0.5f, nullptr, film_out, stats);
+                        x1, y1, n_threads, 0.5f, 0.5f, nullptr, nullptr, film_out, stats);
 }
 // filter_table256 = Film::filter_table (film.rs:52-63), nullptr = box
+// sampler5 = {kind (0 random, 1 stratified, 2 (0,2)-sequence), x_samples, y_samples, jitter, n_sampled_dimensions}
+// or nullptr = random; the samples per pixel become x*y (stratified) / the next power of two ((0,2)).
 void orc_render_filtered(void* h, const float* cam, int integrator, int max_depth, float rr_threshold,
                          int light_strategy, int spp, uint64_t seed, int width, int height, int x0, int y0, int x1,
                          int y1, int n_threads, float filter_rx, float filter_ry, const float* filter_table256,
-                         float* film_out, uint64_t* stats) {
+                         const int32_t* sampler5, float* film_out, uint64_t* stats) {
     const Scene& sc = ((OracleScene*)h)->scene;
     PerspectiveCamera camera;
     std::memcpy(camera.camera_to_world.m, cam, 64);
@@ -310,6 +312,13 @@ void orc_render_filtered(void* h, const float* cam, int integrator, int max_dept
     rp.x1 = x1;
     rp.y1 = y1;
     rp.n_threads = n_threads;
+    if (sampler5) {
+        rp.sampler.kind = sampler5[0];
+        rp.sampler.nx = sampler5[1];
+        rp.sampler.ny = sampler5[2];
+        rp.sampler.jitter = sampler5[3] != 0;
+        rp.sampler.n_dims = sampler5[4];
+    }
     RenderStats st;
     std::unique_ptr<Integrator> integ;
     if (integrator == 0)

@@ -887,14 +887,40 @@ struct DevBuf {
 };
 }  // namespace
 
-int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRenderParams& rp, float* d_film,
+static int round_up_pow2(int v) {  // pbrt.rs:174-182
+    v -= 1;
+    v |= v >> 1;
+    v |= v >> 2;
+    v |= v >> 4;
+    v |= v >> 8;
+    v |= v >> 16;
+    return v + 1;
+}
+
+int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRenderParams& rp_in, float* d_film,
                      PbrtRenderStats* stats) {
     PbrtHipContext* ctx = s->ctx;
     auto invalid = [&](const char* m) {
         ctx->last_error = m;
         return PBRT_HIP_ERR_INVALID;
     };
+    PbrtRenderParams rp = rp_in;
     if (rp.width <= 0 || rp.height <= 0 || rp.spp <= 0) return invalid("width, height and spp must be positive");
+    // ---- sampler: samples per pixel and Sampler::round_count (stratified.rs:30-33, zerotwosequence.rs:20, 62-64) ----
+    if (rp.sampler < PBRT_SAMPLER_RANDOM || rp.sampler > PBRT_SAMPLER_ZEROTWO) return invalid("unknown sampler");
+    const bool tabulated = rp.sampler != PBRT_SAMPLER_RANDOM;
+    if (tabulated && (rp.sampler_dims < 0 || rp.sampler_dims > 255)) return invalid("sampler_dims must be in [0, 255]");
+    if (rp.sampler == PBRT_SAMPLER_STRATIFIED) {
+        if (rp.sampler_x < 1 || rp.sampler_y < 1 || (int64_t)rp.sampler_x * rp.sampler_y > 65536)
+            return invalid("stratified sampler: sampler_x * sampler_y must be in [1, 65536]");
+        rp.spp = rp.sampler_x * rp.sampler_y;
+    } else if (rp.sampler == PBRT_SAMPLER_ZEROTWO) {
+        if (rp.spp > 65536) return invalid("(0,2)-sequence sampler: spp too large");
+        rp.spp = round_up_pow2(rp.spp);
+    }
+    auto round_count = [&](int n) { return rp.sampler == PBRT_SAMPLER_ZEROTWO ? round_up_pow2(n) : n; };
+    if (rp.integrator == PBRT_INTEGRATOR_AO && rp.ao_samples >= 1 && rp.ao_samples <= 65535 && tabulated)
+        rp.ao_samples = round_count(rp.ao_samples);  // ao.rs:36
     float frx = rp.filter_radius[0] > 0.0f ? rp.filter_radius[0] : 0.5f;
     float fry = rp.filter_radius[1] > 0.0f ? rp.filter_radius[1] : 0.5f;
     bool box = true;  // the 0.5 box filter: exact in-order accumulation (k_film_accumulate)
@@ -976,7 +1002,45 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     }
     DirectState ds{};
     std::vector<int> prefix(s->d.n_lights + 1, 0);
-    for (int i = 0; i < s->d.n_lights; ++i) prefix[i + 1] = prefix[i] + s->light_samples[i];
+    for (int i = 0; i < s->d.n_lights; ++i)  // directlighting.rs:58-62: round_count with a tabulating sampler
+        prefix[i + 1] = prefix[i] + (tabulated ? round_count(s->light_samples[i]) : s->light_samples[i]);
+    // ---- PixelSampler tables: n_dims 1D + n_dims 2D dimensions and the requested 2D arrays, per pixel ----
+    SamplerParams smp{};
+    smp.kind = rp.sampler;
+    smp.n_dims = rp.sampler_dims;
+    smp.nx = rp.sampler_x;
+    smp.ny = rp.sampler_y;
+    smp.jitter = rp.sampler_jitter;
+    ps.samp = buf.alloc<int>(N, &ok);
+    if (tabulated) {
+        std::vector<int2> arrays;
+        int64_t elems = (int64_t)smp.n_dims * rp.spp * 3;
+        smp.off2 = smp.n_dims * rp.spp;
+        auto request_2d_array = [&](int n) {  // sampler.rs:41-46
+            arrays.push_back(make_int2(n, (int)elems));
+            elems += (int64_t)n * rp.spp * 2;
+        };
+        if (rp.integrator == PBRT_INTEGRATOR_DIRECT && rp.light_strategy == 0) {
+            for (int i = 0; i < rp.max_depth; ++i)  // directlighting.rs:64-75
+                for (int j = 0; j < s->d.n_lights; ++j) {
+                    request_2d_array(prefix[j + 1] - prefix[j]);
+                    request_2d_array(prefix[j + 1] - prefix[j]);
+                }
+        } else if (rp.integrator == PBRT_INTEGRATOR_AO) {
+            request_2d_array(rp.ao_samples);  // ao.rs:37
+        }
+        if (arrays.size() > 0x7fff) return invalid("too many sample arrays (max_depth x lights)");
+        if (elems * n_pix * 4 > (64ll << 30) || elems >= (1ll << 31))
+            return invalid("sampler tables exceed 64 GB: lower spp, sampler_dims or the light sample counts");
+        smp.n_arrays = (int)arrays.size();
+        smp.n_elems = (int)elems;
+        smp.tables = buf.alloc<float>((size_t)elems * n_pix, &ok);
+        int2* d_arrays = buf.alloc<int2>(arrays.size(), &ok);
+        smp.arrays = d_arrays;
+        if (ok && !arrays.empty())
+            HIP_TRY(ctx, hipMemcpyAsync(d_arrays, arrays.data(), arrays.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+        if (ok) HIP_TRY(ctx, hipStreamSynchronize(st));  // `arrays` leaves scope
+    }
     int* d_prefix = buf.alloc<int>(prefix.size(), &ok);
     if (direct) {
         ds.stage = buf.alloc<int>(N, &ok);
@@ -1044,8 +1108,10 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     if (rc == PBRT_HIP_OK && !hip_ok(ctx, (call), #call)) rc = PBRT_HIP_ERR_DEVICE;
 
     RENDER_TRY(hipEventRecord(e_begin, st));
+    bool tables_ready = !tabulated;
     for (int s0 = 0; s0 < rp.spp && rc == PBRT_HIP_OK; s0 += spp_pass) {
         PassParams pp;
+        pp.smp = smp;
         pp.n_pix = n_pix;
         pp.n_samples = std::min(spp_pass, rp.spp - s0);
         pp.sample0 = s0;
@@ -1065,6 +1131,11 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         pp.filter_table = d_filter;
         uint32_t n_paths = (uint32_t)n_pix * pp.n_samples;
         int cur = 0;
+        if (!tables_ready) {  // Sampler::start_pixel for every pixel of this GPU, once per render
+            hipLaunchKernelGGL(k_sampler_tables, dim3((n_pix + 63) / 64), dim3(64), 0, st, pp, tiles);
+            RENDER_TRY(hipGetLastError());
+            tables_ready = true;
+        }
         hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, st, ps, q[cur], pp, cam, tiles);
         RENDER_TRY(hipGetLastError());
         if (direct) {

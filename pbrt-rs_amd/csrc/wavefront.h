@@ -40,9 +40,25 @@ struct PathState {
     float4* nee_b;   // beta at the NEE vertex rgb, scattering pdf
     int* nee_light;  // light index of the pending estimate
     float2* pfilm;   // CameraSample::p_film
+    int* samp;       // PixelSampler counters: current_1d_dimension | current_2d_dimension << 8 | array_2d_offset << 16
+};
+
+// PixelSampler tables (sampler.rs:252-318) of this GPU's pixels, one column per pixel:
+// tables[elem * n_pix + pix]; elem: 1D dimension d, sample s -> d*spp + s; 2D -> off2 + (d*spp + s)*2 + c;
+// requested 2D array a (n values per pixel sample) -> arrays[a].y + (s*n + k)*2 + c.
+struct SamplerParams {
+    int kind;      // PbrtSamplerKind
+    int n_dims;    // n_sampled_dimensions
+    int nx, ny, jitter;
+    int n_arrays;
+    int off2;      // first element of the 2D tables
+    int n_elems;   // elements per pixel
+    float* tables;
+    const int2* arrays;  // per requested array: (n, first element)
 };
 
 struct PassParams {
+    SamplerParams smp;
     int n_pix;         // pixels in this GPU's tile set (n_tiles * 256)
     int n_samples;     // samples of this pass
     int sample0;       // first sample index of this pass
@@ -146,6 +162,152 @@ struct TileList {
     int n_tiles;
 };
 
+// ---- Sampler (sampler.rs:15-33, PixelSampler :284-302): tabulated dimensions first, then the path's RNG ----
+struct Samp {
+    Rng rng;
+    int pix, s;  // column of the pixel in the tables, pixel sample index
+    int dim1, dim2, arr;
+};
+PB_DEV float samp_1d(const PassParams& pp, Samp& sm) {
+    if (pp.smp.kind != PBRT_SAMPLER_RANDOM && sm.dim1 < pp.smp.n_dims) {
+        int e = sm.dim1 * pp.spp + sm.s;
+        sm.dim1 += 1;
+        return pp.smp.tables[(size_t)e * pp.n_pix + sm.pix];
+    }
+    return rng_float(sm.rng);
+}
+PB_DEV void samp_2d(const PassParams& pp, Samp& sm, float* u0, float* u1) {
+    if (pp.smp.kind != PBRT_SAMPLER_RANDOM && sm.dim2 < pp.smp.n_dims) {
+        int e = pp.smp.off2 + (sm.dim2 * pp.spp + sm.s) * 2;
+        sm.dim2 += 1;
+        *u0 = pp.smp.tables[(size_t)e * pp.n_pix + sm.pix];
+        *u1 = pp.smp.tables[(size_t)(e + 1) * pp.n_pix + sm.pix];
+        return;
+    }
+    *u0 = rng_float(sm.rng);
+    *u1 = rng_float(sm.rng);
+}
+// element k of requested array a for this pixel sample (Sampler::get_2d_array, sampler.rs:64-75)
+PB_DEV void samp_array_2d(const PassParams& pp, const Samp& sm, int a, int k, float* u0, float* u1) {
+    int2 ar = pp.smp.arrays[a];
+    int e = ar.y + (sm.s * ar.x + k) * 2;
+    *u0 = pp.smp.tables[(size_t)e * pp.n_pix + sm.pix];
+    *u1 = pp.smp.tables[(size_t)(e + 1) * pp.n_pix + sm.pix];
+}
+PB_DEV void samp_store(const PathState& ps, uint32_t p, const Samp& sm) {
+    ps.rng[p] = sm.rng.state;
+    ps.samp[p] = sm.dim1 | (sm.dim2 << 8) | (sm.arr << 16);
+}
+
+// ---- PixelSampler::start_pixel for one pixel per thread: StratifiedSampler (stratified.rs:44-104) and
+// ZeroTwoSequenceSampler (zerotwosequence.rs:28-60), drawing from the pixel's own stream ----
+struct PixelColumn {
+    float* base;
+    size_t n_pix;
+    PB_DEV float& at(int e) const { return base[(size_t)e * n_pix]; }
+};
+PB_DEV uint32_t rng_bounded(Rng& r, uint32_t b) {  // rng.rs:37-45
+    uint32_t threshold = (~b + 1u) % b;
+    for (;;) {
+        uint32_t v = rng_u32(r);
+        if (v >= threshold) return v % b;
+    }
+}
+// sampling.rs:280-287 over elements of `width` floats, in blocks of n_dimensions elements
+PB_DEV void table_shuffle(const PixelColumn& c, int off, int count, int n_dimensions, int width, Rng& rng) {
+    for (int i = 0; i < count; ++i) {
+        int other = i + (int)rng_bounded(rng, (uint32_t)(count - i));
+        for (int j = 0; j < n_dimensions * width; ++j) {
+            float& a = c.at(off + n_dimensions * width * i + j);
+            float& b = c.at(off + n_dimensions * width * other + j);
+            float t = a;
+            a = b;
+            b = t;
+        }
+    }
+}
+PB_DEV uint32_t sobol_c1(int i) {  // second generator matrix of the (0,2) sequence (lowdiscrepancy.rs:481-488)
+    // column i of Pascal's triangle mod 2: c1[0] = 1 << 31, c1[i] = c1[i-1] ^ (c1[i-1] >> 1)
+    uint32_t v = 0x80000000u;
+    for (int k = 0; k < i; ++k) v ^= v >> 1;
+    return v;
+}
+// van_der_corput / sobol_2d (lowdiscrepancy.rs:436-505; D54 intended), width = 1 or 2
+PB_DEV void table_gray_code(const PixelColumn& c, int off, int n_per, int n_pixel_samples, int width, Rng& rng) {
+    uint32_t v0 = rng_u32(rng), v1 = width == 2 ? rng_u32(rng) : 0u;
+    int total = n_per * n_pixel_samples;
+    for (int i = 0; i < total; ++i) {
+        c.at(off + i * width) = fminr(kOneMinusEpsilon, (float)v0 * 2.3283064365386963e-10f);
+        if (width == 2) c.at(off + i * 2 + 1) = fminr(kOneMinusEpsilon, (float)v1 * 2.3283064365386963e-10f);
+        int tz = __builtin_ctz((uint32_t)i + 1u);
+        v0 ^= 0x80000000u >> tz;
+        if (width == 2) v1 ^= sobol_c1(tz);
+    }
+    for (int i = 0; i < n_pixel_samples; ++i) table_shuffle(c, off + i * n_per * width, n_per, 1, width, rng);
+    table_shuffle(c, off, n_pixel_samples, n_per, width, rng);
+}
+__global__ void k_sampler_tables(PassParams pp, TileList tiles) {
+    int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= pp.n_pix) return;
+    int2 org = tiles.origin[pix >> 8];
+    int x = org.x + (pix & 15), y = org.y + ((pix & 255) >> 4);
+    if (!(x >= pp.x0 && x < pp.x1 && y >= pp.y0 && y < pp.y1)) return;
+    const SamplerParams& sp = pp.smp;
+    PixelColumn c{sp.tables + pix, (size_t)pp.n_pix};
+    Rng rng;
+    rng_set_sequence(rng, pp.seed ^ (0x4000000000000000ULL | (uint64_t)((int64_t)y * pp.width + x)));
+    const int n = pp.spp;
+    if (sp.kind == PBRT_SAMPLER_STRATIFIED) {
+        for (int d = 0; d < sp.n_dims; ++d) {  // stratified_sample_1d (sampling.rs:11-17) + shuffle
+            float inv_n = 1.0f / (float)n;
+            for (int i = 0; i < n; ++i) {
+                float delta = sp.jitter ? rng_float(rng) : 0.5f;
+                c.at(d * n + i) = fminr(kOneMinusEpsilon, ((float)i + delta) * inv_n);
+            }
+            table_shuffle(c, d * n, n, 1, 1, rng);
+        }
+        for (int d = 0; d < sp.n_dims; ++d) {  // stratified_sample_2d (sampling.rs:19-41) + shuffle
+            float dx = 1.0f / (float)sp.nx, dy = 1.0f / (float)sp.ny;
+            int off = sp.off2 + d * n * 2, i = 0;
+            for (int yy = 0; yy < sp.ny; ++yy)
+                for (int xx = 0; xx < sp.nx; ++xx) {
+                    float jx = 0.5f, jy = 0.5f;
+                    if (sp.jitter) {
+                        jx = rng_float(rng);
+                        jy = rng_float(rng);
+                    }
+                    c.at(off + 2 * i) = fminr(kOneMinusEpsilon, ((float)xx + jx) * dx);
+                    c.at(off + 2 * i + 1) = fminr(kOneMinusEpsilon, ((float)yy + jy) * dy);
+                    ++i;
+                }
+            table_shuffle(c, off, n, 1, 2, rng);
+        }
+        for (int a = 0; a < sp.n_arrays; ++a) {  // latin_hyper_cube per pixel sample (sampling.rs:44-66)
+            int2 ar = sp.arrays[a];
+            int count = ar.x;
+            float inv_n = 1.0f / (float)count;
+            for (int j = 0; j < n; ++j) {
+                int off = ar.y + j * count * 2;
+                for (int i = 0; i < count; ++i)
+                    for (int k = 0; k < 2; ++k) c.at(off + 2 * i + k) = fminr(kOneMinusEpsilon, ((float)i + rng_float(rng)) * inv_n);
+                for (int k = 0; k < 2; ++k)
+                    for (int i = 0; i < count; ++i) {
+                        int other = i + (int)rng_bounded(rng, (uint32_t)(count - i));
+                        float& p0 = c.at(off + 2 * i + k);
+                        float& p1 = c.at(off + 2 * other + k);
+                        float t = p0;
+                        p0 = p1;
+                        p1 = t;
+                    }
+            }
+        }
+    } else {
+        for (int d = 0; d < sp.n_dims; ++d) table_gray_code(c, d * n, 1, n, 1, rng);
+        for (int d = 0; d < sp.n_dims; ++d) table_gray_code(c, sp.off2 + d * n * 2, 1, n, 2, rng);
+        for (int a = 0; a < sp.n_arrays; ++a) table_gray_code(c, sp.arrays[a].y, sp.arrays[a].x, n, 2, rng);
+    }
+}
+
 __global__ void k_generate(PathState ps, Queues q, PassParams pp, DevCamera cam, TileList tiles) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = (uint32_t)pp.n_pix * pp.n_samples;
@@ -158,13 +320,17 @@ __global__ void k_generate(PathState ps, Queues q, PassParams pp, DevCamera cam,
     int flags = 0;
     if (valid) {
         int s = pp.sample0 + s_local;
-        Rng rng;
-        rng_set_sequence(rng, sample_sequence(pp, x, y, s));
+        Samp sm;
+        rng_set_sequence(sm.rng, sample_sequence(pp, x, y, s));
+        sm.pix = pix;
+        sm.s = s;
+        sm.dim1 = sm.dim2 = sm.arr = 0;
         // Sampler::get_camera_sample (sampler.rs:27-33): 2D film, 1D time, 2D lens
-        float u0 = rng_float(rng), u1 = rng_float(rng);
+        float u0, u1, l0, l1;
+        samp_2d(pp, sm, &u0, &u1);
         float pfx = (float)x + u0, pfy = (float)y + u1;
-        float time_u = rng_float(rng);
-        float l0 = rng_float(rng), l1 = rng_float(rng);
+        float time_u = samp_1d(pp, sm);
+        samp_2d(pp, sm, &l0, &l1);
         V3 p_camera = xform_point(cam.r2c, V3{pfx, pfy, 0.0f});
         V3 o = V3{0.0f, 0.0f, 0.0f};
         V3 d = normalize(p_camera);
@@ -195,7 +361,7 @@ __global__ void k_generate(PathState ps, Queues q, PassParams pp, DevCamera cam,
             tmax -= dt;
         }
         store_ray(ps, p, RS_CONT, ow, dw, tmax);
-        ps.rng[p] = rng.state;
+        samp_store(ps, p, sm);
         ps.pfilm[p] = make_float2(pfx, pfy);
         flags = PF_VALID | PF_ALIVE;
     } else {
@@ -455,15 +621,21 @@ struct ShadeConsts {
     int total_light_samples;
 };
 
-PB_DEV Rng path_rng(const PathState& ps, const PassParams& pp, const TileList& tiles, uint32_t p) {
-    // this path's stream: inc from the (pixel, sample) index, state from memory
+PB_DEV Samp path_sampler(const PathState& ps, const PassParams& pp, const TileList& tiles, uint32_t p) {
+    // this path's stream: inc from the (pixel, sample) index, state and the dimension counters from memory
     int s_local = p / pp.n_pix, pix = p % pp.n_pix;
     int2 org = tiles.origin[pix >> 8];
     int x = org.x + (pix & 15), y = org.y + ((pix & 255) >> 4);
-    Rng rng;
-    rng.inc = (sample_sequence(pp, x, y, pp.sample0 + s_local) << 1) | 1;
-    rng.state = ps.rng[p];
-    return rng;
+    Samp sm;
+    sm.rng.inc = (sample_sequence(pp, x, y, pp.sample0 + s_local) << 1) | 1;
+    sm.rng.state = ps.rng[p];
+    sm.pix = pix;
+    sm.s = pp.sample0 + s_local;
+    int c = ps.samp[p];
+    sm.dim1 = c & 0xff;
+    sm.dim2 = (c >> 8) & 0xff;
+    sm.arr = (c >> 16) & 0xffff;
+    return sm;
 }
 
 PB_DEV Frame make_frame(const Surf& sf) {  // BSDF::new (reflection.rs:220-234)
@@ -811,7 +983,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
             }
             if (found && bounces < pp.max_depth) {  // path.rs:90
                 DevMaterial mat = sc.materials[sf.material];
-                Rng rng = path_rng(ps, pp, tiles, p);
+                Samp sm = path_sampler(ps, pp, tiles, p);
                 if (mat.type == PBRT_MAT_NONE) {
                     // path.rs:95-98: no BSDF -> continue through the surface, bounces unchanged
                     V3 o = offset_ray_origin(sf.p, sf.p_error, sf.n, rd);
@@ -830,14 +1002,15 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
 
                     // ---- uniform_sample_one_light (integrator.rs:92-134) ----
                     if (nonspecular && sc.n_lights > 0) {
-                        float u_pick = rng_float(rng);
+                        float u_pick = samp_1d(pp, sm);
                         int light_num = find_interval_cdf(sc.distrib.cdf, sc.distrib.n + 1, u_pick);
                         float pick_pdf = sc.distrib.func_int > 0.0f
                                              ? sc.distrib.func[light_num] / (sc.distrib.func_int * (float)sc.distrib.n)
                                              : 0.0f;
                         if (pick_pdf != 0.0f) {
-                            float ul0 = rng_float(rng), ul1 = rng_float(rng);
-                            float us0 = rng_float(rng), us1 = rng_float(rng);
+                            float ul0, ul1, us0, us1;
+                            samp_2d(pp, sm, &ul0, &ul1);
+                            samp_2d(pp, sm, &us0, &us1);
                             int nee_flags = estimate_direct_emit(sc, ps, p, sf, fr, true, kd, light_num, ul0, ul1, us0, us1,
                                                                  pick_pdf, beta);
                             flags |= nee_flags;
@@ -847,7 +1020,8 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
                     }
 
                     // ---- BSDF sampling for the next vertex (path.rs:123-152) ----
-                    float u0 = rng_float(rng), u1 = rng_float(rng);
+                    float u0, u1;
+                    samp_2d(pp, sm, &u0, &u1);
                     V3 wi = V3{0.0f, 0.0f, 0.0f}, f = V3{0.0f, 0.0f, 0.0f};
                     float pdf = 0.0f;
                     bool sampled_specular = false, sampled_transmission = false;
@@ -881,7 +1055,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
                         V3 rr_beta = beta * eta_scale;
                         if (max_comp(rr_beta) < pp.rr_threshold && bounces > 3) {
                             float qq = fmaxr(0.05f, 1.0f - max_comp(rr_beta));
-                            if (rng_float(rng) < qq) alive = false;
+                            if (samp_1d(pp, sm) < qq) alive = false;
                             else beta = beta / (1.0f - qq);
                         }
                         if (alive) {
@@ -892,7 +1066,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
                         }
                     }
                 }
-                ps.rng[p] = rng.state;
+                samp_store(ps, p, sm);
             }
         }
         ps.L[p] = make_float4(L.x, L.y, L.z, eta_scale);
@@ -944,11 +1118,21 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
         const int mode = ds.mode;
         const bool sample_all = mode == PBRT_INTEGRATOR_DIRECT && ds.light_strategy == 0;
         // stages at a vertex: direct = light samples, Whitted = one per light (whitted.rs:75), AO = hemisphere samples
-        const int total = (mode == PBRT_INTEGRATOR_AO)        ? ds.ao_samples
-                          : (sc.n_lights == 0)                ? 0
-                          : (mode == PBRT_INTEGRATOR_WHITTED) ? sc.n_lights
-                                                              : (sample_all ? sc.total_light_samples : 1);
-        Rng rng = path_rng(ps, pp, tiles, p);
+        Samp sm = path_sampler(ps, pp, tiles, p);
+        // uniform_sample_all_lights with a tabulating sampler (integrator.rs:55-89): the vertex takes its lights'
+        // sample arrays while the max_depth requested sets last (sm.arr counts the arrays handed out); after that
+        // every light gets ONE get_2d pair (bit 15 of sm.arr marks such a vertex).
+        const bool tabulated = pp.smp.kind != PBRT_SAMPLER_RANDOM;
+        bool fallback = (sm.arr & 0x8000) != 0;
+        auto stages_at_vertex = [&]() {
+            return (mode == PBRT_INTEGRATOR_AO)        ? ds.ao_samples
+                   : (sc.n_lights == 0)                ? 0
+                   : (mode == PBRT_INTEGRATOR_WHITTED) ? sc.n_lights
+                   : !sample_all                       ? 1
+                   : fallback                          ? sc.n_lights
+                                                       : sc.total_light_samples;
+        };
+        int total = stages_at_vertex();
         bool have_vertex = !(flags & PF_ALIVE);  // ALIVE: a continuation ray was traced, its hit is a new vertex
 
         // finish the light sample whose rays were traced
@@ -966,6 +1150,11 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
         // uniform_sample_all_lights (integrator.rs:44-90): close a light when its last sample is in
         auto close_light_if_done = [&](int st) {
             if (!sample_all || st == 0) return;
+            if (fallback) {  // one sample per light, no division (integrator.rs:57-69)
+                L = L + mulv(T, ld_acc);
+                ld_acc = V3{0.0f, 0.0f, 0.0f};
+                return;
+            }
             // st = number of light samples finished so far at this vertex
             int lo = 0;
             while (sc.light_sample_prefix[lo + 1] < st) ++lo;  // light of sample st-1
@@ -1022,6 +1211,13 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
                     }
                     if (mode != PBRT_INTEGRATOR_AO) L = L + mulv(T, surface_le(sc, sf, sf.wo));  // D28: + isect.Le(wo)
                     stage = 0;
+                    if (sample_all && tabulated && sc.n_lights > 0) {
+                        int handed = sm.arr & 0x7fff;
+                        fallback = handed + 2 * sc.n_lights > pp.smp.n_arrays;
+                        if (!fallback) handed += 2 * sc.n_lights;
+                        sm.arr = handed | (fallback ? 0x8000 : 0);
+                        total = stages_at_vertex();
+                    }
                 }
                 have_vertex = true;
             }
@@ -1031,7 +1227,11 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
                 V3 n = dot(sf.n, -rd) < 0.0f ? -sf.n : sf.n;  // face_forward(isect.n, -ray.d), D46 intended
                 V3 s = normalize(sf.dpdu);
                 V3 t = cross(sf.n, s);
-                float u0 = rng_float(rng), u1 = rng_float(rng);
+                float u0, u1;
+                if (tabulated)
+                    samp_array_2d(pp, sm, 0, stage, &u0, &u1);  // ao.rs:77-81: the one requested array
+                else
+                    samp_2d(pp, sm, &u0, &u1);
                 V3 wl;
                 float pdf;
                 if (ds.ao_cos_sample) {
@@ -1059,7 +1259,8 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
                 // ---- one light of WhittedIntegrator::li's loop (whitted.rs:75-91) ----
                 if (!surface_ready) load_surface();
                 DevLight lt = sc.lights[stage];
-                float ul0 = rng_float(rng), ul1 = rng_float(rng);
+                float ul0, ul1;
+                samp_2d(pp, sm, &ul0, &ul1);
                 stage += 1;
                 V3 wi, li, p1, p1_err, p1_n;
                 float pdf;
@@ -1084,17 +1285,27 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
                 bool matte = (mat.type == PBRT_MAT_MATTE) && !is_black(kd);
                 int light_num;
                 float pick_pdf = 1.0f;
-                if (sample_all) {
+                if (sample_all && fallback) {
+                    light_num = stage;
+                } else if (sample_all) {
                     light_num = 0;
                     while (sc.light_sample_prefix[light_num + 1] <= stage) ++light_num;
                 } else {
                     // uniform_sample_one_light without a distribution (integrator.rs:113-117)
                     float nl = (float)sc.n_lights;
-                    light_num = (int)fminr(rng_float(rng) * nl, nl - 1.0f);
+                    light_num = (int)fminr(samp_1d(pp, sm) * nl, nl - 1.0f);
                     pick_pdf = 1.0f / nl;
                 }
-                float ul0 = rng_float(rng), ul1 = rng_float(rng);
-                float us0 = rng_float(rng), us1 = rng_float(rng);
+                float ul0, ul1, us0, us1;
+                if (sample_all && tabulated && !fallback) {
+                    int k = stage - sc.light_sample_prefix[light_num];
+                    int first = (sm.arr & 0x7fff) - 2 * sc.n_lights + 2 * light_num;  // this vertex's arrays of this light
+                    samp_array_2d(pp, sm, first, k, &ul0, &ul1);
+                    samp_array_2d(pp, sm, first + 1, k, &us0, &us1);
+                } else {
+                    samp_2d(pp, sm, &ul0, &ul1);
+                    samp_2d(pp, sm, &us0, &us1);
+                }
                 int nee_flags = estimate_direct_emit(sc, ps, p, sf, fr, matte, kd, light_num, ul0, ul1, us0, us1, pick_pdf, T);
                 stage += 1;
                 if (nee_flags) {
@@ -1112,7 +1323,8 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
                 if (!surface_ready) load_surface();
                 for (; stage <= total + 1 && !branched; ++stage) {
                     int which = (stage == total) ? 1 : 2;  // reflect first, then transmit
-                    float u0 = rng_float(rng), u1 = rng_float(rng);
+                    float u0, u1;
+                    samp_2d(pp, sm, &u0, &u1);
                     (void)u1;
                     V3 wol = to_local(fr, sf.wo);
                     // BSDF::sample_f with type = REFLECTION|SPECULAR or TRANSMISSION|SPECULAR (one matching lobe)
@@ -1168,7 +1380,7 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
             surface_ready = false;
             have_vertex = true;
         }
-        ps.rng[p] = rng.state;
+        samp_store(ps, p, sm);
         ps.L[p] = make_float4(L.x, L.y, L.z, 1.0f);
         ps.beta[p] = make_float4(T.x, T.y, T.z, __int_as_float((depth << 8) | flags));
         ds.stage[p] = (stage & 0xffff) | (sp << 16);

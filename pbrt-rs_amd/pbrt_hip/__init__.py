@@ -21,6 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libpbrt_hip.so")
 
 SPLIT_SAH, SPLIT_HLBVH, SPLIT_MIDDLE, SPLIT_EQUAL_COUNTS = 0, 1, 2, 3
 INTEGRATOR_PATH, INTEGRATOR_DIRECT, INTEGRATOR_WHITTED, INTEGRATOR_AO = 0, 1, 2, 3
+SAMPLER_RANDOM, SAMPLER_STRATIFIED, SAMPLER_ZEROTWO = 0, 1, 2
 
 EXPORTS = [
     "pbrt_hip_context_create", "pbrt_hip_context_destroy", "pbrt_hip_last_error", "pbrt_hip_bvh_build",
@@ -38,7 +39,9 @@ class RenderParams(ctypes.Structure):
                 ("height", ctypes.c_int32), ("x0", ctypes.c_int32), ("y0", ctypes.c_int32), ("x1", ctypes.c_int32),
                 ("y1", ctypes.c_int32), ("seed", ctypes.c_uint64), ("tile_rank", ctypes.c_int32),
                 ("tile_world", ctypes.c_int32), ("spp_per_pass", ctypes.c_int32), ("ao_samples", ctypes.c_int32),
-                ("filter_radius", ctypes.c_float * 2), ("filter_table", ctypes.c_void_p)]
+                ("filter_radius", ctypes.c_float * 2), ("filter_table", ctypes.c_void_p),
+                ("sampler", ctypes.c_int32), ("sampler_x", ctypes.c_int32), ("sampler_y", ctypes.c_int32),
+                ("sampler_jitter", ctypes.c_int32), ("sampler_dims", ctypes.c_int32), ("pad3", ctypes.c_int32)]
 
 
 class RenderStats(ctypes.Structure):
@@ -336,27 +339,37 @@ class Scene:
                                                          ctypes.c_void_p(d_out_ptr)), "pbrt_hip_intersect_p_device")
 
     def _params(self, width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
-                tile_rank, tile_world, spp_per_pass, filter=None, ao_samples=64):
+                tile_rank, tile_world, spp_per_pass, filter=None, ao_samples=64, sampler=None):
         rx, ry, table = (0.5, 0.5, None) if filter is None else filter
         if table is not None:
             table = np.ascontiguousarray(table, dtype=np.float32)
             self._filter_keep = table
         x0, y0, x1, y1 = bounds if bounds is not None else sample_bounds(width, height, rx, ry)
+        if sampler is None:
+            smp = (SAMPLER_RANDOM, 0, 0, 0, 0)
+        elif sampler[0] == "stratified":       # ("stratified", nx, ny, jitter, n_dims): StratifiedSampler::new
+            smp = (SAMPLER_STRATIFIED, sampler[1], sampler[2], int(bool(sampler[3])), sampler[4])
+        elif sampler[0] == "zerotwo":          # ("zerotwo", n_dims): ZeroTwoSequenceSampler::new
+            smp = (SAMPLER_ZEROTWO, 1, 1, 1, sampler[1])
+        else:
+            raise ValueError(sampler)
         return RenderParams(integrator, max_depth, rr_threshold, light_strategy, spp, width, height, x0, y0, x1, y1,
                             seed, tile_rank, tile_world, spp_per_pass, ao_samples, (ctypes.c_float * 2)(rx, ry),
-                            None if table is None else table.ctypes.data)
+                            None if table is None else table.ctypes.data, *smp, 0)
 
     def render(self, camera, width, height, spp, integrator=INTEGRATOR_PATH, max_depth=5, rr_threshold=1.0,
                light_strategy=1, seed=0, bounds=None, tile_rank=0, tile_world=1, spp_per_pass=0, d_film_ptr=None,
-               filter=None, ao_samples=64, cos_sample=True):
+               filter=None, ao_samples=64, cos_sample=True, sampler=None):
         """Integrator::render. Returns (film[h,w,4] or None when d_film_ptr is given, stats dict).
         integrator: INTEGRATOR_PATH / _DIRECT / _WHITTED / _AO (ao_samples, cos_sample: AOIntegrator::new).
+        sampler: None (RandomSampler), ("stratified", nx, ny, jitter, n_dims) or ("zerotwo", n_dims); the samples
+        per pixel then become nx * ny / the next power of two of spp.
         filter = (radius_x, radius_y, table256) from filter_table(), None = 0.5 box."""
         camera = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
         if integrator == INTEGRATOR_AO:
             light_strategy = int(bool(cos_sample))
         rp = self._params(width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
-                          tile_rank, tile_world, spp_per_pass, filter, ao_samples)
+                          tile_rank, tile_world, spp_per_pass, filter, ao_samples, sampler)
         st = RenderStats()
         if d_film_ptr is None:
             film = np.zeros((height, width, 4), dtype=np.float32)

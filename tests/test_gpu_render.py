@@ -265,3 +265,65 @@ def test_delta_lights_specular_and_instances(hip_ctx):
                                               max_depth=6, light_strategy=1, seed=47)
     _compare(film_g, film_c)
     assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+
+
+SAMPLERS = [("stratified", 3, 2, True, 4), ("stratified", 4, 4, False, 2), ("zerotwo", 4), ("zerotwo", 0)]
+
+
+@pytest.mark.parametrize("sampler", SAMPLERS)
+@pytest.mark.parametrize("integrator,kw", [(0, dict(max_depth=5, light_strategy=1)), (2, dict(max_depth=3))])
+def test_samplers_path_and_whitted(hip_ctx, sampler, integrator, kw):
+    """StratifiedSampler / ZeroTwoSequenceSampler (PixelSampler tables for the first n dimensions, the path's RNG
+    beyond): the table kernel reproduces Sampler::start_pixel of the oracle value for value."""
+    w, h = 64, 48
+    sc = scenes.with_lights(scenes.mixed_materials_scene(), [scenes.point_light((0.2, 0.9, -0.4), (3.0, 3.0, 3.0))])
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, scenes.random_triangles_camera(w, h), w, h, 6,
+                                              integrator=integrator, seed=53, sampler=sampler, **kw)
+    _compare(film_g, film_c)
+    spp = sampler[1] * sampler[2] if sampler[0] == "stratified" else 8
+    assert st_g["camera_samples"] == st_c["camera_samples"] == w * h * spp
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+
+
+@pytest.mark.parametrize("sampler", [("stratified", 2, 3, True, 4), ("zerotwo", 3)])
+@pytest.mark.parametrize("max_depth", [1, 3, 5])
+def test_samplers_direct_lighting_arrays(hip_ctx, sampler, max_depth):
+    """uniform_sample_all_lights with requested sample arrays (latin hypercube / (0,2) arrays): max_depth sets are
+    requested, glass branches use more vertices than that, so the single-sample fallback (integrator.rs:57-69)
+    is exercised as well; n_samples are rounded to powers of two by the (0,2) sampler."""
+    w, h = 64, 48
+    sc = scenes.mixed_materials_scene()
+    sc["lights"]["n_samples"] = 3
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, scenes.random_triangles_camera(w, h), w, h, 4, integrator=1,
+                                              max_depth=max_depth, light_strategy=0, seed=59, sampler=sampler)
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, scenes.random_triangles_camera(w, h), w, h, 4, integrator=1,
+                                              max_depth=max_depth, light_strategy=1, seed=59, sampler=sampler)
+    _compare(film_g, film_c)
+
+
+@pytest.mark.parametrize("sampler", [("stratified", 2, 2, True, 4), ("zerotwo", 4)])
+def test_samplers_ambient_occlusion_array(hip_ctx, sampler):
+    w = h = 48
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, scenes.cornell_box(), scenes.cornell_camera(w, h), w, h, 4,
+                                              integrator=pbrt_hip.INTEGRATOR_AO, ao_samples=6, cos_sample=True, seed=61,
+                                              sampler=sampler)
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    n = 8 if sampler[0] == "zerotwo" else 6          # round_count (ao.rs:36)
+    assert st_g["rays_shadow"] % n == 0
+
+
+def test_samplers_pass_split_and_tiles(hip_ctx):
+    """Tables are per pixel: the film does not depend on the pass split or on the tile partition."""
+    w, h = 64, 48
+    sc, cam = scenes.random_triangles(20_000, seq=3, size=0.05), scenes.random_triangles_camera(w, h)
+    g = pbrt_hip.Scene(hip_ctx, sc)
+    smp = ("stratified", 3, 3, True, 4)
+    a, _ = g.render(cam, w, h, 9, max_depth=4, seed=5, sampler=smp)
+    b, _ = g.render(cam, w, h, 9, max_depth=4, seed=5, sampler=smp, spp_per_pass=2)
+    assert a.tobytes() == b.tobytes()
+    parts = [g.render(cam, w, h, 9, max_depth=4, seed=5, sampler=smp, tile_rank=r, tile_world=3)[0] for r in range(3)]
+    assert np.allclose(sum(parts), a, rtol=1e-6, atol=1e-6)
+    g.close()
