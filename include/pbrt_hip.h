@@ -133,7 +133,7 @@ enum PbrtIntegratorKind {
 /* Constructor arguments of PathIntegrator (src/integrators/path.rs:31-46) /
  * DirectLightingIntegrator (src/integrators/directlighting.rs:33-46) plus the sampler and film
  * plumbing of SamplerIntegrator::render (src/core/integrator.rs:399-480). */
-enum PbrtSamplerKind { PBRT_SAMPLER_RANDOM = 0, PBRT_SAMPLER_STRATIFIED = 1, PBRT_SAMPLER_ZEROTWO = 2 };
+enum PbrtSamplerKind { PBRT_SAMPLER_RANDOM = 0, PBRT_SAMPLER_STRATIFIED = 1, PBRT_SAMPLER_ZEROTWO = 2, PBRT_SAMPLER_HALTON = 3 };
 typedef struct PbrtRenderParams {
     int32_t integrator;     /* PbrtIntegratorKind */
     int32_t max_depth;
@@ -157,7 +157,8 @@ typedef struct PbrtRenderParams {
     /* Sampler (src/core/sampler.rs): PBRT_SAMPLER_RANDOM (src/samplers/random.rs), PBRT_SAMPLER_STRATIFIED
      * (src/samplers/stratified.rs:22-40: sampler_x * sampler_y samples per pixel replace `spp`, sampler_jitter,
      * sampler_dims = n_sampled_dimensions) or PBRT_SAMPLER_ZEROTWO (src/samplers/zerotwosequence.rs:17-23:
-     * `spp` is rounded up to a power of two, sampler_dims). All zero = the random sampler. */
+     * `spp` is rounded up to a power of two, sampler_dims) or PBRT_SAMPLER_HALTON (src/samplers/halton.rs:63-98 over
+     * the film's sample bounds, sample_at_pixel_center = false). All zero = the random sampler. */
     int32_t sampler;
     int32_t sampler_x, sampler_y;
     int32_t sampler_jitter;

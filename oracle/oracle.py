@@ -212,7 +212,7 @@ class OracleScene:
     def render(self, cam36, width, height, spp, integrator=0, max_depth=5, rr_threshold=1.0, light_strategy=1,
                seed=0, bounds=None, n_threads=8, filter=None, ao_samples=64, cos_sample=True, sampler=None):
         """integrator: 0 path, 1 direct lighting, 2 Whitted, 3 ambient occlusion (ao_samples, cos_sample).
-        sampler: None (random) or ("stratified", nx, ny, jitter, n_dims) / ("zerotwo", n_dims); spp then becomes
+        sampler: None (random) or ("stratified", nx, ny, jitter, n_dims) / ("zerotwo", n_dims) / ("halton",); spp then becomes
         nx * ny / the next power of two.
         filter = (radius_x, radius_y, table[256]) or None for the 0.5 box; with a wider filter the default
         bounds are Film::get_sample_bounds (pixels outside the film are sampled too)."""
@@ -242,6 +242,8 @@ def sampler_spec(sampler):
         return np.array([1, sampler[1], sampler[2], int(bool(sampler[3])), sampler[4]], dtype=np.int32)
     if sampler[0] == "zerotwo":
         return np.array([2, 1, 1, 1, sampler[1]], dtype=np.int32)
+    if sampler[0] == "halton":
+        return np.array([3, 1, 1, 1, 0], dtype=np.int32)
     raise ValueError(sampler)
 
 

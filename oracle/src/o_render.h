@@ -822,6 +822,11 @@ inline void render(const Scene& scene, const PerspectiveCamera& camera, Integrat
     rp.sampler.arrays_2d.clear();
     integrator.request_samples(scene, rp.sampler);
     rp.spp = (int)rp.sampler.samples_per_pixel(rp.spp);
+    if (rp.sampler.kind == SAMPLER_HALTON) {  // HaltonSampler::new(spp, film.get_sample_bounds(), false)
+        int sb[4];
+        film.sample_bounds(&sb[0], &sb[1], &sb[2], &sb[3]);
+        rp.sampler.halton.init(sb[2] - sb[0], sb[3] - sb[1]);
+    }
     const int TILE_SIZE = 16;
     // get_sample_bounds with a 0.5 box filter = the pixel rectangle itself (film.rs:76-81, D42)
     int sx0 = rp.x0, sy0 = rp.y0, sx1 = rp.x1, sy1 = rp.y1;
@@ -848,7 +853,7 @@ inline void render(const Scene& scene, const PerspectiveCamera& camera, Integrat
             FilmTile film_tile(film, std::max(tx0, 0), std::max(ty0, 0), std::min(tx1, film.width), std::min(ty1, film.height));
             for (int py = y0; py < y1; ++py)
                 for (int px = x0; px < x1; ++px) {
-                    rc.sampler.start_pixel(rp.seed, (int64_t)py * film.width + px, rp.spp);
+                    rc.sampler.start_pixel(rp.seed, (int64_t)py * film.width + px, rp.spp, px, py);
                     for (int s = 0; s < rp.spp; ++s) {
                         rc.sampler.start_sample(rp.seed, (int64_t)py * film.width + px, rp.spp, s);
                         CameraSample cs = rc.sampler.get_camera_sample(px, py);

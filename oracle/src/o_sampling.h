@@ -9,6 +9,8 @@
 //   src/samplers/random.rs:12-56      RandomSampler
 //   src/core/sampler.rs:252-318       PixelSampler (per-pixel tables for the first n dimensions, RNG beyond)
 //   src/samplers/stratified.rs:13-112 StratifiedSampler::start_pixel; src/core/sampling.rs:11-66, 280-287
+//   src/samplers/halton.rs:24-155     HaltonSampler; src/core/sampler.rs:320-400 GlobalSampler;
+//                                     src/core/lowdiscrepancy.rs:293-390 radical inverses and their permutations
 //   src/samplers/zerotwosequence.rs   ZeroTwoSequenceSampler; src/core/lowdiscrepancy.rs:416-505 (gray-code
 //                                     van der Corput / Sobol' (0,2) points, scrambles, shuffles)
 //   src/core/sampling.rs:62-154       Distribution1D (find_interval predicate `cdf[i] < u` as written)
@@ -170,7 +172,167 @@ inline int64_t round_up_pow2(int64_t v) {
     return v + 1;
 }
 
-enum SamplerKind { SAMPLER_RANDOM = 0, SAMPLER_STRATIFIED = 1, SAMPLER_ZEROTWO = 2 };
+// ---- Halton points: lowdiscrepancy.rs:11-170 (prime tables), :293-390 ----
+// The first PRIME_TABLE_SIZE + 23 primes and their running sums are generated instead of tabulated.
+static const int PRIME_TABLE_SIZE = 1000;
+struct PrimeTables {
+    std::vector<uint32_t> primes, prime_sums;  // primes[1023], prime_sums[i] = sum of primes[0..i)
+    std::vector<uint16_t> perms;               // compute_radical_inverse_permutations (lowdiscrepancy.rs:333-349)
+    PrimeTables() {
+        for (uint32_t v = 2; primes.size() < (size_t)PRIME_TABLE_SIZE + 23; ++v) {
+            bool is_prime = true;
+            for (uint32_t q : primes) {
+                if (q * q > v) break;
+                if (v % q == 0) {
+                    is_prime = false;
+                    break;
+                }
+            }
+            if (is_prime) primes.push_back(v);
+        }
+        prime_sums.resize(PRIME_TABLE_SIZE);
+        uint32_t acc = 0;
+        for (int i = 0; i < PRIME_TABLE_SIZE; ++i) {
+            prime_sums[i] = acc;
+            acc += primes[i];
+        }
+        perms.resize(acc);
+        RNG rng;  // RNG::default (halton.rs:17-22)
+        uint16_t* p = perms.data();
+        for (int i = 0; i < PRIME_TABLE_SIZE; ++i) {
+            for (uint32_t j = 0; j < primes[i]; ++j) p[j] = (uint16_t)j;
+            shuffle(p, (int)primes[i], 1, rng);
+            p += primes[i];
+        }
+    }
+};
+inline const PrimeTables& prime_tables() {
+    static const PrimeTables t;
+    return t;
+}
+inline uint32_t reverse_bits32(uint32_t n) {  // lowdiscrepancy.rs:371-378
+    n = (n << 16) | (n >> 16);
+    n = ((n & 0x00ff00ffu) << 8) | ((n & 0xff00ff00u) >> 8);
+    n = ((n & 0x0f0f0f0fu) << 4) | ((n & 0xf0f0f0f0u) >> 4);
+    n = ((n & 0x33333333u) << 2) | ((n & 0xccccccccu) >> 2);
+    n = ((n & 0x55555555u) << 1) | ((n & 0xaaaaaaaau) >> 1);
+    return n;
+}
+inline uint64_t reverse_bits64(uint64_t n) {  // :364-369
+    uint64_t n0 = reverse_bits32((uint32_t)n), n1 = reverse_bits32((uint32_t)(n >> 32));
+    return (n0 << 32) | n1;
+}
+// D53 (intended): radical_inverse_specialized never accumulates `reversed_digits` and squares inv_base
+// (lowdiscrepancy.rs:293-305: `let _reversed_digits = ...; inv_base *= inv_base`), so it returns 0 for every
+// index -> pbrt-v3 lowdiscrepancy.cpp RadicalInverseSpecialized.
+inline Float radical_inverse_specialized(uint64_t base, uint64_t a) {
+    Float inv_base = 1.0f / (Float)base;
+    uint64_t reversed_digits = 0;
+    Float inv_base_n = 1.0f;
+    while (a != 0) {
+        uint64_t next = a / base;
+        uint64_t digit = a - next * base;
+        reversed_digits = reversed_digits * base + digit;
+        inv_base_n *= inv_base;
+        a = next;
+    }
+    return fminr(ONE_MINUS_EPSILON, (Float)reversed_digits * inv_base_n);
+}
+// D55 (intended): the closing expression multiplies by inv_base instead of inv_base_n
+// (lowdiscrepancy.rs:318-319) -> pbrt-v3 `invBaseN * (reversedDigits + invBase * perm[0] / (1 - invBase))`.
+inline Float scrambled_radical_inverse_specialized(uint64_t base, const uint16_t* perm, uint64_t a) {
+    Float inv_base = 1.0f / (Float)base;
+    uint64_t reversed_digits = 0;
+    Float inv_base_n = 1.0f;
+    while (a != 0) {
+        uint64_t next = a / base;
+        uint64_t digit = a - next * base;
+        reversed_digits = reversed_digits * base + perm[digit];
+        inv_base_n *= inv_base;
+        a = next;
+    }
+    return fminr(ONE_MINUS_EPSILON, inv_base_n * ((Float)reversed_digits + inv_base * (Float)perm[0] / (1.0f - inv_base)));
+}
+inline Float radical_inverse(int base_index, uint64_t a) {  // :322-331
+    if (base_index == 0) return fminr(ONE_MINUS_EPSILON, (Float)reverse_bits64(a) * 5.4210108624275222e-20f);
+    return radical_inverse_specialized(prime_tables().primes[base_index], a);
+}
+inline uint64_t inverse_radical_inverse(uint64_t base, uint64_t inverse, int n_digits) {  // :381-390
+    uint64_t index = 0;
+    for (int i = 0; i < n_digits; ++i) {
+        uint64_t digit = inverse % base;
+        inverse /= base;
+        index = index * base + digit;
+    }
+    return index;
+}
+// halton.rs:40-61
+inline void extended_gcd(uint64_t a, uint64_t b, int64_t* x, int64_t* y) {
+    if (b == 0) {
+        *x = 1;
+        *y = 0;
+        return;
+    }
+    int64_t d = (int64_t)(a / b), xp = 0, yp = 0;
+    extended_gcd(b, a % b, &xp, &yp);
+    *x = yp;
+    *y = xp - d * yp;
+}
+inline uint64_t multiplicative_inverse(int64_t a, int64_t n) {
+    int64_t x = 0, y = 0;
+    extended_gcd((uint64_t)a, (uint64_t)n, &x, &y);
+    int64_t r = x - (x / n) * n;
+    return (uint64_t)(r < 0 ? r + n : r);
+}
+// HaltonSampler::new (halton.rs:63-98): the constants derived from the film's sample bounds
+struct HaltonSetup {
+    int base_scales[2] = {1, 1}, base_exponents[2] = {0, 0};
+    int64_t sample_stride = 1;
+    uint64_t mult_inverse[2] = {0, 0};
+    static const int MAX_RESOLUTION = 128;
+    void init(int res_x, int res_y) {
+        const int res[2] = {res_x, res_y};
+        for (int i = 0; i < 2; ++i) {
+            int base = i == 0 ? 2 : 3, scale = 1, exp = 0;
+            while (scale < std::min(MAX_RESOLUTION, res[i])) {
+                scale *= base;
+                ++exp;
+            }
+            base_scales[i] = scale;
+            base_exponents[i] = exp;
+        }
+        sample_stride = (int64_t)base_scales[0] * base_scales[1];
+        mult_inverse[0] = multiplicative_inverse(base_scales[1], base_scales[0]);
+        mult_inverse[1] = multiplicative_inverse(base_scales[0], base_scales[1]);
+    }
+    // get_index_for_sample (halton.rs:118-142). D56 (intended): `current_pixel % MAX_RESOLUTION` is negative for
+    // the pixels a wide filter adds left of / above the film -> pbrt-v3's Mod (non-negative remainder).
+    int64_t offset_for_pixel(int px, int py) const {
+        int64_t offset = 0;
+        if (sample_stride > 1) {
+            const int pm[2] = {((px % MAX_RESOLUTION) + MAX_RESOLUTION) % MAX_RESOLUTION,
+                               ((py % MAX_RESOLUTION) + MAX_RESOLUTION) % MAX_RESOLUTION};
+            for (int i = 0; i < 2; ++i) {
+                uint64_t dim_offset = inverse_radical_inverse(i == 0 ? 2 : 3, (uint64_t)pm[i], base_exponents[i]);
+                offset += (int64_t)(dim_offset * (uint64_t)(sample_stride / base_scales[i]) * mult_inverse[i]);
+            }
+            offset %= sample_stride;
+        }
+        return offset;
+    }
+    // sample_dimension (halton.rs:144-155), sample_at_pixel_center = false
+    Float sample_dimension(int64_t index, int dim) const {
+        const PrimeTables& t = prime_tables();
+        // PRIME_TABLE_SIZE dimensions exist; halton.rs:100-108 only logs past that (and then indexes out of range):
+        // later draws reuse the last dimension
+        dim = std::min(dim, PRIME_TABLE_SIZE - 1);
+        if (dim == 0) return radical_inverse(0, (uint64_t)index >> base_exponents[0]);
+        if (dim == 1) return radical_inverse(1, (uint64_t)index / (uint64_t)base_scales[1]);
+        return scrambled_radical_inverse_specialized(t.primes[dim], t.perms.data() + t.prime_sums[dim], (uint64_t)index);
+    }
+};
+
+enum SamplerKind { SAMPLER_RANDOM = 0, SAMPLER_STRATIFIED = 1, SAMPLER_ZEROTWO = 2, SAMPLER_HALTON = 3 };
 // What the sampler constructors and the integrators' request_2d_array calls fix before rendering starts.
 struct SamplerSpec {
     int kind = SAMPLER_RANDOM;
@@ -178,6 +340,7 @@ struct SamplerSpec {
     bool jitter = true;
     int n_dims = 4;           // n_sampled_dimensions
     std::vector<int> arrays_2d;  // Sampler::request_2d_array sizes in request order (sampler.rs:41-46)
+    HaltonSetup halton;          // HaltonSampler::new over the film's sample bounds
     // samples per pixel the sampler actually takes (stratified.rs:30-33, zerotwosequence.rs:20)
     int64_t samples_per_pixel(int64_t requested) const {
         if (kind == SAMPLER_STRATIFIED) return (int64_t)nx * ny;
@@ -203,12 +366,24 @@ struct Sampler {
     int current_1d_dimension = 0, current_2d_dimension = 0, array_2d_offset = 0;
     int64_t current_pixel_sample_index = 0;
     Sampler() : samples_per_pixel(1) {}
-    bool tabulated() const { return spec && spec->kind != SAMPLER_RANDOM; }
+    bool tabulated() const { return spec && spec->kind != SAMPLER_RANDOM; }  // hands out requested sample arrays
+    bool halton() const { return spec && spec->kind == SAMPLER_HALTON; }
+    // GlobalSampler state (sampler.rs:320-400)
+    static const int ARRAY_START_DIM = 5;
+    int dimension = 0, array_end_dim = 0;
+    int64_t interval_sample_index = 0, offset_for_current_pixel = 0;
+    std::vector<std::vector<Point2f>> halton_arrays;  // arrays handed out for the current pixel sample, generated on demand
+    int64_t index_for_sample(int64_t sample_num) const { return offset_for_current_pixel + sample_num * spec->halton.sample_stride; }
     // StratifiedSampler::start_pixel (stratified.rs:44-104), ZeroTwoSequenceSampler::start_pixel
     // (zerotwosequence.rs:28-60); 1D arrays are never requested on this path.
-    void start_pixel(uint64_t seed, int64_t pixel_index, int64_t spp) {
+    void start_pixel(uint64_t seed, int64_t pixel_index, int64_t spp, int px = 0, int py = 0) {
         samples_per_pixel = spp;
         if (!tabulated()) return;
+        if (halton()) {  // GlobalSampler::start_pixel (sampler.rs:341-365); arrays are evaluated when asked for
+            offset_for_current_pixel = spec->halton.offset_for_pixel(px, py);
+            array_end_dim = ARRAY_START_DIM + 2 * (int)spec->arrays_2d.size();
+            return;
+        }
         RNG prng;
         prng.set_sequence(seed ^ (0x4000000000000000ULL | (uint64_t)pixel_index));
         const int n = (int)spp;
@@ -241,16 +416,30 @@ struct Sampler {
         rng.set_sequence(seed ^ (uint64_t)(pixel_index * spp + s));
         current_1d_dimension = current_2d_dimension = array_2d_offset = 0;
         current_pixel_sample_index = s;
+        dimension = 0;  // GlobalSampler::set_sample_number (sampler.rs:394-398)
+        if (halton()) interval_sample_index = index_for_sample(s);
     }
     // sampler.rs:284-292
     Float get_1d() {
         ++n_draws;
+        if (halton()) {  // sampler.rs:367-374
+            if (dimension >= ARRAY_START_DIM && dimension < array_end_dim) dimension = array_end_dim;
+            return spec->halton.sample_dimension(interval_sample_index, dimension++);
+        }
         if (tabulated() && current_1d_dimension < spec->n_dims)
             return samples_1d[current_1d_dimension++][current_pixel_sample_index];
         return rng.uniform_float();
     }
     // sampler.rs:294-302
     Point2f get_2d() {
+        if (halton()) {  // sampler.rs:376-386
+            n_draws += 2;
+            if (dimension + 1 >= ARRAY_START_DIM && dimension < array_end_dim) dimension = array_end_dim;
+            Float a = spec->halton.sample_dimension(interval_sample_index, dimension);
+            Float b = spec->halton.sample_dimension(interval_sample_index, dimension + 1);
+            dimension += 2;
+            return Point2f(a, b);
+        }
         if (tabulated() && current_2d_dimension < spec->n_dims) {
             n_draws += 2;
             return samples_2d[current_2d_dimension++][current_pixel_sample_index];
@@ -263,6 +452,20 @@ struct Sampler {
     // sampler.rs:64-75: the next requested array, or null when all have been handed out. The random sampler
     // keeps its on-demand draws (its arrays are plain uniform numbers, random.rs:29-42), so it returns null.
     const Point2f* get_2d_array(int n) {
+        if (halton()) {
+            // GlobalSampler::start_pixel fills array i, element j with dimensions (5 + 2i, 6 + 2i) of the pixel's
+            // j-th sample index (sampler.rs:354-364); get_2d_array returns the slice of the current pixel sample
+            if (array_2d_offset == (int)spec->arrays_2d.size()) return nullptr;
+            if (halton_arrays.size() < spec->arrays_2d.size()) halton_arrays.resize(spec->arrays_2d.size());
+            std::vector<Point2f>& out = halton_arrays[array_2d_offset];
+            int dim = ARRAY_START_DIM + 2 * array_2d_offset++;
+            out.resize(n);
+            for (int k = 0; k < n; ++k) {
+                int64_t idx = index_for_sample(current_pixel_sample_index * n + k);
+                out[k] = Point2f(spec->halton.sample_dimension(idx, dim), spec->halton.sample_dimension(idx, dim + 1));
+            }
+            return out.data();
+        }
         if (!tabulated() || array_2d_offset == (int)sample_array_2d.size()) return nullptr;
         const std::vector<Point2f>& a = sample_array_2d[array_2d_offset++];
         return a.data() + (size_t)current_pixel_sample_index * n;

@@ -343,6 +343,27 @@ void orc_render_filtered(void* h, const float* cam, int integrator, int max_dept
     }
 }
 
+// HaltonSampler probe: out = {index of pixel (px, py)'s sample_num-th sample as double, sample_dimension(index, dim),
+// unscrambled radical inverse of the index in base 2 and in base 3, base_scales x, y}
+void orc_halton_probe(int res_x, int res_y, int px, int py, int sample_num, int dim, double* out6) {
+    HaltonSetup h;
+    h.init(res_x, res_y);
+    int64_t index = h.offset_for_pixel(px, py) + (int64_t)sample_num * h.sample_stride;
+    out6[0] = (double)index;
+    out6[1] = h.sample_dimension(index, dim);
+    out6[2] = radical_inverse(0, (uint64_t)index);
+    out6[3] = radical_inverse(1, (uint64_t)index);
+    out6[4] = h.base_scales[0];
+    out6[5] = h.base_scales[1];
+}
+// digit permutation of the base-th prime (compute_radical_inverse_permutations), n = that prime
+int orc_halton_permutation(int base_index, int32_t* out, int cap) {
+    const PrimeTables& t = prime_tables();
+    int n = (int)t.primes[base_index];
+    for (int i = 0; i < n && i < cap; ++i) out[i] = t.perms[t.prime_sums[base_index] + i];
+    return n;
+}
+
 void orc_filter_table(int type, float rx, float ry, float a, float b, float* table256) {
     filter_table(type, rx, ry, a, b, table256);
 }

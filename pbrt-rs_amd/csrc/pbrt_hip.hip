@@ -79,6 +79,8 @@ extern "C" void pbrt_hip_context_destroy(PbrtHipContext* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
+    if (ctx->d_halton_primes) (void)hipFree(ctx->d_halton_primes);
+    if (ctx->d_halton_perms) (void)hipFree(ctx->d_halton_perms);
     delete ctx;
 }
 
@@ -887,6 +889,74 @@ struct DevBuf {
 };
 }  // namespace
 
+// ---- HaltonSampler host side: prime tables and compute_radical_inverse_permutations (lowdiscrepancy.rs:11-170,
+// 333-349: RNG::default + shuffle per prime), HaltonSampler::new constants (halton.rs:40-98) ----
+namespace {
+struct HostPcg {  // rng.rs
+    uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
+    uint32_t u32() {
+        uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27), rot = (uint32_t)(old >> 59);
+        return (xs >> rot) | (xs << ((~rot + 1u) & 31u));
+    }
+    uint32_t bounded(uint32_t b) {
+        uint32_t threshold = (~b + 1u) % b;
+        for (;;) {
+            uint32_t r = u32();
+            if (r >= threshold) return r % b;
+        }
+    }
+};
+void halton_host_tables(std::vector<uint32_t>* primes_and_sums, std::vector<uint16_t>* perms) {
+    std::vector<uint32_t> primes;
+    for (uint32_t v = 2; primes.size() < 1000; ++v) {
+        bool is_prime = true;
+        for (uint32_t q : primes) {
+            if (q * q > v) break;
+            if (v % q == 0) {
+                is_prime = false;
+                break;
+            }
+        }
+        if (is_prime) primes.push_back(v);
+    }
+    primes_and_sums->assign(2000, 0);
+    uint32_t acc = 0;
+    for (int i = 0; i < 1000; ++i) {
+        (*primes_and_sums)[i] = primes[i];
+        (*primes_and_sums)[1000 + i] = acc;
+        acc += primes[i];
+    }
+    perms->resize(acc);
+    HostPcg rng;
+    uint16_t* p = perms->data();
+    for (int i = 0; i < 1000; ++i) {
+        int count = (int)primes[i];
+        for (int j = 0; j < count; ++j) p[j] = (uint16_t)j;
+        for (int j = 0; j < count; ++j) std::swap(p[j], p[j + (int)rng.bounded((uint32_t)(count - j))]);  // sampling.rs:280-287
+        p += count;
+    }
+}
+void extended_gcd(uint64_t a, uint64_t b, int64_t* x, int64_t* y) {  // halton.rs:51-61
+    if (b == 0) {
+        *x = 1;
+        *y = 0;
+        return;
+    }
+    int64_t d = (int64_t)(a / b), xp = 0, yp = 0;
+    extended_gcd(b, a % b, &xp, &yp);
+    *x = yp;
+    *y = xp - d * yp;
+}
+uint64_t multiplicative_inverse(int64_t a, int64_t n) {  // halton.rs:40-49
+    int64_t x = 0, y = 0;
+    extended_gcd((uint64_t)a, (uint64_t)n, &x, &y);
+    int64_t r = x - (x / n) * n;
+    return (uint64_t)(r < 0 ? r + n : r);
+}
+}  // namespace
+
 static int round_up_pow2(int v) {  // pbrt.rs:174-182
     v -= 1;
     v |= v >> 1;
@@ -907,9 +977,9 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     PbrtRenderParams rp = rp_in;
     if (rp.width <= 0 || rp.height <= 0 || rp.spp <= 0) return invalid("width, height and spp must be positive");
     // ---- sampler: samples per pixel and Sampler::round_count (stratified.rs:30-33, zerotwosequence.rs:20, 62-64) ----
-    if (rp.sampler < PBRT_SAMPLER_RANDOM || rp.sampler > PBRT_SAMPLER_ZEROTWO) return invalid("unknown sampler");
+    if (rp.sampler < PBRT_SAMPLER_RANDOM || rp.sampler > PBRT_SAMPLER_HALTON) return invalid("unknown sampler");
     const bool tabulated = rp.sampler != PBRT_SAMPLER_RANDOM;
-    if (tabulated && (rp.sampler_dims < 0 || rp.sampler_dims > 255)) return invalid("sampler_dims must be in [0, 255]");
+    if (tabulated && (rp.sampler_dims < 0 || rp.sampler_dims > 63)) return invalid("sampler_dims must be in [0, 63]");
     if (rp.sampler == PBRT_SAMPLER_STRATIFIED) {
         if (rp.sampler_x < 1 || rp.sampler_y < 1 || (int64_t)rp.sampler_x * rp.sampler_y > 65536)
             return invalid("stratified sampler: sampler_x * sampler_y must be in [1, 65536]");
@@ -1012,6 +1082,36 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     smp.ny = rp.sampler_y;
     smp.jitter = rp.sampler_jitter;
     ps.samp = buf.alloc<int>(N, &ok);
+    if (rp.sampler == PBRT_SAMPLER_HALTON) {
+        smp.n_dims = 0;  // nothing is tabulated per pixel: every value is a function of (sample index, dimension)
+        if (!ctx->d_halton_primes) {
+            std::vector<uint32_t> primes;
+            std::vector<uint16_t> perms;
+            halton_host_tables(&primes, &perms);
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_halton_primes, primes.size() * sizeof(uint32_t)));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_halton_perms, perms.size() * sizeof(uint16_t)));
+            HIP_TRY(ctx, hipMemcpy(ctx->d_halton_primes, primes.data(), primes.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            HIP_TRY(ctx, hipMemcpy(ctx->d_halton_perms, perms.data(), perms.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
+        smp.primes = ctx->d_halton_primes;
+        smp.perms = ctx->d_halton_perms;
+        // HaltonSampler::new(spp, film.get_sample_bounds(), false) (halton.rs:63-98)
+        int32_t sb[4];
+        pbrt_hip_sample_bounds(rp.width, rp.height, frx, fry, sb);
+        const int res[2] = {sb[2] - sb[0], sb[3] - sb[1]};
+        for (int i = 0; i < 2; ++i) {
+            int base = i == 0 ? 2 : 3, scale = 1, exp = 0;
+            while (scale < std::min(128, res[i])) {
+                scale *= base;
+                ++exp;
+            }
+            smp.h_scale[i] = scale;
+            smp.h_exp[i] = exp;
+        }
+        smp.h_stride = smp.h_scale[0] * smp.h_scale[1];
+        smp.h_minv[0] = (unsigned int)multiplicative_inverse(smp.h_scale[1], smp.h_scale[0]);
+        smp.h_minv[1] = (unsigned int)multiplicative_inverse(smp.h_scale[0], smp.h_scale[1]);
+    }
     if (tabulated) {
         std::vector<int2> arrays;
         int64_t elems = (int64_t)smp.n_dims * rp.spp * 3;
@@ -1033,6 +1133,11 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         if (elems * n_pix * 4 > (64ll << 30) || elems >= (1ll << 31))
             return invalid("sampler tables exceed 64 GB: lower spp, sampler_dims or the light sample counts");
         smp.n_arrays = (int)arrays.size();
+        smp.array_end_dim = 5 + 2 * smp.n_arrays;  // sampler.rs:344-345
+        if (rp.sampler == PBRT_SAMPLER_HALTON) {
+            if (smp.array_end_dim > 990) return invalid("Halton sampler: too many sample arrays for 1000 dimensions");
+            elems = 0;
+        }
         smp.n_elems = (int)elems;
         smp.tables = buf.alloc<float>((size_t)elems * n_pix, &ok);
         int2* d_arrays = buf.alloc<int2>(arrays.size(), &ok);
@@ -1108,7 +1213,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     if (rc == PBRT_HIP_OK && !hip_ok(ctx, (call), #call)) rc = PBRT_HIP_ERR_DEVICE;
 
     RENDER_TRY(hipEventRecord(e_begin, st));
-    bool tables_ready = !tabulated;
+    bool tables_ready = !tabulated || rp.sampler == PBRT_SAMPLER_HALTON;
     for (int s0 = 0; s0 < rp.spp && rc == PBRT_HIP_OK; s0 += spp_pass) {
         PassParams pp;
         pp.smp = smp;

@@ -29,6 +29,9 @@ struct PbrtHipContext {
     unsigned long long* d_counters = nullptr;
     uint64_t counted_rays = 0;
     unsigned int* d_work_counter = nullptr;  // ray-queue head of the persistent traversal kernel
+    // HaltonSampler tables, uploaded on first use: primes + prime sums, radical-inverse digit permutations
+    uint32_t* d_halton_primes = nullptr;
+    uint16_t* d_halton_perms = nullptr;
 };
 
 namespace pb {

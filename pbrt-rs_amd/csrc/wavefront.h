@@ -40,7 +40,7 @@ struct PathState {
     float4* nee_b;   // beta at the NEE vertex rgb, scattering pdf
     int* nee_light;  // light index of the pending estimate
     float2* pfilm;   // CameraSample::p_film
-    int* samp;       // PixelSampler counters: current_1d_dimension | current_2d_dimension << 8 | array_2d_offset << 16
+    int* samp;       // sampler counters: current_1d_dimension (Halton: dimension) | current_2d_dimension << 10 | array_2d_offset << 16
 };
 
 // PixelSampler tables (sampler.rs:252-318) of this GPU's pixels, one column per pixel:
@@ -55,6 +55,12 @@ struct SamplerParams {
     int n_elems;   // elements per pixel
     float* tables;
     const int2* arrays;  // per requested array: (n, first element)
+    // HaltonSampler (halton.rs:24-37, 63-98) + GlobalSampler::array_end_dim (sampler.rs:344-345)
+    int h_scale[2], h_exp[2];
+    int h_stride, array_end_dim;
+    unsigned int h_minv[2];
+    const uint16_t* perms;         // compute_radical_inverse_permutations (lowdiscrepancy.rs:333-349)
+    const uint32_t* primes;        // [0, 1000): primes, [1000, 2000): prime sums
 };
 
 struct PassParams {
@@ -166,9 +172,69 @@ struct TileList {
 struct Samp {
     Rng rng;
     int pix, s;  // column of the pixel in the tables, pixel sample index
-    int dim1, dim2, arr;
+    int dim1, dim2, arr;  // Halton: dim1 = GlobalSampler::dimension
+    long long h_offset;   // HaltonSampler::offset_for_current_pixel
 };
+// ---- Halton points (lowdiscrepancy.rs:293-390; D53 / D55 intended as in the oracle) ----
+PB_DEV float halton_radical_inverse(uint32_t base, const uint16_t* perm, unsigned long long a) {
+    float inv_base = 1.0f / (float)base;
+    unsigned long long reversed = 0;
+    float inv_base_n = 1.0f;
+    if (a >> 32) {  // rare: 64-bit digits until the rest fits 32 bits
+        while (a >> 32) {
+            unsigned long long next = a / base;
+            uint32_t digit = (uint32_t)(a - next * base);
+            reversed = reversed * base + (perm ? perm[digit] : digit);
+            inv_base_n *= inv_base;
+            a = next;
+        }
+    }
+    uint32_t a32 = (uint32_t)a;
+    while (a32 != 0) {
+        uint32_t next = a32 / base;
+        uint32_t digit = a32 - next * base;
+        reversed = reversed * base + (perm ? perm[digit] : digit);
+        inv_base_n *= inv_base;
+        a32 = next;
+    }
+    if (!perm) return fminr(kOneMinusEpsilon, (float)reversed * inv_base_n);
+    return fminr(kOneMinusEpsilon, inv_base_n * ((float)reversed + inv_base * (float)perm[0] / (1.0f - inv_base)));
+}
+PB_DEV float halton_dimension(const SamplerParams& sp, long long index, int dim) {  // halton.rs:144-155
+    // the tables hold PRIME_TABLE_SIZE = 1000 dimensions (halton.rs:100-108 only logs past that): later draws reuse the last
+    dim = dim > 999 ? 999 : dim;
+    if (dim == 0) {
+        unsigned long long a = (unsigned long long)index >> sp.h_exp[0];
+        unsigned long long r = ((unsigned long long)__brev((uint32_t)a) << 32) | (unsigned long long)__brev((uint32_t)(a >> 32));
+        return fminr(kOneMinusEpsilon, (float)r * 5.4210108624275222e-20f);
+    }
+    if (dim == 1) return halton_radical_inverse(3u, nullptr, (unsigned long long)index / (unsigned long long)sp.h_scale[1]);
+    return halton_radical_inverse(sp.primes[dim], sp.perms + sp.primes[1000 + dim], (unsigned long long)index);
+}
+PB_DEV long long halton_pixel_offset(const SamplerParams& sp, int px, int py) {  // halton.rs:118-142 (D56 intended)
+    long long offset = 0;
+    if (sp.h_stride > 1) {
+        int pm[2] = {((px % 128) + 128) % 128, ((py % 128) + 128) % 128};
+        for (int i = 0; i < 2; ++i) {
+            unsigned int base = i == 0 ? 2u : 3u, inverse = (unsigned int)pm[i], index = 0;
+            for (int d = 0; d < sp.h_exp[i]; ++d) {
+                unsigned int digit = inverse % base;
+                inverse /= base;
+                index = index * base + digit;
+            }
+            offset += (long long)((unsigned long long)index * (unsigned long long)(sp.h_stride / sp.h_scale[i]) * sp.h_minv[i]);
+        }
+        offset %= sp.h_stride;
+    }
+    return offset;
+}
 PB_DEV float samp_1d(const PassParams& pp, Samp& sm) {
+    if (pp.smp.kind == PBRT_SAMPLER_HALTON) {  // GlobalSampler::get_1d (sampler.rs:367-374)
+        if (sm.dim1 >= 5 && sm.dim1 < pp.smp.array_end_dim) sm.dim1 = pp.smp.array_end_dim;
+        float v = halton_dimension(pp.smp, sm.h_offset + (long long)sm.s * pp.smp.h_stride, sm.dim1);
+        sm.dim1 = sm.dim1 + 1 > 1000 ? 1000 : sm.dim1 + 1;
+        return v;
+    }
     if (pp.smp.kind != PBRT_SAMPLER_RANDOM && sm.dim1 < pp.smp.n_dims) {
         int e = sm.dim1 * pp.spp + sm.s;
         sm.dim1 += 1;
@@ -177,6 +243,14 @@ PB_DEV float samp_1d(const PassParams& pp, Samp& sm) {
     return rng_float(sm.rng);
 }
 PB_DEV void samp_2d(const PassParams& pp, Samp& sm, float* u0, float* u1) {
+    if (pp.smp.kind == PBRT_SAMPLER_HALTON) {  // GlobalSampler::get_2d (sampler.rs:376-386)
+        if (sm.dim1 + 1 >= 5 && sm.dim1 < pp.smp.array_end_dim) sm.dim1 = pp.smp.array_end_dim;
+        long long index = sm.h_offset + (long long)sm.s * pp.smp.h_stride;
+        *u0 = halton_dimension(pp.smp, index, sm.dim1);
+        *u1 = halton_dimension(pp.smp, index, sm.dim1 + 1);
+        sm.dim1 = sm.dim1 + 2 > 1000 ? 1000 : sm.dim1 + 2;
+        return;
+    }
     if (pp.smp.kind != PBRT_SAMPLER_RANDOM && sm.dim2 < pp.smp.n_dims) {
         int e = pp.smp.off2 + (sm.dim2 * pp.spp + sm.s) * 2;
         sm.dim2 += 1;
@@ -190,13 +264,19 @@ PB_DEV void samp_2d(const PassParams& pp, Samp& sm, float* u0, float* u1) {
 // element k of requested array a for this pixel sample (Sampler::get_2d_array, sampler.rs:64-75)
 PB_DEV void samp_array_2d(const PassParams& pp, const Samp& sm, int a, int k, float* u0, float* u1) {
     int2 ar = pp.smp.arrays[a];
+    if (pp.smp.kind == PBRT_SAMPLER_HALTON) {  // GlobalSampler::start_pixel (sampler.rs:354-364), evaluated on demand
+        long long index = sm.h_offset + ((long long)sm.s * ar.x + k) * pp.smp.h_stride;
+        *u0 = halton_dimension(pp.smp, index, 5 + 2 * a);
+        *u1 = halton_dimension(pp.smp, index, 6 + 2 * a);
+        return;
+    }
     int e = ar.y + (sm.s * ar.x + k) * 2;
     *u0 = pp.smp.tables[(size_t)e * pp.n_pix + sm.pix];
     *u1 = pp.smp.tables[(size_t)(e + 1) * pp.n_pix + sm.pix];
 }
 PB_DEV void samp_store(const PathState& ps, uint32_t p, const Samp& sm) {
     ps.rng[p] = sm.rng.state;
-    ps.samp[p] = sm.dim1 | (sm.dim2 << 8) | (sm.arr << 16);
+    ps.samp[p] = sm.dim1 | (sm.dim2 << 10) | (sm.arr << 16);
 }
 
 // ---- PixelSampler::start_pixel for one pixel per thread: StratifiedSampler (stratified.rs:44-104) and
@@ -325,6 +405,7 @@ __global__ void k_generate(PathState ps, Queues q, PassParams pp, DevCamera cam,
         sm.pix = pix;
         sm.s = s;
         sm.dim1 = sm.dim2 = sm.arr = 0;
+        sm.h_offset = pp.smp.kind == PBRT_SAMPLER_HALTON ? halton_pixel_offset(pp.smp, x, y) : 0;
         // Sampler::get_camera_sample (sampler.rs:27-33): 2D film, 1D time, 2D lens
         float u0, u1, l0, l1;
         samp_2d(pp, sm, &u0, &u1);
@@ -632,9 +713,10 @@ PB_DEV Samp path_sampler(const PathState& ps, const PassParams& pp, const TileLi
     sm.pix = pix;
     sm.s = pp.sample0 + s_local;
     int c = ps.samp[p];
-    sm.dim1 = c & 0xff;
-    sm.dim2 = (c >> 8) & 0xff;
+    sm.dim1 = c & 0x3ff;
+    sm.dim2 = (c >> 10) & 0x3f;
     sm.arr = (c >> 16) & 0xffff;
+    sm.h_offset = pp.smp.kind == PBRT_SAMPLER_HALTON ? halton_pixel_offset(pp.smp, x, y) : 0;
     return sm;
 }
 

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libpbrt_hip.so")
 
 SPLIT_SAH, SPLIT_HLBVH, SPLIT_MIDDLE, SPLIT_EQUAL_COUNTS = 0, 1, 2, 3
 INTEGRATOR_PATH, INTEGRATOR_DIRECT, INTEGRATOR_WHITTED, INTEGRATOR_AO = 0, 1, 2, 3
-SAMPLER_RANDOM, SAMPLER_STRATIFIED, SAMPLER_ZEROTWO = 0, 1, 2
+SAMPLER_RANDOM, SAMPLER_STRATIFIED, SAMPLER_ZEROTWO, SAMPLER_HALTON = 0, 1, 2, 3
 
 EXPORTS = [
     "pbrt_hip_context_create", "pbrt_hip_context_destroy", "pbrt_hip_last_error", "pbrt_hip_bvh_build",
@@ -351,6 +351,8 @@ class Scene:
             smp = (SAMPLER_STRATIFIED, sampler[1], sampler[2], int(bool(sampler[3])), sampler[4])
         elif sampler[0] == "zerotwo":          # ("zerotwo", n_dims): ZeroTwoSequenceSampler::new
             smp = (SAMPLER_ZEROTWO, 1, 1, 1, sampler[1])
+        elif sampler[0] == "halton":           # ("halton",): HaltonSampler::new over the film's sample bounds
+            smp = (SAMPLER_HALTON, 1, 1, 1, 0)
         else:
             raise ValueError(sampler)
         return RenderParams(integrator, max_depth, rr_threshold, light_strategy, spp, width, height, x0, y0, x1, y1,

@@ -267,7 +267,7 @@ def test_delta_lights_specular_and_instances(hip_ctx):
     assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
 
 
-SAMPLERS = [("stratified", 3, 2, True, 4), ("stratified", 4, 4, False, 2), ("zerotwo", 4), ("zerotwo", 0)]
+SAMPLERS = [("stratified", 3, 2, True, 4), ("stratified", 4, 4, False, 2), ("zerotwo", 4), ("zerotwo", 0), ("halton",)]
 
 
 @pytest.mark.parametrize("sampler", SAMPLERS)
@@ -280,12 +280,12 @@ def test_samplers_path_and_whitted(hip_ctx, sampler, integrator, kw):
     film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, scenes.random_triangles_camera(w, h), w, h, 6,
                                               integrator=integrator, seed=53, sampler=sampler, **kw)
     _compare(film_g, film_c)
-    spp = sampler[1] * sampler[2] if sampler[0] == "stratified" else 8
+    spp = sampler[1] * sampler[2] if sampler[0] == "stratified" else (8 if sampler[0] == "zerotwo" else 6)
     assert st_g["camera_samples"] == st_c["camera_samples"] == w * h * spp
     assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
 
 
-@pytest.mark.parametrize("sampler", [("stratified", 2, 3, True, 4), ("zerotwo", 3)])
+@pytest.mark.parametrize("sampler", [("stratified", 2, 3, True, 4), ("zerotwo", 3), ("halton",)])
 @pytest.mark.parametrize("max_depth", [1, 3, 5])
 def test_samplers_direct_lighting_arrays(hip_ctx, sampler, max_depth):
     """uniform_sample_all_lights with requested sample arrays (latin hypercube / (0,2) arrays): max_depth sets are
@@ -303,7 +303,7 @@ def test_samplers_direct_lighting_arrays(hip_ctx, sampler, max_depth):
     _compare(film_g, film_c)
 
 
-@pytest.mark.parametrize("sampler", [("stratified", 2, 2, True, 4), ("zerotwo", 4)])
+@pytest.mark.parametrize("sampler", [("stratified", 2, 2, True, 4), ("zerotwo", 4), ("halton",)])
 def test_samplers_ambient_occlusion_array(hip_ctx, sampler):
     w = h = 48
     film_g, st_g, film_c, st_c = _render_both(hip_ctx, scenes.cornell_box(), scenes.cornell_camera(w, h), w, h, 4,
@@ -327,3 +327,21 @@ def test_samplers_pass_split_and_tiles(hip_ctx):
     parts = [g.render(cam, w, h, 9, max_depth=4, seed=5, sampler=smp, tile_rank=r, tile_world=3)[0] for r in range(3)]
     assert np.allclose(sum(parts), a, rtol=1e-6, atol=1e-6)
     g.close()
+
+
+def test_halton_wide_filter_and_deep_paths(hip_ctx):
+    """HaltonSampler over sample bounds that reach outside the film (D56: non-negative pixel remainder), and a
+    path deep enough to run past the 1000 tabulated dimensions (the last dimension is reused)."""
+    w, h = 40, 24
+    sc = scenes.mixed_materials_scene()
+    gauss = pbrt_hip.filter_table("gaussian", 2.0, 2.0, 2.0, 0.0)
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, scenes.random_triangles_camera(w, h), w, h, 4, max_depth=5,
+                                              seed=3, sampler=("halton",), filter=gauss)
+    rgb_g, rgb_c = pbrt_hip.film_to_rgb(film_g), oracle.film_to_rgb(film_c)
+    assert np.allclose(film_g, film_c, rtol=2e-5, atol=2e-5)
+    assert float(np.sqrt(np.mean((rgb_g.astype(np.float64) - rgb_c) ** 2))) <= 1e-5
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, scenes.cornell_box(), scenes.cornell_camera(32, 32), 32, 32, 2,
+                                              max_depth=150, rr_threshold=0.0, seed=3, sampler=("halton",))
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]

@@ -330,3 +330,39 @@ def test_degenerate_uv_quirk_d13_changes_shading_frame_only():
     ha, _ = a.intersect(rays, n_threads=2)
     hb, _ = b.intersect(rays, n_threads=2)
     assert ha.tobytes() == hb.tobytes()
+
+
+def test_halton_radical_inverse_and_pixel_mapping():
+    """Halton points: known radical inverses (D53: the reference's version returns 0), the sample indices of a
+    pixel land in that pixel (halton.rs:118-142: x = floor(phi_2(i) * 2^j), y = floor(phi_3(i) * 3^k) modulo the
+    base scales), digit permutations are permutations with the default-seeded RNG."""
+    import ctypes
+    L = oracle.lib()
+    L.orc_halton_probe.argtypes = [ctypes.c_int] * 6 + [ctypes.c_void_p]
+    L.orc_halton_permutation.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    L.orc_halton_permutation.restype = ctypes.c_int
+    out = np.zeros(6)
+
+    def probe(res, px, py, s, dim):
+        L.orc_halton_probe(res[0], res[1], px, py, s, dim, out.ctypes.data)
+        return out.copy()
+
+    # res 1x1: stride 1, index = sample number; phi_2(1..4) = 1/2, 1/4, 3/4, 1/8; phi_3(1..4) = 1/3, 2/3, 1/9, 4/9
+    for s, (r2, r3) in enumerate([(0.5, 1 / 3), (0.25, 2 / 3), (0.75, 1 / 9), (0.125, 4 / 9)], start=1):
+        o = probe((1, 1), 0, 0, s, 0)
+        assert o[0] == s and abs(o[2] - r2) < 1e-7 and abs(o[3] - r3) < 1e-6
+    for res in ((64, 48), (300, 200), (17, 5)):
+        sx, sy = int(probe(res, 0, 0, 0, 0)[4]), int(probe(res, 0, 0, 0, 0)[5])
+        assert sx >= min(res[0], 128) and sy >= min(res[1], 128) and sx & (sx - 1) == 0
+        for px, py in ((0, 0), (3, 2), (res[0] - 1, res[1] - 1), (-2, -1), (130, 131)):
+            for s in (0, 1, 7):
+                o = probe(res, px, py, s, 0)
+                assert int(np.floor(o[2] * sx)) == px % min(sx, 128) % sx
+                assert int(np.floor(o[3] * sy + 1e-6)) == py % 128 % sy
+                # dimension 0 / 1 of the sampler = the position inside the pixel
+                assert 0.0 <= o[1] < 1.0
+    perm = np.zeros(8161, dtype=np.int32)
+    for base_index in (0, 1, 2, 10, 999):
+        n = L.orc_halton_permutation(base_index, perm.ctypes.data, len(perm))
+        assert sorted(perm[:n].tolist()) == list(range(n))
+    assert L.orc_halton_permutation(999, perm.ctypes.data, len(perm)) == 7919
