@@ -131,8 +131,11 @@ struct DeviceTree {
 // uv set (triangle.rs:66-70): degenerate uv frame or dpdu x dpdv == 0, and a zero geometric
 // normal. Ray independent, so it is a per-triangle flag. Same float operation order as the kernel
 // side (this file is compiled with -ffp-contract=off).
-__host__ __device__ inline bool triangle_rejected_by_intersect(const float* a, const float* b, const float* c) {
-    const float uv[3][2] = {{0.0f, 0.0f}, {1.0f, 0.0f}, {1.0f, 1.0f}};
+__host__ __device__ inline bool triangle_rejected_by_intersect(const float* a, const float* b, const float* c,
+                                                              const float* uv6 = nullptr) {
+    float uv[3][2] = {{0.0f, 0.0f}, {1.0f, 0.0f}, {1.0f, 1.0f}};
+    if (uv6)  // per-vertex uvs of the mesh (triangle.rs:60-65)
+        for (int k = 0; k < 6; ++k) uv[k / 2][k % 2] = uv6[k];
     float duv02[2] = {uv[0][0] - uv[2][0], uv[0][1] - uv[2][1]};
     float duv12[2] = {uv[1][0] - uv[2][0], uv[1][1] - uv[2][1]};
     float dp02[3], dp12[3];

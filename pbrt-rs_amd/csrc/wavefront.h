@@ -504,6 +504,7 @@ __global__ void __launch_bounds__(kTraceBlock, COUNT ? 4 : (INST ? PB_INST_WAVES
 // ---- shading helpers ----
 struct Surf {  // the parts of SurfaceInteraction the path needs
     V3 p, p_error, n, dpdu, wo;
+    V3 ns, sdpdu;         // shading.n, shading.dpdu (= n, dpdu without per-vertex normals)
     int material, light;  // light = index or -1
 };
 
@@ -517,29 +518,77 @@ PB_DEV void tri_vertices(const DevBVH& bvh, int slot, V3* p0, V3* p1, V3* p2, in
     *light = (__float_as_int(c.w) & 0x3fffffff) - 1;
 }
 
-// Triangle::intersect past the hit test (triangle.rs:193-250), default uvs (:66-70), no per-vertex n/s
+// Triangle::intersect past the hit test (triangle.rs:193-316): dpdu from the (default or per-vertex) uvs, the
+// geometric normal, and with per-vertex normals the shading frame of :252-312 with
+// set_shading_geometry(.., orientation_is_authoritative = true) (interaction.rs:302-316), which also flips
+// the geometric normal to the shading normal's side. Outputs: n, shading.n, dpdu, shading.dpdu.
+PB_DEV void tri_shading_geometry(const DevBVH& bvh, int slot, V3 p0, V3 p1, V3 p2, float b0, float b1, float b2, V3* n_out,
+                                 V3* ns_out, V3* dpdu_out, V3* sdpdu_out) {
+    float uv0x = 0.0f, uv0y = 0.0f, uv1x = 1.0f, uv1y = 0.0f, uv2x = 1.0f, uv2y = 1.0f;  // triangle.rs:66-70
+    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0;
+    if (bvh.tri_shading) {
+        const float4* sh = bvh.tri_shading + 4 * (size_t)slot;
+        s0 = sh[0];
+        s1 = sh[1];
+        s2 = sh[2];
+        s3 = sh[3];
+        if (bvh.has_uvs) {
+            uv0x = s2.y;
+            uv0y = s2.z;
+            uv1x = s2.w;
+            uv1y = s3.x;
+            uv2x = s3.y;
+            uv2y = s3.z;
+        }
+    }
+    float duv02x = uv0x - uv2x, duv02y = uv0y - uv2y, duv12x = uv1x - uv2x, duv12y = uv1y - uv2y;
+    V3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float determinant = duv02x * duv12y - duv02y * duv12x;
+    bool degenerate_uv = __builtin_fabsf(determinant) < 1e-8f;
+    V3 dpdu = V3{0.0f, 0.0f, 0.0f}, dpdv = V3{0.0f, 0.0f, 0.0f};
+    if (!degenerate_uv) {
+        float inv_det = 1.0f / determinant;
+        dpdu = (dp02 * duv12y - dp12 * duv02y) * inv_det;
+        dpdv = (dp02 * -duv12x + dp12 * duv02x) * inv_det;
+    }
+    if (degenerate_uv || len2(cross(dpdu, dpdv)) == 0.0f) {
+        V3 ng = cross(p2 - p0, p1 - p0);  // zero only for triangles flagged kTriDegenerate, which never get here
+        coordinate_system(normalize(ng), &dpdu, &dpdv);
+    }
+    V3 n = normalize(cross(dp02, dp12));  // triangle.rs:244-245 (no orientation flip: D14)
+    V3 ns = n, sdpdu = dpdu;
+    if (bvh.tri_shading && bvh.has_normals) {
+        V3 n0 = V3{s0.x, s0.y, s0.z}, n1 = V3{s0.w, s1.x, s1.y}, n2 = V3{s1.z, s1.w, s2.x};
+        V3 nsi = n0 * b0 + n1 * b1 + n2 * b2;
+        nsi = len2(nsi) > 0.0f ? normalize(nsi) : n;
+        V3 ss = normalize(dpdu);
+        V3 ts = cross(ss, nsi);
+        if (len2(ts) > 0.0f) {
+            ts = normalize(ts);
+            ss = cross(ts, nsi);
+        } else {
+            coordinate_system(nsi, &ss, &ts);
+        }
+        ns = normalize(cross(ss, ts));          // set_shading_geometry: shading.n = normalize(dpdu x dpdv)
+        if (dot(n, ns) < 0.0f) n = -n;          // n = n.face_forward(shading.n)
+        sdpdu = ss;
+    }
+    *n_out = n;
+    *ns_out = ns;
+    *dpdu_out = dpdu;
+    *sdpdu_out = sdpdu;
+}
 PB_DEV Surf make_surface(const DevBVH& bvh, int slot, float b0, float b1, float b2, V3 ray_d) {
     V3 p0, p1, p2;
     int prim;
     Surf s;
     tri_vertices(bvh, slot, &p0, &p1, &p2, &prim, &s.material, &s.light);
-    const float duv02x = 0.0f - 1.0f, duv02y = 0.0f - 1.0f, duv12x = 1.0f - 1.0f, duv12y = 0.0f - 1.0f;
-    V3 dp02 = p0 - p2, dp12 = p1 - p2;
-    float determinant = duv02x * duv12y - duv02y * duv12x;
-    float inv_det = 1.0f / determinant;
-    V3 dpdu = (dp02 * duv12y - dp12 * duv02y) * inv_det;
-    V3 dpdv = (dp02 * -duv12x + dp12 * duv02x) * inv_det;
-    if (len2(cross(dpdu, dpdv)) == 0.0f) {
-        V3 ng = cross(p2 - p0, p1 - p0);
-        coordinate_system(normalize(ng), &dpdu, &dpdv);
-    }
+    tri_shading_geometry(bvh, slot, p0, p1, p2, b0, b1, b2, &s.n, &s.ns, &s.dpdu, &s.sdpdu);
     float xs = __builtin_fabsf(b0 * p0.x) + __builtin_fabsf(b1 * p1.x) + __builtin_fabsf(b2 * p2.x);
     float ys = __builtin_fabsf(b0 * p0.y) + __builtin_fabsf(b1 * p1.y) + __builtin_fabsf(b2 * p2.y);
     float zs = __builtin_fabsf(b0 * p0.z) + __builtin_fabsf(b1 * p1.z) + __builtin_fabsf(b2 * p2.z);
     s.p_error = V3{xs, ys, zs} * kGamma7;
     s.p = p0 * b0 + p1 * b1 + p2 * b2;
-    s.n = normalize(cross(dp02, dp12));  // triangle.rs:244-245 (no orientation flip: D14)
-    s.dpdu = dpdu;
     s.wo = -ray_d;
     return s;
 }
@@ -568,6 +617,14 @@ PB_DEV void instance_to_world(const DevBVH& bvh, int inst_slot, Surf* s) {
     V3 n = s->n;
     s->n = normalize(V3{o0.x * n.x + o1.x * n.y + o2.x * n.z, o0.y * n.x + o1.y * n.y + o2.y * n.z,
                         o0.z * n.x + o1.z * n.y + o2.z * n.z});
+    {   // shading.n, shading.dpdu, then shading.n = face_forward(shading.n, n) (pbrt-v3 Transform(SurfaceInteraction))
+        V3 sn = s->ns, sd = s->sdpdu;
+        sn = normalize(V3{o0.x * sn.x + o1.x * sn.y + o2.x * sn.z, o0.y * sn.x + o1.y * sn.y + o2.y * sn.z,
+                          o0.z * sn.x + o1.z * sn.y + o2.z * sn.z});
+        s->ns = dot(sn, s->n) < 0.0f ? -sn : sn;
+        s->sdpdu = V3{w0.x * sd.x + w0.y * sd.y + w0.z * sd.z, w1.x * sd.x + w1.y * sd.y + w1.z * sd.z,
+                      w2.x * sd.x + w2.y * sd.y + w2.z * sd.z};
+    }
     V3 wo = s->wo, du = s->dpdu;
     s->wo = normalize(V3{w0.x * wo.x + w0.y * wo.y + w0.z * wo.z, w1.x * wo.x + w1.y * wo.y + w1.z * wo.z,
                          w2.x * wo.x + w2.y * wo.y + w2.z * wo.z});
@@ -591,11 +648,15 @@ PB_DEV Surf surface_from_hit(const DevBVH& bvh, int slot, int inst_slot, float b
     }
     return make_surface(bvh, slot, b0, b1, b2, rd);
 }
-PB_DEV V3 tri_geometric_normal(const DevBVH& bvh, int slot) {
+// SurfaceInteraction::n of a hit at barycentrics (b0, b1, b2): the geometric normal, on the shading normal's side
+PB_DEV V3 tri_interaction_normal(const DevBVH& bvh, int slot, float b0, float b1, float b2) {
     V3 p0, p1, p2;
     int a, b, c;
     tri_vertices(bvh, slot, &p0, &p1, &p2, &a, &b, &c);
-    return normalize(cross(p0 - p2, p1 - p2));
+    if (!(bvh.tri_shading && bvh.has_normals)) return normalize(cross(p0 - p2, p1 - p2));
+    V3 n, ns, dpdu, sdpdu;
+    tri_shading_geometry(bvh, slot, p0, p1, p2, b0, b1, b2, &n, &ns, &dpdu, &sdpdu);
+    return n;
 }
 
 struct Frame {  // BSDF::new (reflection.rs:220-234)
@@ -683,7 +744,7 @@ PB_DEV bool light_triangle_intersect(const DevBVH& bvh, int slot, V3 o, V3 d, V3
     if (!triangle_test(p0, p1, p2, r, c, kInf, &b0, &b1, &b2, &t)) return false;
     if (flags & kTriDegenerate) return false;
     *p_hit = p0 * b0 + p1 * b1 + p2 * b2;
-    *n_hit = normalize(cross(p0 - p2, p1 - p2));
+    *n_hit = tri_interaction_normal(bvh, slot, b0, b1, b2);
     return true;
 }
 
@@ -722,9 +783,9 @@ PB_DEV Samp path_sampler(const PathState& ps, const PassParams& pp, const TileLi
 
 PB_DEV Frame make_frame(const Surf& sf) {  // BSDF::new (reflection.rs:220-234)
     Frame fr;
-    fr.ns = sf.n;
+    fr.ns = sf.ns;
     fr.ng = sf.n;
-    fr.ss = normalize(sf.dpdu);
+    fr.ss = normalize(sf.sdpdu);
     fr.ts = cross(fr.ns, fr.ss);
     return fr;
 }
@@ -757,6 +818,12 @@ PB_DEV void light_sample_li(const ShadeConsts& sc, const Surf& sf, const DevLigh
         float bz = 1.0f - bx - by;
         p1 = q0 * bx + q1 * by + q2 * bz;
         p1_n = normalize(cross(q1 - q0, q2 - q0));
+        if (sc.bvh.tri_shading && sc.bvh.has_normals) {  // Triangle::sample with mesh.n (triangle.rs:337-341)
+            const float4* sh = sc.bvh.tri_shading + 4 * (size_t)lt.slot;
+            float4 s0 = sh[0], s1 = sh[1], s2 = sh[2];
+            V3 nsi = V3{s0.x, s0.y, s0.z} * bx + V3{s0.w, s1.x, s1.y} * by + V3{s1.z, s1.w, s2.x} * bz;
+            if (dot(p1_n, nsi) < 0.0f) p1_n = -p1_n;
+        }
         p1_err = (vabs(q0 * bx) + vabs(q1 * by) + vabs(q2 * bz)) * kGamma6;
         float pdf = 1.0f / lt.area;
         V3 w = p1 - sf.p;
@@ -945,7 +1012,8 @@ PB_DEV V3 estimate_direct_resolve(const ShadeConsts& sc, const PathState& ps, ui
             // D26 (intended): Le only when the hit primitive's area light is this light
             int hl = (__float_as_int(sc.bvh.tris[3 * (size_t)hslot + 2].w) & 0x3fffffff) - 1;
             if (hl == light_id) {
-                V3 n = tri_geometric_normal(sc.bvh, hslot);
+                float4 hb = ps.hit[rbase + RS_MIS * 2];
+                V3 n = tri_interaction_normal(sc.bvh, hslot, hb.y, hb.z, hb.w);
                 if (lt.two_sided || dot(n, -wi) > 0.0f) li = V3{lt.L[0], lt.L[1], lt.L[2]};
             }
         } else if (lt.type == PBRT_LIGHT_INFINITE) {

@@ -29,7 +29,7 @@ EXPORTS = [
     "pbrt_hip_scene_create_instanced", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
     "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
-    "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm",
+    "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm",
 ]
 
 
@@ -77,6 +77,7 @@ def lib():
                                                       ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_double)]
         L.pbrt_hip_scene_create_hlbvh.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, i32, ctypes.POINTER(vp),
                                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        L.pbrt_hip_scene_set_shading_data.argtypes = [vp, vp, i32, vp, i32, vp, vp]
         L.pbrt_hip_free.argtypes = [vp]
         L.pbrt_hip_free.restype = None
         L.pbrt_hip_scene_create.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp,
@@ -280,6 +281,18 @@ class Scene:
         ctx.check(rc, "pbrt_hip_scene_create")
         self.h = h
         ctx._scenes.add(self)
+        self._set_shading_data(scene)
+
+    def _set_shading_data(self, scene):
+        """TriangleMesh n / uv (triangle.rs:17-26): scene["normals"] (n_verts, 3), scene["uvs"] (n_verts, 2), optional."""
+        normals, uvs = scene.get("normals"), scene.get("uvs")
+        if normals is None and uvs is None:
+            return
+        normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32)
+        uvs = None if uvs is None else np.ascontiguousarray(uvs, dtype=np.float32)
+        rc = lib().pbrt_hip_scene_set_shading_data(self.h, _p(self.positions), self.positions.shape[0], _p(self.indices),
+                                                   self.indices.shape[0], _p(normals), _p(uvs))
+        self.ctx.check(rc, "pbrt_hip_scene_set_shading_data")
 
     def _init_device_build(self, scene, max_prims_in_node):
         self.positions = np.ascontiguousarray(scene["positions"], dtype=np.float32)
@@ -298,6 +311,7 @@ class Scene:
         self.h = h
         self.build_ms, self.layout_ms = b_ms.value, l_ms.value
         self.ctx._scenes.add(self)
+        self._set_shading_data(scene)
 
     def _init_instanced(self, scene, max_prims_in_node, split_method, bvh):
         self.positions = np.ascontiguousarray(scene["positions"], dtype=np.float32)
@@ -317,6 +331,7 @@ class Scene:
         self.ctx.check(rc, "pbrt_hip_scene_create_instanced")
         self.h = h
         self.ctx._scenes.add(self)
+        self._set_shading_data(scene)
 
     def intersect(self, rays):
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)

@@ -185,6 +185,39 @@ def with_lights(scene, extra, keep_existing=True):
     return out
 
 
+def with_vertex_shading(scene, seq=5, normals=True, uvs=True, flip_fraction=0.3):
+    """Copy of `scene` (unshared vertices: random_triangles / mixed_materials) with per-vertex shading normals
+    (the geometric normal bent by up to ~35 degrees, `flip_fraction` of the triangles with all three pointing to
+    the back side) and / or per-vertex uvs (random, a few triangles with a degenerate uv map)."""
+    out = dict(scene)
+    pos, idx = scene["positions"], scene["indices"]
+    tri = pos[idx].astype(np.float64)
+    ng = np.cross(tri[:, 0] - tri[:, 2], tri[:, 1] - tri[:, 2])
+    ng /= np.maximum(np.linalg.norm(ng, axis=1, keepdims=True), 1e-30)
+    u = pcg32_float(seq, idx.shape[0] * 16).reshape(idx.shape[0], 16).astype(np.float64)
+    if normals:
+        n = np.zeros((pos.shape[0], 3), dtype=np.float64)
+        for k in range(3):
+            bent = ng + 0.7 * (u[:, 3 * k:3 * k + 3] - 0.5)
+            n[idx[:, k]] = bent / np.linalg.norm(bent, axis=1, keepdims=True)
+        flip = u[:, 9] < flip_fraction
+        for k in range(3):
+            n[idx[flip, k]] *= -1.0
+        zero = u[:, 15] < 0.01                                   # a few all-zero normals: ns falls back to n
+        for k in range(3):
+            n[idx[zero, k]] = 0.0
+        out["normals"] = n.astype(np.float32)
+    if uvs:
+        uv = np.zeros((pos.shape[0], 2), dtype=np.float64)
+        for k in range(3):
+            uv[idx[:, k]] = u[:, 10 + 0:10 + 2] * (k + 1) + u[:, 12:14] * (k == 1) - u[:, 13:15] * (k == 2)
+        degenerate = u[:, 9] > 0.97
+        for k in range(3):
+            uv[idx[degenerate, k]] = 0.25                            # determinant 0: the coordinate_system fallback
+        out["uvs"] = uv.astype(np.float32)
+    return out
+
+
 def cornell_delta_lights():
     """Point, spot and distant lights placed inside the Cornell box (intensities sized to its 555-unit scale)."""
     return [point_light((278.0, 450.0, 279.0), (4.0e5, 3.5e5, 3.0e5)),

@@ -345,3 +345,56 @@ def test_halton_wide_filter_and_deep_paths(hip_ctx):
                                               max_depth=150, rr_threshold=0.0, seed=3, sampler=("halton",))
     _compare(film_g, film_c)
     assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+
+
+@pytest.mark.parametrize("normals,uvs", [(True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("integrator,kw", [(0, dict(max_depth=5, light_strategy=1)), (1, dict(max_depth=3, light_strategy=0)),
+                                           (2, dict(max_depth=3)), (3, dict(ao_samples=4))])
+def test_vertex_normals_and_uvs(hip_ctx, normals, uvs, integrator, kw):
+    """TriangleMesh n / uv (triangle.rs:60-72, 197-216, 252-312): dpdu from the uvs, the shading frame from the
+    interpolated normals, the geometric normal flipped to the shading side; matte / mirror / glass surfaces."""
+    w, h = 64, 48
+    sc = scenes.with_vertex_shading(scenes.mixed_materials_scene(), seq=7, normals=normals, uvs=uvs)
+    osc = oracle.OracleScene(sc, normals=sc.get("normals"), uvs=sc.get("uvs"))
+    gsc = pbrt_hip.Scene(hip_ctx, sc)
+    cam = scenes.random_triangles_camera(w, h)
+    film_c, st_c = osc.render(scenes.camera_dict_to_floats(cam), w, h, 4, integrator=integrator, seed=67, **kw)
+    film_g, st_g = gsc.render(cam, w, h, 4, integrator=integrator, seed=67, **kw)
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    # the data matters: without it the image differs
+    plain = pbrt_hip.Scene(hip_ctx, scenes.mixed_materials_scene())
+    film_p, _ = plain.render(cam, w, h, 4, integrator=integrator, seed=67, **kw)
+    assert film_p.tobytes() != film_g.tobytes()
+    for s_ in (osc, gsc, plain):
+        s_.close()
+
+
+def test_vertex_normals_flip_area_lights(hip_ctx):
+    """Per-vertex normals on emitters: Triangle::sample (triangle.rs:337-341) and the hit's n both follow the
+    shading side, so a one-sided emitter whose vertex normals point up shines upwards."""
+    w = h = 48
+    sc = scenes.cornell_box()
+    n = np.zeros_like(sc["positions"])
+    tri = sc["positions"][sc["indices"]]
+    ng = np.cross(tri[:, 0] - tri[:, 2], tri[:, 1] - tri[:, 2])
+    ng /= np.linalg.norm(ng, axis=1, keepdims=True)
+    for k in range(3):
+        n[sc["indices"][:, k]] = ng
+    emit = sc["tri_light"] >= 0
+    for k in range(3):
+        n[sc["indices"][emit, k]] *= -1.0                          # emitter normals reversed
+    sc["normals"] = n
+    osc = oracle.OracleScene(sc, normals=n)
+    gsc = pbrt_hip.Scene(hip_ctx, sc, device_build=True)          # device-built tree + shading data
+    cam = scenes.cornell_camera(w, h)
+    for integrator, kw in ((0, dict(max_depth=4, light_strategy=1)), (1, dict(max_depth=2, light_strategy=0))):
+        film_c, st_c = osc.render(scenes.camera_dict_to_floats(cam), w, h, 4, integrator=integrator, seed=71, **kw)
+        film_g, st_g = gsc.render(cam, w, h, 4, integrator=integrator, seed=71, **kw)
+        _compare(film_g, film_c)
+        assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    plain = pbrt_hip.Scene(hip_ctx, scenes.cornell_box())
+    film_p, _ = plain.render(cam, w, h, 4, max_depth=4, light_strategy=1, seed=71)
+    assert pbrt_hip.film_to_rgb(film_g).mean() < 0.5 * pbrt_hip.film_to_rgb(film_p).mean()   # the floor went dark
+    for s_ in (osc, gsc, plain):
+        s_.close()
