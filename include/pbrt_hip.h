@@ -227,11 +227,11 @@ int pbrt_hip_scene_create(PbrtHipContext* ctx, const float* positions, int32_t n
                           const PbrtLinearBVHNode* nodes, int32_t n_nodes, const int32_t* prim_order,
                           PbrtHipScene** out);
 /* Optional per-vertex data of the TriangleMesh (src/shapes/triangle.rs:17-26): shading normals `n`
- * (n_verts x 3, used at triangle.rs:252-312 and :337-341) and/or texture coordinates `uv` (n_verts x 2, used for
- * dpdu / dpdv at :60-72, 197-216). positions / indices are the arrays the scene was created from. Call once,
- * after scene creation; either pointer may be NULL. */
+ * (n_verts x 3, used at triangle.rs:252-312 and :337-341), tangents `s` (n_verts x 3, :265-275) and texture
+ * coordinates `uv` (n_verts x 2, used for dpdu / dpdv at :60-72, 197-216). positions / indices are the arrays
+ * the scene was created from. Call once, after scene creation; any of the three pointers may be NULL. */
 int pbrt_hip_scene_set_shading_data(PbrtHipScene* scene, const float* positions, int32_t n_verts, const int32_t* indices,
-                                    int32_t n_tris, const float* normals, const float* uvs);
+                                    int32_t n_tris, const float* normals, const float* tangents, const float* uvs);
 /* Two-level scene (BASELINE config 5): `n_instances` TransformedPrimitives of ONE object-space
  * triangle aggregate. blas_* = BVHAccel over the triangles (object space); tlas_* = BVHAccel over the
  * instances' world bounds, tlas_order[slot] = instance index. Only infinite lights are accepted. */

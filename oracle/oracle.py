@@ -37,6 +37,8 @@ def lib():
         L.orc_scene_create.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
         L.orc_scene_create_with_spheres.restype = vp
+        L.orc_scene_set_tangents.argtypes = [vp, vp, ctypes.c_int]
+        L.orc_scene_set_tangents.restype = None
         L.orc_scene_create_with_spheres.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp,
                                                     vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                     ctypes.c_uint32]
@@ -120,7 +122,7 @@ NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4")
 class OracleScene:
     """Scene::new over GeometricPrimitive triangles in a BVHAccel (CPU restatement)."""
 
-    def __init__(self, scene, max_prims_in_node=4, split_method=0, quirks=0, normals=None, uvs=None):
+    def __init__(self, scene, max_prims_in_node=4, split_method=0, quirks=0, normals=None, uvs=None, tangents=None):
         L = lib()
         if "instances" in scene:
             self._init_instanced(scene, max_prims_in_node, split_method, quirks)
@@ -142,6 +144,9 @@ class OracleScene:
             _p(k["positions"]), k["positions"].shape[0], _p(k["indices"]), self.n_tris, _p(k["normals"]), _p(k["uvs"]),
             _p(k["tri_material"]), _p(k["materials"]), len(k["materials"]), _p(k["tri_light"]), _p(k["lights"]),
             len(k["lights"]), _p(k["spheres"]), n_spheres, max_prims_in_node, split_method, quirks)
+        if tangents is not None:
+            k["tangents"] = _f32(tangents)
+            L.orc_scene_set_tangents(self.h, _p(k["tangents"]), k["positions"].shape[0])
 
     def _init_instanced(self, scene, max_prims_in_node, split_method, quirks):
         """Config 5: TransformedPrimitive instances of one base mesh (scene["instances"] = (n,2,4,4) float32

@@ -136,6 +136,7 @@ struct TriangleMesh {
     std::vector<int32_t> vertex_indices;
     std::vector<Point3f> p;
     std::vector<Normal3f> n;  // optional (empty = None)
+    std::vector<Vector3f> s;  // optional per-vertex tangents
     std::vector<Point2f> uv;  // optional
     int n_triangles = 0, n_vertices = 0;
 };
@@ -294,14 +295,21 @@ struct Triangle : Shape {
             si->n = -si->n;
             si->shading.n = si->n;
         }
-        if (!mesh->n.empty()) {
+        if (!mesh->n.empty() || !mesh->s.empty()) {  // triangle.rs:252-312
             const std::vector<Normal3f>& n = mesh->n;
-            Normal3f ns = n[v[0]] * b0 + n[v[1]] * b1 + n[v[2]] * b2;
-            if (ns.length_squared() > 0.0f)
-                ns = ns.normalize();
-            else
-                ns = si->n;
+            Normal3f ns = si->n;
+            if (!n.empty()) {
+                ns = n[v[0]] * b0 + n[v[1]] * b1 + n[v[2]] * b2;
+                if (ns.length_squared() > 0.0f)
+                    ns = ns.normalize();
+                else
+                    ns = si->n;
+            }
             Vector3f ss = si->dpdu.normalize();
+            if (!mesh->s.empty()) {
+                Vector3f si_ = mesh->s[v[0]] * b0 + mesh->s[v[1]] * b1 + mesh->s[v[2]] * b2;
+                if (si_.length_squared() > 0.0f) ss = si_.normalize();
+            }
             Vector3f ts = ss.cross(ns);
             if (ts.length_squared() > 0.0f) {
                 ts = ts.normalize();
@@ -310,7 +318,7 @@ struct Triangle : Shape {
                 ns.coordinate_system(&ss, &ts);
             }
             Normal3f dndu, dndv;
-            {
+            if (!n.empty()) {
                 Vector3f dn1 = n[v[0]] - n[v[2]];
                 Vector3f dn2 = n[v[1]] - n[v[2]];
                 if (degenerate_uv) {

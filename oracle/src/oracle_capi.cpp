@@ -343,6 +343,13 @@ void orc_render_filtered(void* h, const float* cam, int integrator, int max_dept
     }
 }
 
+// TriangleMesh.s (triangle.rs:21): per-vertex tangents, n_verts x 3; call before rendering
+void orc_scene_set_tangents(void* h, const float* tangents, int n_verts) {
+    OracleScene* os = (OracleScene*)h;
+    os->mesh->s.resize(n_verts);
+    for (int i = 0; i < n_verts; ++i) os->mesh->s[i] = Vector3f(tangents[3 * i], tangents[3 * i + 1], tangents[3 * i + 2]);
+}
+
 // HaltonSampler probe: out = {index of pixel (px, py)'s sample_num-th sample as double, sample_dimension(index, dim),
 // unscrambled radical inverse of the index in base 2 and in base 3, base_scales x, y}
 void orc_halton_probe(int res_x, int res_y, int px, int py, int sample_num, int dim, double* out6) {

@@ -891,24 +891,28 @@ struct DevBuf {
 
 // ---- optional per-vertex normals / uvs of the TriangleMesh (triangle.rs:17-26, used at :60-72, 252-312, 337-341) ----
 __global__ void k_set_shading(const int* __restrict__ slot_prim, const int* __restrict__ idx, const float* __restrict__ pos,
-                              const float* __restrict__ normals, const float* __restrict__ uvs, int n, float4* __restrict__ out,
-                              float4* __restrict__ tris) {
+                              const float* __restrict__ normals, const float* __restrict__ tangents,
+                              const float* __restrict__ uvs, int n, float4* __restrict__ out, float4* __restrict__ tris) {
     int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n) return;
     int prim = slot_prim[slot];
     int v[3] = {idx[3 * (size_t)prim], idx[3 * (size_t)prim + 1], idx[3 * (size_t)prim + 2]};
-    float nn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, uv[6] = {0.0f, 0.0f, 1.0f, 0.0f, 1.0f, 1.0f};
+    float nn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, uv[6] = {0.0f, 0.0f, 1.0f, 0.0f, 1.0f, 1.0f};
     for (int k = 0; k < 3; ++k) {
         if (normals)
             for (int c = 0; c < 3; ++c) nn[3 * k + c] = normals[3 * (size_t)v[k] + c];
+        if (tangents)
+            for (int c = 0; c < 3; ++c) tt[3 * k + c] = tangents[3 * (size_t)v[k] + c];
         if (uvs)
             for (int c = 0; c < 2; ++c) uv[2 * k + c] = uvs[2 * (size_t)v[k] + c];
     }
-    float4* o = out + 4 * (size_t)slot;
+    float4* o = out + 6 * (size_t)slot;
     o[0] = make_float4(nn[0], nn[1], nn[2], nn[3]);
     o[1] = make_float4(nn[4], nn[5], nn[6], nn[7]);
-    o[2] = make_float4(nn[8], uv[0], uv[1], uv[2]);
-    o[3] = make_float4(uv[3], uv[4], uv[5], 0.0f);
+    o[2] = make_float4(nn[8], tt[0], tt[1], tt[2]);
+    o[3] = make_float4(tt[3], tt[4], tt[5], tt[6]);
+    o[4] = make_float4(tt[7], tt[8], uv[0], uv[1]);
+    o[5] = make_float4(uv[2], uv[3], uv[4], uv[5]);
     // "Triangle::intersect returns false" depends on the uvs (triangle.rs:197-216): refresh the flag
     float a[3], b[3], c[3];
     for (int k = 0; k < 3; ++k) {
@@ -925,7 +929,7 @@ __global__ void k_set_shading(const int* __restrict__ slot_prim, const int* __re
 
 extern "C" int pbrt_hip_scene_set_shading_data(PbrtHipScene* s, const float* positions, int32_t n_verts,
                                                const int32_t* indices, int32_t n_tris, const float* normals,
-                                               const float* uvs) {
+                                               const float* tangents, const float* uvs) {
     if (!s) return PBRT_HIP_ERR_INVALID;
     PbrtHipContext* ctx = s->ctx;
     auto fail = [&](const char* msg) {
@@ -933,7 +937,7 @@ extern "C" int pbrt_hip_scene_set_shading_data(PbrtHipScene* s, const float* pos
         return PBRT_HIP_ERR_INVALID;
     };
     if (!positions || !indices || n_tris != s->n_tris || n_verts <= 0) return fail("mesh does not match the scene");
-    if (!normals && !uvs) return fail("neither normals nor uvs given");
+    if (!normals && !tangents && !uvs) return fail("no normals, tangents or uvs given");
     if (s->d.bvh.tri_shading) return fail("shading data already set");
     for (int64_t i = 0; i < 3 * (int64_t)n_tris; ++i)
         if (indices[i] < 0 || indices[i] >= n_verts) return fail("vertex index out of range");
@@ -943,21 +947,24 @@ extern "C" int pbrt_hip_scene_set_shading_data(PbrtHipScene* s, const float* pos
     int* d_idx = tmp.alloc<int>(3 * (size_t)n_tris, &ok);
     float* d_pos = tmp.alloc<float>(3 * (size_t)n_verts, &ok);
     float* d_n = normals ? tmp.alloc<float>(3 * (size_t)n_verts, &ok) : nullptr;
+    float* d_t = tangents ? tmp.alloc<float>(3 * (size_t)n_verts, &ok) : nullptr;
     float* d_uv = uvs ? tmp.alloc<float>(2 * (size_t)n_verts, &ok) : nullptr;
     void* out = nullptr;
-    if (!ok || !hip_ok(ctx, hipMalloc(&out, (size_t)n_tris * 64), "hipMalloc shading data")) return PBRT_HIP_ERR_OOM;
+    if (!ok || !hip_ok(ctx, hipMalloc(&out, (size_t)n_tris * 96), "hipMalloc shading data")) return PBRT_HIP_ERR_OOM;
     s->allocs.push_back(out);
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemcpyAsync(d_idx, indices, 3 * (size_t)n_tris * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(d_pos, positions, 3 * (size_t)n_verts * sizeof(float), hipMemcpyHostToDevice, st));
     if (d_n) HIP_TRY(ctx, hipMemcpyAsync(d_n, normals, 3 * (size_t)n_verts * sizeof(float), hipMemcpyHostToDevice, st));
+    if (d_t) HIP_TRY(ctx, hipMemcpyAsync(d_t, tangents, 3 * (size_t)n_verts * sizeof(float), hipMemcpyHostToDevice, st));
     if (d_uv) HIP_TRY(ctx, hipMemcpyAsync(d_uv, uvs, 2 * (size_t)n_verts * sizeof(float), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_set_shading, dim3((n_tris + 255) / 256), dim3(256), 0, st, s->d.slot_prim, d_idx, d_pos, d_n, d_uv,
+    hipLaunchKernelGGL(k_set_shading, dim3((n_tris + 255) / 256), dim3(256), 0, st, s->d.slot_prim, d_idx, d_pos, d_n, d_t, d_uv,
                        n_tris, (float4*)out, const_cast<float4*>(s->d.bvh.tris));
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));
     s->d.bvh.tri_shading = (const float4*)out;
     s->d.bvh.has_normals = normals ? 1 : 0;
+    s->d.bvh.has_tangents = tangents ? 1 : 0;
     s->d.bvh.has_uvs = uvs ? 1 : 0;
     return PBRT_HIP_OK;
 }

@@ -38,10 +38,10 @@ struct DevBVH {
     int blas_root_ref;
     int blas_count_bits;
     float blas_root_min[3], blas_root_max[3];
-    // optional per-vertex shading data of TriangleMesh (triangle.rs:17-26: n, uv), 4 x float4 per leaf slot:
-    // (n0.xyz, n1.x) (n1.yz, n2.xy) (n2.z, uv0.xy, uv1.x) (uv1.y, uv2.xy, -); null = neither
+    // optional per-vertex shading data of TriangleMesh (triangle.rs:17-26: n, s, uv), 6 x float4 per leaf slot:
+    // (n0.xyz, n1.x) (n1.yz, n2.xy) (n2.z, s0.xyz) (s1.xyz, s2.x) (s2.yz, uv0.xy) (uv1.xy, uv2.xy); null = none
     const float4* __restrict__ tri_shading;
-    int has_normals, has_uvs;
+    int has_normals, has_tangents, has_uvs;
 };
 
 #ifndef PB_STACK_LDS

@@ -525,20 +525,22 @@ PB_DEV void tri_vertices(const DevBVH& bvh, int slot, V3* p0, V3* p1, V3* p2, in
 PB_DEV void tri_shading_geometry(const DevBVH& bvh, int slot, V3 p0, V3 p1, V3 p2, float b0, float b1, float b2, V3* n_out,
                                  V3* ns_out, V3* dpdu_out, V3* sdpdu_out) {
     float uv0x = 0.0f, uv0y = 0.0f, uv1x = 1.0f, uv1y = 0.0f, uv2x = 1.0f, uv2y = 1.0f;  // triangle.rs:66-70
-    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0;
+    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
     if (bvh.tri_shading) {
-        const float4* sh = bvh.tri_shading + 4 * (size_t)slot;
+        const float4* sh = bvh.tri_shading + 6 * (size_t)slot;
         s0 = sh[0];
         s1 = sh[1];
         s2 = sh[2];
         s3 = sh[3];
+        s4 = sh[4];
         if (bvh.has_uvs) {
-            uv0x = s2.y;
-            uv0y = s2.z;
-            uv1x = s2.w;
-            uv1y = s3.x;
-            uv2x = s3.y;
-            uv2y = s3.z;
+            float4 s5 = sh[5];
+            uv0x = s4.z;
+            uv0y = s4.w;
+            uv1x = s5.x;
+            uv1y = s5.y;
+            uv2x = s5.z;
+            uv2y = s5.w;
         }
     }
     float duv02x = uv0x - uv2x, duv02y = uv0y - uv2y, duv12x = uv1x - uv2x, duv12y = uv1y - uv2y;
@@ -557,11 +559,19 @@ PB_DEV void tri_shading_geometry(const DevBVH& bvh, int slot, V3 p0, V3 p1, V3 p
     }
     V3 n = normalize(cross(dp02, dp12));  // triangle.rs:244-245 (no orientation flip: D14)
     V3 ns = n, sdpdu = dpdu;
-    if (bvh.tri_shading && bvh.has_normals) {
-        V3 n0 = V3{s0.x, s0.y, s0.z}, n1 = V3{s0.w, s1.x, s1.y}, n2 = V3{s1.z, s1.w, s2.x};
-        V3 nsi = n0 * b0 + n1 * b1 + n2 * b2;
-        nsi = len2(nsi) > 0.0f ? normalize(nsi) : n;
+    if (bvh.tri_shading && (bvh.has_normals || bvh.has_tangents)) {
+        V3 nsi = n;
+        if (bvh.has_normals) {
+            V3 n0 = V3{s0.x, s0.y, s0.z}, n1 = V3{s0.w, s1.x, s1.y}, n2 = V3{s1.z, s1.w, s2.x};
+            nsi = n0 * b0 + n1 * b1 + n2 * b2;
+            nsi = len2(nsi) > 0.0f ? normalize(nsi) : n;
+        }
         V3 ss = normalize(dpdu);
+        if (bvh.has_tangents) {  // triangle.rs:265-275
+            V3 t0 = V3{s2.y, s2.z, s2.w}, t1 = V3{s3.x, s3.y, s3.z}, t2 = V3{s3.w, s4.x, s4.y};
+            V3 si = t0 * b0 + t1 * b1 + t2 * b2;
+            if (len2(si) > 0.0f) ss = normalize(si);
+        }
         V3 ts = cross(ss, nsi);
         if (len2(ts) > 0.0f) {
             ts = normalize(ts);
@@ -653,7 +663,7 @@ PB_DEV V3 tri_interaction_normal(const DevBVH& bvh, int slot, float b0, float b1
     V3 p0, p1, p2;
     int a, b, c;
     tri_vertices(bvh, slot, &p0, &p1, &p2, &a, &b, &c);
-    if (!(bvh.tri_shading && bvh.has_normals)) return normalize(cross(p0 - p2, p1 - p2));
+    if (!(bvh.tri_shading && (bvh.has_normals || bvh.has_tangents))) return normalize(cross(p0 - p2, p1 - p2));
     V3 n, ns, dpdu, sdpdu;
     tri_shading_geometry(bvh, slot, p0, p1, p2, b0, b1, b2, &n, &ns, &dpdu, &sdpdu);
     return n;
@@ -819,7 +829,7 @@ PB_DEV void light_sample_li(const ShadeConsts& sc, const Surf& sf, const DevLigh
         p1 = q0 * bx + q1 * by + q2 * bz;
         p1_n = normalize(cross(q1 - q0, q2 - q0));
         if (sc.bvh.tri_shading && sc.bvh.has_normals) {  // Triangle::sample with mesh.n (triangle.rs:337-341)
-            const float4* sh = sc.bvh.tri_shading + 4 * (size_t)lt.slot;
+            const float4* sh = sc.bvh.tri_shading + 6 * (size_t)lt.slot;
             float4 s0 = sh[0], s1 = sh[1], s2 = sh[2];
             V3 nsi = V3{s0.x, s0.y, s0.z} * bx + V3{s0.w, s1.x, s1.y} * by + V3{s1.z, s1.w, s2.x} * bz;
             if (dot(p1_n, nsi) < 0.0f) p1_n = -p1_n;

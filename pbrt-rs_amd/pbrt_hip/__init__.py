@@ -77,7 +77,7 @@ def lib():
                                                       ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_double)]
         L.pbrt_hip_scene_create_hlbvh.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, i32, ctypes.POINTER(vp),
                                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
-        L.pbrt_hip_scene_set_shading_data.argtypes = [vp, vp, i32, vp, i32, vp, vp]
+        L.pbrt_hip_scene_set_shading_data.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
         L.pbrt_hip_free.argtypes = [vp]
         L.pbrt_hip_free.restype = None
         L.pbrt_hip_scene_create.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp,
@@ -284,14 +284,15 @@ class Scene:
         self._set_shading_data(scene)
 
     def _set_shading_data(self, scene):
-        """TriangleMesh n / uv (triangle.rs:17-26): scene["normals"] (n_verts, 3), scene["uvs"] (n_verts, 2), optional."""
-        normals, uvs = scene.get("normals"), scene.get("uvs")
-        if normals is None and uvs is None:
+        """TriangleMesh n / uv (triangle.rs:17-26): scene["normals"] / scene["tangents"] (n_verts, 3), scene["uvs"] (n_verts, 2), optional."""
+        normals, tangents, uvs = scene.get("normals"), scene.get("tangents"), scene.get("uvs")
+        if normals is None and tangents is None and uvs is None:
             return
         normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32)
+        tangents = None if tangents is None else np.ascontiguousarray(tangents, dtype=np.float32)
         uvs = None if uvs is None else np.ascontiguousarray(uvs, dtype=np.float32)
         rc = lib().pbrt_hip_scene_set_shading_data(self.h, _p(self.positions), self.positions.shape[0], _p(self.indices),
-                                                   self.indices.shape[0], _p(normals), _p(uvs))
+                                                   self.indices.shape[0], _p(normals), _p(tangents), _p(uvs))
         self.ctx.check(rc, "pbrt_hip_scene_set_shading_data")
 
     def _init_device_build(self, scene, max_prims_in_node):

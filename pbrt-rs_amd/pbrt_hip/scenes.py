@@ -185,7 +185,7 @@ def with_lights(scene, extra, keep_existing=True):
     return out
 
 
-def with_vertex_shading(scene, seq=5, normals=True, uvs=True, flip_fraction=0.3):
+def with_vertex_shading(scene, seq=5, normals=True, uvs=True, flip_fraction=0.3, tangents=False):
     """Copy of `scene` (unshared vertices: random_triangles / mixed_materials) with per-vertex shading normals
     (the geometric normal bent by up to ~35 degrees, `flip_fraction` of the triangles with all three pointing to
     the back side) and / or per-vertex uvs (random, a few triangles with a degenerate uv map)."""
@@ -207,6 +207,10 @@ def with_vertex_shading(scene, seq=5, normals=True, uvs=True, flip_fraction=0.3)
         for k in range(3):
             n[idx[zero, k]] = 0.0
         out["normals"] = n.astype(np.float32)
+    if tangents:                                                  # random directions; a few zero (fallback to dpdu)
+        t = pcg32_float(seq + 100, pos.shape[0] * 3).reshape(-1, 3).astype(np.float64) - 0.5
+        t[pcg32_float(seq + 200, pos.shape[0]) < 0.03] = 0.0
+        out["tangents"] = t.astype(np.float32)
     if uvs:
         uv = np.zeros((pos.shape[0], 2), dtype=np.float64)
         for k in range(3):

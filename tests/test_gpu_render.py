@@ -347,15 +347,16 @@ def test_halton_wide_filter_and_deep_paths(hip_ctx):
     assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
 
 
-@pytest.mark.parametrize("normals,uvs", [(True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("normals,uvs,tangents", [(True, False, False), (False, True, False), (True, True, False),
+                                                  (False, False, True), (True, True, True)])
 @pytest.mark.parametrize("integrator,kw", [(0, dict(max_depth=5, light_strategy=1)), (1, dict(max_depth=3, light_strategy=0)),
                                            (2, dict(max_depth=3)), (3, dict(ao_samples=4))])
-def test_vertex_normals_and_uvs(hip_ctx, normals, uvs, integrator, kw):
+def test_vertex_normals_and_uvs(hip_ctx, normals, uvs, tangents, integrator, kw):
     """TriangleMesh n / uv (triangle.rs:60-72, 197-216, 252-312): dpdu from the uvs, the shading frame from the
     interpolated normals, the geometric normal flipped to the shading side; matte / mirror / glass surfaces."""
     w, h = 64, 48
-    sc = scenes.with_vertex_shading(scenes.mixed_materials_scene(), seq=7, normals=normals, uvs=uvs)
-    osc = oracle.OracleScene(sc, normals=sc.get("normals"), uvs=sc.get("uvs"))
+    sc = scenes.with_vertex_shading(scenes.mixed_materials_scene(), seq=7, normals=normals, uvs=uvs, tangents=tangents)
+    osc = oracle.OracleScene(sc, normals=sc.get("normals"), uvs=sc.get("uvs"), tangents=sc.get("tangents"))
     gsc = pbrt_hip.Scene(hip_ctx, sc)
     cam = scenes.random_triangles_camera(w, h)
     film_c, st_c = osc.render(scenes.camera_dict_to_floats(cam), w, h, 4, integrator=integrator, seed=67, **kw)
@@ -365,7 +366,8 @@ def test_vertex_normals_and_uvs(hip_ctx, normals, uvs, integrator, kw):
     # the data matters: without it the image differs
     plain = pbrt_hip.Scene(hip_ctx, scenes.mixed_materials_scene())
     film_p, _ = plain.render(cam, w, h, 4, integrator=integrator, seed=67, **kw)
-    assert film_p.tobytes() != film_g.tobytes()
+    if integrator != 3 or uvs or normals:         # AO reads the geometric frame only: tangents alone change nothing
+        assert film_p.tobytes() != film_g.tobytes()
     for s_ in (osc, gsc, plain):
         s_.close()
 
