@@ -163,7 +163,7 @@ typedef struct PbrtRenderParams {
     int32_t sampler_x, sampler_y;
     int32_t sampler_jitter;
     int32_t sampler_dims;
-    int32_t pad3;
+    float max_sample_luminance; /* Film::max_sample_luminance (src/core/film.rs:24, 253-255); 0 = infinity (no clamp) */
 } PbrtRenderParams;
 
 typedef struct PbrtRenderStats {

@@ -215,7 +215,8 @@ class OracleScene:
         return d
 
     def render(self, cam36, width, height, spp, integrator=0, max_depth=5, rr_threshold=1.0, light_strategy=1,
-               seed=0, bounds=None, n_threads=8, filter=None, ao_samples=64, cos_sample=True, sampler=None):
+               seed=0, bounds=None, n_threads=8, filter=None, ao_samples=64, cos_sample=True, sampler=None,
+               max_sample_luminance=0.0):
         """integrator: 0 path, 1 direct lighting, 2 Whitted, 3 ambient occlusion (ao_samples, cos_sample).
         sampler: None (random) or ("stratified", nx, ny, jitter, n_dims) / ("zerotwo", n_dims) / ("halton",); spp then becomes
         nx * ny / the next power of two.
@@ -230,7 +231,7 @@ class OracleScene:
         if integrator == 3:
             max_depth, light_strategy = ao_samples, int(bool(cos_sample))
         lib().orc_render_filtered(self.h, _p(cam36), integrator, max_depth, rr_threshold, light_strategy, spp, seed,
-                                  width, height, x0, y0, x1, y1, n_threads, rx, ry, _p(table), _p(sampler_spec(sampler)),
+                                  width, height, x0, y0, x1, y1, n_threads, rx, ry, _p(table), _p(sampler_spec(sampler, max_sample_luminance)),
                                   _p(film), _p(stats))
         st = dict(rays=int(stats[0]), node_tests=int(stats[1]), prim_tests=int(stats[2]),
                   camera_samples=int(stats[3]), seconds=float(stats[4]) * 1e-9)
@@ -239,17 +240,23 @@ class OracleScene:
         return film, st
 
 
-def sampler_spec(sampler):
-    """("stratified", nx, ny, jitter, n_dims) / ("zerotwo", n_dims) / None -> int32[5] or None."""
+def sampler_spec(sampler, max_sample_luminance=0.0):
+    """("stratified", nx, ny, jitter, n_dims) / ("zerotwo", n_dims) / ("halton",) / None -> int32[6]; the last entry
+    carries the float bits of Film::max_sample_luminance (0 = infinity)."""
     if sampler is None:
-        return None
-    if sampler[0] == "stratified":
-        return np.array([1, sampler[1], sampler[2], int(bool(sampler[3])), sampler[4]], dtype=np.int32)
-    if sampler[0] == "zerotwo":
-        return np.array([2, 1, 1, 1, sampler[1]], dtype=np.int32)
-    if sampler[0] == "halton":
-        return np.array([3, 1, 1, 1, 0], dtype=np.int32)
-    raise ValueError(sampler)
+        spec = [0, 1, 1, 1, 0]
+    elif sampler[0] == "stratified":
+        spec = [1, sampler[1], sampler[2], int(bool(sampler[3])), sampler[4]]
+    elif sampler[0] == "zerotwo":
+        spec = [2, 1, 1, 1, sampler[1]]
+    elif sampler[0] == "halton":
+        spec = [3, 1, 1, 1, 0]
+    else:
+        raise ValueError(sampler)
+    out = np.zeros(6, dtype=np.int32)
+    out[:5] = spec
+    out[5:6] = np.array([max_sample_luminance], dtype=np.float32).view(np.int32)
+    return out
 
 
 FILTERS = dict(box=0, gaussian=1, mitchell=2, lanczos=3, triangle=4)

@@ -286,7 +286,8 @@ void orc_render(void* h, const float* cam, int integrator, int max_depth, float 
                         x1, y1, n_threads, 0.5f, 0.5f, nullptr, nullptr, film_out, stats);
 }
 // filter_table256 = Film::filter_table (film.rs:52-63), nullptr = box
-// sampler5 = {kind (0 random, 1 stratified, 2 (0,2)-sequence), x_samples, y_samples, jitter, n_sampled_dimensions}
+// sampler5 = {kind (0 random, 1 stratified, 2 (0,2)-sequence, 3 Halton), x_samples, y_samples, jitter,
+// n_sampled_dimensions, float bits of Film::max_sample_luminance (0 = infinity)}
 // or nullptr = random; the samples per pixel become x*y (stratified) / the next power of two ((0,2)).
 void orc_render_filtered(void* h, const float* cam, int integrator, int max_depth, float rr_threshold,
                          int light_strategy, int spp, uint64_t seed, int width, int height, int x0, int y0, int x1,
@@ -318,6 +319,9 @@ void orc_render_filtered(void* h, const float* cam, int integrator, int max_dept
         rp.sampler.ny = sampler5[2];
         rp.sampler.jitter = sampler5[3] != 0;
         rp.sampler.n_dims = sampler5[4];
+        float max_lum;  // sixth entry: the bits of Film::max_sample_luminance, 0 = infinity
+        std::memcpy(&max_lum, &sampler5[5], 4);
+        if (max_lum > 0.0f) film.max_sample_luminance = max_lum;
     }
     RenderStats st;
     std::unique_ptr<Integrator> integ;

@@ -1314,6 +1314,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         pp.filter_rx = frx;
         pp.filter_ry = fry;
         pp.filter_table = d_filter;
+        pp.max_sample_luminance = rp.max_sample_luminance > 0.0f ? rp.max_sample_luminance : INFINITY;
         uint32_t n_paths = (uint32_t)n_pix * pp.n_samples;
         int cur = 0;
         if (!tables_ready) {  // Sampler::start_pixel for every pixel of this GPU, once per render

@@ -77,6 +77,7 @@ struct PassParams {
     int light_strategy;
     float filter_rx, filter_ry;       // reconstruction filter radius
     const float* filter_table;        // 16 x 16 table (device), nullptr = 0.5 box (exact in-order path)
+    float max_sample_luminance;       // Film::max_sample_luminance (film.rs:24), +inf = no clamp
 };
 
 struct Queues {
@@ -1551,6 +1552,13 @@ __global__ void __launch_bounds__(256) k_shade_direct(ShadeConsts sc, PathState 
     block_append(sh, qout, p, emit_cont, emit_mis, emit_shadow, emit_cont || emit_mis || emit_shadow);
 }
 
+// FilmTile::add_sample's first statement (film.rs:253-255): scale the sample down to Film::max_sample_luminance
+PB_DEV V3 clamp_sample_luminance(V3 L, float max_lum) {
+    float y = 0.212671f * L.x + 0.715160f * L.y + 0.072169f * L.z;
+    if (y > max_lum) L = L * (max_lum / y);
+    return L;
+}
+
 // ---- film: FilmTile::add_sample (film.rs:252-295) with the 0.5 box filter, samples summed in order ----
 __global__ void k_film_accumulate(PathState ps, PassParams pp, TileList tiles, float4* accum, float* d_film) {
     uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1568,6 +1576,7 @@ __global__ void k_film_accumulate(PathState ps, PassParams pp, TileList tiles, f
         // integrator.rs:455 (D23 intended: is_infinite)
         if (__builtin_isnan(L.x) || __builtin_isnan(L.y) || __builtin_isnan(L.z) || yv < -1e-5f || __builtin_isinf(yv))
             L = V3{0.0f, 0.0f, 0.0f};
+        L = clamp_sample_luminance(L, pp.max_sample_luminance);
         float2 pf = ps.pfilm[p];
         float dx = pf.x - 0.5f, dy = pf.y - 0.5f;
         int px0 = max((int)__builtin_ceilf(dx - 0.5f), 0), py0 = max((int)__builtin_ceilf(dy - 0.5f), 0);
@@ -1607,6 +1616,7 @@ __global__ void k_film_splat(PathState ps, PassParams pp, TileList tiles, float*
     float yv = 0.212671f * L.x + 0.715160f * L.y + 0.072169f * L.z;
     if (__builtin_isnan(L.x) || __builtin_isnan(L.y) || __builtin_isnan(L.z) || yv < -1e-5f || __builtin_isinf(yv))
         L = V3{0.0f, 0.0f, 0.0f};
+    L = clamp_sample_luminance(L, pp.max_sample_luminance);
     float2 pf = ps.pfilm[p];
     float dx = pf.x - 0.5f, dy = pf.y - 0.5f;
     int px0 = max((int)__builtin_ceilf(dx - pp.filter_rx), 0), py0 = max((int)__builtin_ceilf(dy - pp.filter_ry), 0);

@@ -400,3 +400,18 @@ def test_vertex_normals_flip_area_lights(hip_ctx):
     assert pbrt_hip.film_to_rgb(film_g).mean() < 0.5 * pbrt_hip.film_to_rgb(film_p).mean()   # the floor went dark
     for s_ in (osc, gsc, plain):
         s_.close()
+
+
+def test_max_sample_luminance(hip_ctx):
+    """Film::max_sample_luminance (film.rs:24, 253-255): samples brighter than the bound are scaled down to it."""
+    w = h = 64
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, scenes.cornell_box(), scenes.cornell_camera(w, h), w, h, 4,
+                                              max_depth=4, seed=73, max_sample_luminance=2.5)
+    _compare(film_g, film_c)
+    rgb = pbrt_hip.film_to_rgb(film_g)
+    y = 0.212671 * rgb[..., 0] + 0.715160 * rgb[..., 1] + 0.072169 * rgb[..., 2]
+    assert y.max() <= 2.5 * (1 + 1e-5)                     # the emitter (Y ~ 12.5) is clamped
+    gauss = pbrt_hip.filter_table("gaussian", 1.5, 1.5, 2.0, 0.0)
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, scenes.cornell_box(), scenes.cornell_camera(w, h), w, h, 4,
+                                              max_depth=4, seed=73, max_sample_luminance=2.5, filter=gauss)
+    assert np.allclose(film_g, film_c, rtol=2e-5, atol=2e-5)
