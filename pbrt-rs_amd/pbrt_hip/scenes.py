@@ -319,6 +319,28 @@ def instanced_scene(n_base_tris=10_000, n_instances=1000, seq_mesh=2, seq_xf=3, 
                 tri_material=base["tri_material"], tri_light=base["tri_light"])
 
 
+def world_space_instances(scene):
+    """The same geometry without TransformedPrimitives: one world-space TriangleMesh per instance, vertices put
+    through `Transform * Point3f` (transform.rs:351-370, float32, the operation order of the reference) as
+    TriangleMesh::new does for a shape that is not instanced (triangle.rs: object_to_world applied to `p`).
+    n_instances x n_base triangles in one flat scene: 10 M triangles = 1.1 GB of triangles + nodes, which is what
+    288 GB of HBM is for. Materials follow the instance's material override."""
+    inst = scene["instances"]
+    base_p, base_i = scene["positions"], scene["indices"]
+    nv, nt, n = base_p.shape[0], base_i.shape[0], inst.shape[0]
+    pos = np.empty((n, nv, 3), dtype=np.float32)
+    x, y, z = base_p[:, 0], base_p[:, 1], base_p[:, 2]
+    for i in range(n):
+        m = inst[i, 0]
+        for r in range(3):
+            pos[i, :, r] = m[r, 0] * x + m[r, 1] * y + m[r, 2] * z + m[r, 3]     # w' = 1 for an affine matrix
+    idx = (base_i[None, :, :] + (np.arange(n, dtype=np.int32) * nv)[:, None, None]).astype(np.int32)
+    im = scene["instance_material"]
+    mat = np.where(im[:, None] >= 0, im[:, None], scene["tri_material"][None, :]).astype(np.int32)
+    return dict(positions=pos.reshape(-1, 3), indices=idx.reshape(-1, 3), tri_material=mat.reshape(-1),
+                materials=scene["materials"], tri_light=np.full(n * nt, -1, dtype=np.int32), lights=scene["lights"])
+
+
 def instanced_camera(width, height, extent=4.0):
     return perspective_camera((0.0, 0.0, 3.2 * extent), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 40.0, width, height)
 
