@@ -1415,3 +1415,14 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     if (stats) *stats = local;
     return rc;
 }
+
+#ifdef PB_LANE_STATS
+extern "C" int pbrt_hip_debug_lane_stats(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(pb::g_lane_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pb::g_lane_stats), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif

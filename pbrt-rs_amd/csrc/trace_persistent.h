@@ -38,6 +38,14 @@ constexpr int kChunk = PB_CHUNK;                    // rays per wave-level queue
 constexpr int kRefillThresh = PB_REFILL_THRESH;     // refill when at least this many lanes are idle
 constexpr int kInteriorThresh = PB_INTERIOR_THRESH; // keep stepping interior nodes while at least this many lanes do
 
+#ifdef PB_LANE_STATS
+// development instrumentation (tools/lane_stats.py): wave-level iteration counts and active-lane sums
+__device__ unsigned long long g_lane_stats[8];
+#define PB_STAT(i, v) stat[i] += (v)
+#else
+#define PB_STAT(i, v)
+#endif
+
 struct LaneState {
     TravRay r;  // the ray being traversed (object-space inside an instance)
     float idx, idy, idz;
@@ -111,6 +119,9 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
     uint32_t n_node = 0, n_prim = 0, n_inst = 0, n_rays = 0;
+#ifdef PB_LANE_STATS
+    unsigned long long stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     auto finish = [&](bool found) {
         io.store(s.index, s.any, found, s.tmax, s.b0, s.b1, s.b2, s.hit_slot, INST ? w.hit_inst : -1);
@@ -269,6 +280,8 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
                 bool can_refill = !exhausted && (__popcll(__ballot(!s.has_work)) >= kRefillThresh);
                 if (leaf_pending || can_refill) break;
             }
+            PB_STAT(0, 1);      // interior iterations of this wave
+            PB_STAT(1, n_int);  // lanes doing a node step
             if (interior) {
                 const float4* nd = bvh.inodes + 4 * (size_t)s.cur;
                 float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
@@ -299,6 +312,24 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
         }
 
         // ---------------- leaves ----------------
+#ifdef PB_LANE_STATS
+        {
+            unsigned long long lm = __ballot(s.has_work && s.cur < 0);
+            if (lm) {
+                int my_cnt = (s.has_work && s.cur < 0) ? (((~s.cur) & tri_count_mask) + 1) : 0, mx = my_cnt, sum = my_cnt;
+                for (int o = 32; o > 0; o >>= 1) {
+                    mx = max(mx, __shfl_xor(mx, o, 64));
+                    sum += __shfl_xor(sum, o, 64);
+                }
+                PB_STAT(2, 1);                // leaf sections
+                PB_STAT(3, __popcll(lm));     // lanes with a leaf
+                PB_STAT(4, mx);               // triangle-loop trips of the wave
+                PB_STAT(5, sum);              // triangle tests
+            }
+            PB_STAT(6, 1);                    // outer iterations
+            PB_STAT(7, __popcll(__ballot(s.has_work)));
+        }
+#endif
         if (s.has_work && s.cur < 0) {
             if (INST && !w.in_instance) {
                 // top-level leaf: TransformedPrimitives in leaf order (bvh.rs:844-850)
@@ -353,6 +384,10 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
         }
     }
     if (COUNT) count_flush(counters, n_node, n_prim, n_rays, n_inst);
+#ifdef PB_LANE_STATS
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_lane_stats[i], stat[i]);
+#endif
 }
 
 }  // namespace pb

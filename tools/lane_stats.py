@@ -1,0 +1,27 @@
+"""Lane-utilisation breakdown of the traversal kernel (needs a library built with PB_DEFS=-DPB_LANE_STATS):
+    PB_DEFS=-DPB_LANE_STATS PB_OUT=/tmp/libpbrt_stats.so pbrt-rs_amd/build.sh; python tools/lane_stats.py /tmp/libpbrt_stats.so"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pbrt-rs_amd"))
+import numpy as np, pbrt_hip
+pbrt_hip.LIB_PATH = sys.argv[1]
+from pbrt_hip import scenes
+W, H, spp = 1920, 1080, int(os.environ.get("SPP", "8"))
+sc = scenes.random_triangles(int(os.environ.get("TRIS", "1000000")), seq=1)
+cam = scenes.random_triangles_camera(W, H)
+ctx = pbrt_hip.Context(0)
+g = pbrt_hip.Scene(ctx, sc)
+g.render(cam, W, H, spp, max_depth=5, seed=0)
+L = pbrt_hip.lib()
+out = (ctypes.c_uint64 * 8)()
+L.pbrt_hip_debug_lane_stats(out, 1)
+film, st = g.render(cam, W, H, spp, max_depth=5, seed=0)
+L.pbrt_hip_debug_lane_stats(out, 1)
+s = [int(v) for v in out]
+rays = st["rays_closest"] + st["rays_shadow"]
+print(f"rays {rays/1e6:.1f} M, trace {st['trace_ms']:.1f} ms")
+print(f"interior: {s[0]/1e6:.1f} M wave iterations, {s[1]/max(s[0],1):.1f} lanes active of 64 ({s[1]/rays:.1f} node steps per ray)")
+print(f"leaves:   {s[2]/1e6:.1f} M wave sections, {s[3]/max(s[2],1):.1f} lanes with a leaf, {s[4]/max(s[2],1):.2f} loop trips per section, "
+      f"{s[5]/max(s[3],1):.2f} triangles per lane-leaf, {s[5]/rays:.2f} tri tests per ray; lane-trip utilisation {s[5]/max(s[4]*64,1):.2f}")
+print(f"outer:    {s[6]/1e6:.1f} M iterations, {s[7]/max(s[6],1):.1f} lanes with work")
+print(f"wave-instruction slots: interior {s[0]/1e6:.1f} M vs leaf trips {s[4]/1e6:.1f} M")
