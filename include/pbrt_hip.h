@@ -294,6 +294,8 @@ int pbrt_hip_sample_bounds(int32_t width, int32_t height, float radius_x, float 
 /* Image output: Film::write_image ends in a file writer that is todo!() in the reference
  * (src/core/imageio.rs:3-5); this writes the RGB image as a little-endian PFM (top row first in memory). */
 int pbrt_hip_write_pfm(const char* path, const float* rgb, int32_t width, int32_t height);
+/* The same image as an 8-bit sRGB PNG (pbrt-v3's WriteImage for ".png": gamma-corrected, 255 v + 0.5 clamped). */
+int pbrt_hip_write_png(const char* path, const float* rgb, int32_t width, int32_t height);
 
 /* Film::write_image's per-pixel arithmetic (src/core/film.rs:153-178, without the file
  * writer, which is todo!() in the reference): rgb = max(0, xyz_to_rgb(xyz) / filter_weight_sum). Host. */

@@ -804,6 +804,90 @@ extern "C" int pbrt_hip_write_pfm(const char* path, const float* rgb, int32_t wi
     return ok ? PBRT_HIP_OK : PBRT_HIP_ERR_INVALID;
 }
 
+// 8-bit sRGB PNG (what pbrt-v3's WriteImage does for ".png": gamma_correct, 255 * v + 0.5 clamped to [0, 255]);
+// the reference's own writer is todo!() (src/core/imageio.rs:3-5). zlib stream of stored (uncompressed) deflate
+// blocks: no dependency, every PNG reader accepts it.
+namespace {
+struct Crc32 {
+    uint32_t table[256];
+    Crc32() {
+        for (uint32_t n = 0; n < 256; ++n) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+            table[n] = c;
+        }
+    }
+    uint32_t run(uint32_t crc, const unsigned char* p, size_t n) const {
+        for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+        return crc;
+    }
+};
+void png_chunk(FILE* f, const Crc32& crc, const char* type, const std::vector<unsigned char>& data) {
+    unsigned char len[4] = {(unsigned char)(data.size() >> 24), (unsigned char)(data.size() >> 16),
+                            (unsigned char)(data.size() >> 8), (unsigned char)data.size()};
+    std::fwrite(len, 1, 4, f);
+    std::fwrite(type, 1, 4, f);
+    if (!data.empty()) std::fwrite(data.data(), 1, data.size(), f);
+    uint32_t c = crc.run(0xffffffffu, (const unsigned char*)type, 4);
+    if (!data.empty()) c = crc.run(c, data.data(), data.size());
+    c ^= 0xffffffffu;
+    unsigned char out[4] = {(unsigned char)(c >> 24), (unsigned char)(c >> 16), (unsigned char)(c >> 8), (unsigned char)c};
+    std::fwrite(out, 1, 4, f);
+}
+float gamma_correct(float v) {  // pbrt.rs GammaCorrect: sRGB transfer curve
+    if (v <= 0.0031308f) return 12.92f * v;
+    return 1.055f * std::pow(v, 1.0f / 2.4f) - 0.055f;
+}
+}  // namespace
+
+extern "C" int pbrt_hip_write_png(const char* path, const float* rgb, int32_t width, int32_t height) {
+    if (!path || !rgb || width <= 0 || height <= 0) return PBRT_HIP_ERR_INVALID;
+    const size_t row = (size_t)width * 3 + 1;  // filter byte + pixels
+    std::vector<unsigned char> raw(row * height);
+    for (int32_t y = 0; y < height; ++y) {
+        unsigned char* o = &raw[row * y];
+        *o++ = 0;  // filter type None
+        for (int32_t x = 0; x < width * 3; ++x) {
+            float v = 255.0f * gamma_correct(rgb[(size_t)y * width * 3 + x]) + 0.5f;
+            *o++ = (unsigned char)(v < 0.0f || v != v ? 0.0f : (v > 255.0f ? 255.0f : v));
+        }
+    }
+    std::vector<unsigned char> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78);
+    z.push_back(0x01);
+    uint32_t a = 1, b = 0;  // Adler-32
+    for (size_t pos = 0; pos < raw.size();) {
+        size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n == raw.size() ? 1 : 0);  // BFINAL, BTYPE = 00 (stored)
+        z.push_back((unsigned char)(n & 0xff));
+        z.push_back((unsigned char)(n >> 8));
+        z.push_back((unsigned char)(~n & 0xff));
+        z.push_back((unsigned char)((~n >> 8) & 0xff));
+        for (size_t i = 0; i < n; ++i) {
+            a = (a + raw[pos + i]) % 65521u;
+            b = (b + a) % 65521u;
+        }
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+        pos += n;
+    }
+    uint32_t adler = (b << 16) | a;
+    for (int k = 3; k >= 0; --k) z.push_back((unsigned char)(adler >> (8 * k)));
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return PBRT_HIP_ERR_INVALID;
+    static const Crc32 crc;
+    const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    std::fwrite(sig, 1, 8, f);
+    std::vector<unsigned char> ihdr = {(unsigned char)(width >> 24), (unsigned char)(width >> 16), (unsigned char)(width >> 8),
+                                       (unsigned char)width, (unsigned char)(height >> 24), (unsigned char)(height >> 16),
+                                       (unsigned char)(height >> 8), (unsigned char)height, 8, 2, 0, 0, 0};  // 8-bit RGB
+    png_chunk(f, crc, "IHDR", ihdr);
+    png_chunk(f, crc, "IDAT", z);
+    png_chunk(f, crc, "IEND", {});
+    bool ok = std::fclose(f) == 0;
+    return ok ? PBRT_HIP_OK : PBRT_HIP_ERR_INVALID;
+}
+
 extern "C" void pbrt_hip_film_to_rgb(const float* film, int64_t n_pixels, float* rgb) {
     for (int64_t i = 0; i < n_pixels; ++i) {
         const float* p = film + 4 * i;

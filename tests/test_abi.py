@@ -145,3 +145,34 @@ def test_write_pfm_roundtrip(tmp_path):
     assert header == b"PF\n7 5\n"
     back = np.frombuffer(body, dtype="<f4").reshape(5, 7, 3)[::-1]
     assert np.array_equal(back, rgb)
+
+
+def test_write_png_decodes_back(tmp_path):
+    """pbrt_hip_write_png: a valid PNG (signature, chunk CRCs, zlib stream with Adler-32) whose pixels are the
+    sRGB-encoded image; decoded here with zlib and checked against the transfer curve."""
+    import struct
+    import zlib
+    w, h = 301, 223                                           # > 65535 raw bytes: several stored deflate blocks
+    rgb = (scenes.pcg32_float(5, w * h * 3).reshape(h, w, 3) * 1.2 - 0.1).astype(np.float32)   # some < 0 and > 1
+    path = tmp_path / "img.png"
+    pbrt_hip.write_png(path, rgb)
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])
+        assert crc == zlib.crc32(typ + data) & 0xffffffff
+        chunks.append((typ, data))
+        pos += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (w, h, 8, 2, 0, 0, 0)
+    pix = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(h, 1 + 3 * w)
+    assert np.all(pix[:, 0] == 0)
+    v = np.clip(rgb.astype(np.float64), 0.0, None)
+    srgb = np.where(v <= 0.0031308, 12.92 * v, 1.055 * np.power(v, 1 / 2.4) - 0.055)
+    expect = np.clip(np.floor(255.0 * srgb + 0.5), 0, 255)
+    got = pix[:, 1:].reshape(h, w, 3).astype(np.float64)
+    assert np.abs(got - expect).max() <= 1                    # float32 pow vs float64
+    assert (got == expect).mean() > 0.99
