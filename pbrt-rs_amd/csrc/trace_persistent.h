@@ -176,6 +176,10 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
         w.in_instance = false;
     };
     // After a node / leaf is done: find the next node to visit. Returns false when the ray is finished.
+    // Leaving an instance (and entering the next one of the same top-level leaf) is NOT done here: advance() runs
+    // inside the interior loop for single lanes, and the ray transform + root test are ~300 instructions. The lane
+    // is parked on kLeaveInstance instead and the transition happens in the leaf phase, for all such lanes together.
+    constexpr int kLeaveInstance = (int)0x80000000;
     auto advance = [&]() -> bool {
         for (;;) {
             if (INST && w.in_instance) {
@@ -189,15 +193,8 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
                     }
                     continue;
                 }
-                exit_instance();
-                // remaining instances of the top-level leaf (bvh.rs:844-850)
-                while (w.leaf_next < w.leaf_cnt) {
-                    int slot = w.leaf_first + w.leaf_next;
-                    w.leaf_next += 1;
-                    if (enter_instance(slot)) return true;
-                    exit_instance();
-                }
-                continue;
+                s.cur = kLeaveInstance;
+                return true;
             }
             if (s.sp == 0) return false;
             --s.sp;
@@ -331,12 +328,16 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
         }
 #endif
         if (s.has_work && s.cur < 0) {
-            if (INST && !w.in_instance) {
-                // top-level leaf: TransformedPrimitives in leaf order (bvh.rs:844-850)
-                int ref = ~s.cur;
-                w.leaf_cnt = (ref & count_mask) + 1;
-                w.leaf_first = ref >> bvh.count_bits;
-                w.leaf_next = 0;
+            if (INST && (!w.in_instance || s.cur == kLeaveInstance)) {
+                if (w.in_instance) {
+                    exit_instance();  // second half of TransformedPrimitive::intersect; the leaf's other instances follow
+                } else {
+                    // top-level leaf: TransformedPrimitives in leaf order (bvh.rs:844-850)
+                    int ref = ~s.cur;
+                    w.leaf_cnt = (ref & count_mask) + 1;
+                    w.leaf_first = ref >> bvh.count_bits;
+                    w.leaf_next = 0;
+                }
                 bool entered = false;
                 while (w.leaf_next < w.leaf_cnt && !entered) {
                     int slot = w.leaf_first + w.leaf_next;

@@ -7,15 +7,17 @@ import numpy as np, pbrt_hip
 pbrt_hip.LIB_PATH = sys.argv[1]
 from pbrt_hip import scenes
 W, H, spp = 1920, 1080, int(os.environ.get("SPP", "8"))
-sc = scenes.random_triangles(int(os.environ.get("TRIS", "1000000")), seq=1)
-cam = scenes.random_triangles_camera(W, H)
+if os.environ.get("INSTANCED"):
+    sc, cam, depth = scenes.instanced_scene(10_000, 1000), scenes.instanced_camera(W, H), 16
+else:
+    sc, cam, depth = scenes.random_triangles(int(os.environ.get("TRIS", "1000000")), seq=1), scenes.random_triangles_camera(W, H), 5
 ctx = pbrt_hip.Context(0)
 g = pbrt_hip.Scene(ctx, sc)
-g.render(cam, W, H, spp, max_depth=5, seed=0)
+g.render(cam, W, H, spp, max_depth=depth, seed=0)
 L = pbrt_hip.lib()
 out = (ctypes.c_uint64 * 8)()
 L.pbrt_hip_debug_lane_stats(out, 1)
-film, st = g.render(cam, W, H, spp, max_depth=5, seed=0)
+film, st = g.render(cam, W, H, spp, max_depth=depth, seed=0)
 L.pbrt_hip_debug_lane_stats(out, 1)
 s = [int(v) for v in out]
 rays = st["rays_closest"] + st["rays_shadow"]
