@@ -172,7 +172,12 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
         if (w.hit_here) w.tmax_world = s.tmax;
         s.r = TravRay{w.wox, w.woy, w.woz, w.wdx, w.wdy, w.wdz, w.tmax_world};
         s.tmax = w.tmax_world;
-        ray_constants(s);
+        s.idx = 1.0f / s.r.dx;  // no triangles at the top level: the triangle constants are set at the next entry
+        s.idy = 1.0f / s.r.dy;
+        s.idz = 1.0f / s.r.dz;
+        s.nx = s.idx < 0.0f;
+        s.ny = s.idy < 0.0f;
+        s.nz = s.idz < 0.0f;
         w.in_instance = false;
     };
     // After a node / leaf is done: find the next node to visit. Returns false when the ray is finished.
