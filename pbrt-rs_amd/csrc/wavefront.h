@@ -490,7 +490,7 @@ struct WavefrontRayIO {
 #define PB_TRACE_WAVES 6
 #endif
 #ifndef PB_INST_WAVES
-#define PB_INST_WAVES 4
+#define PB_INST_WAVES 5
 #endif
 template <bool COUNT, bool INST>
 __global__ void __launch_bounds__(kTraceBlock, COUNT ? 4 : (INST ? PB_INST_WAVES : PB_TRACE_WAVES))
