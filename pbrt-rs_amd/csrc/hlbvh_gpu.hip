@@ -647,6 +647,16 @@ extern "C" int pbrt_hip_bvh_build_hlbvh_device(PbrtHipContext* ctx, const float*
     return PBRT_HIP_OK;
 }
 
+// Stable radix sort of (key, value) pairs on `bits` key bits (rocPRIM), used by the render loop to put the ray queue
+// into spatial order. temp == nullptr: only reports the scratch size.
+namespace pb {
+int sort_pairs_u32(hipStream_t st, void* temp, size_t* temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                   const uint32_t* vals_in, uint32_t* vals_out, size_t n, int bits) {
+    hipError_t e = rocprim::radix_sort_pairs(temp, *temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, (unsigned)bits, st);
+    return e == hipSuccess ? 0 : 1;
+}
+}  // namespace pb
+
 // Tree + triangle records + leaf order for a single-level scene, all produced on the device. Inputs are
 // validated by the caller (scene_create_impl's checks on indices / tri_material / tri_light / lights).
 namespace pb {

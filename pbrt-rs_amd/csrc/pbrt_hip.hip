@@ -1053,6 +1053,11 @@ extern "C" int pbrt_hip_scene_set_shading_data(PbrtHipScene* s, const float* pos
     return PBRT_HIP_OK;
 }
 
+namespace pb {
+int sort_pairs_u32(hipStream_t st, void* temp, size_t* temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                   const uint32_t* vals_in, uint32_t* vals_out, size_t n, int bits);
+}
+
 // ---- HaltonSampler host side: prime tables and compute_radical_inverse_permutations (lowdiscrepancy.rs:11-170,
 // 333-349: RNG::default + shuffle per prime), HaltonSampler::new constants (halton.rs:40-98) ----
 namespace {
@@ -1233,6 +1238,20 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         q[k].trace = buf.alloc<uint32_t>(N * 3, &ok);
         q[k].shade = buf.alloc<uint32_t>(N, &ok);
         q[k].counts64 = buf.alloc<unsigned long long>(2, &ok);
+    }
+    // ray-queue sort (spatial order for the bounce rays): keys in / out, sorted entries, rocPRIM scratch
+    const char* sort_env = std::getenv("PBRT_HIP_SORT_RAYS");
+    const bool sort_rays = !(sort_env && sort_env[0] == '0');
+    uint32_t *sort_keys[2] = {nullptr, nullptr}, *sort_vals = nullptr;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    if (sort_rays) {
+        sort_keys[0] = buf.alloc<uint32_t>(N * 3, &ok);
+        sort_keys[1] = buf.alloc<uint32_t>(N * 3, &ok);
+        sort_vals = buf.alloc<uint32_t>(N * 3, &ok);
+        if (pb::sort_pairs_u32(st, nullptr, &sort_tmp_bytes, sort_keys[0], sort_keys[1], sort_vals, sort_vals, N * 3, 16) != 0)
+            return invalid("rocPRIM radix sort: size query failed");
+        sort_tmp = buf.alloc<char>(sort_tmp_bytes, &ok);
     }
     DirectState ds{};
     std::vector<int> prefix(s->d.n_lights + 1, 0);
@@ -1417,27 +1436,47 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         local.camera_samples += (uint64_t)valid_pixels * pp.n_samples;
         local.rays_closest += (uint64_t)valid_pixels * pp.n_samples;
         bool first = true;
+        int wavefront = 0;  // 0 = camera rays, 1 = first bounce + its shadow rays, ...
         while (rc == PBRT_HIP_OK && counts[1] > 0) {
             uint32_t n_trace = (uint32_t)counts[0], n_shade = (uint32_t)counts[1];
             if (n_trace > 0) {
                 RENDER_TRY(hipMemsetAsync(ctx->d_work_counter, 0, sizeof(unsigned int), st));
+                const uint32_t* trace_queue = q[cur].trace;
+                if (sort_rays && wavefront >= 2 && n_trace >= (1u << 20)) {
+                    // from the second bounce on the rays of a wavefront start all over the scene (the first bounce still
+                    // follows the pixel order of its camera rays): trace them in Morton order of their origins
+                    const float* mn = s->d.bvh.root_min;
+                    const float* mx = s->d.bvh.root_max;
+                    float3 lo = make_float3(mn[0], mn[1], mn[2]);
+                    float3 inv = make_float3(mx[0] > mn[0] ? 1.0f / (mx[0] - mn[0]) : 0.0f, mx[1] > mn[1] ? 1.0f / (mx[1] - mn[1]) : 0.0f,
+                                             mx[2] > mn[2] ? 1.0f / (mx[2] - mn[2]) : 0.0f);
+                    hipLaunchKernelGGL(k_ray_sort_keys, dim3((n_trace + 255) / 256), dim3(256), 0, st, ps, q[cur].trace, n_trace, lo,
+                                       inv, sort_keys[0]);
+                    size_t tb = sort_tmp_bytes;
+                    if (pb::sort_pairs_u32(st, sort_tmp, &tb, sort_keys[0], sort_keys[1], q[cur].trace, sort_vals, n_trace, 16) != 0 &&
+                        rc == PBRT_HIP_OK) {
+                        ctx->last_error = "rocPRIM radix sort failed";
+                        rc = PBRT_HIP_ERR_DEVICE;
+                    }
+                    trace_queue = sort_vals;
+                }
                 RENDER_TRY(hipEventRecord(e_t0, st));
                 {
                     dim3 grid(persistent_grid(s)), block(kTraceBlock);
                     const bool inst = s->d.bvh.instanced != 0;
                     if (ctx->count_traversal) {
                         if (inst)
-                            hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, st, s->d.bvh, ps, q[cur].trace,
+                            hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
                                                n_trace, ctx->d_work_counter, ctx->d_counters);
                         else
-                            hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, st, s->d.bvh, ps, q[cur].trace,
+                            hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
                                                n_trace, ctx->d_work_counter, ctx->d_counters);
                     } else {
                         if (inst)
-                            hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, st, s->d.bvh, ps, q[cur].trace,
+                            hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
                                                n_trace, ctx->d_work_counter, ctx->d_counters);
                         else
-                            hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, st, s->d.bvh, ps, q[cur].trace,
+                            hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
                                                n_trace, ctx->d_work_counter, ctx->d_counters);
                     }
                 }
@@ -1473,6 +1512,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             }
             (void)first;
             first = false;
+            wavefront += 1;
             cur = nxt;
         }
         if (!box) {

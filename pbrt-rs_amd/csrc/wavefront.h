@@ -486,6 +486,25 @@ struct WavefrontRayIO {
         }
     }
 };
+// Sort key of a queued ray: any-hit flag, then a 15-bit Morton code of the origin inside the scene bounds. Rays that
+// start close together walk the same part of the tree: in cache order the traversal kernel runs 20 % faster on
+// incoherent bounce rays (tools/probe_sorting.py), which pays for the two 8-bit radix passes.
+__global__ void k_ray_sort_keys(PathState ps, const uint32_t* __restrict__ queue, uint32_t n, float3 lo, float3 inv_extent,
+                                uint32_t* __restrict__ keys) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t e = queue[i];
+    uint32_t p = e >> 2, slot = e & 3u;
+    float4 a = ps.ray[((size_t)p * 3 + slot) * 2];
+    float fx = (a.x - lo.x) * inv_extent.x, fy = (a.y - lo.y) * inv_extent.y, fz = (a.z - lo.z) * inv_extent.z;
+    uint32_t q[3] = {(uint32_t)fminf(fmaxf(fx * 32.0f, 0.0f), 31.0f), (uint32_t)fminf(fmaxf(fy * 32.0f, 0.0f), 31.0f),
+                     (uint32_t)fminf(fmaxf(fz * 32.0f, 0.0f), 31.0f)};
+    uint32_t code = 0;
+    for (int b = 0; b < 5; ++b)
+        for (int k = 0; k < 3; ++k) code |= ((q[k] >> b) & 1u) << (3 * b + k);
+    keys[i] = code | ((slot == RS_SHADOW ? 1u : 0u) << 15);
+}
+
 #ifndef PB_TRACE_WAVES
 #define PB_TRACE_WAVES 6
 #endif

@@ -441,3 +441,17 @@ def test_world_space_instances(hip_ctx):
     assert abs(rgb_f.mean() - rgb_t.mean()) < 1e-3 * rgb_t.mean()
     for s_ in (osc, gsc, two):
         s_.close()
+
+
+def test_ray_queue_sorting_does_not_change_the_film(hip_ctx, monkeypatch):
+    """The render loop puts the ray queue into Morton order from the second bounce on (PBRT_HIP_SORT_RAYS, default
+    on; only queues of >= 2^20 rays are sorted): the film and the ray counts are identical either way."""
+    w, h = 512, 288
+    sc, cam = scenes.random_triangles(100_000, seq=4, size=0.03), scenes.random_triangles_camera(w, h)
+    g = pbrt_hip.Scene(hip_ctx, sc)
+    a, st_a = g.render(cam, w, h, 16, max_depth=5, seed=9)
+    monkeypatch.setenv("PBRT_HIP_SORT_RAYS", "0")
+    b, st_b = g.render(cam, w, h, 16, max_depth=5, seed=9)
+    assert a.tobytes() == b.tobytes()
+    assert (st_a["rays_closest"], st_a["rays_shadow"]) == (st_b["rays_closest"], st_b["rays_shadow"])
+    g.close()
