@@ -58,7 +58,7 @@ extern "C" int pbrt_hip_context_create(int device_id, PbrtHipContext** out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipMalloc((void**)&ctx->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_work_counter, sizeof(unsigned int)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_work_counter, kQueueSegments * sizeof(unsigned int)) != hipSuccess ||
         hipMemset(ctx->d_counters, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
         g_create_error = "stream / event creation failed";
         delete ctx;
@@ -657,7 +657,7 @@ template <bool ANY>
 static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtHit* d_hits, uint8_t* d_flags) {
     PbrtHipContext* ctx = s->ctx;
     if (n == 0) return PBRT_HIP_OK;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_work_counter, 0, sizeof(unsigned int), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_work_counter, 0, kQueueSegments * sizeof(unsigned int), ctx->stream));
     if (ctx->time_trace) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (n >= (1ll << 32) - kChunk * 8192ll) {
         ctx->last_error = "batch too large for one launch (split it below 2^32 rays)";
@@ -1440,7 +1440,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         while (rc == PBRT_HIP_OK && counts[1] > 0) {
             uint32_t n_trace = (uint32_t)counts[0], n_shade = (uint32_t)counts[1];
             if (n_trace > 0) {
-                RENDER_TRY(hipMemsetAsync(ctx->d_work_counter, 0, sizeof(unsigned int), st));
+                RENDER_TRY(hipMemsetAsync(ctx->d_work_counter, 0, kQueueSegments * sizeof(unsigned int), st));
                 const uint32_t* trace_queue = q[cur].trace;
                 if (sort_rays && wavefront >= 2 && n_trace >= (1u << 20)) {
                     // from the second bounce on the rays of a wavefront start all over the scene (the first bounce still

@@ -118,6 +118,7 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
     w.leaf_first = w.leaf_cnt = w.leaf_next = 0;
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
+    int seg = (int)(blockIdx.x % kQueueSegments), seg_tries = 0;
     uint32_t n_node = 0, n_prim = 0, n_inst = 0, n_rays = 0;
 #ifdef PB_LANE_STATS
     unsigned long long stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -218,11 +219,21 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
         int n_idle = __popcll(idle_mask);
         if (!exhausted && (n_idle >= kRefillThresh)) {
             if (chunk_next >= chunk_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work_counter, (unsigned int)kChunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                chunk_next = base < n ? base : n;
-                chunk_end = (base + kChunk) < n ? (base + kChunk) : n;
+                // next chunk of this workgroup's queue segment; when the segment has run dry, of the following ones
+                while (seg_tries < kQueueSegments) {
+                    uint32_t seg_begin = (uint32_t)(((unsigned long long)n * (unsigned)seg) / kQueueSegments);
+                    uint32_t seg_end = (uint32_t)(((unsigned long long)n * (unsigned)(seg + 1)) / kQueueSegments);
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(work_counter + seg, (unsigned int)kChunk);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane(base) + seg_begin;
+                    if (base < seg_end && base >= seg_begin) {
+                        chunk_next = base;
+                        chunk_end = (base + kChunk) < seg_end ? (base + kChunk) : seg_end;
+                        break;
+                    }
+                    seg = (seg + 1 == kQueueSegments) ? 0 : seg + 1;
+                    seg_tries += 1;
+                }
                 if (chunk_next >= chunk_end) exhausted = true;
             }
             uint32_t avail = chunk_end - chunk_next;
