@@ -619,6 +619,7 @@ struct BatchRayIO {
     PbrtHit* __restrict__ out_hits;
     uint8_t* __restrict__ out_flags;
     PB_DEV uint32_t n() const { return count; }
+    PB_DEV int segments() const { return 1; }
     PB_DEV bool load(uint32_t i, TravRay* r, bool* any) const {
         const float4* rp = reinterpret_cast<const float4*>(rays + i);
         float4 a = rp[0], b = rp[1];
@@ -1464,20 +1465,21 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                 {
                     dim3 grid(persistent_grid(s)), block(kTraceBlock);
                     const bool inst = s->d.bvh.instanced != 0;
+                    const int segments = (wavefront == 0 && !inst) ? kQueueSegments : 1;  // see trace.h
                     if (ctx->count_traversal) {
                         if (inst)
                             hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
-                                               n_trace, ctx->d_work_counter, ctx->d_counters);
+                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
                         else
                             hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
-                                               n_trace, ctx->d_work_counter, ctx->d_counters);
+                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
                     } else {
                         if (inst)
                             hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
-                                               n_trace, ctx->d_work_counter, ctx->d_counters);
+                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
                         else
                             hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
-                                               n_trace, ctx->d_work_counter, ctx->d_counters);
+                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
                     }
                 }
                 RENDER_TRY(hipGetLastError());

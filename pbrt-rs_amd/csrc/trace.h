@@ -50,13 +50,11 @@ struct DevBVH {
 constexpr int kStackLds = PB_STACK_LDS;
 constexpr int kStackSpill = 64 - PB_STACK_LDS;  // together: the reference's 64-entry stack (bvh.rs:839)
 constexpr int kTraceBlock = 256;
-// Optional: the ray queue cut into one contiguous segment per XCD (workgroups are dealt round-robin over the 8 XCDs,
-// each with its own L2; a workgroup whose segment is empty helps the others). Measured with 8 segments: camera rays
-// +9 %, bounce rays +-1 %, config 3 frame within noise, config 5 -3 %: left at one segment.
-#ifndef PB_QUEUE_SEGMENTS
-#define PB_QUEUE_SEGMENTS 1
-#endif
-constexpr int kQueueSegments = PB_QUEUE_SEGMENTS;
+// The ray queue can be cut into one contiguous segment per XCD (workgroups are dealt round-robin over the 8 XCDs,
+// each with its own L2; a workgroup whose segment is empty helps the others): IO::segments(). Measured with 8
+// segments: camera rays +9 % (neighbouring pixels walk the same part of the tree), bounce rays +-1 %, the two-level
+// kernel -3 %: the render loop uses 8 segments for the camera-ray wavefront of single-level scenes and 1 otherwise.
+constexpr int kQueueSegments = 8;  // counters allocated per context
 
 struct TravRay {
     float ox, oy, oz, dx, dy, dz, tmax;

@@ -95,7 +95,7 @@ PB_DEV bool root_box_test(const LaneState& s, const float* mn, const float* mx) 
                      s.nz ? mx[2] : mn[2], s.nz ? mn[2] : mx[2], s.r, s.idx, s.idy, s.idz, s.tmax, &e);
 }
 
-// IO policy: n(), load(i, &ray, &any) -> bool real ray, store(i, any, found, t, b0, b1, b2, slot, instance)
+// IO policy: n(), segments(), load(i, &ray, &any) -> bool real ray, store(i, any, found, t, b0, b1, b2, slot, instance)
 template <class IO, bool COUNT, bool INST>
 PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __restrict__ work_counter,
                              uint2* lds_stack, int spill_lane, unsigned long long* counters) {
@@ -118,7 +118,8 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
     w.leaf_first = w.leaf_cnt = w.leaf_next = 0;
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
-    int seg = (int)(blockIdx.x % kQueueSegments), seg_tries = 0;
+    const int n_seg = io.segments();
+    int seg = (int)(blockIdx.x % (unsigned)n_seg), seg_tries = 0;
     uint32_t n_node = 0, n_prim = 0, n_inst = 0, n_rays = 0;
 #ifdef PB_LANE_STATS
     unsigned long long stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -220,9 +221,9 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
         if (!exhausted && (n_idle >= kRefillThresh)) {
             if (chunk_next >= chunk_end) {
                 // next chunk of this workgroup's queue segment; when the segment has run dry, of the following ones
-                while (seg_tries < kQueueSegments) {
-                    uint32_t seg_begin = (uint32_t)(((unsigned long long)n * (unsigned)seg) / kQueueSegments);
-                    uint32_t seg_end = (uint32_t)(((unsigned long long)n * (unsigned)(seg + 1)) / kQueueSegments);
+                while (seg_tries < n_seg) {
+                    uint32_t seg_begin = (uint32_t)(((unsigned long long)n * (unsigned)seg) / (unsigned)n_seg);
+                    uint32_t seg_end = (uint32_t)(((unsigned long long)n * (unsigned)(seg + 1)) / (unsigned)n_seg);
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(work_counter + seg, (unsigned int)kChunk);
                     base = (uint32_t)__builtin_amdgcn_readfirstlane(base) + seg_begin;
@@ -231,7 +232,7 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
                         chunk_end = (base + kChunk) < seg_end ? (base + kChunk) : seg_end;
                         break;
                     }
-                    seg = (seg + 1 == kQueueSegments) ? 0 : seg + 1;
+                    seg = (seg + 1 == n_seg) ? 0 : seg + 1;
                     seg_tries += 1;
                 }
                 if (chunk_next >= chunk_end) exhausted = true;

@@ -463,7 +463,9 @@ struct WavefrontRayIO {
     PathState ps;
     const uint32_t* __restrict__ queue;
     uint32_t count;
+    int n_segments;
     PB_DEV uint32_t n() const { return count; }
+    PB_DEV int segments() const { return n_segments; }
     PB_DEV bool load(uint32_t i, TravRay* r, bool* any) const {
         uint32_t e = queue[i];
         uint32_t p = e >> 2, slot = e & 3u;
@@ -514,9 +516,9 @@ __global__ void k_ray_sort_keys(PathState ps, const uint32_t* __restrict__ queue
 template <bool COUNT, bool INST>
 __global__ void __launch_bounds__(kTraceBlock, COUNT ? 4 : (INST ? PB_INST_WAVES : PB_TRACE_WAVES))
     k_trace(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
-            unsigned long long* counters) {
+            unsigned long long* counters, int segments) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
-    WavefrontRayIO io{ps, queue, n};
+    WavefrontRayIO io{ps, queue, n, segments};
     trace_persistent<WavefrontRayIO, COUNT, INST>(bvh, io, work_counter, lds_stack + threadIdx.x,
                                                   blockIdx.x * kTraceBlock + threadIdx.x, counters);
 }
