@@ -455,3 +455,18 @@ def test_ray_queue_sorting_does_not_change_the_film(hip_ctx, monkeypatch):
     assert a.tobytes() == b.tobytes()
     assert (st_a["rays_closest"], st_a["rays_shadow"]) == (st_b["rays_closest"], st_b["rays_shadow"])
     g.close()
+
+
+@pytest.mark.parametrize("integrator,kw", [(0, dict(max_depth=4)), (1, dict(max_depth=3, light_strategy=0)),
+                                           (1, dict(max_depth=3, light_strategy=1)), (2, dict(max_depth=3))])
+def test_scene_without_lights(hip_ctx, integrator, kw):
+    """No lights at all (integrator.rs:100-102 returns early, scene.lights is empty): a black film, and the same
+    rays as the oracle traces (bounce rays and specular branches still happen)."""
+    w, h = 48, 32
+    sc = scenes.with_lights(scenes.mixed_materials_scene(), [], keep_existing=False)
+    assert len(sc["lights"]) == 0
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, scenes.random_triangles_camera(w, h), w, h, 4,
+                                              integrator=integrator, seed=79, **kw)
+    _compare(film_g, film_c)
+    assert not film_g[..., :3].any()
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"] and st_g["rays_shadow"] == 0
