@@ -139,3 +139,30 @@ def test_config5_instanced_4k(hip_ctx):
     assert np.array_equal(hits["prim_id"] >= 0, occl.astype(bool))
     assert np.all((hits["instance_id"] >= 0) == (hits["prim_id"] >= 0))
     gsc.close()
+
+
+@pytest.mark.parametrize("sampler", [("stratified", 4, 4, True, 4), ("zerotwo", 4), ("halton",)])
+def test_config3_samplers_full_frame(hip_ctx, config3, sampler):
+    """The tabulating / Halton samplers at config 3's size (1 M triangles, 1920x1080, 16 spp): a 128x128 crop
+    against the oracle, and the full frame independent of the pass split (per-pixel tables, 1.6 GB here)."""
+    sc, gsc = config3
+    w, h = 1920, 1080
+    cam = scenes.random_triangles_camera(w, h)
+    bounds = (896, 476, 1024, 604)
+    osc = oracle.OracleScene(sc)
+    film_c, st_c = osc.render(scenes.camera_dict_to_floats(cam), w, h, 16, max_depth=5, seed=2, bounds=bounds,
+                              n_threads=16, sampler=sampler)
+    osc.close()
+    film_g, st_g = gsc.render(cam, w, h, 16, max_depth=5, seed=2, bounds=bounds, sampler=sampler)
+    crop = (slice(bounds[1], bounds[3]), slice(bounds[0], bounds[2]))
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    rgb_g, rgb_c = pbrt_hip.film_to_rgb(film_g[crop]), oracle.film_to_rgb(film_c[crop])
+    assert np.all(np.abs(rgb_g - rgb_c) <= 1e-5 * np.maximum(1.0, np.abs(rgb_c)))
+    a, st_a = gsc.render(cam, w, h, 16, max_depth=5, seed=2, sampler=sampler)
+    b, st_b = gsc.render(cam, w, h, 16, max_depth=5, seed=2, sampler=sampler, spp_per_pass=5)
+    assert a.tobytes() == b.tobytes() and st_a["rays_closest"] == st_b["rays_closest"]
+    # inside the crop the frame is the crop render (its border also receives the samples that neighbours outside the
+    # crop place exactly on a pixel corner: Halton's first sample of a pixel has offset 0)
+    inner = (slice(bounds[1] + 1, bounds[3] - 1), slice(bounds[0] + 1, bounds[2] - 1))
+    assert np.array_equal(a[inner][..., 3], film_g[inner][..., 3])
+    assert np.allclose(a[inner], film_g[inner], rtol=1e-6, atol=1e-6)
