@@ -138,7 +138,8 @@ typedef struct PbrtRenderParams {
     int32_t integrator;     /* PbrtIntegratorKind */
     int32_t max_depth;
     float rr_threshold;     /* path only */
-    int32_t light_strategy; /* path: 0 "uniform", 1 "power"; direct: 0 UniformSampleAll, 1 UniformSampleOne;
+    int32_t light_strategy; /* path: 0 "uniform", 1 "power", 2 "spatial" (src/core/lightdistrib.rs:222-232);
+                             * direct: 0 UniformSampleAll, 1 UniformSampleOne;
                              * ao: cos_sample (0 uniform hemisphere, 1 cosine-weighted) */
     int32_t spp;            /* RandomSampler samples per pixel */
     int32_t width, height;  /* film full_resolution */

@@ -29,6 +29,7 @@
 // (delta if either bit), D31 (un_occluded = !intersect_p), D32/D33/D34, D42 (film bounds / clamp),
 // D43 (box radius 0.5 x 0.5).
 #pragma once
+#include <unordered_map>
 #include <atomic>
 #include <functional>
 #include <mutex>
@@ -300,14 +301,85 @@ inline std::shared_ptr<Distribution1D> compute_light_power_distribution(const Sc
     for (auto& l : scene.lights) light_power.push_back(l->power().y_value());
     return std::make_shared<Distribution1D>(light_power.data(), (int)light_power.size());
 }
-// lightdistrib.rs:222-232 ("spatial" is out of scope)
-inline std::shared_ptr<Distribution1D> create_light_sample_distribution(const std::string& name, const Scene& scene) {
-    if (scene.lights.empty()) return nullptr;
+// lightdistrib.rs:21-24, 222-232: LightDistribution::lookup(p). "uniform" / "power" hold one Distribution1D;
+// "spatial" (lightdistrib.rs:76-220) one per voxel of a grid over the scene bounds, filled in on first use.
+// D57 (intended): compute_distribution's upper corner is written `pi as Float + 1.0 / n_voxel`
+// (lightdistrib.rs:117-121), i.e. pi + 1/n instead of (pi + 1)/n, which puts the voxel's samples outside the scene
+// for every pi > 0 -> pbrt-v3 `(pi + 1) / nVoxels`. Its sample points use radical_inverse (D53 intended).
+struct LightDistribution {
+    std::shared_ptr<Distribution1D> fixed;  // uniform / power
+    // spatial
+    const Scene* scene = nullptr;
+    int n_voxel[3] = {1, 1, 1};
+    mutable std::mutex mutex;
+    mutable std::unordered_map<uint64_t, std::shared_ptr<Distribution1D>> voxels;
+    static Float lerp1(Float t, Float a, Float b) { return (1.0f - t) * a + t * b; }  // pbrt.rs:224-226
+    // SpatialLightDistribution::new (lightdistrib.rs:85-107), max_voxels = 64 (:228)
+    void init_spatial(const Scene& sc, int max_voxels) {
+        scene = &sc;
+        Vector3f diag = sc.world_bound.diagonal();
+        Float b_max = diag[sc.world_bound.maximum_extent()];
+        for (int i = 0; i < 3; ++i) n_voxel[i] = std::max(1, (int)std::round(diag[i] / b_max * (Float)max_voxels));
+    }
+    // lightdistrib.rs:109-163
+    std::shared_ptr<Distribution1D> compute_distribution(const int pi[3]) const {
+        const Bounds3f& wb = scene->world_bound;
+        Point3f p0((Float)pi[0] / (Float)n_voxel[0], (Float)pi[1] / (Float)n_voxel[1], (Float)pi[2] / (Float)n_voxel[2]);
+        Point3f p1((Float)(pi[0] + 1) / (Float)n_voxel[0], (Float)(pi[1] + 1) / (Float)n_voxel[1],
+                   (Float)(pi[2] + 1) / (Float)n_voxel[2]);
+        auto lerp_b = [&](const Bounds3f& b, const Point3f& t) {
+            return Point3f(lerp1(t.x, b.min.x, b.max.x), lerp1(t.y, b.min.y, b.max.y), lerp1(t.z, b.min.z, b.max.z));
+        };
+        Bounds3f voxel_bounds(lerp_b(wb, p0), lerp_b(wb, p1));
+        const int n_samples = 128;
+        std::vector<Float> light_contrib(scene->lights.size(), 0.0f);
+        for (int i = 0; i < n_samples; ++i) {
+            Point3f po = lerp_b(voxel_bounds, Point3f(radical_inverse(0, (uint64_t)i), radical_inverse(1, (uint64_t)i),
+                                                      radical_inverse(2, (uint64_t)i)));
+            BaseInteraction intr;
+            intr.p = po;
+            intr.wo = Vector3f(1.0f, 0.0f, 0.0f);
+            Point2f u(radical_inverse(3, (uint64_t)i), radical_inverse(4, (uint64_t)i));
+            for (size_t j = 0; j < scene->lights.size(); ++j) {
+                Float pdf = 0.0f;
+                Vector3f wi;
+                VisibilityTester vis;
+                Spectrum li = scene->lights[j]->sample_li(intr, u, &wi, &pdf, &vis);
+                if (pdf > 0.0f) light_contrib[j] += li.y_value() / pdf;
+            }
+        }
+        Float sum_contrib = 0.0f;
+        for (Float c : light_contrib) sum_contrib += c;
+        Float avg_contrib = sum_contrib / (Float)(n_samples * (int)light_contrib.size());
+        Float min_contrib = avg_contrib > 0.0f ? 0.001f * avg_contrib : 1.0f;
+        for (Float& c : light_contrib) c = fmaxr(c, min_contrib);
+        return std::make_shared<Distribution1D>(light_contrib.data(), (int)light_contrib.size());
+    }
+    // lightdistrib.rs:43-46, 66-69, 171-219 (the hash table is a cache: any map from the voxel to its distribution does)
+    const Distribution1D* lookup(const Point3f& p) const {
+        if (fixed || !scene) return fixed.get();
+        Vector3f offset = scene->world_bound.offset(p);
+        int pi[3];
+        for (int i = 0; i < 3; ++i) pi[i] = std::min(std::max((int)(offset[i] * (Float)n_voxel[i]), 0), n_voxel[i] - 1);
+        uint64_t packed = ((uint64_t)pi[0] << 40) | ((uint64_t)pi[1] << 20) | (uint64_t)pi[2];
+        std::lock_guard<std::mutex> guard(mutex);
+        auto it = voxels.find(packed);
+        if (it == voxels.end()) it = voxels.emplace(packed, compute_distribution(pi)).first;
+        return it->second.get();
+    }
+};
+inline std::shared_ptr<LightDistribution> create_light_sample_distribution(const std::string& name, const Scene& scene) {
+    auto ld = std::make_shared<LightDistribution>();
+    if (scene.lights.empty()) return ld;
     if (name == "uniform" || scene.lights.size() == 1) {
         std::vector<Float> prob(scene.lights.size(), 1.0f);
-        return std::make_shared<Distribution1D>(prob.data(), (int)prob.size());
+        ld->fixed = std::make_shared<Distribution1D>(prob.data(), (int)prob.size());
+    } else if (name == "power") {
+        ld->fixed = compute_light_power_distribution(scene);
+    } else {
+        ld->init_spatial(scene, 64);
     }
-    return compute_light_power_distribution(scene);
+    return ld;
 }
 
 struct RenderCtx {  // per-thread state threaded through li()
@@ -441,7 +513,7 @@ struct PathIntegrator : Integrator {
     int max_depth;
     Float rr_threshold;
     std::string light_sample_strategy;
-    std::shared_ptr<Distribution1D> light_distribution;
+    std::shared_ptr<LightDistribution> light_distribution;
     PathIntegrator(int md, Float rr, const std::string& strat)
         : max_depth(md), rr_threshold(rr), light_sample_strategy(strat) {}
     void pre_process(const Scene& scene) override {
@@ -471,7 +543,8 @@ struct PathIntegrator : Integrator {
                 continue;
             }
             if (bsdf->num_components((uint8_t)(BSDF_ALL & ~BSDF_SPECULAR)) > 0) {
-                Spectrum ld = beta * uniform_sample_one_light(isect, *bsdf, scene, rc, light_distribution.get());
+                const Distribution1D* distrib = light_distribution->lookup(isect.p);  // path.rs:115
+                Spectrum ld = beta * uniform_sample_one_light(isect, *bsdf, scene, rc, distrib);
                 l += ld;
             }
             Vector3f wo = -ray.d, wi;

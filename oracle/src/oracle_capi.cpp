@@ -272,7 +272,7 @@ void orc_intersect_p(void* h, const float* rays, int64_t n, uint8_t* out, uint64
 
 // camera: 36 floats {camera_to_world[16] row-major, raster_to_camera[16], lens_radius, focal_distance, shutter_open, shutter_close}
 // integrator: 0 = path, 1 = direct lighting, 2 = Whitted, 3 = ambient occlusion.
-// light_strategy: path {0 uniform, 1 power}; direct {0 all, 1 one}; AO {0 uniform hemisphere, 1 cosine};
+// light_strategy: path {0 uniform, 1 power, 2 spatial}; direct {0 all, 1 one}; AO {0 uniform hemisphere, 1 cosine};
 // for AO max_depth carries n_samples.
 // stats: {rays, node_tests, prim_tests, camera_samples, nanoseconds, inst_tests}
 void orc_render_filtered(void* h, const float* cam, int integrator, int max_depth, float rr_threshold,
@@ -326,7 +326,8 @@ void orc_render_filtered(void* h, const float* cam, int integrator, int max_dept
     RenderStats st;
     std::unique_ptr<Integrator> integ;
     if (integrator == 0)
-        integ.reset(new PathIntegrator(max_depth, rr_threshold, light_strategy == 0 ? "uniform" : "power"));
+        integ.reset(new PathIntegrator(max_depth, rr_threshold,
+                                       light_strategy == 0 ? "uniform" : (light_strategy == 1 ? "power" : "spatial")));
     else if (integrator == 1)
         integ.reset(new DirectLightingIntegrator((LightStrategy)light_strategy, max_depth));
     else if (integrator == 2)

@@ -1371,6 +1371,8 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     sc.infinite_ids = s->d.infinite_ids;
     // create_light_sample_distribution (lightdistrib.rs:222-232): "uniform", or one light -> uniform
     sc.distrib = (rp.light_strategy == 0 || s->d.n_lights == 1) ? s->d.light_distrib_uniform : s->d.light_distrib_power;
+    if (rp.integrator == PBRT_INTEGRATOR_PATH && (rp.light_strategy < 0 || rp.light_strategy > 2))
+        return invalid("path: light_strategy must be 0 (uniform), 1 (power) or 2 (spatial)");
     std::memcpy(sc.env_cond_func, s->d.env_cond_func, sizeof(sc.env_cond_func));
     std::memcpy(sc.env_cond_cdf, s->d.env_cond_cdf, sizeof(sc.env_cond_cdf));
     std::memcpy(sc.env_cond_int, s->d.env_cond_int, sizeof(sc.env_cond_int));
@@ -1380,6 +1382,31 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     sc.world_radius = s->d.world_radius;
     sc.light_sample_prefix = d_prefix;
     sc.total_light_samples = prefix.back();
+    sc.spatial = nullptr;
+    sc.n_voxel[0] = sc.n_voxel[1] = sc.n_voxel[2] = 1;
+    if (rp.integrator == PBRT_INTEGRATOR_PATH && rp.light_strategy == 2 && s->d.n_lights > 1) {
+        // create_light_sample_distribution("spatial") -> SpatialLightDistribution::new(scene, 64) (lightdistrib.rs:85-107, 228)
+        if (!s->d_spatial) {
+            const float* mn = s->d.bvh.root_min;
+            const float* mx = s->d.bvh.root_max;
+            float diag[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+            int ext = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2);
+            for (int i = 0; i < 3; ++i) s->spatial_voxels[i] = std::max(1, (int)std::round(diag[i] / diag[ext] * 64.0f));
+            size_t n_voxels = (size_t)s->spatial_voxels[0] * s->spatial_voxels[1] * s->spatial_voxels[2];
+            size_t floats = n_voxels * (size_t)(2 * s->d.n_lights + 2);
+            if (floats > (1ull << 30)) return invalid("spatial light distribution: voxels x lights exceed 4 GB; use \"power\"");
+            void* p = nullptr;
+            HIP_TRY(ctx, hipMalloc(&p, floats * sizeof(float)));
+            s->allocs.push_back(p);
+            for (int i = 0; i < 3; ++i) sc.n_voxel[i] = s->spatial_voxels[i];
+            hipLaunchKernelGGL(k_spatial_light_tables, dim3((unsigned)((n_voxels + 63) / 64)), dim3(64), 0, st, sc, (float*)p);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            s->d_spatial = (float*)p;
+        }
+        sc.spatial = s->d_spatial;
+        for (int i = 0; i < 3; ++i) sc.n_voxel[i] = s->spatial_voxels[i];
+    }
 
     hipEvent_t e_begin, e_end, e_t0, e_t1;
     HIP_TRY(ctx, hipEventCreate(&e_begin));

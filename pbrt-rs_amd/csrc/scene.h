@@ -91,6 +91,9 @@ struct PbrtHipScene {
     int spill_lanes = 0;
     std::vector<pb::DevLight> h_lights;
     std::vector<int> light_samples;  // max(1, n_samples) per light (light.rs:76)
+    // SpatialLightDistribution tables (lightdistrib.rs:76-220), built on first use by a render with that strategy
+    float* d_spatial = nullptr;
+    int spatial_voxels[3] = {0, 0, 0};
 };
 
 namespace pb {

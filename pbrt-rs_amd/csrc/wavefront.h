@@ -793,7 +793,33 @@ struct ShadeConsts {
     // DirectLightingIntegrator (directlighting.rs:58-78): per-light sample counts, prefix sums
     const int* light_sample_prefix;  // [n_lights + 1]
     int total_light_samples;
+    // SpatialLightDistribution (lightdistrib.rs:76-220): one Distribution1D per voxel of the scene bounds,
+    // spatial[v * (2 n + 2)] = func[n], cdf[n + 1], func_int; null = the fixed `distrib`
+    const float* spatial;
+    int n_voxel[3];
 };
+
+// SpatialLightDistribution::lookup (lightdistrib.rs:171-182): the voxel of p, then its distribution
+PB_DEV DevDistribution1D light_distribution_lookup(const ShadeConsts& sc, V3 p) {
+    if (!sc.spatial) return sc.distrib;
+    const float* mn = sc.bvh.root_min;
+    const float* mx = sc.bvh.root_max;
+    float o[3] = {p.x - mn[0], p.y - mn[1], p.z - mn[2]};  // Bounds3::offset
+    int pi[3];
+    for (int i = 0; i < 3; ++i) {
+        if (mx[i] > mn[i]) o[i] /= mx[i] - mn[i];
+        int v = (int)(o[i] * (float)sc.n_voxel[i]);
+        pi[i] = v < 0 ? 0 : (v > sc.n_voxel[i] - 1 ? sc.n_voxel[i] - 1 : v);
+    }
+    size_t voxel = ((size_t)pi[2] * sc.n_voxel[1] + pi[1]) * sc.n_voxel[0] + pi[0];
+    const float* t = sc.spatial + voxel * (size_t)(2 * sc.n_lights + 2);
+    DevDistribution1D d;
+    d.func = t;
+    d.cdf = t + sc.n_lights;
+    d.func_int = t[2 * sc.n_lights + 1];
+    d.n = sc.n_lights;
+    return d;
+}
 
 PB_DEV Samp path_sampler(const PathState& ps, const PassParams& pp, const TileList& tiles, uint32_t p) {
     // this path's stream: inc from the (pixel, sample) index, state and the dimension counters from memory
@@ -933,6 +959,65 @@ PB_DEV void light_sample_li(const ShadeConsts& sc, const Surf& sf, const DevLigh
     *p1_o = p1;
     *p1_err_o = p1_err;
     *p1_n_o = p1_n;
+}
+
+// SpatialLightDistribution::compute_distribution (lightdistrib.rs:109-163; D57 / D53 intended) for every voxel:
+// 128 radical-inverse points of the voxel, Light::sample_li from each, Distribution1D over sum(Li.y / pdf).
+PB_DEV float radical_inverse_small(int base_index, uint32_t a) {  // lowdiscrepancy.rs:322-331 for the first five primes
+    if (base_index == 0) {
+        unsigned long long r = (unsigned long long)__brev(a) << 32;
+        return fminr(kOneMinusEpsilon, (float)r * 5.4210108624275222e-20f);
+    }
+    const uint32_t primes[5] = {2u, 3u, 5u, 7u, 11u};
+    return halton_radical_inverse(primes[base_index], nullptr, a);
+}
+__global__ void k_spatial_light_tables(ShadeConsts sc, float* __restrict__ table) {
+    size_t voxel = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n_voxels = (size_t)sc.n_voxel[0] * sc.n_voxel[1] * sc.n_voxel[2];
+    if (voxel >= n_voxels) return;
+    int pi[3] = {(int)(voxel % sc.n_voxel[0]), (int)((voxel / sc.n_voxel[0]) % sc.n_voxel[1]),
+                 (int)(voxel / ((size_t)sc.n_voxel[0] * sc.n_voxel[1]))};
+    const float* mn = sc.bvh.root_min;
+    const float* mx = sc.bvh.root_max;
+    float vlo[3], vhi[3];
+    for (int i = 0; i < 3; ++i) {
+        float t0 = (float)pi[i] / (float)sc.n_voxel[i], t1 = (float)(pi[i] + 1) / (float)sc.n_voxel[i];
+        float a = (1.0f - t0) * mn[i] + t0 * mx[i], b = (1.0f - t1) * mn[i] + t1 * mx[i];  // Bounds3::lerp
+        vlo[i] = fminr(a, b);                                                                // Bounds3::from((p0, p1))
+        vhi[i] = fmaxr(a, b);
+    }
+    const int n = sc.n_lights;
+    float* func = table + voxel * (size_t)(2 * n + 2);
+    float* cdf = func + n;
+    for (int j = 0; j < n; ++j) func[j] = 0.0f;
+    for (uint32_t i = 0; i < 128u; ++i) {
+        float t[3] = {radical_inverse_small(0, i), radical_inverse_small(1, i), radical_inverse_small(2, i)};
+        Surf sf;
+        sf.p = V3{(1.0f - t[0]) * vlo[0] + t[0] * vhi[0], (1.0f - t[1]) * vlo[1] + t[1] * vhi[1], (1.0f - t[2]) * vlo[2] + t[2] * vhi[2]};
+        float u0 = radical_inverse_small(3, i), u1 = radical_inverse_small(4, i);
+        for (int j = 0; j < n; ++j) {
+            DevLight lt = sc.lights[j];
+            V3 wi, li, p1, p1_err, p1_n;
+            float pdf;
+            light_sample_li(sc, sf, lt, u0, u1, &wi, &pdf, &li, &p1, &p1_err, &p1_n);
+            if (pdf > 0.0f) func[j] += (0.212671f * li.x + 0.715160f * li.y + 0.072169f * li.z) / pdf;
+        }
+    }
+    float sum = 0.0f;
+    for (int j = 0; j < n; ++j) sum += func[j];
+    float avg = sum / (float)(128 * n);
+    float min_contrib = avg > 0.0f ? 0.001f * avg : 1.0f;
+    for (int j = 0; j < n; ++j) func[j] = fmaxr(func[j], min_contrib);
+    // Distribution1D::new (sampling.rs:69-95)
+    cdf[0] = 0.0f;
+    for (int j = 1; j < n + 1; ++j) cdf[j] = cdf[j - 1] + func[j - 1] / (float)n;
+    float func_int = cdf[n];
+    if (func_int == 0.0f) {
+        for (int j = 1; j < n + 1; ++j) cdf[j] = (float)j / (float)n;
+    } else {
+        for (int j = 1; j < n + 1; ++j) cdf[j] /= func_int;
+    }
+    func[2 * n + 1] = func_int;
 }
 
 // estimate_direct (integrator.rs:136-266), first part: sample the light, evaluate the BSDF, sample the
@@ -1185,10 +1270,10 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
                     // ---- uniform_sample_one_light (integrator.rs:92-134) ----
                     if (nonspecular && sc.n_lights > 0) {
                         float u_pick = samp_1d(pp, sm);
-                        int light_num = find_interval_cdf(sc.distrib.cdf, sc.distrib.n + 1, u_pick);
-                        float pick_pdf = sc.distrib.func_int > 0.0f
-                                             ? sc.distrib.func[light_num] / (sc.distrib.func_int * (float)sc.distrib.n)
-                                             : 0.0f;
+                        DevDistribution1D distrib = light_distribution_lookup(sc, sf.p);  // path.rs:115
+                        int light_num = find_interval_cdf(distrib.cdf, distrib.n + 1, u_pick);
+                        float pick_pdf = distrib.func_int > 0.0f ? distrib.func[light_num] / (distrib.func_int * (float)distrib.n)
+                                                                 : 0.0f;
                         if (pick_pdf != 0.0f) {
                             float ul0, ul1, us0, us1;
                             samp_2d(pp, sm, &ul0, &ul1);
