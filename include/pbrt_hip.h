@@ -113,7 +113,11 @@ typedef struct PbrtInstance {
     int32_t pad[3];
 } PbrtInstance;
 
-/* src/cameras/perspective.rs:19-32: the two matrices the ray generator applies. Row-major. */
+/* src/cameras/perspective.rs:19-32: the two matrices the ray generator applies. Row-major. kind selects
+ * PerspectiveCamera::generate_ray (perspective.rs:90-112), OrthographicCamera::generate_ray
+ * (src/cameras/orthographic.rs:82-104; raster_to_camera of the orthographic projection) or
+ * EnvironmentCamera::generate_ray (src/cameras/environment.rs:37-56; only camera_to_world is used). */
+enum PbrtCameraKind { PBRT_CAMERA_PERSPECTIVE = 0, PBRT_CAMERA_ORTHOGRAPHIC = 1, PBRT_CAMERA_ENVIRONMENT = 2 };
 typedef struct PbrtCamera {
     float camera_to_world[16];
     float raster_to_camera[16];
@@ -121,6 +125,8 @@ typedef struct PbrtCamera {
     float focal_distance;
     float shutter_open;
     float shutter_close;
+    int32_t kind; /* PbrtCameraKind */
+    int32_t pad[3];
 } PbrtCamera;
 
 enum PbrtIntegratorKind {

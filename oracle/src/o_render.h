@@ -742,12 +742,49 @@ struct AOIntegrator : Integrator {
 // Camera — cameras/perspective.rs. The 4x4 matrices are supplied by the caller (the host side
 // computes Transform::perspective / look_at, transform.rs:510-566); the oracle applies them.
 // ---------------------------------------------------------------------------------
+enum CameraKind { CAMERA_PERSPECTIVE = 0, CAMERA_ORTHOGRAPHIC = 1, CAMERA_ENVIRONMENT = 2 };
 struct PerspectiveCamera {
     Matrix4 camera_to_world, raster_to_camera;
     Float lens_radius = 0.0f, focal_distance = 1e6f;
     Float shutter_open = 0.0f, shutter_close = 1.0f;
+    int kind = CAMERA_PERSPECTIVE;
+    int film_width = 1, film_height = 1;  // full_resolution (environment camera)
+    // cameras/orthographic.rs:82-104. D58 (intended): with a lens the reference REPLACES the ray origin by the lens
+    // point (orthographic.rs:97), which collapses the parallel projection onto the lens -> pbrt-v3 adds the lens
+    // offset to the origin (orthographic.cpp:70-72).
+    Float generate_ray_orthographic(const CameraSample& sample, Ray* ray) const {
+        Point3f p_film(sample.p_film.x, sample.p_film.y, 0.0f);
+        Point3f p_camera = xform_point(raster_to_camera, p_film);
+        *ray = Ray(p_camera, Vector3f(0.0f, 0.0f, 1.0f), FLOAT_INF, 0.0f);
+        if (lens_radius > 0.0f) {
+            Point2f pl = concentric_sample_disk(sample.p_lens);
+            Point2f p_lens(pl.x * lens_radius, pl.y * lens_radius);
+            Float ft = focal_distance / ray->d.z;
+            Point3f p_focus = ray->at(ft);
+            ray->o.x += p_lens.x;
+            ray->o.y += p_lens.y;
+            ray->d = (p_focus - ray->o).normalize();
+        }
+        ray->time = (1.0f - sample.time) * shutter_open + sample.time * shutter_close;
+        *ray = xform_ray(camera_to_world, *ray);
+        return 1.0f;
+    }
+    // cameras/environment.rs:37-56
+    Float generate_ray_environment(const CameraSample& sample, Ray* ray) const {
+        Float theta = PI * sample.p_film.y / (Float)film_height;
+        Float phi = 2.0f * PI * sample.p_film.x / (Float)film_width;
+        Float st, ct, sp, cp;
+        det_sincos(theta, &st, &ct);
+        det_sincos(phi, &sp, &cp);
+        *ray = Ray(Point3f(0.0f, 0.0f, 0.0f), Vector3f(st * cp, ct, st * sp), FLOAT_INF,
+                   (1.0f - sample.time) * shutter_open + sample.time * shutter_close);
+        *ray = xform_ray(camera_to_world, *ray);
+        return 1.0f;
+    }
     // perspective.rs:90-112 (generate_ray_differential :114-161 differs only in the differentials)
     Float generate_ray(const CameraSample& sample, Ray* ray) const {
+        if (kind == CAMERA_ORTHOGRAPHIC) return generate_ray_orthographic(sample, ray);
+        if (kind == CAMERA_ENVIRONMENT) return generate_ray_environment(sample, ray);
         Point3f p_film(sample.p_film.x, sample.p_film.y, 0.0f);
         Point3f p_camera = xform_point(raster_to_camera, p_film);
         *ray = Ray(Point3f(0.0f, 0.0f, 0.0f), p_camera.normalize(), FLOAT_INF, 0.0f);

@@ -270,7 +270,8 @@ void orc_intersect_p(void* h, const float* rays, int64_t n, uint8_t* out, uint64
     }
 }
 
-// camera: 36 floats {camera_to_world[16] row-major, raster_to_camera[16], lens_radius, focal_distance, shutter_open, shutter_close}
+// camera: 37 floats {camera_to_world[16] row-major, raster_to_camera[16], lens_radius, focal_distance, shutter_open,
+// shutter_close, kind (0 perspective, 1 orthographic, 2 environment)}
 // integrator: 0 = path, 1 = direct lighting, 2 = Whitted, 3 = ambient occlusion.
 // light_strategy: path {0 uniform, 1 power, 2 spatial}; direct {0 all, 1 one}; AO {0 uniform hemisphere, 1 cosine};
 // for AO max_depth carries n_samples.
@@ -301,6 +302,9 @@ void orc_render_filtered(void* h, const float* cam, int integrator, int max_dept
     camera.focal_distance = cam[33];
     camera.shutter_open = cam[34];
     camera.shutter_close = cam[35];
+    camera.kind = (int)cam[36];  // 0 perspective, 1 orthographic, 2 environment
+    camera.film_width = width;
+    camera.film_height = height;
     Film film(width, height);
     film.filter_radius_x = filter_rx;
     film.filter_radius_y = filter_ry;

@@ -1361,6 +1361,8 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     cam.focal_distance = camera.focal_distance;
     cam.shutter_open = camera.shutter_open;
     cam.shutter_close = camera.shutter_close;
+    cam.kind = camera.kind;
+    if (camera.kind < PBRT_CAMERA_PERSPECTIVE || camera.kind > PBRT_CAMERA_ENVIRONMENT) return invalid("unknown camera kind");
 
     ShadeConsts sc;
     sc.bvh = s->d.bvh;

@@ -150,6 +150,7 @@ PB_DEV void store_ray(const PathState& ps, uint32_t p, int slot, V3 o, V3 d, flo
 struct DevCamera {
     float c2w[16], r2c[16];
     float lens_radius, focal_distance, shutter_open, shutter_close;
+    int kind;  // PbrtCameraKind
 };
 PB_DEV V3 xform_point(const float* m, V3 p) {  // transform.rs:351-370
     float xp = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
@@ -413,18 +414,43 @@ __global__ void k_generate(PathState ps, Queues q, PassParams pp, DevCamera cam,
         float pfx = (float)x + u0, pfy = (float)y + u1;
         float time_u = samp_1d(pp, sm);
         samp_2d(pp, sm, &l0, &l1);
-        V3 p_camera = xform_point(cam.r2c, V3{pfx, pfy, 0.0f});
-        V3 o = V3{0.0f, 0.0f, 0.0f};
-        V3 d = normalize(p_camera);
-        if (cam.lens_radius > 0.0f) {
-            float lx, ly;
-            concentric_sample_disk(l0, l1, &lx, &ly);
-            lx *= cam.lens_radius;
-            ly *= cam.lens_radius;
-            float ft = cam.focal_distance / d.z;
-            V3 p_focus = o + d * ft;
-            o = V3{lx, ly, 0.0f};
-            d = normalize(p_focus - o);
+        V3 o = V3{0.0f, 0.0f, 0.0f}, d;
+        if (cam.kind == PBRT_CAMERA_ENVIRONMENT) {
+            // EnvironmentCamera::generate_ray (cameras/environment.rs:37-56)
+            float theta = kPi * pfy / (float)pp.height;
+            float phi = 2.0f * kPi * pfx / (float)pp.width;
+            float st, ct, sp, cp;
+            det_sincos(theta, &st, &ct);
+            det_sincos(phi, &sp, &cp);
+            d = V3{st * cp, ct, st * sp};
+        } else if (cam.kind == PBRT_CAMERA_ORTHOGRAPHIC) {
+            // OrthographicCamera::generate_ray (cameras/orthographic.rs:82-104; D58: the lens point is added to the origin)
+            o = xform_point(cam.r2c, V3{pfx, pfy, 0.0f});
+            d = V3{0.0f, 0.0f, 1.0f};
+            if (cam.lens_radius > 0.0f) {
+                float lx, ly;
+                concentric_sample_disk(l0, l1, &lx, &ly);
+                lx *= cam.lens_radius;
+                ly *= cam.lens_radius;
+                float ft = cam.focal_distance / d.z;
+                V3 p_focus = o + d * ft;
+                o.x += lx;
+                o.y += ly;
+                d = normalize(p_focus - o);
+            }
+        } else {
+            V3 p_camera = xform_point(cam.r2c, V3{pfx, pfy, 0.0f});
+            d = normalize(p_camera);
+            if (cam.lens_radius > 0.0f) {
+                float lx, ly;
+                concentric_sample_disk(l0, l1, &lx, &ly);
+                lx *= cam.lens_radius;
+                ly *= cam.lens_radius;
+                float ft = cam.focal_distance / d.z;
+                V3 p_focus = o + d * ft;
+                o = V3{lx, ly, 0.0f};
+                d = normalize(p_focus - o);
+            }
         }
         (void)time_u;  // ray.time only feeds animated transforms / media (out of scope)
         // Ray through camera_to_world with origin error (geometry.rs:865-881, 898-935)

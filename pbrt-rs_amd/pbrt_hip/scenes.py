@@ -15,7 +15,8 @@ LIGHT_DTYPE = np.dtype([("type", "<i4"), ("L", "<f4", 3), ("prim", "<i4"), ("two
                         ("cos_falloff_start", "<f4"), ("world_to_light", "<f4", 9), ("pad2", "<i4", 2)])
 CAMERA_DTYPE = np.dtype([("camera_to_world", "<f4", 16), ("raster_to_camera", "<f4", 16),
                          ("lens_radius", "<f4"), ("focal_distance", "<f4"),
-                         ("shutter_open", "<f4"), ("shutter_close", "<f4")])
+                         ("shutter_open", "<f4"), ("shutter_close", "<f4"), ("kind", "<i4"), ("pad", "<i4", 3)])
+CAMERA_PERSPECTIVE, CAMERA_ORTHOGRAPHIC, CAMERA_ENVIRONMENT = 0, 1, 2
 RAY_DTYPE = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("t_max", "<f4"), ("time", "<f4")])
 HIT_DTYPE = np.dtype([("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"), ("prim_id", "<i4"),
                       ("instance_id", "<i4"), ("pad", "<i4", 2)])
@@ -422,6 +423,33 @@ def perspective_camera(eye, look, up, fov_deg, width, height, lens_radius=0.0, f
     return cam
 
 
+def orthographic_camera(eye, look, up, half_height, width, height, lens_radius=0.0, focal_distance=1e6):
+    """OrthographicCamera::new (cameras/orthographic.rs:37-80): camera_to_screen = orthographic(0, 1) (z unchanged for
+    near 0, far 1), screen window [-a, a] x [-1, 1] scaled by `half_height`."""
+    c2w = look_at(eye, look, up)
+    aspect = width / height
+    sw = (-aspect * half_height, aspect * half_height, -half_height, half_height)
+    screen_to_raster = (np.diag([width, height, 1.0, 1.0]) @
+                        np.diag([1.0 / (sw[1] - sw[0]), 1.0 / (sw[2] - sw[3]), 1.0, 1.0]) @ _translate(-sw[0], -sw[3], 0.0))
+    raster_to_camera = np.linalg.inv(screen_to_raster)        # orthographic(0, 1) is the identity
+    cam = np.zeros((), dtype=CAMERA_DTYPE)
+    cam["camera_to_world"] = c2w.astype(np.float32).reshape(16)
+    cam["raster_to_camera"] = raster_to_camera.astype(np.float32).reshape(16)
+    cam["lens_radius"], cam["focal_distance"], cam["shutter_open"], cam["shutter_close"] = lens_radius, focal_distance, 0.0, 1.0
+    cam["kind"] = CAMERA_ORTHOGRAPHIC
+    return cam
+
+
+def environment_camera(eye, look, up):
+    """EnvironmentCamera::new (cameras/environment.rs:19-29): only camera_to_world matters."""
+    cam = np.zeros((), dtype=CAMERA_DTYPE)
+    cam["camera_to_world"] = look_at(eye, look, up).astype(np.float32).reshape(16)
+    cam["raster_to_camera"] = np.eye(4, dtype=np.float32).reshape(16)
+    cam["shutter_close"] = 1.0
+    cam["kind"] = CAMERA_ENVIRONMENT
+    return cam
+
+
 def _translate(x, y, z):
     m = np.eye(4)
     m[:3, 3] = (x, y, z)
@@ -444,7 +472,7 @@ def random_rays(n, seq, origin_extent=1.5, t_max=np.inf):
 
 
 def camera_dict_to_floats(cam):
-    """36 floats for the oracle's flat entry point."""
+    """37 floats for the oracle's flat entry point."""
     return np.concatenate([cam["camera_to_world"].reshape(-1), cam["raster_to_camera"].reshape(-1),
-                           [cam["lens_radius"], cam["focal_distance"], cam["shutter_open"], cam["shutter_close"]]]
-                          ).astype(np.float32)
+                           [cam["lens_radius"], cam["focal_distance"], cam["shutter_open"], cam["shutter_close"],
+                            float(cam["kind"])]]).astype(np.float32)

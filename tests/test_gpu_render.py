@@ -494,3 +494,24 @@ def test_spatial_light_distribution(hip_ctx, scene_name):
     gsc.close()
     assert film_s.tobytes() == film_g.tobytes() and film_p.tobytes() != film_g.tobytes()
     assert abs(pbrt_hip.film_to_rgb(film_p).mean() - pbrt_hip.film_to_rgb(film_g).mean()) < 0.05 * pbrt_hip.film_to_rgb(film_p).mean()
+
+
+@pytest.mark.parametrize("kind", ["orthographic", "orthographic_lens", "environment"])
+def test_other_cameras(hip_ctx, kind):
+    """OrthographicCamera (cameras/orthographic.rs:82-104, D58 intended) and EnvironmentCamera
+    (cameras/environment.rs:37-56) ray generation."""
+    sc = scenes.cornell_box()
+    if kind == "environment":
+        w, h = 96, 48
+        cam = scenes.environment_camera((278.0, 273.0, 200.0), (278.0, 273.0, 500.0), (0.0, 1.0, 0.0))
+    else:
+        w, h = 64, 64
+        cam = scenes.orthographic_camera((278.0, 273.0, -800.0), (278.0, 273.0, 0.0), (0.0, 1.0, 0.0), 280.0, w, h,
+                                         lens_radius=15.0 if kind == "orthographic_lens" else 0.0, focal_distance=1100.0)
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, cam, w, h, 4, max_depth=4, light_strategy=1, seed=89)
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    rgb = pbrt_hip.film_to_rgb(film_g)
+    assert rgb.mean() > 0.05
+    if kind == "environment":
+        assert rgb.max() > 10.0          # the camera sits inside the box and sees the emitter overhead
