@@ -226,6 +226,13 @@ static const char* convert_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes,
     return nullptr;
 }
 
+// Spheres next to the triangles (src/shapes/sphere.rs; BASELINE config 1): full spheres placed by a translation.
+// Primitive ids n_tris .. n_tris + n - 1 in prim_order; not usable as area lights on the device.
+struct SphereArgs {
+    const float* spheres = nullptr;  // n x {centre.xyz, radius}
+    const int32_t* material = nullptr;
+    int32_t n = 0;
+};
 struct InstancingArgs {
     const PbrtInstance* instances = nullptr;
     int32_t n_instances = 0;
@@ -238,7 +245,8 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
                              int32_t n_tris, const int32_t* tri_material, const PbrtMaterial* materials,
                              int32_t n_materials, const int32_t* tri_light, const PbrtLight* lights, int32_t n_lights,
                              const PbrtLinearBVHNode* nodes, int32_t n_nodes, const int32_t* prim_order,
-                             const InstancingArgs& ia, PbrtHipScene** out, pb::DeviceTree* dt = nullptr);
+                             const InstancingArgs& ia, PbrtHipScene** out, pb::DeviceTree* dt = nullptr,
+                             const SphereArgs& sa = SphereArgs());
 
 extern "C" int pbrt_hip_scene_create(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
                                      const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
@@ -293,6 +301,21 @@ extern "C" int pbrt_hip_scene_create_hlbvh(PbrtHipContext* ctx, const float* pos
     return rc;
 }
 
+extern "C" int pbrt_hip_scene_create_with_spheres(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
+                                                  const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
+                                                  const PbrtMaterial* materials, int32_t n_materials, const int32_t* tri_light,
+                                                  const PbrtLight* lights, int32_t n_lights, const float* spheres,
+                                                  const int32_t* sphere_material, int32_t n_spheres,
+                                                  const PbrtLinearBVHNode* nodes, int32_t n_nodes, const int32_t* prim_order,
+                                                  PbrtHipScene** out) {
+    SphereArgs sa;
+    sa.spheres = spheres;
+    sa.material = sphere_material;
+    sa.n = n_spheres;
+    return scene_create_impl(ctx, positions, n_verts, indices, n_tris, tri_material, materials, n_materials, tri_light,
+                             lights, n_lights, nodes, n_nodes, prim_order, InstancingArgs(), out, nullptr, sa);
+}
+
 extern "C" int pbrt_hip_scene_create_instanced(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
                                                const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
                                                const PbrtMaterial* materials, int32_t n_materials,
@@ -325,7 +348,7 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
                              int32_t n_tris, const int32_t* tri_material, const PbrtMaterial* materials,
                              int32_t n_materials, const int32_t* tri_light, const PbrtLight* lights, int32_t n_lights,
                              const PbrtLinearBVHNode* nodes, int32_t n_nodes, const int32_t* prim_order,
-                             const InstancingArgs& ia, PbrtHipScene** out, pb::DeviceTree* dt) {
+                             const InstancingArgs& ia, PbrtHipScene** out, pb::DeviceTree* dt, const SphereArgs& sa) {
     // dt != nullptr: the tree, the triangle records and the leaf order are already on the device
     // (pbrt_hip_scene_create_hlbvh); nodes / prim_order are then unused.
     if (!ctx || !out) return PBRT_HIP_ERR_INVALID;
@@ -341,8 +364,15 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     if (n_lights < 0 || (n_lights > 0 && !lights)) return fail("bad light table");
     for (int64_t i = 0; i < 3 * (int64_t)n_tris; ++i)
         if (indices[i] < 0 || indices[i] >= n_verts) return fail("vertex index out of range");
+    const int32_t n_prims = n_tris + sa.n;
+    if (sa.n < 0 || (sa.n > 0 && (!sa.spheres || dt || ia.n_instances > 0))) return fail("bad sphere arguments");
+    for (int32_t i = 0; i < sa.n; ++i) {
+        if (!(sa.spheres[4 * i + 3] > 0.0f)) return fail("sphere radius must be positive");
+        if (sa.material && (sa.material[i] < 0 || sa.material[i] >= n_materials)) return fail("sphere material out of range");
+    }
+    for (int32_t i = 0; i < n_prims && !dt; ++i)
+        if (prim_order[i] < 0 || prim_order[i] >= n_prims) return fail("prim_order entry out of range");
     for (int32_t i = 0; i < n_tris; ++i) {
-        if (!dt && (prim_order[i] < 0 || prim_order[i] >= n_tris)) return fail("prim_order entry out of range");
         if (tri_material && (tri_material[i] < 0 || tri_material[i] >= n_materials)) return fail("tri_material out of range");
         if (tri_light && (tri_light[i] < -1 || tri_light[i] >= n_lights)) return fail("tri_light out of range");
     }
@@ -375,7 +405,7 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         top.root_ref = dt->root_ref;
         top.count_bits = dt->count_bits;
     } else {
-        if (const char* e = convert_tree(nodes, n_nodes, n_tris, 0, &top)) return fail(e);
+        if (const char* e = convert_tree(nodes, n_nodes, n_prims, 0, &top)) return fail(e);
     }
     const int n_interior = top.n_interior + obj.n_interior;
 
@@ -391,15 +421,24 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     inodes.insert(inodes.end(), obj.inodes.begin(), obj.inodes.end());
     if (inodes.empty()) inodes.assign(16, 0.0f);
     // ---- triangles in leaf order (48 B) ----
-    std::vector<float> tris(dt ? 0 : (size_t)n_tris * 12);
-    std::vector<int32_t> prim_slot(dt ? 0 : n_tris, -1);
-    for (int32_t slot = 0; slot < n_tris && !dt; ++slot) {
+    std::vector<float> tris(dt ? 0 : (size_t)n_prims * 12);
+    std::vector<int32_t> prim_slot(dt ? 0 : n_prims, -1);
+    for (int32_t slot = 0; slot < n_prims && !dt; ++slot) {
         int32_t prim = prim_order[slot];
         if (prim_slot[prim] != -1) {
             delete s;
             return fail("prim_order is not a permutation");
         }
         prim_slot[prim] = slot;
+        if (prim >= n_tris) {  // sphere record: (centre.xyz, radius) | - | (-, prim, material, kPrimSphere)
+            const float* sp = sa.spheres + 4 * (size_t)(prim - n_tris);
+            float* t = &tris[(size_t)slot * 12];
+            t[0] = sp[0]; t[1] = sp[1]; t[2] = sp[2]; t[3] = sp[3];
+            for (int k = 4; k < 9; ++k) t[k] = 0.0f;
+            int32_t meta[3] = {prim, sa.material ? sa.material[prim - n_tris] : 0, kPrimSphere};
+            std::memcpy(t + 9, meta, 12);
+            continue;
+        }
         const float* a = positions + 3 * (size_t)indices[3 * (size_t)prim];
         const float* b = positions + 3 * (size_t)indices[3 * (size_t)prim + 1];
         const float* c = positions + 3 * (size_t)indices[3 * (size_t)prim + 2];
@@ -499,7 +538,8 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     }
     d.bvh.root_ref = top.root_ref;
     d.bvh.count_bits = top.count_bits;
-    d.bvh.n_slots = n_tris;
+    d.bvh.n_slots = n_prims;
+    d.bvh.has_spheres = sa.n > 0 ? 1 : 0;
     d.bvh.instanced = instanced ? 1 : 0;
     if (instanced) {
         std::memcpy(d.bvh.blas_root_min, nodes[0].bounds_min, 12);
@@ -535,7 +575,7 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         d.bvh.spill = (uint2*)p;
         d.bvh.spill_stride = s->spill_lanes;
     }
-    if (!dt) d.slot_prim = dev_upload(s, prim_order, n_tris, &ok);
+    if (!dt) d.slot_prim = dev_upload(s, prim_order, n_prims, &ok);
     d.materials = dev_upload(s, dm.data(), dm.size(), &ok);
     d.lights = dev_upload(s, dl.data(), dl.size(), &ok);
     d.n_lights = n_lights;
@@ -640,12 +680,12 @@ struct BatchRayIO {
         }
     }
 };
-template <bool ANY, bool COUNT, bool INST>
-__global__ void __launch_bounds__(kTraceBlock, COUNT ? 4 : (INST ? PB_INST_WAVES : PB_TRACE_WAVES))
+template <bool ANY, bool COUNT, bool INST, bool SPH = false>
+__global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_INST_WAVES : PB_TRACE_WAVES))
     k_intersect_batch(DevBVH bvh, BatchRayIO<ANY> io, unsigned int* work_counter, unsigned long long* counters) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
-    trace_persistent<BatchRayIO<ANY>, COUNT, INST>(bvh, io, work_counter, lds_stack + threadIdx.x,
-                                                   blockIdx.x * kTraceBlock + threadIdx.x, counters);
+    trace_persistent<BatchRayIO<ANY>, COUNT, INST, SPH>(bvh, io, work_counter, lds_stack + threadIdx.x,
+                                                        blockIdx.x * kTraceBlock + threadIdx.x, counters);
 }
 
 // persistent kernels: enough blocks to fill every CU (LDS: 160 KiB / (kStackLds * 2 KiB) blocks of 256, at most 8)
@@ -668,7 +708,14 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
         BatchRayIO<ANY> io{s->d.slot_prim, s->d.slot_instance, d_rays, (uint32_t)n, d_hits, d_flags};
         dim3 grid(persistent_grid(s)), block(kTraceBlock);
         const bool inst = s->d.bvh.instanced != 0;
-        if (ctx->count_traversal) {
+        if (s->d.bvh.has_spheres) {  // single-level scenes only (checked at creation)
+            if (ctx->count_traversal)
+                hipLaunchKernelGGL((k_intersect_batch<ANY, true, false, true>), grid, block, 0, ctx->stream, s->d.bvh, io,
+                                   ctx->d_work_counter, ctx->d_counters);
+            else
+                hipLaunchKernelGGL((k_intersect_batch<ANY, false, false, true>), grid, block, 0, ctx->stream, s->d.bvh, io,
+                                   ctx->d_work_counter, ctx->d_counters);
+        } else if (ctx->count_traversal) {
             if (inst)
                 hipLaunchKernelGGL((k_intersect_batch<ANY, true, true>), grid, block, 0, ctx->stream, s->d.bvh, io,
                                    ctx->d_work_counter, ctx->d_counters);
@@ -1024,6 +1071,7 @@ extern "C" int pbrt_hip_scene_set_shading_data(PbrtHipScene* s, const float* pos
     if (!positions || !indices || n_tris != s->n_tris || n_verts <= 0) return fail("mesh does not match the scene");
     if (!normals && !tangents && !uvs) return fail("no normals, tangents or uvs given");
     if (s->d.bvh.tri_shading) return fail("shading data already set");
+    if (s->d.bvh.has_spheres) return fail("per-vertex shading data is not supported for scenes with spheres");
     for (int64_t i = 0; i < 3 * (int64_t)n_tris; ++i)
         if (indices[i] < 0 || indices[i] >= n_verts) return fail("vertex index out of range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1495,7 +1543,14 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                     dim3 grid(persistent_grid(s)), block(kTraceBlock);
                     const bool inst = s->d.bvh.instanced != 0;
                     const int segments = (wavefront == 0 && !inst) ? kQueueSegments : 1;  // see trace.h
-                    if (ctx->count_traversal) {
+                    if (s->d.bvh.has_spheres) {
+                        if (ctx->count_traversal)
+                            hipLaunchKernelGGL((k_trace<true, false, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
+                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
+                        else
+                            hipLaunchKernelGGL((k_trace<false, false, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
+                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
+                    } else if (ctx->count_traversal) {
                         if (inst)
                             hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
                                                n_trace, ctx->d_work_counter, ctx->d_counters, segments);

@@ -42,6 +42,7 @@ struct DevBVH {
     // (n0.xyz, n1.x) (n1.yz, n2.xy) (n2.z, s0.xyz) (s1.xyz, s2.x) (s2.yz, uv0.xy) (uv1.xy, uv2.xy); null = none
     const float4* __restrict__ tri_shading;
     int has_normals, has_tangents, has_uvs;
+    int has_spheres;  // some leaf slots hold spheres (kPrimSphere): the SPH kernels are launched
 };
 
 #ifndef PB_STACK_LDS
@@ -66,6 +67,8 @@ struct TravHit {
 
 // tri.z.w of the third float4 carries flags in the top bits of `light`: see scene.h
 constexpr int kTriDegenerate = 1 << 30;  // Triangle::intersect returns false (triangle.rs:212-216)
+constexpr int kPrimSphere = 1 << 29;     // the slot holds a Sphere: (centre.xyz, radius) in the first float4 (shapes/sphere.rs)
+constexpr int kPrimLightMask = 0x1fffffff;  // light index + 1
 
 PB_DEV bool slab_test(float bx0, float bx1, float by0, float by1, float bz0, float bz1, const TravRay& r, float idx,
                       float idy, float idz, float tmax_ray, float* entry) {
@@ -165,6 +168,129 @@ PB_DEV void load_tri(const float4* __restrict__ tris, int slot, V3* p0, V3* p1, 
     *p1 = V3{a.w, b.x, b.y};
     *p2 = V3{b.z, b.w, c.x};
     *flags = __float_as_int(c.w);
+}
+
+// ---- Sphere (src/shapes/sphere.rs) with EFloat (src/core/efloat.rs; D7 intended), full spheres placed by a
+// translation: object_to_world = translate(centre). Same operation order as the oracle (o_sphere.h). ----
+struct EFloat {
+    float v, low, high;
+};
+PB_DEV EFloat ef_make(float v, float err) {  // efloat.rs:15-25
+    EFloat e;
+    e.v = v;
+    if (err == 0.0f) {
+        e.low = e.high = v;
+    } else {
+        e.low = next_float_down(v - err);
+        e.high = next_float_up(v + err);
+    }
+    return e;
+}
+PB_DEV EFloat ef_add(EFloat a, EFloat b) {
+    return EFloat{a.v + b.v, next_float_down(a.low + b.low), next_float_up(a.high + b.high)};
+}
+PB_DEV EFloat ef_sub(EFloat a, EFloat b) {
+    return EFloat{a.v - b.v, next_float_down(a.low - b.high), next_float_up(a.high - b.low)};
+}
+PB_DEV float ef_min4(float a, float b, float c, float d) {
+    float ab = a < b ? a : b, cd = c < d ? c : d;  // fminr(fminr(a, b), fminr(c, d))
+    return ab < cd ? ab : cd;
+}
+PB_DEV float ef_max4(float a, float b, float c, float d) {
+    float ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+PB_DEV EFloat ef_mul(EFloat a, EFloat b) {
+    float p0 = a.low * b.low, p1 = a.high * b.low, p2 = a.low * b.high, p3 = a.high * b.high;
+    return EFloat{a.v * b.v, next_float_down(ef_min4(p0, p1, p2, p3)), next_float_up(ef_max4(p0, p1, p2, p3))};
+}
+PB_DEV EFloat ef_div(EFloat a, EFloat b) {
+    EFloat o;
+    o.v = a.v / b.v;
+    if (b.low < 0.0f && b.high > 0.0f) {
+        o.low = -kInf;
+        o.high = kInf;
+    } else {
+        float d0 = a.low / b.low, d1 = a.high / b.low, d2 = a.low / b.high, d3 = a.high / b.high;
+        o.low = next_float_down(ef_min4(d0, d1, d2, d3));
+        o.high = next_float_up(ef_max4(d0, d1, d2, d3));
+    }
+    return o;
+}
+PB_DEV EFloat ef_mulf(EFloat a, float f) { return ef_mul(a, ef_make(f, 0.0f)); }
+
+// The object-space ray of Sphere::intersect_test (geometry.rs:1077-1137 through translate(-centre)) with its
+// origin / direction error bounds.
+struct SphereRay {
+    float ox, oy, oz, dx, dy, dz;
+    float oex, oey, oez, dex, dey, dez;
+};
+PB_DEV SphereRay sphere_object_ray(float cx, float cy, float cz, const TravRay& r) {
+    SphereRay q;
+    float x = r.ox, y = r.oy, z = r.oz;
+    // rows of translate(-c): (1 0 0 -cx) (0 1 0 -cy) (0 0 1 -cz); every product of the general formula is kept
+    q.ox = 1.0f * x + 0.0f * y + 0.0f * z + (-cx);
+    q.oy = 0.0f * x + 1.0f * y + 0.0f * z + (-cy);
+    q.oz = 0.0f * x + 0.0f * y + 1.0f * z + (-cz);
+    q.oex = (__builtin_fabsf(1.0f * x) + __builtin_fabsf(0.0f * y) + __builtin_fabsf(0.0f * z) + __builtin_fabsf(-cx)) * kGamma3;
+    q.oey = (__builtin_fabsf(0.0f * x) + __builtin_fabsf(1.0f * y) + __builtin_fabsf(0.0f * z) + __builtin_fabsf(-cy)) * kGamma3;
+    q.oez = (__builtin_fabsf(0.0f * x) + __builtin_fabsf(0.0f * y) + __builtin_fabsf(1.0f * z) + __builtin_fabsf(-cz)) * kGamma3;
+    float dx = r.dx, dy = r.dy, dz = r.dz;
+    q.dex = (__builtin_fabsf(1.0f * dx) + __builtin_fabsf(0.0f * dy) + __builtin_fabsf(0.0f * dz)) * kGamma3;
+    q.dey = (__builtin_fabsf(0.0f * dx) + __builtin_fabsf(1.0f * dy) + __builtin_fabsf(0.0f * dz)) * kGamma3;
+    q.dez = (__builtin_fabsf(0.0f * dx) + __builtin_fabsf(0.0f * dy) + __builtin_fabsf(1.0f * dz)) * kGamma3;
+    q.dx = 1.0f * dx + 0.0f * dy + 0.0f * dz;
+    q.dy = 0.0f * dx + 1.0f * dy + 0.0f * dz;
+    q.dz = 0.0f * dx + 0.0f * dy + 1.0f * dz;
+    float l2 = q.dx * q.dx + q.dy * q.dy + q.dz * q.dz;
+    if (l2 > 0.0f) {
+        float dt = (__builtin_fabsf(q.dx) * q.oex + __builtin_fabsf(q.dy) * q.oey + __builtin_fabsf(q.dz) * q.oez) / l2;
+        q.ox += q.dx * dt;
+        q.oy += q.dy * dt;
+        q.oz += q.dz * dt;
+    }
+    return q;
+}
+// Sphere::intersect_test (sphere.rs:228-284) for a full sphere; t_max is the world ray's. Outputs t (EFloat value)
+// and the refined object-space hit point + its phi.
+PB_DEV bool sphere_test(float cx, float cy, float cz, float radius, const TravRay& r, float tmax, float* t_out, V3* p_hit,
+                        float* phi_out) {
+    SphereRay q = sphere_object_ray(cx, cy, cz, r);
+    EFloat ox = ef_make(q.ox, q.oex), oy = ef_make(q.oy, q.oey), oz = ef_make(q.oz, q.oez);
+    EFloat dx = ef_make(q.dx, q.dex), dy = ef_make(q.dy, q.dey), dz = ef_make(q.dz, q.dez);
+    EFloat a = ef_add(ef_add(ef_mul(dx, dx), ef_mul(dy, dy)), ef_mul(dz, dz));
+    EFloat b = ef_mulf(ef_add(ef_add(ef_mul(dx, ox), ef_mul(dy, oy)), ef_mul(dz, oz)), 2.0f);
+    EFloat rr = ef_make(radius, 0.0f);
+    EFloat c = ef_sub(ef_add(ef_add(ef_mul(ox, ox), ef_mul(oy, oy)), ef_mul(oz, oz)), ef_mul(rr, rr));
+    // EFloat::quadratic (efloat.rs:64-87)
+    double discrim = (double)b.v * (double)b.v - 4.0 * (double)a.v * (double)c.v;
+    if (discrim < 0.0) return false;
+    double root = __builtin_sqrt(discrim);
+    EFloat froot = ef_make((float)root, kMachineEpsilon * (float)root);
+    EFloat qq = (b.v < 0.0f) ? ef_mulf(ef_sub(b, froot), -0.5f) : ef_mulf(ef_add(b, froot), -0.5f);
+    EFloat t0 = ef_div(qq, a), t1 = ef_div(c, qq);
+    if (t0.v > t1.v) {
+        EFloat tmp = t0;
+        t0 = t1;
+        t1 = tmp;
+    }
+    const float phi_max = 360.0f * (kPi / 180.0f);
+    for (int k = 0; k < 2; ++k) {  // the hit-selection loop of sphere.rs:259-281
+        EFloat t = k == 0 ? t0 : t1;
+        if (t.low < 0.0f || t.high > tmax) continue;
+        V3 ph = V3{q.ox + q.dx * t.v, q.oy + q.dy * t.v, q.oz + q.dz * t.v};
+        float scale = radius / __builtin_sqrtf(ph.x * ph.x + ph.y * ph.y + ph.z * ph.z);
+        ph = V3{ph.x * scale, ph.y * scale, ph.z * scale};
+        if (ph.x == 0.0f && ph.y == 0.0f) ph.x = 1e-5f * radius;
+        float phi = det_atan2(ph.y, ph.x);
+        if (phi < 0.0f) phi += 2.0f * kPi;
+        if (phi > phi_max) continue;
+        *t_out = t.v;
+        *p_hit = ph;
+        *phi_out = phi;
+        return true;
+    }
+    return false;
 }
 
 // wave-reduce the instrumented counts (all 64 lanes active), one atomic set per wave

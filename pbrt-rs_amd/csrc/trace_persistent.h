@@ -15,6 +15,7 @@
 //     together (while-while with postponed leaves).
 // Traversal state lives in registers, the stack in LDS ([entry][lane]) with a global spill slab.
 //
+// SPH = true: leaf slots may hold spheres (kPrimSphere; BASELINE config 1).
 // COUNT = true is the instrumented variant: it also counts the box tests (bvh.rs:841-842),
 // triangle tests (triangle.rs:74) and instance entries (primitive.rs:136) that the REFERENCE's
 // loops perform for the same rays. The reference pushes the far child untested and tests it when
@@ -96,7 +97,7 @@ PB_DEV bool root_box_test(const LaneState& s, const float* mn, const float* mx) 
 }
 
 // IO policy: n(), segments(), load(i, &ray, &any) -> bool real ray, store(i, any, found, t, b0, b1, b2, slot, instance)
-template <class IO, bool COUNT, bool INST>
+template <class IO, bool COUNT, bool INST, bool SPH = false>
 PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __restrict__ work_counter,
                              uint2* lds_stack, int spill_lane, unsigned long long* counters) {
     const uint32_t n = io.n();
@@ -374,7 +375,19 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
                     load_tri(bvh.tris, first + i, &p0, &p1, &p2, &flags);
                     float b0, b1, b2, t;
                     if (COUNT) n_prim += 1;
-                    if (triangle_test(p0, p1, p2, s.r, s.trc, s.tmax, &b0, &b1, &b2, &t)) {
+                    bool hit;
+                    if (SPH && (flags & kPrimSphere)) {
+                        // Sphere::intersect_test (sphere.rs:228-284); the hit record carries the refined hit point
+                        V3 ph;
+                        float phi;
+                        hit = sphere_test(p0.x, p0.y, p0.z, p1.x, s.r, s.tmax, &t, &ph, &phi);
+                        b0 = ph.x;  // a sphere's hit record carries the refined object-space hit point
+                        b1 = ph.y;
+                        b2 = ph.z;
+                    } else {
+                        hit = triangle_test(p0, p1, p2, s.r, s.trc, s.tmax, &b0, &b1, &b2, &t);
+                    }
+                    if (hit) {
                         if (s.any) {
                             done = true;
                             break;

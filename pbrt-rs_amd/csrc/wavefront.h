@@ -539,13 +539,13 @@ __global__ void k_ray_sort_keys(PathState ps, const uint32_t* __restrict__ queue
 #ifndef PB_INST_WAVES
 #define PB_INST_WAVES 5
 #endif
-template <bool COUNT, bool INST>
-__global__ void __launch_bounds__(kTraceBlock, COUNT ? 4 : (INST ? PB_INST_WAVES : PB_TRACE_WAVES))
+template <bool COUNT, bool INST, bool SPH = false>
+__global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_INST_WAVES : PB_TRACE_WAVES))
     k_trace(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
             unsigned long long* counters, int segments) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
     WavefrontRayIO io{ps, queue, n, segments};
-    trace_persistent<WavefrontRayIO, COUNT, INST>(bvh, io, work_counter, lds_stack + threadIdx.x,
+    trace_persistent<WavefrontRayIO, COUNT, INST, SPH>(bvh, io, work_counter, lds_stack + threadIdx.x,
                                                   blockIdx.x * kTraceBlock + threadIdx.x, counters);
 }
 
@@ -563,7 +563,7 @@ PB_DEV void tri_vertices(const DevBVH& bvh, int slot, V3* p0, V3* p1, V3* p2, in
     *p2 = V3{b.z, b.w, c.x};
     *prim = __float_as_int(c.y);
     *mat = __float_as_int(c.z);
-    *light = (__float_as_int(c.w) & 0x3fffffff) - 1;
+    *light = (__float_as_int(c.w) & kPrimLightMask) - 1;
 }
 
 // Triangle::intersect past the hit test (triangle.rs:193-316): dpdu from the (default or per-vertex) uvs, the
@@ -692,8 +692,52 @@ PB_DEV void instance_to_world(const DevBVH& bvh, int inst_slot, Surf* s) {
     if (mat >= 0) s->material = mat;
     s->light = -1;  // instanced primitives carry no area lights
 }
+// Sphere::intersect past the hit test (sphere.rs:38-92) for a full sphere placed by translate(centre): partial
+// derivatives, SurfaceInteraction::new, then pbrt-v3's Transform(SurfaceInteraction) through that translation (every
+// product of the general matrix formulas is kept, as in sphere_object_ray). ph = the refined object-space hit point.
+PB_DEV Surf make_surface_sphere(const DevBVH& bvh, int slot, V3 ph, V3 rd) {
+    float4 a = bvh.tris[3 * (size_t)slot], c4 = bvh.tris[3 * (size_t)slot + 2];
+    float cx = a.x, cy = a.y, cz = a.z, radius = a.w;
+    Surf s;
+    s.material = __float_as_int(c4.z);
+    s.light = (__float_as_int(c4.w) & kPrimLightMask) - 1;
+    const float phi_max = 360.0f * (kPi / 180.0f);
+    const float theta_min = det_acos(clampf(fminr(-radius, radius) / radius, -1.0f, 1.0f));
+    const float theta_max = det_acos(clampf(fmaxr(-radius, radius) / radius, -1.0f, 1.0f));
+    float theta = det_acos(clampf(ph.z / radius, -1.0f, 1.0f));
+    float z_radius = __builtin_sqrtf(ph.x * ph.x + ph.y * ph.y);
+    float inv_z_radius = 1.0f / z_radius;
+    float cos_phi = ph.x * inv_z_radius, sin_phi = ph.y * inv_z_radius;
+    V3 dpdu = V3{-phi_max * ph.y, phi_max * ph.x, 0.0f};
+    V3 dpdv = V3{ph.z * cos_phi, ph.z * sin_phi, -radius * det_sin(theta)} * (theta_max - theta_min);
+    V3 n = normalize(cross(dpdu, dpdv));  // SurfaceInteraction::new (interaction.rs:248-300)
+    V3 pe = vabs(ph) * kGamma5;
+    // Transform(SurfaceInteraction) with m = translate(c), m_inv = translate(-c)
+    const float g3 = kGamma3;
+    float x = ph.x, y = ph.y, z = ph.z;
+    s.p = V3{1.0f * x + 0.0f * y + 0.0f * z + cx, 0.0f * x + 1.0f * y + 0.0f * z + cy, 0.0f * x + 0.0f * y + 1.0f * z + cz};
+    s.p_error.x = (g3 + 1.0f) * (__builtin_fabsf(1.0f * pe.x) + __builtin_fabsf(0.0f * pe.y) + __builtin_fabsf(0.0f * pe.z)) +
+                  g3 * (__builtin_fabsf(1.0f * x) + __builtin_fabsf(0.0f * y) + __builtin_fabsf(0.0f * z) + __builtin_fabsf(cx));
+    s.p_error.y = (g3 + 1.0f) * (__builtin_fabsf(0.0f * pe.x) + __builtin_fabsf(1.0f * pe.y) + __builtin_fabsf(0.0f * pe.z)) +
+                  g3 * (__builtin_fabsf(0.0f * x) + __builtin_fabsf(1.0f * y) + __builtin_fabsf(0.0f * z) + __builtin_fabsf(cy));
+    s.p_error.z = (g3 + 1.0f) * (__builtin_fabsf(0.0f * pe.x) + __builtin_fabsf(0.0f * pe.y) + __builtin_fabsf(1.0f * pe.z)) +
+                  g3 * (__builtin_fabsf(0.0f * x) + __builtin_fabsf(0.0f * y) + __builtin_fabsf(1.0f * z) + __builtin_fabsf(cz));
+    auto through = [](V3 v) {  // upper 3x3 of either matrix (the identity), as xform_vector / xform_normal evaluate it
+        return V3{1.0f * v.x + 0.0f * v.y + 0.0f * v.z, 0.0f * v.x + 1.0f * v.y + 0.0f * v.z, 0.0f * v.x + 0.0f * v.y + 1.0f * v.z};
+    };
+    s.n = normalize(through(n));
+    V3 d_obj = through(rd);  // the object-space ray direction of sphere_object_ray
+    s.wo = normalize(through(-d_obj));
+    s.dpdu = through(dpdu);
+    V3 sn = normalize(through(n));  // shading.n = n before the transform (D47)
+    s.ns = dot(sn, s.n) < 0.0f ? -sn : sn;
+    s.sdpdu = through(dpdu);
+    return s;
+}
 // Hit record -> world-space surface. `rd` is the world-space ray direction.
 PB_DEV Surf surface_from_hit(const DevBVH& bvh, int slot, int inst_slot, float b0, float b1, float b2, V3 rd) {
+    if (bvh.has_spheres && (__float_as_int(bvh.tris[3 * (size_t)slot + 2].w) & kPrimSphere))
+        return make_surface_sphere(bvh, slot, V3{b0, b1, b2}, rd);
     if (bvh.instanced && inst_slot >= 0) {
         const float4* m = bvh.instances + 7 * (size_t)inst_slot;
         float4 r0 = m[0], r1 = m[1], r2 = m[2];
@@ -1153,7 +1197,7 @@ PB_DEV V3 estimate_direct_resolve(const ShadeConsts& sc, const PathState& ps, ui
         V3 li = V3{0.0f, 0.0f, 0.0f};
         if (hslot >= 0) {
             // D26 (intended): Le only when the hit primitive's area light is this light
-            int hl = (__float_as_int(sc.bvh.tris[3 * (size_t)hslot + 2].w) & 0x3fffffff) - 1;
+            int hl = (__float_as_int(sc.bvh.tris[3 * (size_t)hslot + 2].w) & kPrimLightMask) - 1;
             if (hl == light_id) {
                 float4 hb = ps.hit[rbase + RS_MIS * 2];
                 V3 n = tri_interaction_normal(sc.bvh, hslot, hb.y, hb.z, hb.w);

@@ -26,7 +26,7 @@ SAMPLER_RANDOM, SAMPLER_STRATIFIED, SAMPLER_ZEROTWO, SAMPLER_HALTON = 0, 1, 2, 3
 EXPORTS = [
     "pbrt_hip_context_create", "pbrt_hip_context_destroy", "pbrt_hip_last_error", "pbrt_hip_bvh_build",
     "pbrt_hip_free", "pbrt_hip_bvh_build_boxes", "pbrt_hip_instance_bounds", "pbrt_hip_scene_create",
-    "pbrt_hip_scene_create_instanced", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
+    "pbrt_hip_scene_create_instanced", "pbrt_hip_scene_create_with_spheres", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
     "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
     "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png",
@@ -78,6 +78,8 @@ def lib():
         L.pbrt_hip_scene_create_hlbvh.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, i32, ctypes.POINTER(vp),
                                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.pbrt_hip_scene_set_shading_data.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
+        L.pbrt_hip_scene_create_with_spheres.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp,
+                                                         ctypes.POINTER(vp)]
         L.pbrt_hip_free.argtypes = [vp]
         L.pbrt_hip_free.restype = None
         L.pbrt_hip_scene_create.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp,
@@ -271,6 +273,10 @@ class Scene:
         materials = np.ascontiguousarray(scene["materials"], dtype=MATERIAL_DTYPE)
         tri_light = np.ascontiguousarray(scene["tri_light"], dtype=np.int32)
         lights = np.ascontiguousarray(scene["lights"], dtype=LIGHT_DTYPE)
+        spheres = scene.get("spheres")
+        if spheres is not None and len(spheres):
+            self._init_with_spheres(scene, tri_material, materials, tri_light, lights, max_prims_in_node, split_method, bvh)
+            return
         if bvh is None:
             bvh = bvh_build(self.positions, self.indices, max_prims_in_node, split_method)
         self.nodes, self.prim_order = bvh
@@ -283,6 +289,29 @@ class Scene:
         self.h = h
         ctx._scenes.add(self)
         self._set_shading_data(scene)
+
+    def _init_with_spheres(self, scene, tri_material, materials, tri_light, lights, max_prims_in_node, split_method, bvh):
+        """scene["spheres"]: (n, 8) {centre.xyz, radius, material, light (-1), 0, 0}; sphere i is primitive n_tris + i."""
+        sph = np.ascontiguousarray(scene["spheres"], dtype=np.float32).reshape(-1, 8)
+        if np.any(sph[:, 5] >= 0):
+            raise PbrtHipError("spheres cannot be area lights on the device")
+        if bvh is None:
+            tri = self.positions[self.indices]                       # Triangle::world_bound (triangle.rs:175-180)
+            c, r = sph[:, :3], sph[:, 3:4]
+            lo = np.concatenate([tri.min(axis=1), c + (-r)])         # Sphere::world_bound through translate(c)
+            hi = np.concatenate([tri.max(axis=1), c + r])
+            bvh = bvh_build_boxes(lo, hi, max_prims_in_node, split_method)
+        self.nodes, self.prim_order = bvh
+        sph4 = np.ascontiguousarray(sph[:, :4])
+        sph_mat = np.ascontiguousarray(sph[:, 4].astype(np.int32))
+        h = ctypes.c_void_p()
+        rc = lib().pbrt_hip_scene_create_with_spheres(
+            self.ctx.h, _p(self.positions), self.positions.shape[0], _p(self.indices), self.indices.shape[0], _p(tri_material),
+            _p(materials), len(materials), _p(tri_light), _p(lights) if len(lights) else None, len(lights), _p(sph4),
+            _p(sph_mat), len(sph4), _p(self.nodes), len(self.nodes), _p(self.prim_order), ctypes.byref(h))
+        self.ctx.check(rc, "pbrt_hip_scene_create_with_spheres")
+        self.h = h
+        self.ctx._scenes.add(self)
 
     def _set_shading_data(self, scene):
         """TriangleMesh n / uv (triangle.rs:17-26): scene["normals"] / scene["tangents"] (n_verts, 3), scene["uvs"] (n_verts, 2), optional."""

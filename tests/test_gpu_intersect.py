@@ -249,3 +249,37 @@ def test_scene_create_hlbvh_on_device(hip_ctx, which):
     assert f_dev.tobytes() == f_host.tobytes() and st_dev["rays_shadow"] == st_host["rays_shadow"]
     g_dev.close()
     g_host.close()
+
+
+def test_sphere_intersection_parity(hip_ctx):
+    """Ray batches against spheres + triangles: same hit primitive and bit-identical t as the oracle's
+    Sphere::intersect_test (EFloat quadratic), same any-hit answers, same reference-loop test counts, same tree."""
+    sc = scenes.mixed_materials_scene()
+    u = scenes.pcg32_float(13, 40 * 4).reshape(40, 4)
+    sph = np.zeros((40, 8), dtype=np.float32)
+    sph[:, :3], sph[:, 3], sph[:, 5] = u[:, :3] * 1.6 - 0.8, 0.03 + 0.25 * u[:, 3], -1
+    sc["spheres"] = sph
+    osc = oracle.OracleScene(sc)
+    gsc = pbrt_hip.Scene(hip_ctx, sc)
+    assert osc.nodes().tobytes() == gsc.nodes.tobytes() and np.array_equal(osc.prim_order(), gsc.prim_order)
+    rays = scenes.random_rays(300_000, 31, origin_extent=1.5)
+    rays["t_max"][:1000] = 0.5                                   # some short rays
+    inside = rays[:2000].copy()
+    inside["o"] = sph[np.arange(2000) % 40, :3]                  # rays starting at sphere centres (second root is the hit)
+    rays = np.concatenate([rays, inside])
+    cpu, st_c = osc.intersect(rays)
+    hip_ctx.set_counting(True)
+    hip_ctx.counters(reset=True)
+    gpu = gsc.intersect(rays)
+    c_g = hip_ctx.counters(reset=True)
+    hip_ctx.set_counting(False)
+    assert np.array_equal(gpu["prim_id"], cpu["prim_id"]) and np.array_equal(gpu["t"], cpu["t"])
+    n_tris = sc["indices"].shape[0]
+    tri_hit = (cpu["prim_id"] >= 0) & (cpu["prim_id"] < n_tris)
+    for f in ("b0", "b1", "b2"):
+        assert np.array_equal(gpu[f][tri_hit], cpu[f][tri_hit])
+    assert (cpu["prim_id"] >= n_tris).sum() > 10_000
+    assert (c_g["node_tests"], c_g["prim_tests"]) == (st_c["node_tests"], st_c["prim_tests"])
+    assert np.array_equal(gsc.intersect_p(rays), osc.intersect_p(rays)[0])
+    gsc.close()
+    osc.close()

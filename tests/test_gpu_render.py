@@ -515,3 +515,40 @@ def test_other_cameras(hip_ctx, kind):
     assert rgb.mean() > 0.05
     if kind == "environment":
         assert rgb.max() > 10.0          # the camera sits inside the box and sees the emitter overhead
+
+
+def _sphere_cloud(n_spheres, seq=11):
+    """The mixed-material triangle scene plus `n_spheres` spheres of the three materials."""
+    sc = scenes.mixed_materials_scene()
+    u = scenes.pcg32_float(seq, n_spheres * 4).reshape(n_spheres, 4)
+    sph = np.zeros((n_spheres, 8), dtype=np.float32)
+    sph[:, :3] = u[:, :3] * 1.6 - 0.8
+    sph[:, 3] = 0.05 + 0.2 * u[:, 3]
+    sph[:, 4] = np.arange(n_spheres) % len(sc["materials"])
+    sph[:, 5] = -1
+    sc["spheres"] = sph
+    return sc
+
+
+def test_config1_sphere_on_device(hip_ctx):
+    """BASELINE config 1 on the GPU: unit matte sphere under a quad area light, DirectLightingIntegrator,
+    256x256x4 spp (Sphere::intersect with EFloat error bounds, sphere.rs:38-92, 228-284; efloat.rs)."""
+    w = h = 256
+    sc, cam = scenes.sphere_scene(), scenes.sphere_camera(w, h)
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, cam, w, h, 4, integrator=1, max_depth=5, light_strategy=0, seed=0)
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    rgb = pbrt_hip.film_to_rgb(film_g)
+    assert rgb[h // 2, w // 2].mean() > 0.01 and rgb[4, 4].mean() == 0.0     # lit sphere in the middle, black corner
+
+
+@pytest.mark.parametrize("integrator,kw", [(0, dict(max_depth=6, light_strategy=1)), (1, dict(max_depth=3, light_strategy=1)),
+                                           (2, dict(max_depth=4)), (3, dict(ao_samples=4))])
+def test_spheres_among_triangles(hip_ctx, integrator, kw):
+    """Spheres (matte / mirror / glass) mixed with triangles in one BVHAccel, every integrator."""
+    w, h = 64, 48
+    sc = _sphere_cloud(24)
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, scenes.random_triangles_camera(w, h), w, h, 4,
+                                              integrator=integrator, seed=97, **kw)
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
