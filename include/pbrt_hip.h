@@ -242,13 +242,14 @@ int pbrt_hip_scene_set_shading_data(PbrtHipScene* scene, const float* positions,
 /* Scene with spheres next to the triangles (src/shapes/sphere.rs:38-92, 228-284 with src/core/efloat.rs; BASELINE
  * config 1): n_spheres full spheres {centre.xyz, radius}, i.e. Sphere::new with object_to_world = translate(centre).
  * Sphere i is primitive n_tris + i in prim_order; nodes come from pbrt_hip_bvh_build_boxes over the primitives' world
- * bounds (triangles first). Spheres cannot be area lights here. Hit records of spheres carry the refined object-space
- * hit point in (b0, b1, b2). */
+ * bounds (triangles first). sphere_light[i] = index of the sphere's DiffuseAreaLight (whose `prim` is n_tris + i) or -1
+ * (Sphere::sample2 / pdf2, sphere.rs:123-192). Hit records of spheres carry the refined object-space hit point in
+ * (b0, b1, b2). */
 int pbrt_hip_scene_create_with_spheres(PbrtHipContext* ctx, const float* positions, int32_t n_verts, const int32_t* indices,
                                        int32_t n_tris, const int32_t* tri_material, const PbrtMaterial* materials,
                                        int32_t n_materials, const int32_t* tri_light, const PbrtLight* lights,
                                        int32_t n_lights, const float* spheres, const int32_t* sphere_material,
-                                       int32_t n_spheres, const PbrtLinearBVHNode* nodes, int32_t n_nodes,
+                                       const int32_t* sphere_light, int32_t n_spheres, const PbrtLinearBVHNode* nodes, int32_t n_nodes,
                                        const int32_t* prim_order, PbrtHipScene** out);
 /* Two-level scene (BASELINE config 5): `n_instances` TransformedPrimitives of ONE object-space
  * triangle aggregate. blas_* = BVHAccel over the triangles (object space); tlas_* = BVHAccel over the

@@ -231,6 +231,7 @@ static const char* convert_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes,
 struct SphereArgs {
     const float* spheres = nullptr;  // n x {centre.xyz, radius}
     const int32_t* material = nullptr;
+    const int32_t* light = nullptr;  // per sphere: index of its DiffuseAreaLight or -1
     int32_t n = 0;
 };
 struct InstancingArgs {
@@ -305,12 +306,13 @@ extern "C" int pbrt_hip_scene_create_with_spheres(PbrtHipContext* ctx, const flo
                                                   const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
                                                   const PbrtMaterial* materials, int32_t n_materials, const int32_t* tri_light,
                                                   const PbrtLight* lights, int32_t n_lights, const float* spheres,
-                                                  const int32_t* sphere_material, int32_t n_spheres,
+                                                  const int32_t* sphere_material, const int32_t* sphere_light, int32_t n_spheres,
                                                   const PbrtLinearBVHNode* nodes, int32_t n_nodes, const int32_t* prim_order,
                                                   PbrtHipScene** out) {
     SphereArgs sa;
     sa.spheres = spheres;
     sa.material = sphere_material;
+    sa.light = sphere_light;
     sa.n = n_spheres;
     return scene_create_impl(ctx, positions, n_verts, indices, n_tris, tri_material, materials, n_materials, tri_light,
                              lights, n_lights, nodes, n_nodes, prim_order, InstancingArgs(), out, nullptr, sa);
@@ -369,6 +371,7 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     for (int32_t i = 0; i < sa.n; ++i) {
         if (!(sa.spheres[4 * i + 3] > 0.0f)) return fail("sphere radius must be positive");
         if (sa.material && (sa.material[i] < 0 || sa.material[i] >= n_materials)) return fail("sphere material out of range");
+        if (sa.light && (sa.light[i] < -1 || sa.light[i] >= n_lights)) return fail("sphere light out of range");
     }
     for (int32_t i = 0; i < n_prims && !dt; ++i)
         if (prim_order[i] < 0 || prim_order[i] >= n_prims) return fail("prim_order entry out of range");
@@ -378,8 +381,8 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     }
     for (int32_t i = 0; i < n_lights; ++i) {
         if (lights[i].type < PBRT_LIGHT_DIFFUSE_AREA || lights[i].type > PBRT_LIGHT_DISTANT) return fail("unknown light type");
-        if (lights[i].type == PBRT_LIGHT_DIFFUSE_AREA && (lights[i].prim < 0 || lights[i].prim >= n_tris))
-            return fail("area light triangle out of range");
+        if (lights[i].type == PBRT_LIGHT_DIFFUSE_AREA && (lights[i].prim < 0 || lights[i].prim >= n_tris + sa.n))
+            return fail("area light primitive out of range");
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
@@ -435,7 +438,8 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
             float* t = &tris[(size_t)slot * 12];
             t[0] = sp[0]; t[1] = sp[1]; t[2] = sp[2]; t[3] = sp[3];
             for (int k = 4; k < 9; ++k) t[k] = 0.0f;
-            int32_t meta[3] = {prim, sa.material ? sa.material[prim - n_tris] : 0, kPrimSphere};
+            int32_t meta[3] = {prim, sa.material ? sa.material[prim - n_tris] : 0,
+                               (sa.light ? sa.light[prim - n_tris] + 1 : 0) | kPrimSphere};
             std::memcpy(t + 9, meta, 12);
             continue;
         }
@@ -486,10 +490,15 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         if (l.type == PBRT_LIGHT_DIFFUSE_AREA) {
             int32_t prim = lights[i].prim;
             l.slot = dt ? dt->light_slot[i] : prim_slot[prim];
-            const float* a = positions + 3 * (size_t)indices[3 * (size_t)prim];
-            const float* b = positions + 3 * (size_t)indices[3 * (size_t)prim + 1];
-            const float* c = positions + 3 * (size_t)indices[3 * (size_t)prim + 2];
-            l.area = tri_area(a, b, c);
+            if (prim >= n_tris) {
+                float r = sa.spheres[4 * (size_t)(prim - n_tris) + 3];
+                l.area = (360.0f * (kPi / 180.0f)) * r * (r - (-r));  // Sphere::area (sphere.rs:99-101)
+            } else {
+                const float* a = positions + 3 * (size_t)indices[3 * (size_t)prim];
+                const float* b = positions + 3 * (size_t)indices[3 * (size_t)prim + 1];
+                const float* c = positions + 3 * (size_t)indices[3 * (size_t)prim + 2];
+                l.area = tri_area(a, b, c);
+            }
             scale = (l.two_sided ? 2.0f : 1.0f) * l.area * kPi;  // diffuse.rs:83-85
         } else if (l.type == PBRT_LIGHT_POINT) {
             scale = 4.0f * kPi;  // point.rs:65-67

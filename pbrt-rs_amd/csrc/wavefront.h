@@ -752,6 +752,8 @@ PB_DEV Surf surface_from_hit(const DevBVH& bvh, int slot, int inst_slot, float b
 }
 // SurfaceInteraction::n of a hit at barycentrics (b0, b1, b2): the geometric normal, on the shading normal's side
 PB_DEV V3 tri_interaction_normal(const DevBVH& bvh, int slot, float b0, float b1, float b2) {
+    if (bvh.has_spheres && (__float_as_int(bvh.tris[3 * (size_t)slot + 2].w) & kPrimSphere))
+        return make_surface_sphere(bvh, slot, V3{b0, b1, b2}, V3{0.0f, 0.0f, 1.0f}).n;  // (b0, b1, b2) = the hit point
     V3 p0, p1, p2;
     int a, b, c;
     tri_vertices(bvh, slot, &p0, &p1, &p2, &a, &b, &c);
@@ -927,6 +929,81 @@ PB_DEV V3 surface_le(const ShadeConsts& sc, const Surf& sf, V3 w) {
     return V3{0.0f, 0.0f, 0.0f};
 }
 
+// ---- a Sphere as the shape of a DiffuseAreaLight: Sphere::sample / sample2 / pdf2 (sphere.rs:103-192), full sphere
+// placed by translate(c) ----
+PB_DEV V3 sphere_through(V3 v) {  // upper 3x3 of translate(+-c) as the matrix formulas evaluate it
+    return V3{1.0f * v.x + 0.0f * v.y + 0.0f * v.z, 0.0f * v.x + 1.0f * v.y + 0.0f * v.z, 0.0f * v.x + 0.0f * v.y + 1.0f * v.z};
+}
+PB_DEV float sphere_area(float radius) { return (360.0f * (kPi / 180.0f)) * radius * (radius - (-radius)); }  // sphere.rs:99-101
+// Shape::sample2 for the sphere: point, error, normal on the sphere and the solid-angle pdf from `sf`
+PB_DEV void sphere_light_sample(float cx, float cy, float cz, float radius, const Surf& sf, float u0, float u1, V3* p_o,
+                                V3* err_o, V3* n_o, float* pdf_o) {
+    V3 pc = V3{1.0f * 0.0f + 0.0f * 0.0f + 0.0f * 0.0f + cx, 0.0f * 0.0f + 1.0f * 0.0f + 0.0f * 0.0f + cy,
+               0.0f * 0.0f + 0.0f * 0.0f + 1.0f * 0.0f + cz};
+    V3 p_origin = offset_ray_origin(sf.p, sf.p_error, sf.n, pc - sf.p);
+    if (len2(p_origin - pc) <= radius * radius) {
+        // inside: Sphere::sample (sphere.rs:103-121), area pdf converted to solid angle
+        float z = 1.0f - 2.0f * u0;
+        float rr = __builtin_sqrtf(fmaxr(1.0f - z * z, 0.0f));
+        float sp, cp;
+        det_sincos(2.0f * kPi * u1, &sp, &cp);
+        V3 obj = V3{rr * cp, rr * sp, z} * radius;
+        V3 n = normalize(sphere_through(obj));
+        obj = obj * (radius / length(obj));
+        V3 oe = vabs(obj) * kGamma5;
+        const float g3 = kGamma3;
+        V3 p = V3{1.0f * obj.x + 0.0f * obj.y + 0.0f * obj.z + cx, 0.0f * obj.x + 1.0f * obj.y + 0.0f * obj.z + cy,
+                  0.0f * obj.x + 0.0f * obj.y + 1.0f * obj.z + cz};
+        V3 err;
+        err.x = (g3 + 1.0f) * (__builtin_fabsf(1.0f * oe.x) + __builtin_fabsf(0.0f * oe.y) + __builtin_fabsf(0.0f * oe.z)) +
+                g3 * (__builtin_fabsf(1.0f * obj.x) + __builtin_fabsf(0.0f * obj.y) + __builtin_fabsf(0.0f * obj.z) + __builtin_fabsf(cx));
+        err.y = (g3 + 1.0f) * (__builtin_fabsf(0.0f * oe.x) + __builtin_fabsf(1.0f * oe.y) + __builtin_fabsf(0.0f * oe.z)) +
+                g3 * (__builtin_fabsf(0.0f * obj.x) + __builtin_fabsf(1.0f * obj.y) + __builtin_fabsf(0.0f * obj.z) + __builtin_fabsf(cy));
+        err.z = (g3 + 1.0f) * (__builtin_fabsf(0.0f * oe.x) + __builtin_fabsf(0.0f * oe.y) + __builtin_fabsf(1.0f * oe.z)) +
+                g3 * (__builtin_fabsf(0.0f * obj.x) + __builtin_fabsf(0.0f * obj.y) + __builtin_fabsf(1.0f * obj.z) + __builtin_fabsf(cz));
+        float pdf = 1.0f / sphere_area(radius);
+        V3 wi = p - sf.p;
+        if (len2(wi) == 0.0f) {
+            pdf = 0.0f;
+        } else {
+            wi = normalize(wi);
+            pdf *= len2(sf.p - p) / absdot(n, -wi);
+        }
+        if (__builtin_isinf(pdf)) pdf = 0.0f;
+        *p_o = p;
+        *err_o = err;
+        *n_o = n;
+        *pdf_o = pdf;
+        return;
+    }
+    // outside: uniform sampling of the cone the sphere subtends (sphere.rs:140-178)
+    float dc = length(sf.p - pc);
+    float inv_dc = 1.0f / dc;
+    V3 wc = (pc - sf.p) * inv_dc, wc_x, wc_y;
+    coordinate_system(wc, &wc_x, &wc_y);
+    float sin_theta_max = radius * inv_dc;
+    float sin_theta_max2 = sin_theta_max * sin_theta_max;
+    float inv_sin_theta_max = 1.0f / sin_theta_max;
+    float cos_theta_max = __builtin_sqrtf(fmaxr(1.0f - sin_theta_max2, 0.0f));
+    float cos_theta = (cos_theta_max - 1.0f) * u0 + 1.0f;
+    float sin_theta2 = 1.0f - cos_theta * cos_theta;
+    if (sin_theta_max2 < 0.00068523f) {
+        sin_theta2 = sin_theta_max2 * u0;
+        cos_theta = __builtin_sqrtf(1.0f - sin_theta2);
+    }
+    float cos_alpha = sin_theta2 * inv_sin_theta_max +
+                      cos_theta * __builtin_sqrtf(fmaxr(1.0f - sin_theta2 * inv_sin_theta_max * inv_sin_theta_max, 0.0f));
+    float sin_alpha = __builtin_sqrtf(fmaxr(1.0f - cos_alpha * cos_alpha, 0.0f));
+    float sp, cp;
+    det_sincos(u1 * 2.0f * kPi, &sp, &cp);
+    V3 n_world = (-wc_x) * sin_alpha * cp + (-wc_y) * sin_alpha * sp + (-wc) * cos_alpha;
+    V3 p_world = pc + n_world * radius;
+    *p_o = p_world;
+    *err_o = vabs(p_world) * kGamma5;
+    *n_o = n_world;
+    *pdf_o = 1.0f / (2.0f * kPi * (1.0f - cos_theta_max));
+}
+
 // Light::sample_li (light.rs:35-42): DiffuseAreaLight (diffuse.rs:60-81 with Triangle::sample / Shape::sample2)
 // or InfiniteAreaLight (infinite.rs:96-129). Outputs the visibility tester's far point (p1, error, normal).
 PB_DEV void light_sample_li(const ShadeConsts& sc, const Surf& sf, const DevLight& lt, float ul0, float ul1, V3* wi_o,
@@ -936,7 +1013,20 @@ PB_DEV void light_sample_li(const ShadeConsts& sc, const Surf& sf, const DevLigh
     V3 li = V3{0.0f, 0.0f, 0.0f};
     V3 p1 = V3{0.0f, 0.0f, 0.0f}, p1_err = V3{0.0f, 0.0f, 0.0f}, p1_n = V3{0.0f, 0.0f, 0.0f};
     V3 Lc = V3{lt.L[0], lt.L[1], lt.L[2]};
-    if (lt.type == PBRT_LIGHT_DIFFUSE_AREA) {
+    if (lt.type == PBRT_LIGHT_DIFFUSE_AREA && sc.bvh.has_spheres &&
+        (__float_as_int(sc.bvh.tris[3 * (size_t)lt.slot + 2].w) & kPrimSphere)) {
+        float4 rec = sc.bvh.tris[3 * (size_t)lt.slot];
+        float pdf;
+        sphere_light_sample(rec.x, rec.y, rec.z, rec.w, sf, ul0, ul1, &p1, &p1_err, &p1_n, &pdf);
+        // DiffuseAreaLight::sample_li (diffuse.rs:60-81)
+        if (pdf == 0.0f || len2(p1 - sf.p) == 0.0f) {
+            light_pdf = 0.0f;
+        } else {
+            light_pdf = pdf;
+            wi = normalize(p1 - sf.p);
+            if (lt.two_sided || dot(p1_n, -wi) > 0.0f) li = Lc;
+        }
+    } else if (lt.type == PBRT_LIGHT_DIFFUSE_AREA) {
         // Triangle::sample (triangle.rs:330-348) + Shape::sample2 (shape.rs:38-53)
         V3 q0, q1, q2;
         int fl;
@@ -1063,6 +1153,8 @@ __global__ void k_spatial_light_tables(ShadeConsts sc, float* __restrict__ table
     for (uint32_t i = 0; i < 128u; ++i) {
         float t[3] = {radical_inverse_small(0, i), radical_inverse_small(1, i), radical_inverse_small(2, i)};
         Surf sf;
+        sf.n = V3{0.0f, 0.0f, 0.0f};        // BaseInteraction::new(po, Normal3f::default(), ..) (lightdistrib.rs:133-140)
+        sf.p_error = V3{0.0f, 0.0f, 0.0f};
         sf.p = V3{(1.0f - t[0]) * vlo[0] + t[0] * vhi[0], (1.0f - t[1]) * vlo[1] + t[1] * vhi[1], (1.0f - t[2]) * vlo[2] + t[2] * vhi[2]};
         float u0 = radical_inverse_small(3, i), u1 = radical_inverse_small(4, i);
         for (int j = 0; j < n; ++j) {
@@ -1135,7 +1227,33 @@ PB_DEV int estimate_direct_emit(const ShadeConsts& sc, const PathState& ps, uint
     if (ok) f2 = f2 * absdot(wi2, fr.ns);
     if (ok && !is_black(f2) && spdf > 0.0f) {
         float lpdf;
-        if (lt.type == PBRT_LIGHT_DIFFUSE_AREA) {
+        if (lt.type == PBRT_LIGHT_DIFFUSE_AREA && sc.bvh.has_spheres &&
+            (__float_as_int(sc.bvh.tris[3 * (size_t)lt.slot + 2].w) & kPrimSphere)) {
+            // Sphere::pdf2 (sphere.rs:181-192)
+            float4 rec = sc.bvh.tris[3 * (size_t)lt.slot];
+            float radius = rec.w;
+            V3 pc = V3{1.0f * 0.0f + 0.0f * 0.0f + 0.0f * 0.0f + rec.x, 0.0f * 0.0f + 1.0f * 0.0f + 0.0f * 0.0f + rec.y,
+                       0.0f * 0.0f + 0.0f * 0.0f + 1.0f * 0.0f + rec.z};
+            V3 p_origin = offset_ray_origin(sf.p, sf.p_error, sf.n, pc - sf.p);
+            if (len2(p_origin - pc) < radius * radius) {
+                // Shape::pdf2 (shape.rs:54-69): intersect the sphere along wi
+                V3 o2 = offset_ray_origin(sf.p, sf.p_error, sf.n, wi2);
+                TravRay rr{o2.x, o2.y, o2.z, wi2.x, wi2.y, wi2.z, kInf};
+                float th, phi_h;
+                V3 ph;
+                if (!sphere_test(rec.x, rec.y, rec.z, radius, rr, kInf, &th, &ph, &phi_h)) {
+                    lpdf = 0.0f;
+                } else {
+                    Surf hs = make_surface_sphere(sc.bvh, lt.slot, ph, wi2);
+                    lpdf = len2(sf.p - hs.p) / (absdot(hs.n, -wi2) * sphere_area(radius));
+                    if (__builtin_isinf(lpdf)) lpdf = 0.0f;
+                }
+            } else {
+                float sin_theta_max2 = radius * radius / len2(sf.p - pc);
+                float cos_theta_max = __builtin_sqrtf(fmaxr(1.0f - sin_theta_max2, 0.0f));
+                lpdf = 1.0f / (2.0f * kPi * (1.0f - cos_theta_max));
+            }
+        } else if (lt.type == PBRT_LIGHT_DIFFUSE_AREA) {
             // Shape::pdf2 (shape.rs:54-69)
             V3 o2 = offset_ray_origin(sf.p, sf.p_error, sf.n, wi2);
             V3 ph, nh;

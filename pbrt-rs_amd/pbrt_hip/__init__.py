@@ -78,7 +78,7 @@ def lib():
         L.pbrt_hip_scene_create_hlbvh.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, i32, ctypes.POINTER(vp),
                                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.pbrt_hip_scene_set_shading_data.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
-        L.pbrt_hip_scene_create_with_spheres.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp,
+        L.pbrt_hip_scene_create_with_spheres.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp,
                                                          ctypes.POINTER(vp)]
         L.pbrt_hip_free.argtypes = [vp]
         L.pbrt_hip_free.restype = None
@@ -291,10 +291,8 @@ class Scene:
         self._set_shading_data(scene)
 
     def _init_with_spheres(self, scene, tri_material, materials, tri_light, lights, max_prims_in_node, split_method, bvh):
-        """scene["spheres"]: (n, 8) {centre.xyz, radius, material, light (-1), 0, 0}; sphere i is primitive n_tris + i."""
+        """scene["spheres"]: (n, 8) {centre.xyz, radius, material, light index or -1, 0, 0}; sphere i is primitive n_tris + i."""
         sph = np.ascontiguousarray(scene["spheres"], dtype=np.float32).reshape(-1, 8)
-        if np.any(sph[:, 5] >= 0):
-            raise PbrtHipError("spheres cannot be area lights on the device")
         if bvh is None:
             tri = self.positions[self.indices]                       # Triangle::world_bound (triangle.rs:175-180)
             c, r = sph[:, :3], sph[:, 3:4]
@@ -304,11 +302,12 @@ class Scene:
         self.nodes, self.prim_order = bvh
         sph4 = np.ascontiguousarray(sph[:, :4])
         sph_mat = np.ascontiguousarray(sph[:, 4].astype(np.int32))
+        sph_light = np.ascontiguousarray(sph[:, 5].astype(np.int32))
         h = ctypes.c_void_p()
         rc = lib().pbrt_hip_scene_create_with_spheres(
             self.ctx.h, _p(self.positions), self.positions.shape[0], _p(self.indices), self.indices.shape[0], _p(tri_material),
             _p(materials), len(materials), _p(tri_light), _p(lights) if len(lights) else None, len(lights), _p(sph4),
-            _p(sph_mat), len(sph4), _p(self.nodes), len(self.nodes), _p(self.prim_order), ctypes.byref(h))
+            _p(sph_mat), _p(sph_light), len(sph4), _p(self.nodes), len(self.nodes), _p(self.prim_order), ctypes.byref(h))
         self.ctx.check(rc, "pbrt_hip_scene_create_with_spheres")
         self.h = h
         self.ctx._scenes.add(self)

@@ -552,3 +552,25 @@ def test_spheres_among_triangles(hip_ctx, integrator, kw):
                                               integrator=integrator, seed=97, **kw)
     _compare(film_g, film_c)
     assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+
+
+@pytest.mark.parametrize("integrator,kw", [(0, dict(max_depth=5, light_strategy=1)), (0, dict(max_depth=4, light_strategy=2)),
+                                           (1, dict(max_depth=3, light_strategy=0)), (2, dict(max_depth=3))])
+def test_sphere_area_lights(hip_ctx, integrator, kw):
+    """Spheres as DiffuseAreaLights: Sphere::sample2 (cone sampling from outside, area sampling from inside,
+    sphere.rs:123-179) and pdf2 (:181-192) for MIS; a small emitter inside the Cornell box and a large one that
+    encloses the camera path's vertices."""
+    w = h = 64
+    sc = scenes.cornell_box()
+    n_tris, n_l = sc["indices"].shape[0], len(sc["lights"])
+    sph = np.zeros((2, 8), dtype=np.float32)
+    sph[0] = (400.0, 300.0, 200.0, 40.0, 0, n_l, 0, 0)              # small two-sided-off emitter inside the box
+    sph[1] = (278.0, 278.0, 278.0, 2000.0, 0, n_l + 1, 0, 0)        # encloses the whole scene: "inside" branch
+    sc["spheres"] = sph
+    extra = scenes._lights([(scenes.LIGHT_DIFFUSE_AREA, (30.0, 25.0, 20.0), n_tris, 0, 2),
+                            (scenes.LIGHT_DIFFUSE_AREA, (0.2, 0.25, 0.3), n_tris + 1, 1, 1)])
+    sc["lights"] = np.concatenate([sc["lights"], extra])
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, scenes.cornell_camera(w, h), w, h, 4, integrator=integrator,
+                                              seed=101, **kw)
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
