@@ -16,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "pbrt-rs_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, HERE)
 import oracle  # noqa: E402
 from pbrt_hip import scenes  # noqa: E402
 
@@ -77,6 +78,20 @@ def main():
                         stats=np.array([st["rays"], st["node_tests"], st["prim_tests"], st["camera_samples"]],
                                        dtype=np.uint64))
     osc.close()
+    # (vii) one small render per widened row (variants.py): films + ray counts
+    from variants import W, H, SPP, oracle_scene, variants
+    out = {}
+    for name, (sc, cam, kw) in variants().items():
+        kw = dict(kw)
+        spec = kw.pop("filter_spec", None)
+        if spec is not None:
+            kw["filter"] = (spec[1], spec[1], oracle.filter_table(spec[0], spec[1], spec[1], spec[2], spec[3]))
+        osc = oracle_scene(oracle, sc)
+        film, st = osc.render(scenes.camera_dict_to_floats(cam), W, H, SPP, n_threads=1, **kw)
+        osc.close()
+        out[name] = film
+        out[name + "__rays"] = np.array([st["rays"], st["camera_samples"]], dtype=np.uint64)
+    np.savez_compressed(os.path.join(HERE, "variants_48x32.npz"), **out)
     print("golden fixtures written to", HERE)
 
 

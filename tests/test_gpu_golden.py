@@ -72,3 +72,28 @@ def test_thin_lens_camera(hip_ctx):
     assert np.all(np.abs(rgb_g - rgb_c) <= 1e-5 * np.maximum(1.0, np.abs(rgb_c)))
     gsc.close()
     osc.close()
+
+
+def test_variant_fixtures(hip_ctx):
+    """The device against the committed fixture of every widened row (tests/golden/variants.py)."""
+    import sys
+    sys.path.insert(0, G)
+    from variants import W, H, SPP, variants
+    d = np.load(os.path.join(G, "variants_48x32.npz"))
+    for name, (sc, cam, kw) in variants().items():
+        kw = dict(kw)
+        spec = kw.pop("filter_spec", None)
+        if spec is not None:
+            kw["filter"] = pbrt_hip.filter_table(spec[0], spec[1], spec[1], spec[2], spec[3])
+        gsc = pbrt_hip.Scene(hip_ctx, sc)
+        film, st = gsc.render(cam, W, H, SPP, **kw)
+        gsc.close()
+        exp = d[name]
+        if spec is None:
+            assert np.array_equal(film[..., 3], exp[..., 3]), name
+        else:
+            assert np.allclose(film[..., 3], exp[..., 3], rtol=2e-5, atol=2e-5), name
+        rgb, rgb_e = pbrt_hip.film_to_rgb(film), pbrt_hip.film_to_rgb(exp)
+        assert np.all(np.abs(rgb - rgb_e) <= 2e-5 * np.maximum(1.0, np.abs(rgb_e))), name
+        assert st["rays_closest"] + st["rays_shadow"] == int(d[name + "__rays"][0]), name
+        assert st["camera_samples"] == int(d[name + "__rays"][1]), name
