@@ -283,3 +283,33 @@ def test_sphere_intersection_parity(hip_ctx):
     assert np.array_equal(gsc.intersect_p(rays), osc.intersect_p(rays)[0])
     gsc.close()
     osc.close()
+
+
+def test_gpu_hlbvh_adversarial_meshes(hip_ctx):
+    """Hypothesis-generated small meshes (coincident vertices, zero-area triangles, repeated triangles, large and
+    tiny coordinates): the device HLBVH equals the host builder byte for byte, and a scene over it answers rays
+    like the oracle."""
+    from hypothesis import given, settings, strategies as st
+    from test_property_host import meshes
+
+    @settings(max_examples=60, deadline=None)
+    @given(mesh=meshes(), max_prims=st.sampled_from([1, 2, 4, 255]))
+    def check(mesh, max_prims):
+        verts, idx = mesh
+        nodes_h, order_h = pbrt_hip.bvh_build(verts, idx, max_prims, pbrt_hip.SPLIT_HLBVH)
+        nodes_g, order_g, _ = pbrt_hip.bvh_build_hlbvh_device(hip_ctx, verts, idx, max_prims)
+        assert np.array_equal(order_g, order_h) and nodes_g.tobytes() == nodes_h.tobytes()
+        sc = dict(positions=verts, indices=idx, tri_material=np.zeros(len(idx), dtype=np.int32),
+                  materials=scenes._materials([(1, (0.5, 0.5, 0.5), (0, 0, 0), 1.0)]),
+                  tri_light=np.full(len(idx), -1, dtype=np.int32), lights=scenes._lights([]))
+        rays = scenes.random_rays(256, 3, origin_extent=5.0)
+        osc = oracle.OracleScene(sc, max_prims, 1)
+        gsc = pbrt_hip.Scene(hip_ctx, sc, max_prims_in_node=max_prims, device_build=True)
+        try:
+            cpu, _ = osc.intersect(rays)
+            _assert_hits_equal(gsc.intersect(rays), cpu)
+        finally:
+            gsc.close()
+            osc.close()
+
+    check()
