@@ -73,23 +73,26 @@ constexpr int kPrimLightMask = 0x1fffffff;  // light index + 1
 PB_DEV bool slab_test(float bx0, float bx1, float by0, float by1, float bz0, float bz1, const TravRay& r, float idx,
                       float idy, float idz, float tmax_ray, float* entry) {
     // bx0 = bounds[dir_is_neg[0]].x, bx1 = bounds[1 - dir_is_neg[0]].x, ...
+    // Straight-line form of geometry.rs:709-751: the early returns of the reference become flags that are and-ed at
+    // the end (same comparisons, same NaN behaviour); a wave almost always holds a lane that passes the x / y test,
+    // so skipping the z slab per lane only costs exec-mask bookkeeping.
     float t_min = (bx0 - r.ox) * idx;
     float t_max = (bx1 - r.ox) * idx;
     float ty_min = (by0 - r.oy) * idy;
     float ty_max = (by1 - r.oy) * idy;
-    t_max *= kSlabScale;
-    ty_max *= kSlabScale;
-    bool ok = !(t_min > ty_max || ty_min > t_max);
-    t_min = (ty_min > t_min) ? ty_min : t_min;
-    t_max = (ty_max < t_max) ? ty_max : t_max;
     float tz_min = (bz0 - r.oz) * idz;
     float tz_max = (bz1 - r.oz) * idz;
+    t_max *= kSlabScale;
+    ty_max *= kSlabScale;
     tz_max *= kSlabScale;
-    ok = ok && !(t_min > tz_max || tz_min > t_max);
+    int fail_xy = (int)(t_min > ty_max) | (int)(ty_min > t_max);
+    t_min = (ty_min > t_min) ? ty_min : t_min;
+    t_max = (ty_max < t_max) ? ty_max : t_max;
+    int fail_z = (int)(t_min > tz_max) | (int)(tz_min > t_max);
     t_min = (tz_min > t_min) ? tz_min : t_min;
     t_max = (tz_max < t_max) ? tz_max : t_max;
     *entry = t_min;
-    return ok && (t_min < tmax_ray) && (t_max > 0.0f);
+    return ((fail_xy | fail_z) == 0) & (t_min < tmax_ray) & (t_max > 0.0f);
 }
 
 // Per-ray constants of the watertight test (triangle.rs:84-101)
