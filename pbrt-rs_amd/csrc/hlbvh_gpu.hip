@@ -38,7 +38,7 @@
 namespace pb {
 void hlbvh_upper_tree(const float* boxes6, const int32_t* sizes, int32_t n, std::vector<int32_t>& treelet_offset,
                       std::vector<int32_t>& upper_index, std::vector<PbrtLinearBVHNode>& upper_nodes,
-                      int32_t* n_nodes_total);
+                      int32_t* n_nodes_total, int32_t* upper_depth);
 }
 
 namespace {
@@ -493,7 +493,12 @@ int hlbvh_build_core(PbrtHipContext* ctx, DeviceArena& mem, const float* d_pos, 
     std::vector<int32_t> treelet_offset, upper_index;
     std::vector<PbrtLinearBVHNode> upper_nodes;
     int32_t n_nodes = 0;
-    pb::hlbvh_upper_tree(rs.box, rs.size, rs.n_treelets, treelet_offset, upper_index, upper_nodes, &n_nodes);
+    int32_t upper_depth = 0;
+    pb::hlbvh_upper_tree(rs.box, rs.size, rs.n_treelets, treelet_offset, upper_index, upper_nodes, &n_nodes, &upper_depth);
+    if (upper_depth + kLevels - 1 > 64) {  // a treelet adds at most kLevels - 1 levels below its root
+        ctx->last_error = "hlbvh: tree deeper than the 64-entry traversal stack (bvh.rs:839)";
+        return PBRT_HIP_ERR_INVALID;
+    }
     if ((size_t)n_nodes != (size_t)rs.n_nodes + upper_nodes.size()) {
         ctx->last_error = "hlbvh: node count mismatch";
         return PBRT_HIP_ERR_DEVICE;

@@ -403,7 +403,7 @@ struct HlbvhBuilder {
 namespace pb {
 void hlbvh_upper_tree(const float* boxes6, const int32_t* sizes, int32_t n, std::vector<int32_t>& treelet_offset,
                       std::vector<int32_t>& upper_index, std::vector<PbrtLinearBVHNode>& upper_nodes,
-                      int32_t* n_nodes_total) {
+                      int32_t* n_nodes_total, int32_t* upper_depth) {
     HlbvhBuilder hb;
     hb.lo = hb.hi = hb.ctr = nullptr;
     hb.max_prims = 0;
@@ -421,12 +421,14 @@ void hlbvh_upper_tree(const float* boxes6, const int32_t* sizes, int32_t n, std:
     upper_nodes.clear();
     int32_t next = 0;
     // explicit stack: (node, slot of the parent's record waiting for its second-child offset or -1)
-    struct Item { int node; int parent_slot; };
+    struct Item { int node; int parent_slot; int depth; };
     std::vector<Item> stack;
-    stack.push_back({root, -1});
+    stack.push_back({root, -1, 1});
+    int max_depth = 0;
     while (!stack.empty()) {
         Item it = stack.back();
         stack.pop_back();
+        max_depth = std::max(max_depth, it.depth);
         if (it.parent_slot >= 0) upper_nodes[it.parent_slot].offset = next;  // this subtree is a second child
         if (it.node < n) {
             treelet_offset[it.node] = next;
@@ -444,10 +446,11 @@ void hlbvh_upper_tree(const float* boxes6, const int32_t* sizes, int32_t n, std:
         upper_index.push_back(next++);
         upper_nodes.push_back(ln);
         int slot = (int)upper_nodes.size() - 1;
-        stack.push_back({nd.child[1], slot});   // popped after the whole first subtree
-        stack.push_back({nd.child[0], -1});
+        stack.push_back({nd.child[1], slot, it.depth + 1});   // popped after the whole first subtree
+        stack.push_back({nd.child[0], -1, it.depth + 1});
     }
     *n_nodes_total = next;
+    if (upper_depth) *upper_depth = max_depth;  // levels down to and including the treelet roots
 }
 }  // namespace pb
 

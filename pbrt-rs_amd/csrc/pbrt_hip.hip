@@ -177,7 +177,7 @@ static float host_det_sin(float x) {
 // (trace.h): interior nodes get indices base + 0.. in DFS order, leaves are encoded with count_bits.
 struct TreeLayout {
     std::vector<float> inodes;   // 16 floats per interior node
-    int n_interior = 0, count_bits = 0;
+    int n_interior = 0, count_bits = 0, depth = 0;
     int32_t root_ref = 0;
 };
 static const char* convert_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, int32_t n_prims, int32_t base,
@@ -198,6 +198,25 @@ static const char* convert_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes,
         }
     }
     if (leaf_prims != n_prims) return "leaves do not cover the primitive list exactly once";
+    {
+        // the traversal stack holds one entry per level, 64 in all (bvh.rs:839 `nodes_to_visit = [0; 64]`, where the
+        // reference would index out of bounds): refuse deeper trees instead of overrunning the spill slab
+        std::vector<std::pair<int32_t, int>> st;  // (node, depth)
+        st.emplace_back(0, 1);
+        int max_depth = 0;
+        int64_t visited = 0;
+        while (!st.empty()) {
+            auto [node, depth] = st.back();
+            st.pop_back();
+            if (++visited > n_nodes) return "node array is not a tree";
+            max_depth = std::max(max_depth, depth);
+            if (nodes[node].n_primitives == 0) {
+                st.emplace_back(node + 1, depth + 1);
+                st.emplace_back(nodes[node].offset, depth + 1);
+            }
+        }
+        out->depth = max_depth;
+    }
     if (n_interior != (n_nodes - 1) / 2 || (n_nodes & 1) == 0) return "node array is not a full binary tree";
     int count_bits = 0;
     while ((1 << count_bits) < max_count) ++count_bits;
@@ -411,6 +430,7 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         if (const char* e = convert_tree(nodes, n_nodes, n_prims, 0, &top)) return fail(e);
     }
     const int n_interior = top.n_interior + obj.n_interior;
+    if (top.depth + obj.depth > 64) return fail("BVH deeper than the 64-entry traversal stack (bvh.rs:839)");
 
     PbrtHipScene* s = new PbrtHipScene();
     s->ctx = ctx;

@@ -176,3 +176,24 @@ def test_write_png_decodes_back(tmp_path):
     got = pix[:, 1:].reshape(h, w, 3).astype(np.float64)
     assert np.abs(got - expect).max() <= 1                    # float32 pow vs float64
     assert (got == expect).mean() > 0.99
+
+
+def test_too_deep_tree_is_refused_without_a_gpu_fault():
+    """A BVH deeper than the reference's 64-entry stack (bvh.rs:839) is rejected at scene creation. The check runs on
+    the host before any device work; without a GPU the call fails earlier on the missing context, so only the
+    builder side is exercised here: a degenerate "Middle" split over collinear, exponentially spaced centroids."""
+    n = 80
+    x = (3.0 ** np.arange(n)).astype(np.float32)      # the midpoint of the centroid bounds peels off one triangle per level
+    pos = np.zeros((3 * n, 3), dtype=np.float32)
+    pos[0::3, 0], pos[1::3, 0], pos[2::3, 0] = x, x, x
+    pos[1::3, 1], pos[2::3, 2] = 1e-3, 1e-3
+    idx = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    nodes, order = pbrt_hip.bvh_build(pos, idx, 1, pbrt_hip.SPLIT_MIDDLE)
+    # depth of the flat tree
+    depth, stack = 0, [(0, 1)]
+    while stack:
+        i, d = stack.pop()
+        depth = max(depth, d)
+        if nodes["n_primitives"][i] == 0:
+            stack += [(i + 1, d + 1), (int(nodes["offset"][i]), d + 1)]
+    assert depth > 64                      # the scene below must be refused (checked on the GPU box in test_gpu_intersect)

@@ -313,3 +313,21 @@ def test_gpu_hlbvh_adversarial_meshes(hip_ctx):
             osc.close()
 
     check()
+
+
+def test_too_deep_tree_is_refused(hip_ctx):
+    """Trees deeper than the 64-entry traversal stack are refused at scene creation (no spill-slab overrun)."""
+    n = 80
+    x = (3.0 ** np.arange(n)).astype(np.float32)      # the midpoint of the centroid bounds peels off one triangle per level
+    pos = np.zeros((3 * n, 3), dtype=np.float32)
+    pos[0::3, 0], pos[1::3, 0], pos[2::3, 0] = x, x, x
+    pos[1::3, 1], pos[2::3, 2] = 1e-3, 1e-3
+    idx = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    sc = dict(positions=pos, indices=idx, tri_material=np.zeros(n, dtype=np.int32),
+              materials=scenes._materials([(1, (0.5, 0.5, 0.5), (0, 0, 0), 1.0)]),
+              tri_light=np.full(n, -1, dtype=np.int32), lights=scenes._lights([]))
+    with pytest.raises(pbrt_hip.PbrtHipError, match="deeper than the 64-entry"):
+        pbrt_hip.Scene(hip_ctx, sc, max_prims_in_node=1, split_method=pbrt_hip.SPLIT_MIDDLE)
+    g = pbrt_hip.Scene(hip_ctx, sc, max_prims_in_node=1, split_method=pbrt_hip.SPLIT_SAH)   # a balanced tree is fine
+    assert (g.intersect(scenes.random_rays(100, 1))["prim_id"] >= -1).all()
+    g.close()
