@@ -398,6 +398,10 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         if (tri_material && (tri_material[i] < 0 || tri_material[i] >= n_materials)) return fail("tri_material out of range");
         if (tri_light && (tri_light[i] < -1 || tri_light[i] >= n_lights)) return fail("tri_light out of range");
     }
+    for (int32_t i = 0; i < n_materials; ++i) {
+        if (materials[i].type < PBRT_MAT_NONE || materials[i].type > PBRT_MAT_GLASS) return fail("unknown material type");
+        if (materials[i].type == PBRT_MAT_GLASS && !(materials[i].eta > 0.0f)) return fail("glass needs eta > 0");
+    }
     for (int32_t i = 0; i < n_lights; ++i) {
         if (lights[i].type < PBRT_LIGHT_DIFFUSE_AREA || lights[i].type > PBRT_LIGHT_DISTANT) return fail("unknown light type");
         if (lights[i].type == PBRT_LIGHT_DIFFUSE_AREA && (lights[i].prim < 0 || lights[i].prim >= n_tris + sa.n))
