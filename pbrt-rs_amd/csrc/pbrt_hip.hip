@@ -1323,7 +1323,9 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     }
     // ray-queue sort (spatial order for the bounce rays): keys in / out, sorted entries, rocPRIM scratch
     const char* sort_env = std::getenv("PBRT_HIP_SORT_RAYS");
-    const bool sort_rays = !(sort_env && sort_env[0] == '0');
+    // only the path integrator's later bounces are incoherent; the stage machine of the other integrators keeps
+    // shooting from the camera rays' hit points, which are already in pixel order (AO: -6 % with the sort)
+    const bool sort_rays = !(sort_env && sort_env[0] == '0') && rp.integrator == PBRT_INTEGRATOR_PATH;
     uint32_t *sort_keys[2] = {nullptr, nullptr}, *sort_vals = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
