@@ -1607,8 +1607,15 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             int nxt = cur ^ 1;
             RENDER_TRY(hipMemsetAsync(q[nxt].counts64, 0, 2 * sizeof(unsigned long long), st));
             if (direct)
-                hipLaunchKernelGGL(k_shade_direct, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, ds, q[cur],
-                                   q[nxt], pp, tiles, n_shade);
+{
+                dim3 sg((n_shade + 255) / 256), sb(256);
+                if (rp.integrator == PBRT_INTEGRATOR_DIRECT)
+                    hipLaunchKernelGGL((k_shade_direct<PBRT_INTEGRATOR_DIRECT>), sg, sb, 0, st, sc, ps, ds, q[cur], q[nxt], pp, tiles, n_shade);
+                else if (rp.integrator == PBRT_INTEGRATOR_WHITTED)
+                    hipLaunchKernelGGL((k_shade_direct<PBRT_INTEGRATOR_WHITTED>), sg, sb, 0, st, sc, ps, ds, q[cur], q[nxt], pp, tiles, n_shade);
+                else
+                    hipLaunchKernelGGL((k_shade_direct<PBRT_INTEGRATOR_AO>), sg, sb, 0, st, sc, ps, ds, q[cur], q[nxt], pp, tiles, n_shade);
+            }
             else
                 hipLaunchKernelGGL(k_shade, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, q[cur], q[nxt], pp,
                                    tiles, n_shade);

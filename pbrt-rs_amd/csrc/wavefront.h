@@ -1554,6 +1554,7 @@ struct DirectState {
 #ifndef PB_DIRECT_WAVES
 #define PB_DIRECT_WAVES 2  // 128 VGPRs: +5..9 % on direct lighting / Whitted / AO over the unconstrained 256-VGPR build
 #endif
+template <int MODE>  // PBRT_INTEGRATOR_DIRECT / _WHITTED / _AO: one instantiation each, the other integrators' stages compile away
 __global__ void __launch_bounds__(256, PB_DIRECT_WAVES) k_shade_direct(ShadeConsts sc, PathState ps, DirectState ds, Queues qin,
                                                         Queues qout, PassParams pp, TileList tiles, uint32_t n_in) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1573,7 +1574,7 @@ __global__ void __launch_bounds__(256, PB_DIRECT_WAVES) k_shade_direct(ShadeCons
         float4 accq = ds.ld_acc[p];
         V3 ld_acc = V3{accq.x, accq.y, accq.z};
         size_t rbase = (size_t)p * 3 * 2;
-        const int mode = ds.mode;
+        constexpr int mode = MODE;
         const bool sample_all = mode == PBRT_INTEGRATOR_DIRECT && ds.light_strategy == 0;
         // stages at a vertex: direct = light samples, Whitted = one per light (whitted.rs:75), AO = hemisphere samples
         Samp sm = path_sampler(ps, pp, tiles, p);
