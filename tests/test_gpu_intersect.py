@@ -331,3 +331,68 @@ def test_too_deep_tree_is_refused(hip_ctx):
     g = pbrt_hip.Scene(hip_ctx, sc, max_prims_in_node=1, split_method=pbrt_hip.SPLIT_SAH)   # a balanced tree is fine
     assert (g.intersect(scenes.random_rays(100, 1))["prim_id"] >= -1).all()
     g.close()
+
+
+def test_error_behaviour_of_the_c_abi(hip_ctx):
+    """Same error behaviour as the binding documents: bad arguments give an error code and a message, never a crash
+    or a device fault (the reference would panic on most of these)."""
+    sc = scenes.cornell_box()
+    nodes, order = pbrt_hip.bvh_build(sc["positions"], sc["indices"], 4, pbrt_hip.SPLIT_SAH)
+
+    def create(**changes):
+        s2 = dict(sc)
+        bvh = changes.pop("bvh", (nodes, order))
+        s2.update(changes)
+        return pbrt_hip.Scene(hip_ctx, s2, bvh=bvh)
+
+    bad_idx = sc["indices"].copy()
+    bad_idx[3, 1] = 10_000
+    with pytest.raises(pbrt_hip.PbrtHipError, match="vertex index"):
+        create(indices=bad_idx)
+    bad_order = order.copy()
+    bad_order[0] = bad_order[1]
+    with pytest.raises(pbrt_hip.PbrtHipError, match="permutation"):
+        create(bvh=(nodes, bad_order))
+    bad_nodes = nodes.copy()
+    bad_nodes["offset"][0] = 1                       # second child must come after the first subtree
+    with pytest.raises(pbrt_hip.PbrtHipError, match="offset"):
+        create(bvh=(bad_nodes, order))
+    with pytest.raises(pbrt_hip.PbrtHipError, match="full binary tree|leaves do not cover|offset out of range"):
+        create(bvh=(nodes[:-2].copy(), order))
+    bad_mat = sc["tri_material"].copy()
+    bad_mat[0] = 99
+    with pytest.raises(pbrt_hip.PbrtHipError, match="tri_material"):
+        create(tri_material=bad_mat)
+    bad_materials = sc["materials"].copy()
+    bad_materials["type"][0] = 17
+    with pytest.raises(pbrt_hip.PbrtHipError, match="material type"):
+        create(materials=bad_materials)
+    bad_lights = sc["lights"].copy()
+    bad_lights["prim"][0] = 10_000
+    with pytest.raises(pbrt_hip.PbrtHipError, match="area light"):
+        create(lights=bad_lights)
+    bad_lights = sc["lights"].copy()
+    bad_lights["type"][0] = 42
+    with pytest.raises(pbrt_hip.PbrtHipError, match="light type"):
+        create(lights=bad_lights)
+    g = create()
+    cam = scenes.cornell_camera(32, 32)
+    for kw, msg in ((dict(integrator=9), "integrator"), (dict(sampler=("stratified", 0, 4, True, 4)), "stratified"),
+                    (dict(bounds=(0, 0, 64, 64)), "bounds"), (dict(tile_rank=3, tile_world=2), "tile_rank"),
+                    (dict(light_strategy=7), "light_strategy"), (dict(integrator=3, ao_samples=0), "ao_samples")):
+        with pytest.raises(pbrt_hip.PbrtHipError, match=msg):
+            g.render(cam, 32, 32, 2, **kw)
+    bad_cam = cam.copy()
+    bad_cam["kind"] = 5
+    with pytest.raises(pbrt_hip.PbrtHipError, match="camera"):
+        g.render(bad_cam, 32, 32, 2)
+    film, st = g.render(cam, 32, 32, 2)               # the scene still works after all the refusals
+    assert st["camera_samples"] == 32 * 32 * 2 and np.isfinite(film).all()
+    # rays with NaN / infinite components are misses, not hangs
+    rays = scenes.random_rays(64, 3)
+    rays["d"][:16] = np.nan
+    rays["o"][16:32] = np.inf
+    rays["d"][32:48] = 0.0
+    hits = g.intersect(rays)
+    assert np.all(hits["prim_id"][:48] == -1)
+    g.close()
