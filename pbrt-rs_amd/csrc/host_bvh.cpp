@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/pbrt_hip.h"
@@ -54,7 +55,7 @@ struct Builder {
     const float* lo;   // n x 3 primitive bounds min
     const float* hi;   // n x 3 primitive bounds max
     const float* ctr;  // n x 3 centroids
-    std::vector<int32_t> perm;          // working permutation of primitive indices
+    int32_t* perm = nullptr;            // working permutation of primitive indices (shared by the parallel sub-builders)
     std::vector<PbrtLinearBVHNode> out;
     std::vector<int32_t> order;         // leaf slots -> primitive index
     int max_prims;
@@ -93,7 +94,9 @@ struct Builder {
         return o;
     }
 
-    int build(int start, int end) {
+    // par_depth > 0: the two children of a large range are built concurrently (they own disjoint ranges of `perm`);
+    // the second child goes into a builder of its own and is appended afterwards, so the output is the serial one.
+    int build(int start, int end, int par_depth = 0) {
         int self = (int)out.size();
         out.emplace_back();
         Box b;
@@ -160,11 +163,34 @@ struct Builder {
         }
         if (median_split) {
             mid = (start + end) / 2;
-            std::nth_element(perm.begin() + start, perm.begin() + mid, perm.begin() + end,
+            std::nth_element(perm + start, perm + mid, perm + end,
                              [&](int a, int c) { return ctr[3 * a + dim] < ctr[3 * c + dim]; });
         }
-        int c0 = build(start, mid);
-        int c1 = build(mid, end);
+        int c0, c1;
+        if (par_depth > 0 && n >= (1 << 14)) {
+            Builder right;
+            right.lo = lo;
+            right.hi = hi;
+            right.ctr = ctr;
+            right.perm = perm;
+            right.max_prims = max_prims;
+            right.method = method;
+            right.out.reserve(2 * (size_t)(end - mid));
+            right.order.reserve(end - mid);
+            std::thread worker([&]() { right.build(mid, end, par_depth - 1); });
+            c0 = build(start, mid, par_depth - 1);
+            worker.join();
+            c1 = (int)out.size();
+            const int32_t order_base = (int32_t)order.size();
+            for (PbrtLinearBVHNode nd : right.out) {
+                nd.offset += nd.n_primitives > 0 ? order_base : c1;  // leaf: first slot; interior: second child
+                out.push_back(nd);
+            }
+            order.insert(order.end(), right.order.begin(), right.order.end());
+        } else {
+            c0 = build(start, mid, 0);
+            c1 = build(mid, end, 0);
+        }
         Box u;
         u.reset();
         u.grow(out[c0].bounds_min, out[c0].bounds_max);
@@ -474,13 +500,14 @@ static int build_from_boxes(std::vector<float>& lo, std::vector<float>& hi, int3
         bl.lo = lo.data();
         bl.hi = hi.data();
         bl.ctr = ctr.data();
-        bl.perm.resize(n);
-        for (int32_t i = 0; i < n; ++i) bl.perm[i] = i;
+        std::vector<int32_t> perm(n);
+        for (int32_t i = 0; i < n; ++i) perm[i] = i;
+        bl.perm = perm.data();
         bl.max_prims = std::min(max_prims_in_node, 255);  // bvh.rs:222
         bl.method = split_method;
         bl.out.reserve(2 * (size_t)n);
         bl.order.reserve(n);
-        bl.build(0, n);
+        bl.build(0, n, 3);  // up to 8 concurrent subtrees
     }
 
     size_t nn = bl.out.size();
