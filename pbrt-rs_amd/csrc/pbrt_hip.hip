@@ -59,6 +59,8 @@ extern "C" int pbrt_hip_context_create(int device_id, PbrtHipContext** out) {
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipMalloc((void**)&ctx->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_work_counter, kQueueSegments * sizeof(unsigned int)) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->h_counts, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_sync, hipEventDisableTiming) != hipSuccess ||
         hipMemset(ctx->d_counters, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
         g_create_error = "stream / event creation failed";
         delete ctx;
@@ -79,6 +81,8 @@ extern "C" void pbrt_hip_context_destroy(PbrtHipContext* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
+    if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+    if (ctx->ev_sync) (void)hipEventDestroy(ctx->ev_sync);
     if (ctx->d_halton_primes) (void)hipFree(ctx->d_halton_primes);
     if (ctx->d_halton_perms) (void)hipFree(ctx->d_halton_perms);
     delete ctx;
@@ -1620,8 +1624,16 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                 hipLaunchKernelGGL(k_shade, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, q[cur], q[nxt], pp,
                                    tiles, n_shade);
             RENDER_TRY(hipGetLastError());
-            RENDER_TRY(hipMemcpyAsync(counts, q[nxt].counts64, sizeof(counts), hipMemcpyDeviceToHost, st));
-            RENDER_TRY(hipStreamSynchronize(st));
+            RENDER_TRY(hipMemcpyAsync(ctx->h_counts, q[nxt].counts64, sizeof(counts), hipMemcpyDeviceToHost, st));
+            RENDER_TRY(hipEventRecord(ctx->ev_sync, st));
+            if (rc == PBRT_HIP_OK) {
+                hipError_t qe;
+                while ((qe = hipEventQuery(ctx->ev_sync)) == hipErrorNotReady) {
+                }
+                RENDER_TRY(qe);
+            }
+            counts[0] = ctx->h_counts[0];
+            counts[1] = ctx->h_counts[1];
             if (n_trace > 0 && rc == PBRT_HIP_OK) {
                 float ms = 0.0f;
                 RENDER_TRY(hipEventElapsedTime(&ms, e_t0, e_t1));

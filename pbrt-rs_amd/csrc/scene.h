@@ -29,6 +29,10 @@ struct PbrtHipContext {
     unsigned long long* d_counters = nullptr;
     uint64_t counted_rays = 0;
     unsigned int* d_work_counter = nullptr;  // ray-queue head of the persistent traversal kernel
+    // the render loop reads the queue lengths back once per wavefront: pinned landing buffer + an event the host
+    // spins on (a blocking stream sync costs a scheduler wake-up per wavefront, milliseconds on a busy host)
+    unsigned long long* h_counts = nullptr;
+    hipEvent_t ev_sync = nullptr;
     // HaltonSampler tables, uploaded on first use: primes + prime sums, radical-inverse digit permutations
     uint32_t* d_halton_primes = nullptr;
     uint16_t* d_halton_perms = nullptr;
