@@ -81,6 +81,9 @@ extern "C" void pbrt_hip_context_destroy(PbrtHipContext* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
+    for (auto& b : ctx->block_cache)
+        if (b.ptr) (void)hipFree(b.ptr);
+    ctx->block_cache.clear();
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->ev_sync) (void)hipEventDestroy(ctx->ev_sync);
     if (ctx->d_halton_primes) (void)hipFree(ctx->d_halton_primes);
@@ -1038,21 +1041,63 @@ extern "C" int pbrt_hip_tile_partition(int32_t x0, int32_t y0, int32_t x1, int32
 // wavefront_render — host driver of the kernels in wavefront.h
 // ------------------------------------------------------------------------------------
 namespace {
+// Device buffers of one call. Blocks come from (and return to) the context's cache, so that repeated renders of the
+// same size do not pay hipMalloc / hipFree again.
 struct DevBuf {
-    std::vector<void*> ptrs;
+    std::vector<size_t> taken;  // indices into ctx->block_cache
     PbrtHipContext* ctx;
     explicit DevBuf(PbrtHipContext* c) : ctx(c) {}
     ~DevBuf() {
-        for (void* p : ptrs) (void)hipFree(p);
+        for (size_t i : taken) ctx->block_cache[i].in_use = false;
+        size_t idle = 0;
+        for (const auto& b : ctx->block_cache)
+            if (!b.in_use) idle += b.bytes;
+        if (idle > ((size_t)160 << 30)) trim(ctx);  // renders of many different sizes: do not sit on most of the HBM
+    }
+    static void trim(PbrtHipContext* ctx) {  // release every block no call is using (slots stay, indices are stable)
+        for (auto& b : ctx->block_cache)
+            if (!b.in_use && b.ptr) {
+                (void)hipFree(b.ptr);
+                b.ptr = nullptr;
+                b.bytes = 0;
+            }
     }
     template <class T>
     T* alloc(size_t n, bool* ok) {
+        const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        // best fit among the free cached blocks that are not wastefully large
+        size_t best = SIZE_MAX;
+        for (size_t i = 0; i < ctx->block_cache.size(); ++i) {
+            const auto& b = ctx->block_cache[i];
+            if (!b.in_use && b.ptr && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 + 4096 &&
+                (best == SIZE_MAX || b.bytes < ctx->block_cache[best].bytes))
+                best = i;
+        }
+        if (best != SIZE_MAX) {
+            ctx->block_cache[best].in_use = true;
+            taken.push_back(best);
+            return (T*)ctx->block_cache[best].ptr;
+        }
         void* p = nullptr;
-        if (!hip_ok(ctx, hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)), "hipMalloc (path state)")) {
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {  // out of memory with idle cached blocks around: drop them and retry once
+            (void)hipGetLastError();
+            trim(ctx);
+            e = hipMalloc(&p, bytes);
+        }
+        if (!hip_ok(ctx, e, "hipMalloc (path state)")) {
             *ok = false;
             return nullptr;
         }
-        ptrs.push_back(p);
+        size_t slot = ctx->block_cache.size();
+        for (size_t i = 0; i < ctx->block_cache.size(); ++i)
+            if (!ctx->block_cache[i].ptr && !ctx->block_cache[i].in_use) {
+                slot = i;
+                break;
+            }
+        if (slot == ctx->block_cache.size()) ctx->block_cache.push_back({nullptr, 0, false});
+        ctx->block_cache[slot] = {p, bytes, true};
+        taken.push_back(slot);
         return (T*)p;
     }
 };
@@ -1299,7 +1344,16 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         valid_pixels += (int64_t)(std::min(o.x + kTile, rp.x1) - o.x) * (std::min(o.y + kTile, rp.y1) - o.y);
     int spp_pass = rp.spp_per_pass > 0 ? rp.spp_per_pass : 0;
     if (spp_pass == 0) {
-        const int64_t target_paths = 16ll << 20;  // ~16.8 M concurrent paths (~5 GB of state)
+        // As many samples of a pixel in flight as half of the free HBM holds (about 400 B of path state, queue and
+        // sort slots per path; the stage machine of the other integrators adds its frame stack): a whole 64-spp
+        // 1080p frame is 133 M paths = 50 GB of the 288 GB and runs 6 large wavefronts instead of 48 small ones
+        // (+10 % on config 3: fewer launches and host round trips, shorter tails).
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+        for (const auto& b : ctx->block_cache)
+            if (!b.in_use) free_b += b.bytes;  // blocks kept from the previous render are available to this one
+        const int64_t per_path = 400 + (rp.integrator != PBRT_INTEGRATOR_PATH ? 24 + 48ll * std::max(1, rp.max_depth) : 0);
+        const int64_t target_paths = std::max<int64_t>(1ll << 20, std::min<int64_t>(1ll << 28, (int64_t)(free_b / 2) / per_path));
         spp_pass = (int)std::max<int64_t>(1, std::min<int64_t>(rp.spp, target_paths / n_pix));
     }
     spp_pass = std::min(spp_pass, rp.spp);

@@ -33,6 +33,14 @@ struct PbrtHipContext {
     // spins on (a blocking stream sync costs a scheduler wake-up per wavefront, milliseconds on a busy host)
     unsigned long long* h_counts = nullptr;
     hipEvent_t ev_sync = nullptr;
+    // Device blocks of finished renders, kept for the next one: a 64-spp 1080p frame holds 50 GB of path state and
+    // hipMalloc / hipFree of that much costs seconds. Freed with the context (or when an allocation fails).
+    struct CachedBlock {
+        void* ptr;
+        size_t bytes;
+        bool in_use;
+    };
+    std::vector<CachedBlock> block_cache;
     // HaltonSampler tables, uploaded on first use: primes + prime sums, radical-inverse digit permutations
     uint32_t* d_halton_primes = nullptr;
     uint16_t* d_halton_perms = nullptr;
