@@ -1384,6 +1384,8 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     // only the path integrator's later bounces are incoherent; the stage machine of the other integrators keeps
     // shooting from the camera rays' hit points, which are already in pixel order (AO: -6 % with the sort)
     const bool sort_rays = !(sort_env && sort_env[0] == '0') && rp.integrator == PBRT_INTEGRATOR_PATH;
+    const char* sort_from_env = std::getenv("PBRT_HIP_SORT_FROM");  // first sorted wavefront (development knob)
+    const int sort_from = sort_from_env ? std::atoi(sort_from_env) : 2;
     uint32_t *sort_keys[2] = {nullptr, nullptr}, *sort_vals = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
@@ -1613,7 +1615,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             if (n_trace > 0) {
                 RENDER_TRY(hipMemsetAsync(ctx->d_work_counter, 0, kQueueSegments * sizeof(unsigned int), st));
                 const uint32_t* trace_queue = q[cur].trace;
-                if (sort_rays && wavefront >= 2 && n_trace >= (1u << 20)) {
+                if (sort_rays && wavefront >= sort_from && n_trace >= (1u << 20)) {
                     // from the second bounce on the rays of a wavefront start all over the scene (the first bounce still
                     // follows the pixel order of its camera rays): trace them in Morton order of their origins
                     const float* mn = s->d.bvh.root_min;
