@@ -1363,6 +1363,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     DevBuf buf(ctx);
     bool ok = true;
     PathState ps;
+    ps.n_paths = N;
     ps.ray = buf.alloc<float4>(N * 6, &ok);
     ps.hit = buf.alloc<float4>(N * 6, &ok);
     ps.rng = buf.alloc<uint64_t>(N, &ok);
@@ -1393,7 +1394,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         sort_keys[0] = buf.alloc<uint32_t>(N * 3, &ok);
         sort_keys[1] = buf.alloc<uint32_t>(N * 3, &ok);
         sort_vals = buf.alloc<uint32_t>(N * 3, &ok);
-        if (pb::sort_pairs_u32(st, nullptr, &sort_tmp_bytes, sort_keys[0], sort_keys[1], sort_vals, sort_vals, N * 3, 16) != 0)
+        if (pb::sort_pairs_u32(st, nullptr, &sort_tmp_bytes, sort_keys[0], sort_keys[1], sort_vals, sort_vals, N * 3, kSortKeyBits) != 0)
             return invalid("rocPRIM radix sort: size query failed");
         sort_tmp = buf.alloc<char>(sort_tmp_bytes, &ok);
     }
@@ -1626,7 +1627,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                     hipLaunchKernelGGL(k_ray_sort_keys, dim3((n_trace + 255) / 256), dim3(256), 0, st, ps, q[cur].trace, n_trace, lo,
                                        inv, sort_keys[0]);
                     size_t tb = sort_tmp_bytes;
-                    if (pb::sort_pairs_u32(st, sort_tmp, &tb, sort_keys[0], sort_keys[1], q[cur].trace, sort_vals, n_trace, 16) != 0 &&
+                    if (pb::sort_pairs_u32(st, sort_tmp, &tb, sort_keys[0], sort_keys[1], q[cur].trace, sort_vals, n_trace, kSortKeyBits) != 0 &&
                         rc == PBRT_HIP_OK) {
                         ctx->last_error = "rocPRIM radix sort failed";
                         rc = PBRT_HIP_ERR_DEVICE;

@@ -30,8 +30,9 @@ enum PathFlags : int {
 enum RaySlot : int { RS_CONT = 0, RS_MIS = 1, RS_SHADOW = 2 };
 
 struct PathState {
-    float4* ray;     // [(p*3 + slot)*2 + k]: (o.xyz, d.x) (d.yz, t_max, -)
-    float4* hit;     // [(p*3 + slot)*2 + k]: (t, b0, b1, b2) (slot, -, -, -); shadow slot: .x = occluded
+    float4* ray;     // [ray_index(p, slot) + k]: (o.xyz, d.x) (d.yz, t_max, -)
+    float4* hit;     // [ray_index(p, slot) + k]: (t, b0, b1, b2) (slot, -, -, -); shadow slot: .x = occluded
+    size_t n_paths;  // paths of a pass (the stride between the three slots' arrays)
     uint64_t* rng;   // PCG32 state (inc is recomputed from the sample index)
     float4* L;       // L.rgb, eta_scale
     float4* beta;    // beta.rgb, (bounces << 8 | flags) as int bits
@@ -42,6 +43,22 @@ struct PathState {
     float2* pfilm;   // CameraSample::p_film
     int* samp;       // sampler counters: current_1d_dimension (Halton: dimension) | current_2d_dimension << 10 | array_2d_offset << 16
 };
+
+// Rays and hit records are kept slot-major, [slot][path][2 x float4]: the lanes of a wave that write (k_generate,
+// k_shade) or read (the unsorted wavefronts of k_trace) the same slot of consecutive paths touch consecutive 32-B
+// pieces, i.e. whole cache lines; path-major [path][slot] left two thirds of every written line untouched.
+#ifndef PB_RAY_PATH_MAJOR
+#define PB_RAY_PATH_MAJOR 0
+#endif
+#ifndef PB_HIT_PATH_MAJOR
+#define PB_HIT_PATH_MAJOR 0
+#endif
+PB_DEV size_t ray_index(const PathState& ps, uint32_t p, int slot) {
+    return PB_RAY_PATH_MAJOR ? ((size_t)p * 3 + slot) * 2 : ((size_t)slot * ps.n_paths + p) * 2;
+}
+PB_DEV size_t hit_index(const PathState& ps, uint32_t p, int slot) {
+    return PB_HIT_PATH_MAJOR ? ((size_t)p * 3 + slot) * 2 : ((size_t)slot * ps.n_paths + p) * 2;
+}
 
 // PixelSampler tables (sampler.rs:252-318) of this GPU's pixels, one column per pixel:
 // tables[elem * n_pix + pix]; elem: 1D dimension d, sample s -> d*spp + s; 2D -> off2 + (d*spp + s)*2 + c;
@@ -141,7 +158,7 @@ PB_DEV void block_append(BlockAppend& sh, const Queues& q, uint32_t p, bool cont
 }
 
 PB_DEV void store_ray(const PathState& ps, uint32_t p, int slot, V3 o, V3 d, float tmax) {
-    size_t i = ((size_t)p * 3 + slot) * 2;
+    size_t i = ray_index(ps, p, slot);
     ps.ray[i] = make_float4(o.x, o.y, o.z, d.x);
     ps.ray[i + 1] = make_float4(d.y, d.z, tmax, 0.0f);
 }
@@ -495,7 +512,7 @@ struct WavefrontRayIO {
     PB_DEV bool load(uint32_t i, TravRay* r, bool* any) const {
         uint32_t e = queue[i];
         uint32_t p = e >> 2, slot = e & 3u;
-        size_t ri = ((size_t)p * 3 + slot) * 2;
+        size_t ri = ray_index(ps, p, slot);
         float4 a = ps.ray[ri], b = ps.ray[ri + 1];
         *r = TravRay{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
         *any = slot == RS_SHADOW;
@@ -505,7 +522,7 @@ struct WavefrontRayIO {
     PB_DEV void store(uint32_t i, bool any, bool found, float t, float b0, float b1, float b2, int slot, int inst) const {
         uint32_t e = queue[i];
         uint32_t p = e >> 2, rs = e & 3u;
-        size_t ri = ((size_t)p * 3 + rs) * 2;
+        size_t ri = hit_index(ps, p, rs);
         if (any) {
             ps.hit[ri] = make_float4(found ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
         } else {
@@ -517,20 +534,32 @@ struct WavefrontRayIO {
 // Sort key of a queued ray: any-hit flag, then a 15-bit Morton code of the origin inside the scene bounds. Rays that
 // start close together walk the same part of the tree: in cache order the traversal kernel runs 20 % faster on
 // incoherent bounce rays (tools/probe_sorting.py), which pays for the two 8-bit radix passes.
+#ifndef PB_SORT_AXIS_BITS
+#define PB_SORT_AXIS_BITS 5
+#endif
+#ifndef PB_SORT_OCTANT
+#define PB_SORT_OCTANT 0
+#endif
+constexpr int kSortKeyBits = 3 * PB_SORT_AXIS_BITS + 3 * PB_SORT_OCTANT + 1;
 __global__ void k_ray_sort_keys(PathState ps, const uint32_t* __restrict__ queue, uint32_t n, float3 lo, float3 inv_extent,
                                 uint32_t* __restrict__ keys) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t e = queue[i];
     uint32_t p = e >> 2, slot = e & 3u;
-    float4 a = ps.ray[((size_t)p * 3 + slot) * 2];
+    float4 a = ps.ray[ray_index(ps, p, slot)];
+    constexpr float kCells = (float)(1 << PB_SORT_AXIS_BITS);
     float fx = (a.x - lo.x) * inv_extent.x, fy = (a.y - lo.y) * inv_extent.y, fz = (a.z - lo.z) * inv_extent.z;
-    uint32_t q[3] = {(uint32_t)fminf(fmaxf(fx * 32.0f, 0.0f), 31.0f), (uint32_t)fminf(fmaxf(fy * 32.0f, 0.0f), 31.0f),
-                     (uint32_t)fminf(fmaxf(fz * 32.0f, 0.0f), 31.0f)};
+    uint32_t q[3] = {(uint32_t)fminf(fmaxf(fx * kCells, 0.0f), kCells - 1.0f), (uint32_t)fminf(fmaxf(fy * kCells, 0.0f), kCells - 1.0f),
+                     (uint32_t)fminf(fmaxf(fz * kCells, 0.0f), kCells - 1.0f)};
     uint32_t code = 0;
-    for (int b = 0; b < 5; ++b)
+    for (int b = 0; b < PB_SORT_AXIS_BITS; ++b)
         for (int k = 0; k < 3; ++k) code |= ((q[k] >> b) & 1u) << (3 * b + k);
-    keys[i] = code | ((slot == RS_SHADOW ? 1u : 0u) << 15);
+#if PB_SORT_OCTANT
+    float4 d = ps.ray[ray_index(ps, p, slot) + 1];  // (d.y, d.z, t_max, -); d.x rides in a.w
+    code = (code << 3) | (a.w < 0.0f ? 1u : 0u) | (d.x < 0.0f ? 2u : 0u) | (d.y < 0.0f ? 4u : 0u);
+#endif
+    keys[i] = code | ((slot == RS_SHADOW ? 1u : 0u) << (kSortKeyBits - 1));
 }
 
 #ifndef PB_TRACE_WAVES
@@ -1299,17 +1328,16 @@ PB_DEV int estimate_direct_emit(const ShadeConsts& sc, const PathState& ps, uint
 // by the light-pick pdf). Also returns the pick pdf and the throughput stored with the estimate.
 PB_DEV V3 estimate_direct_resolve(const ShadeConsts& sc, const PathState& ps, uint32_t p, int flags, float* pick_pdf,
                                   V3* beta_at_vertex) {
-    size_t rbase = (size_t)p * 3 * 2;
     float4 na = ps.nee_a[p], nf = ps.nee_f[p], nb = ps.nee_b[p];
     int light_id = ps.nee_light[p];
     V3 ld = V3{0.0f, 0.0f, 0.0f};
     if (flags & PF_NEE_SHADOW) {
-        bool occluded = ps.hit[rbase + RS_SHADOW * 2].x != 0.0f;
+        bool occluded = ps.hit[hit_index(ps, p, RS_SHADOW)].x != 0.0f;
         if (!occluded) ld = ld + V3{na.x, na.y, na.z};
     }
     if (flags & PF_NEE_MIS) {
-        int hslot = __float_as_int(ps.hit[rbase + RS_MIS * 2 + 1].x);
-        float4 r0 = ps.ray[rbase + RS_MIS * 2], r1 = ps.ray[rbase + RS_MIS * 2 + 1];
+        int hslot = __float_as_int(ps.hit[hit_index(ps, p, RS_MIS) + 1].x);
+        float4 r0 = ps.ray[ray_index(ps, p, RS_MIS)], r1 = ps.ray[ray_index(ps, p, RS_MIS) + 1];
         V3 wi = V3{r0.w, r1.x, r1.y};
         DevLight lt = sc.lights[light_id];
         V3 li = V3{0.0f, 0.0f, 0.0f};
@@ -1317,7 +1345,7 @@ PB_DEV V3 estimate_direct_resolve(const ShadeConsts& sc, const PathState& ps, ui
             // D26 (intended): Le only when the hit primitive's area light is this light
             int hl = (__float_as_int(sc.bvh.tris[3 * (size_t)hslot + 2].w) & kPrimLightMask) - 1;
             if (hl == light_id) {
-                float4 hb = ps.hit[rbase + RS_MIS * 2];
+                float4 hb = ps.hit[hit_index(ps, p, RS_MIS)];
                 V3 n = tri_interaction_normal(sc.bvh, hslot, hb.y, hb.z, hb.w);
                 if (lt.two_sided || dot(n, -wi) > 0.0f) li = V3{lt.L[0], lt.L[1], lt.L[2]};
             }
@@ -1402,7 +1430,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
         V3 beta = V3{bq.x, bq.y, bq.z};
         int fb = __float_as_int(bq.w);
         int flags = fb & 0xff, bounces = fb >> 8;
-        size_t rbase = (size_t)p * 3 * 2;
+        size_t rbase = ray_index(ps, p, RS_CONT), hbase = hit_index(ps, p, RS_CONT);
 
         // ---- (1) resolve the pending direct-lighting estimate (integrator.rs:136-266) ----
         if (flags & (PF_NEE_SHADOW | PF_NEE_MIS)) {
@@ -1419,8 +1447,8 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
             flags &= ~PF_ALIVE;
             float4 r0 = ps.ray[rbase], r1 = ps.ray[rbase + 1];
             V3 rd = V3{r0.w, r1.x, r1.y};
-            float4 h0 = ps.hit[rbase];
-            float4 h1 = ps.hit[rbase + 1];
+            float4 h0 = ps.hit[hbase];
+            float4 h1 = ps.hit[hbase + 1];
             int hslot = __float_as_int(h1.x);
             bool found = hslot >= 0;
             Surf sf;
@@ -1573,7 +1601,7 @@ __global__ void __launch_bounds__(256, PB_DIRECT_WAVES) k_shade_direct(ShadeCons
         int stage = sg & 0xffff, sp = sg >> 16;
         float4 accq = ds.ld_acc[p];
         V3 ld_acc = V3{accq.x, accq.y, accq.z};
-        size_t rbase = (size_t)p * 3 * 2;
+        size_t rbase = ray_index(ps, p, RS_CONT), hbase = hit_index(ps, p, RS_CONT);
         constexpr int mode = MODE;
         const bool sample_all = mode == PBRT_INTEGRATOR_DIRECT && ds.light_strategy == 0;
         // stages at a vertex: direct = light samples, Whitted = one per light (whitted.rs:75), AO = hemisphere samples
@@ -1633,7 +1661,7 @@ __global__ void __launch_bounds__(256, PB_DIRECT_WAVES) k_shade_direct(ShadeCons
         auto load_surface = [&]() {
             float4 r0 = ps.ray[rbase], r1 = ps.ray[rbase + 1];
             rd = V3{r0.w, r1.x, r1.y};
-            float4 h0 = ps.hit[rbase], h1 = ps.hit[rbase + 1];
+            float4 h0 = ps.hit[hbase], h1 = ps.hit[hbase + 1];
             int hslot = __float_as_int(h1.x);
             sf = surface_from_hit(sc.bvh, hslot, __float_as_int(h1.y), h0.y, h0.z, h0.w, rd);
             mat = sc.materials[sf.material];
@@ -1648,7 +1676,7 @@ __global__ void __launch_bounds__(256, PB_DIRECT_WAVES) k_shade_direct(ShadeCons
             if (!have_vertex) {
                 // ---- arrive at the hit of the continuation ray: directlighting.rs:86-106 ----
                 flags &= ~PF_ALIVE;
-                int hslot = __float_as_int(ps.hit[rbase + 1].x);
+                int hslot = __float_as_int(ps.hit[hbase + 1].x);
                 if (hslot < 0) {
                     float4 r0 = ps.ray[rbase];
                     (void)r0;
@@ -1802,9 +1830,9 @@ __global__ void __launch_bounds__(256, PB_DIRECT_WAVES) k_shade_direct(ShadeCons
                     if (which == 1) {
                         // remember this vertex: its transmit branch runs after the reflected subtree
                         size_t fi = ((size_t)p * pp.max_depth + sp) * 3;
-                        float4 h0 = ps.hit[rbase];
+                        float4 h0 = ps.hit[hbase];
                         ds.frames[fi] = make_float4(rd.x, rd.y, rd.z, h0.y);
-                        float4 h1 = ps.hit[rbase + 1];
+                        float4 h1 = ps.hit[hbase + 1];
                         ds.frames[fi + 1] = make_float4(h0.z, h0.w, h1.x, __int_as_float(depth));
                         ds.frames[fi + 2] = make_float4(T.x, T.y, T.z, h1.y);
                         sp += 1;
@@ -1831,8 +1859,8 @@ __global__ void __launch_bounds__(256, PB_DIRECT_WAVES) k_shade_direct(ShadeCons
             float4 r0 = ps.ray[rbase];
             ps.ray[rbase] = make_float4(r0.x, r0.y, r0.z, f0.x);
             ps.ray[rbase + 1] = make_float4(f0.y, f0.z, kInf, 0.0f);
-            ps.hit[rbase] = make_float4(0.0f, f0.w, f1.x, f1.y);
-            ps.hit[rbase + 1] = make_float4(f1.z, f2.w, 0.0f, 0.0f);
+            ps.hit[hbase] = make_float4(0.0f, f0.w, f1.x, f1.y);
+            ps.hit[hbase + 1] = make_float4(f1.z, f2.w, 0.0f, 0.0f);
             depth = __float_as_int(f1.w);
             T = V3{f2.x, f2.y, f2.z};
             stage = total + 1;  // transmit branch
