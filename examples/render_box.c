@@ -1,0 +1,187 @@
+/* A C99 caller of include/pbrt_hip.h: an open box lit by a ceiling emitter, PathIntegrator, 8-bit PNG out.
+ * Shows the order of calls a host renderer makes at the boundary: host BVH build, context,
+ * scene, render, film -> RGB, image file. No GPU: pbrt_hip_context_create fails and the program exits 3.
+ *
+ *   gcc -std=c99 -Wall -Iinclude examples/render_box.c -o render_box -Lpbrt-rs_amd/pbrt_hip -lpbrt_hip -lm \
+ *       -Wl,-rpath,$PWD/pbrt-rs_amd/pbrt_hip
+ *   ./render_box out.png [width height spp]
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pbrt_hip.h"
+
+static void cross(const double a[3], const double b[3], double out[3]) {
+    out[0] = a[1] * b[2] - a[2] * b[1];
+    out[1] = a[2] * b[0] - a[0] * b[2];
+    out[2] = a[0] * b[1] - a[1] * b[0];
+}
+static void normalize(double v[3]) {
+    double l = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    v[0] /= l;
+    v[1] /= l;
+    v[2] /= l;
+}
+
+/* PerspectiveCamera::new's two matrices (src/cameras/perspective.rs:38-87), row-major. */
+static void perspective_camera(const double eye[3], const double look[3], const double up_in[3], double fov_deg, int w, int h,
+                               PbrtCamera* cam) {
+    double d[3] = {look[0] - eye[0], look[1] - eye[1], look[2] - eye[2]}, up[3] = {up_in[0], up_in[1], up_in[2]};
+    double right[3], new_up[3];
+    normalize(d);
+    normalize(up);
+    cross(up, d, right);
+    normalize(right);
+    cross(d, right, new_up);
+    memset(cam, 0, sizeof(*cam));
+    for (int r = 0; r < 3; ++r) {
+        cam->camera_to_world[4 * r + 0] = (float)right[r];
+        cam->camera_to_world[4 * r + 1] = (float)new_up[r];
+        cam->camera_to_world[4 * r + 2] = (float)d[r];
+        cam->camera_to_world[4 * r + 3] = (float)eye[r];
+    }
+    cam->camera_to_world[15] = 1.0f;
+    const double n = 1e-2, f = 1000.0, A = f / (f - n), B = -f * n / (f - n);
+    const double inv_tan = 1.0 / tan(fov_deg * 3.14159265358979323846 / 360.0);
+    const double aspect = (double)w / h;
+    const double sx0 = aspect > 1.0 ? -aspect : -1.0, sx1 = -sx0;
+    const double sy0 = aspect > 1.0 ? -1.0 : -1.0 / aspect, sy1 = -sy0;
+    float* m = cam->raster_to_camera; /* inverse(camera_to_screen) * raster_to_screen */
+    m[0] = (float)((sx1 - sx0) / (w * inv_tan));
+    m[3] = (float)(sx0 / inv_tan);
+    m[5] = (float)((sy0 - sy1) / (h * inv_tan));
+    m[7] = (float)(sy1 / inv_tan);
+    m[11] = 1.0f;
+    m[14] = (float)(1.0 / B);
+    m[15] = (float)(-A / B);
+    cam->focal_distance = 1e6f;
+    cam->shutter_close = 1.0f;
+    cam->kind = PBRT_CAMERA_PERSPECTIVE;
+}
+
+static int n_verts = 0, n_tris = 0;
+static float positions[3 * 64];
+static int32_t indices[3 * 32], tri_material[32], tri_light[32];
+
+static void add_quad(const float a[3], const float b[3], const float c[3], const float d[3], int material, int emitter) {
+    const float* v[4] = {a, b, c, d};
+    for (int i = 0; i < 4; ++i) memcpy(positions + 3 * (n_verts + i), v[i], 3 * sizeof(float));
+    const int tri[2][3] = {{0, 1, 2}, {0, 2, 3}};
+    for (int t = 0; t < 2; ++t) {
+        for (int k = 0; k < 3; ++k) indices[3 * n_tris + k] = n_verts + tri[t][k];
+        tri_material[n_tris] = material;
+        tri_light[n_tris] = emitter ? 1 : -1; /* patched to light indices below */
+        n_tris += 1;
+    }
+    n_verts += 4;
+}
+
+int main(int argc, char** argv) {
+    const char* out_path = argc > 1 ? argv[1] : "render_box.png";
+    const int width = argc > 4 ? atoi(argv[2]) : 128, height = argc > 4 ? atoi(argv[3]) : 128, spp = argc > 4 ? atoi(argv[4]) : 16;
+
+    /* geometry: floor, ceiling, back wall, left (red) and right (green) walls of a 2 x 2 x 2 box, an emitter under the ceiling */
+    const float p000[3] = {-1, -1, -1}, p100[3] = {1, -1, -1}, p010[3] = {-1, 1, -1}, p110[3] = {1, 1, -1};
+    const float p001[3] = {-1, -1, 1}, p101[3] = {1, -1, 1}, p011[3] = {-1, 1, 1}, p111[3] = {1, 1, 1};
+    add_quad(p000, p100, p101, p001, 0, 0); /* floor   y = -1 */
+    add_quad(p010, p011, p111, p110, 0, 0); /* ceiling y = +1 */
+    add_quad(p001, p101, p111, p011, 0, 0); /* back    z = +1 */
+    add_quad(p000, p001, p011, p010, 1, 0); /* left    x = -1 */
+    add_quad(p100, p110, p111, p101, 2, 0); /* right   x = +1 */
+    const float e0[3] = {-0.3f, 0.99f, -0.3f}, e1[3] = {0.3f, 0.99f, -0.3f}, e2[3] = {0.3f, 0.99f, 0.3f}, e3[3] = {-0.3f, 0.99f, 0.3f};
+    add_quad(e0, e1, e2, e3, 0, 1);
+
+    PbrtMaterial materials[3];
+    memset(materials, 0, sizeof(materials));
+    const float kd[3][3] = {{0.73f, 0.73f, 0.73f}, {0.65f, 0.05f, 0.05f}, {0.12f, 0.45f, 0.15f}};
+    for (int i = 0; i < 3; ++i) {
+        materials[i].type = PBRT_MAT_MATTE;
+        memcpy(materials[i].kd, kd[i], sizeof(kd[i]));
+        materials[i].eta = 1.0f;
+    }
+    /* DiffuseAreaLight per emitting triangle (src/lights/diffuse.rs) */
+    PbrtLight lights[2];
+    memset(lights, 0, sizeof(lights));
+    int n_lights = 0;
+    for (int t = 0; t < n_tris; ++t) {
+        if (tri_light[t] < 0) continue;
+        lights[n_lights].type = PBRT_LIGHT_DIFFUSE_AREA;
+        lights[n_lights].L[0] = lights[n_lights].L[1] = lights[n_lights].L[2] = 17.0f;
+        lights[n_lights].prim = t;
+        lights[n_lights].two_sided = 1;
+        lights[n_lights].n_samples = 1;
+        tri_light[t] = n_lights++;
+    }
+
+    /* BVHAccel::new on the host (SAH, <= 4 primitives per leaf) */
+    PbrtLinearBVHNode* nodes = NULL;
+    int32_t n_nodes = 0;
+    int32_t* prim_order = NULL;
+    int rc = pbrt_hip_bvh_build(positions, n_verts, indices, n_tris, 4, 0, &nodes, &n_nodes, &prim_order);
+    if (rc != PBRT_HIP_OK) {
+        fprintf(stderr, "pbrt_hip_bvh_build failed (%d)\n", rc);
+        return 2;
+    }
+    printf("BVH: %d nodes over %d triangles\n", (int)n_nodes, n_tris);
+
+    PbrtHipContext* ctx = NULL;
+    rc = pbrt_hip_context_create(0, &ctx);
+    if (rc != PBRT_HIP_OK) {
+        fprintf(stderr, "pbrt_hip_context_create failed (%d): %s\n", rc, pbrt_hip_last_error(NULL));
+        pbrt_hip_free(nodes);
+        pbrt_hip_free(prim_order);
+        return 3; /* no CPU fallback */
+    }
+    PbrtHipScene* scene = NULL;
+    rc = pbrt_hip_scene_create(ctx, positions, n_verts, indices, n_tris, tri_material, materials, 3, tri_light, lights, n_lights,
+                               nodes, n_nodes, prim_order, &scene);
+    pbrt_hip_free(nodes);
+    pbrt_hip_free(prim_order);
+    if (rc != PBRT_HIP_OK) {
+        fprintf(stderr, "pbrt_hip_scene_create failed (%d): %s\n", rc, pbrt_hip_last_error(ctx));
+        pbrt_hip_context_destroy(ctx);
+        return 4;
+    }
+
+    PbrtCamera cam;
+    const double eye[3] = {0.0, 0.0, -3.4}, look[3] = {0.0, 0.0, 0.0}, up[3] = {0.0, 1.0, 0.0};
+    perspective_camera(eye, look, up, 40.0, width, height, &cam);
+    PbrtRenderParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.integrator = PBRT_INTEGRATOR_PATH;
+    rp.max_depth = 5;
+    rp.rr_threshold = 1.0f;
+    rp.light_strategy = 1; /* "power" */
+    rp.spp = spp;
+    rp.width = width;
+    rp.height = height;
+    rp.x1 = width;
+    rp.y1 = height;
+    rp.tile_world = 1;
+    rp.filter_radius[0] = rp.filter_radius[1] = 0.5f; /* box filter, no table */
+    rp.sampler = PBRT_SAMPLER_RANDOM;
+    float* film = (float*)calloc((size_t)width * height * 4, sizeof(float));
+    float* rgb = (float*)calloc((size_t)width * height * 3, sizeof(float));
+    PbrtRenderStats stats;
+    rc = pbrt_hip_render(scene, &cam, &rp, film, &stats);
+    if (rc != PBRT_HIP_OK) {
+        fprintf(stderr, "pbrt_hip_render failed (%d): %s\n", rc, pbrt_hip_last_error(ctx));
+    } else {
+        pbrt_hip_film_to_rgb(film, (int64_t)width * height, rgb);
+        double mean = 0.0;
+        for (size_t i = 0; i < (size_t)width * height * 3; ++i) mean += rgb[i];
+        mean /= (double)width * height * 3;
+        printf("%llu camera samples, %llu closest-hit + %llu shadow rays in %.2f ms; mean RGB %.4f\n",
+               (unsigned long long)stats.camera_samples, (unsigned long long)stats.rays_closest,
+               (unsigned long long)stats.rays_shadow, stats.total_ms, mean);
+        rc = pbrt_hip_write_png(out_path, rgb, width, height);
+        if (rc != PBRT_HIP_OK) fprintf(stderr, "pbrt_hip_write_png(%s) failed (%d)\n", out_path, rc);
+    }
+    free(film);
+    free(rgb);
+    pbrt_hip_scene_destroy(scene);
+    pbrt_hip_context_destroy(ctx);
+    return rc == PBRT_HIP_OK ? 0 : 5;
+}
