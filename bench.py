@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--cpu-crop", type=int, nargs=2, default=[320, 180], help="crop rendered by the CPU oracle")
     ap.add_argument("--cpu-spp", type=int, default=16)
     ap.add_argument("--spp-per-pass", type=int, default=0)
+    ap.add_argument("--abi-reduce-check", action="store_true",
+                    help="run the C-ABI film-reduce check even with one rank (needs torch.distributed.run)")
     return ap.parse_args()
 
 
@@ -64,6 +66,37 @@ def host_cores():
 def algorithmic_bytes(rays_closest, rays_shadow, node_tests, prim_tests):
     """32 B ray in + 32 B per box test + 48 B per triangle test + 16 B (closest) or 4 B (any) out."""
     return 32 * (rays_closest + rays_shadow) + 32 * node_tests + 48 * prim_tests + 16 * rays_closest + 4 * rays_shadow
+
+
+def abi_film_reduce_check(pbrt_hip, dist, torch, ctx, scene, cam, W, H, spp_total, args, rank, world, local_rank):
+    """This rank's film, summed onto rank 0 twice: by torch.distributed (reference) and by pbrt_hip_film_reduce."""
+    try:
+        f = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+        scene.render(cam, W, H, spp_total, max_depth=args.max_depth, rr_threshold=1.0, light_strategy=1, seed=0,
+                     tile_rank=rank, tile_world=world, spp_per_pass=args.spp_per_pass, d_film_ptr=f.data_ptr())
+        ref = f.clone()
+        dist.reduce(ref, dst=0, op=dist.ReduceOp.SUM)
+        ids = [pbrt_hip.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0, device=torch.device("cuda", local_rank))
+        torch.cuda.synchronize()
+        comm = pbrt_hip.Comm(ctx, world, rank, ids[0])
+        comm.film_reduce(f.data_ptr(), W * H, root=0)
+        comm.close()
+        ok = torch.ones(1, device=f"cuda:{local_rank}")
+        msg = "ok"
+        if rank == 0:
+            diff = float((f - ref).abs().max())
+            scale = float(ref.abs().max())
+            msg = f"max |abi - torch| = {diff:.3g} of {scale:.3g}"
+            if not diff <= 1e-5 * scale:
+                ok.zero_()
+                msg = "MISMATCH: " + msg
+            else:
+                msg = "ok: " + msg
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return msg
+    except Exception as e:  # reported, never fatal for the measurement
+        return f"error: {type(e).__name__}: {e}"
 
 
 def main():
@@ -100,14 +133,25 @@ def main():
     t_bvh = time.time() - t0
     ctx = pbrt_hip.Context(local_rank)
     scene = pbrt_hip.Scene(ctx, sc, bvh=bvh)
-    film = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+    # Two films: the reduce of frame k (torch's stream) may still be reading its film while frame k+1 is rendered
+    # (the library's stream); a film is reused only after the reduce that read it has finished.
+    films = [torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(2 if use_dist else 1)]
+    reduced = [None] * len(films)
+    frame = [0]
 
     def step():
+        k = frame[0] % len(films)
+        frame[0] += 1
+        film = films[k]
+        if reduced[k] is not None:
+            reduced[k].synchronize()
         _, st = scene.render(cam, W, H, spp_total, max_depth=args.max_depth, rr_threshold=1.0, light_strategy=1,
                              seed=0, tile_rank=rank, tile_world=world, spp_per_pass=args.spp_per_pass,
                              d_film_ptr=film.data_ptr())
         if use_dist:
             dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)  # the only collective: Film reduce over xGMI
+            reduced[k] = torch.cuda.Event()
+            reduced[k].record()
         return st
 
     for _ in range(args.warmup):
@@ -143,7 +187,7 @@ def main():
         ctx.counters(reset=True)
         st_c = step() if world == 1 else scene.render(cam, W, H, spp_total, max_depth=args.max_depth, seed=0,
                                                        tile_rank=rank, tile_world=world,
-                                                       spp_per_pass=args.spp_per_pass, d_film_ptr=film.data_ptr())[1]
+                                                       spp_per_pass=args.spp_per_pass, d_film_ptr=films[0].data_ptr())[1]
         c = ctx.counters(reset=True)
         ctx.set_counting(False)
         frame_bytes = algorithmic_bytes(st_c["rays_closest"], st_c["rays_shadow"], c["node_tests"], c["prim_tests"])
@@ -203,6 +247,26 @@ def main():
             },
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+    if world > 1 or (args.abi_reduce_check and use_dist):
+        # Untimed: the same film merge through the C ABI's own RCCL communicator (pbrt_hip_comm_create /
+        # pbrt_hip_film_reduce), checked against torch.distributed's reduce. A watchdog prints the line anyway
+        # should RCCL's second communicator not come up.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["config"]["abi_film_reduce"] = "timeout"
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(150.0, give_up)
+        dog.daemon = True
+        dog.start()
+        status = abi_film_reduce_check(pbrt_hip, dist, torch, ctx, scene, cam, W, H, spp_total, args, rank, world, local_rank)
+        dog.cancel()
+        if rank == 0:
+            out["config"]["abi_film_reduce"] = status
+    if rank == 0:
         print(json.dumps(out), flush=True)
     barrier()
     scene.close()

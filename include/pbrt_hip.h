@@ -296,6 +296,22 @@ int pbrt_hip_render(PbrtHipScene* scene, const PbrtCamera* camera, const PbrtRen
 int pbrt_hip_render_device(PbrtHipScene* scene, const PbrtCamera* camera, const PbrtRenderParams* params,
                            float* d_film_xyzw, PbrtRenderStats* stats);
 
+/* ---- multi-GPU film merge (replaces the cross-tile part of Film::merge_film_tile,
+ * src/core/film.rs:93-123, and parallel_for_2d's join, src/core/parallel.rs:4-21) ----
+ * One process per GPU. Rank 0 draws a communicator id and hands it to the other ranks out of band (the host
+ * renderer's launcher: a file, MPI, torch.distributed ...); every rank then creates its communicator on its own
+ * context (ncclCommInitRank over xGMI) and, after pbrt_hip_render_device, sums the per-rank films in place with one
+ * RCCL reduce on the context's stream: root >= 0 leaves the frame on that rank, root < 0 on every rank.
+ * RCCL is loaded on first use; pbrt_hip_comm_last_error gives the text when no context is at hand. */
+typedef struct PbrtHipComm PbrtHipComm;
+#define PBRT_HIP_COMM_ID_BYTES 128
+int pbrt_hip_comm_unique_id(uint8_t id[PBRT_HIP_COMM_ID_BYTES]);
+int pbrt_hip_comm_create(PbrtHipContext* ctx, int32_t world, int32_t rank, const uint8_t id[PBRT_HIP_COMM_ID_BYTES],
+                         PbrtHipComm** out);
+void pbrt_hip_comm_destroy(PbrtHipComm* comm);
+int pbrt_hip_film_reduce(PbrtHipComm* comm, float* d_film_xyzw, int64_t n_pixels, int32_t root);
+const char* pbrt_hip_comm_last_error(void);
+
 /* Tile partition used by pbrt_hip_render (host only, no GPU needed): the 16x16 tiles of the pixel
  * bounds (src/core/integrator.rs:402-409) in row-major order; tile t belongs to rank t % world.
  * Writes this rank's tile origins (x, y pairs) to origins_xy (capacity in tiles) and their count

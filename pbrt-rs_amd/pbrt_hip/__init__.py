@@ -30,6 +30,8 @@ EXPORTS = [
     "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
     "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png",
+    "pbrt_hip_comm_unique_id", "pbrt_hip_comm_create", "pbrt_hip_comm_destroy", "pbrt_hip_film_reduce",
+    "pbrt_hip_comm_last_error",
 ]
 
 
@@ -94,6 +96,13 @@ def lib():
         for name in ("pbrt_hip_intersect", "pbrt_hip_intersect_p", "pbrt_hip_intersect_device",
                      "pbrt_hip_intersect_p_device"):
             getattr(L, name).argtypes = [vp, vp, i64, vp]
+        L.pbrt_hip_comm_unique_id.argtypes = [vp]
+        L.pbrt_hip_comm_create.argtypes = [vp, i32, i32, vp, ctypes.POINTER(vp)]
+        L.pbrt_hip_comm_destroy.argtypes = [vp]
+        L.pbrt_hip_comm_destroy.restype = None
+        L.pbrt_hip_film_reduce.argtypes = [vp, vp, i64, i32]
+        L.pbrt_hip_comm_last_error.argtypes = []
+        L.pbrt_hip_comm_last_error.restype = ctypes.c_char_p
         L.pbrt_hip_synchronize.argtypes = [vp]
         L.pbrt_hip_trace_timing.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_uint64)]
@@ -433,6 +442,50 @@ class Scene:
         if getattr(self, "h", None):
             if self.ctx.h:
                 lib().pbrt_hip_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """ncclGetUniqueId: 128 bytes that rank 0 hands to the other ranks out of band."""
+    buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
+    rc = lib().pbrt_hip_comm_unique_id(buf)
+    if rc != 0:
+        raise PbrtHipError(f"pbrt_hip_comm_unique_id failed ({rc}): {lib().pbrt_hip_comm_last_error().decode()}")
+    return bytes(buf)
+
+
+class Comm:
+    """RCCL communicator of one rank (one process per GPU) for the film merge."""
+
+    def __init__(self, ctx, world, rank, unique_id):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique_id must be 128 bytes")
+        self.ctx, self.world, self.rank = ctx, world, rank
+        h = ctypes.c_void_p()
+        buf = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        rc = lib().pbrt_hip_comm_create(ctx.h, world, rank, buf, ctypes.byref(h))
+        if rc != 0:
+            raise PbrtHipError(f"pbrt_hip_comm_create failed ({rc}): {lib().pbrt_hip_comm_last_error().decode()}")
+        self.h = h
+
+    def film_reduce(self, d_film_ptr, n_pixels, root=0):
+        """Sum of the ranks' device films in place; root < 0: all-reduce."""
+        rc = lib().pbrt_hip_film_reduce(self.h, ctypes.c_void_p(d_film_ptr), n_pixels, root)
+        if rc != 0:
+            raise PbrtHipError(f"pbrt_hip_film_reduce failed ({rc}): {lib().pbrt_hip_comm_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().pbrt_hip_comm_destroy(self.h)
             self.h = None
 
     def __del__(self):

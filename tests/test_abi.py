@@ -116,6 +116,22 @@ def test_no_gpu_is_an_error_not_a_fallback():
     assert "no HIP device" in str(e.value) or "failed" in str(e.value)
 
 
+def test_comm_without_a_gpu_is_an_error():
+    """The RCCL film-merge entry points refuse to start without a device; bad arguments are errors."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pbrt_hip.PbrtHipError) as e:
+        pbrt_hip.comm_unique_id()
+    assert "no HIP device" in str(e.value) or "RCCL" in str(e.value)
+    L = pbrt_hip.lib()
+    out = ctypes.c_void_p()
+    buf = (ctypes.c_uint8 * 128)()
+    assert L.pbrt_hip_comm_create(None, 2, 0, buf, ctypes.byref(out)) == 1 and not out.value      # no context
+    assert L.pbrt_hip_film_reduce(None, None, 0, 0) == 1
+    L.pbrt_hip_comm_destroy(None)                                                                   # a no-op
+
+
 @pytest.mark.parametrize("kind,rx,ry,a,b", [("box", 0.5, 0.5, 0, 0), ("gaussian", 2.0, 2.0, 2.0, 0),
                                             ("mitchell", 2.0, 2.0, 1 / 3, 1 / 3), ("lanczos", 4.0, 4.0, 3.0, 0),
                                             ("triangle", 2.0, 1.5, 0, 0)])
