@@ -247,32 +247,41 @@ def main():
             },
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+    printed = [False]
+
+    def emit():
+        if rank == 0 and not printed[0]:
+            printed[0] = True
+            print(json.dumps(out), flush=True)
+
+    dog = None
     if world > 1 or (args.abi_reduce_check and use_dist):
         # Untimed: the same film merge through the C ABI's own RCCL communicator (pbrt_hip_comm_create /
-        # pbrt_hip_film_reduce), checked against torch.distributed's reduce. A watchdog prints the line anyway
-        # should RCCL's second communicator not come up.
+        # pbrt_hip_film_reduce), checked against torch.distributed's reduce. Should a rank fail to bring the second
+        # communicator up, the others would wait for it: a watchdog, armed until the process ends, prints the
+        # measured line and ends the rank.
         import threading
 
         def give_up():
             if rank == 0:
-                out["config"]["abi_film_reduce"] = "timeout"
-                print(json.dumps(out), flush=True)
+                out["config"].setdefault("abi_film_reduce", "timeout")
+            emit()
             os._exit(0)
 
         dog = threading.Timer(150.0, give_up)
         dog.daemon = True
         dog.start()
         status = abi_film_reduce_check(pbrt_hip, dist, torch, ctx, scene, cam, W, H, spp_total, args, rank, world, local_rank)
-        dog.cancel()
         if rank == 0:
             out["config"]["abi_film_reduce"] = status
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    emit()
     barrier()
     scene.close()
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+    if dog is not None:
+        dog.cancel()
 
 
 if __name__ == "__main__":
