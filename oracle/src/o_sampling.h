@@ -289,7 +289,7 @@ struct HaltonSetup {
     int base_scales[2] = {1, 1}, base_exponents[2] = {0, 0};
     int64_t sample_stride = 1;
     uint64_t mult_inverse[2] = {0, 0};
-    static const int MAX_RESOLUTION = 128;
+    static constexpr int MAX_RESOLUTION = 128;
     void init(int res_x, int res_y) {
         const int res[2] = {res_x, res_y};
         for (int i = 0; i < 2; ++i) {
