@@ -1379,6 +1379,12 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         q[k].trace = buf.alloc<uint32_t>(N * 3, &ok);
         q[k].shade = buf.alloc<uint32_t>(N, &ok);
         q[k].counts64 = buf.alloc<unsigned long long>(2, &ok);
+        q[k].keys = nullptr;
+        for (int a = 0; a < 3; ++a) {
+            const float lo = s->d.bvh.root_min[a], hi = s->d.bvh.root_max[a];
+            q[k].key_lo[a] = lo;
+            q[k].key_inv[a] = hi > lo ? 1.0f / (hi - lo) : 0.0f;
+        }
     }
     // ray-queue sort (spatial order for the bounce rays): keys in / out, sorted entries, rocPRIM scratch
     const char* sort_env = std::getenv("PBRT_HIP_SORT_RAYS");
@@ -1387,6 +1393,10 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     const bool sort_rays = !(sort_env && sort_env[0] == '0') && rp.integrator == PBRT_INTEGRATOR_PATH;
     const char* sort_from_env = std::getenv("PBRT_HIP_SORT_FROM");  // first sorted wavefront (development knob)
     const int sort_from = sort_from_env ? std::atoi(sort_from_env) : 2;
+    // the keys are written by k_shade together with the queue entries; PBRT_HIP_SORT_FUSED=0 (and the builds with
+    // direction-octant bits) compute them in a pass of their own
+    const char* fused_env = std::getenv("PBRT_HIP_SORT_FUSED");
+    const bool fused_keys = !(fused_env && fused_env[0] == '0') && PB_SORT_OCTANT == 0;
     uint32_t *sort_keys[2] = {nullptr, nullptr}, *sort_vals = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
@@ -1619,13 +1629,12 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                 if (sort_rays && wavefront >= sort_from && n_trace >= (1u << 20)) {
                     // from the second bounce on the rays of a wavefront start all over the scene (the first bounce still
                     // follows the pixel order of its camera rays): trace them in Morton order of their origins
-                    const float* mn = s->d.bvh.root_min;
-                    const float* mx = s->d.bvh.root_max;
-                    float3 lo = make_float3(mn[0], mn[1], mn[2]);
-                    float3 inv = make_float3(mx[0] > mn[0] ? 1.0f / (mx[0] - mn[0]) : 0.0f, mx[1] > mn[1] ? 1.0f / (mx[1] - mn[1]) : 0.0f,
-                                             mx[2] > mn[2] ? 1.0f / (mx[2] - mn[2]) : 0.0f);
-                    hipLaunchKernelGGL(k_ray_sort_keys, dim3((n_trace + 255) / 256), dim3(256), 0, st, ps, q[cur].trace, n_trace, lo,
-                                       inv, sort_keys[0]);
+                    if (!fused_keys) {
+                        float3 lo = make_float3(q[cur].key_lo[0], q[cur].key_lo[1], q[cur].key_lo[2]);
+                        float3 inv = make_float3(q[cur].key_inv[0], q[cur].key_inv[1], q[cur].key_inv[2]);
+                        hipLaunchKernelGGL(k_ray_sort_keys, dim3((n_trace + 255) / 256), dim3(256), 0, st, ps, q[cur].trace, n_trace, lo,
+                                           inv, sort_keys[0]);
+                    }
                     size_t tb = sort_tmp_bytes;
                     if (pb::sort_pairs_u32(st, sort_tmp, &tb, sort_keys[0], sort_keys[1], q[cur].trace, sort_vals, n_trace, kSortKeyBits) != 0 &&
                         rc == PBRT_HIP_OK) {
@@ -1667,6 +1676,8 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             }
             int nxt = cur ^ 1;
             RENDER_TRY(hipMemsetAsync(q[nxt].counts64, 0, 2 * sizeof(unsigned long long), st));
+            // the wavefront this launch of k_shade fills is traced in Morton order: have it write the keys as well
+            q[nxt].keys = (sort_rays && fused_keys && wavefront + 1 >= sort_from) ? sort_keys[0] : nullptr;
             if (direct)
 {
                 dim3 sg((n_shade + 255) / 256), sb(256);

@@ -103,7 +103,30 @@ struct Queues {
     // counts64[0]: low 32 bits = trace-queue length, high 32 bits = shadow rays among them;
     // counts64[1]: shade-queue length
     unsigned long long* counts64;
+    // sort key of every trace-queue entry (ray_sort_key), written with the entry when the next wavefront will be
+    // traced in Morton order; null otherwise
+    uint32_t* keys;
+    float key_lo[3], key_inv[3];  // scene bounds: lower corner, 1 / extent
 };
+
+#ifndef PB_SORT_AXIS_BITS
+#define PB_SORT_AXIS_BITS 5
+#endif
+#ifndef PB_SORT_OCTANT
+#define PB_SORT_OCTANT 0
+#endif
+constexpr int kSortKeyBits = 3 * PB_SORT_AXIS_BITS + 3 * PB_SORT_OCTANT + 1;
+// Morton code of the cell of `o` in the scene bounds, PB_SORT_AXIS_BITS bits per axis
+PB_DEV uint32_t ray_sort_cell(float ox, float oy, float oz, const float* lo, const float* inv) {
+    constexpr float kCells = (float)(1 << PB_SORT_AXIS_BITS);
+    float fx = (ox - lo[0]) * inv[0], fy = (oy - lo[1]) * inv[1], fz = (oz - lo[2]) * inv[2];
+    uint32_t q[3] = {(uint32_t)fminf(fmaxf(fx * kCells, 0.0f), kCells - 1.0f), (uint32_t)fminf(fmaxf(fy * kCells, 0.0f), kCells - 1.0f),
+                     (uint32_t)fminf(fmaxf(fz * kCells, 0.0f), kCells - 1.0f)};
+    uint32_t code = 0;
+    for (int b = 0; b < PB_SORT_AXIS_BITS; ++b)
+        for (int k = 0; k < 3; ++k) code |= ((q[k] >> b) & 1u) << (3 * b + k);
+    return code;
+}
 
 PB_DEV uint64_t sample_sequence(const PassParams& pp, int x, int y, int s) {
     return pp.seed ^ (uint64_t)(((int64_t)y * pp.width + x) * (int64_t)pp.spp + s);
@@ -123,7 +146,9 @@ PB_DEV uint32_t lane_prefix(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 // Every thread of the block must call this. n_cont/n_mis/n_shadow in {0,1}; again = path stays in the shade queue.
-PB_DEV void block_append(BlockAppend& sh, const Queues& q, uint32_t p, bool cont, bool mis, bool shadow, bool again) {
+// cell = ray_sort_cell of the point the path's rays leave from (used only when q.keys is set).
+PB_DEV void block_append(BlockAppend& sh, const Queues& q, uint32_t p, bool cont, bool mis, bool shadow, bool again,
+                         uint32_t cell = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63) >> 6;
     unsigned long long mc = __ballot(cont), mm = __ballot(mis), ms = __ballot(shadow), ma = __ballot(again);
     uint32_t wc = (uint32_t)__popcll(mc), wm = (uint32_t)__popcll(mm), ws = (uint32_t)__popcll(ms);
@@ -151,9 +176,16 @@ PB_DEV void block_append(BlockAppend& sh, const Queues& q, uint32_t p, bool cont
     __syncthreads();
     uint32_t rbase = sh.base_rays + sh.wave_rays[wave];
     // within the wave: all continuation rays, then MIS rays, then shadow rays
-    if (cont) q.trace[rbase + lane_prefix(mc)] = p * 4u + RS_CONT;
-    if (mis) q.trace[rbase + wc + lane_prefix(mm)] = p * 4u + RS_MIS;
-    if (shadow) q.trace[rbase + wc + wm + lane_prefix(ms)] = p * 4u + RS_SHADOW;
+    uint32_t ic = rbase + lane_prefix(mc), im = rbase + wc + lane_prefix(mm), is = rbase + wc + wm + lane_prefix(ms);
+    if (cont) q.trace[ic] = p * 4u + RS_CONT;
+    if (mis) q.trace[im] = p * 4u + RS_MIS;
+    if (shadow) q.trace[is] = p * 4u + RS_SHADOW;
+    if (q.keys) {  // the three rays leave from the same surface point: one cell, the any-hit flag on top
+        if (PB_SORT_OCTANT) cell <<= 3;
+        if (cont) q.keys[ic] = cell;
+        if (mis) q.keys[im] = cell;
+        if (shadow) q.keys[is] = cell | (1u << (kSortKeyBits - 1));
+    }
     if (again) q.shade[sh.base_paths + sh.wave_paths[wave] + lane_prefix(ma)] = p;
 }
 
@@ -534,13 +566,8 @@ struct WavefrontRayIO {
 // Sort key of a queued ray: any-hit flag, then a 15-bit Morton code of the origin inside the scene bounds. Rays that
 // start close together walk the same part of the tree: in cache order the traversal kernel runs 20 % faster on
 // incoherent bounce rays (tools/probe_sorting.py), which pays for the two 8-bit radix passes.
-#ifndef PB_SORT_AXIS_BITS
-#define PB_SORT_AXIS_BITS 5
-#endif
-#ifndef PB_SORT_OCTANT
-#define PB_SORT_OCTANT 0
-#endif
-constexpr int kSortKeyBits = 3 * PB_SORT_AXIS_BITS + 3 * PB_SORT_OCTANT + 1;
+// The stand-alone form of the key (the fused one is written by k_shade's block_append): PBRT_HIP_SORT_FUSED=0, and
+// the builds with direction-octant bits.
 __global__ void k_ray_sort_keys(PathState ps, const uint32_t* __restrict__ queue, uint32_t n, float3 lo, float3 inv_extent,
                                 uint32_t* __restrict__ keys) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -548,13 +575,8 @@ __global__ void k_ray_sort_keys(PathState ps, const uint32_t* __restrict__ queue
     uint32_t e = queue[i];
     uint32_t p = e >> 2, slot = e & 3u;
     float4 a = ps.ray[ray_index(ps, p, slot)];
-    constexpr float kCells = (float)(1 << PB_SORT_AXIS_BITS);
-    float fx = (a.x - lo.x) * inv_extent.x, fy = (a.y - lo.y) * inv_extent.y, fz = (a.z - lo.z) * inv_extent.z;
-    uint32_t q[3] = {(uint32_t)fminf(fmaxf(fx * kCells, 0.0f), kCells - 1.0f), (uint32_t)fminf(fmaxf(fy * kCells, 0.0f), kCells - 1.0f),
-                     (uint32_t)fminf(fmaxf(fz * kCells, 0.0f), kCells - 1.0f)};
-    uint32_t code = 0;
-    for (int b = 0; b < PB_SORT_AXIS_BITS; ++b)
-        for (int k = 0; k < 3; ++k) code |= ((q[k] >> b) & 1u) << (3 * b + k);
+    const float l[3] = {lo.x, lo.y, lo.z}, iv[3] = {inv_extent.x, inv_extent.y, inv_extent.z};
+    uint32_t code = ray_sort_cell(a.x, a.y, a.z, l, iv);
 #if PB_SORT_OCTANT
     float4 d = ps.ray[ray_index(ps, p, slot) + 1];  // (d.y, d.z, t_max, -); d.x rides in a.w
     code = (code << 3) | (a.w < 0.0f ? 1u : 0u) | (d.x < 0.0f ? 2u : 0u) | (d.y < 0.0f ? 4u : 0u);
@@ -1423,6 +1445,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
     uint32_t p = active ? qin.shade[i] : 0u;
     bool emit_cont = false, emit_mis = false, emit_shadow = false;
 
+    uint32_t cell = 0;  // sort cell of the rays this path emits
     if (active) {
         float4 Lq = ps.L[p], bq = ps.beta[p];
         V3 L = V3{Lq.x, Lq.y, Lq.z};
@@ -1452,7 +1475,10 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
             int hslot = __float_as_int(h1.x);
             bool found = hslot >= 0;
             Surf sf;
-            if (found) sf = surface_from_hit(sc.bvh, hslot, __float_as_int(h1.y), h0.y, h0.z, h0.w, rd);
+            if (found) {
+                sf = surface_from_hit(sc.bvh, hslot, __float_as_int(h1.y), h0.y, h0.z, h0.w, rd);
+                if (qout.keys) cell = ray_sort_cell(sf.p.x, sf.p.y, sf.p.z, qout.key_lo, qout.key_inv);
+            }
             // path.rs:80-88
             if (bounces == 0 || (flags & PF_SPECULAR_BOUNCE)) {
                 if (found) {
@@ -1558,7 +1584,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
 
     // ---- queue appends (block-aggregated) ----
     __shared__ BlockAppend sh;
-    block_append(sh, qout, p, emit_cont, emit_mis, emit_shadow, emit_cont || emit_mis || emit_shadow);
+    block_append(sh, qout, p, emit_cont, emit_mis, emit_shadow, emit_cont || emit_mis || emit_shadow, cell);
 }
 
 // -----------------------------------------------------------------------------------------------
