@@ -9,8 +9,9 @@
  *
  * Conventions: plain C, int status returns (0 = PBRT_HIP_OK), no exceptions cross the
  * boundary; host buffers are borrowed for the duration of the call; the library owns all
- * device memory behind the opaque handles; a handle is used from one thread at a time; one
- * device per context. Float = f32 everywhere (src/core/pbrt.rs:16).
+ * device memory behind the opaque handles; handles may be shared between host threads (the
+ * reference's Primitive is Sync + Send, src/core/primitive.rs:179): calls that reach the device
+ * through one context are serialised inside the library; one device per context. Float = f32 everywhere (src/core/pbrt.rs:16).
  */
 #ifndef PBRT_HIP_H
 #define PBRT_HIP_H

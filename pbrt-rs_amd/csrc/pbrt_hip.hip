@@ -97,12 +97,14 @@ extern "C" const char* pbrt_hip_last_error(const PbrtHipContext* ctx) {
 
 extern "C" int pbrt_hip_synchronize(PbrtHipContext* ctx) {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
+    PB_LOCK(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PBRT_HIP_OK;
 }
 
 extern "C" int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* total_ms, uint64_t* launches) {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
+    PB_LOCK(ctx);
     if (total_ms) *total_ms = ctx->trace_ms;
     if (launches) *launches = ctx->trace_launches;
     if (reset) {
@@ -114,12 +116,14 @@ extern "C" int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* tot
 
 extern "C" int pbrt_hip_set_counting(PbrtHipContext* ctx, int enable) {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
+    PB_LOCK(ctx);
     ctx->count_traversal = enable != 0;
     return PBRT_HIP_OK;
 }
 
 extern "C" int pbrt_hip_get_counters(PbrtHipContext* ctx, int reset, uint64_t counters[4]) {
     if (!ctx || !counters) return PBRT_HIP_ERR_INVALID;
+    PB_LOCK(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     unsigned long long h[4] = {0, 0, 0, 0};
@@ -297,6 +301,7 @@ extern "C" int pbrt_hip_scene_create_hlbvh(PbrtHipContext* ctx, const float* pos
                                            const PbrtLight* lights, int32_t n_lights, int32_t max_prims_in_node,
                                            PbrtHipScene** out, double* build_ms, double* layout_ms) {
     if (!ctx || !out) return PBRT_HIP_ERR_INVALID;
+    PB_LOCK(ctx);
     *out = nullptr;
     auto fail = [&](const char* msg) {
         ctx->last_error = msg;
@@ -380,6 +385,7 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     // dt != nullptr: the tree, the triangle records and the leaf order are already on the device
     // (pbrt_hip_scene_create_hlbvh); nodes / prim_order are then unused.
     if (!ctx || !out) return PBRT_HIP_ERR_INVALID;
+    PB_LOCK(ctx);
     *out = nullptr;
     if (dt) n_nodes = dt->n_nodes;
     auto fail = [&](const char* msg) {
@@ -680,6 +686,7 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
 
 extern "C" void pbrt_hip_scene_destroy(PbrtHipScene* s) {
     if (!s) return;
+    PB_LOCK(s->ctx);
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     for (void* p : s->allocs) (void)hipFree(p);
@@ -785,11 +792,13 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
 
 extern "C" int pbrt_hip_intersect_device(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtHit* d_out) {
     if (!s || n < 0 || (n > 0 && (!d_rays || !d_out))) return PBRT_HIP_ERR_INVALID;
+    PB_LOCK(s->ctx);
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     return launch_batch<false>(s, d_rays, n, d_out, nullptr);
 }
 extern "C" int pbrt_hip_intersect_p_device(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, uint8_t* d_out) {
     if (!s || n < 0 || (n > 0 && (!d_rays || !d_out))) return PBRT_HIP_ERR_INVALID;
+    PB_LOCK(s->ctx);
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     return launch_batch<true>(s, d_rays, n, nullptr, d_out);
 }
@@ -799,6 +808,7 @@ static int intersect_host(PbrtHipScene* s, const PbrtRay* rays, int64_t n, void*
     if (!s || n < 0 || (n > 0 && (!rays || !out))) return PBRT_HIP_ERR_INVALID;
     if (n == 0) return PBRT_HIP_OK;
     PbrtHipContext* ctx = s->ctx;
+    PB_LOCK(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     PbrtRay* d_rays = nullptr;
     void* d_out = nullptr;
@@ -1000,6 +1010,7 @@ extern "C" void pbrt_hip_film_to_rgb(const float* film, int64_t n_pixels, float*
 extern "C" int pbrt_hip_render_device(PbrtHipScene* s, const PbrtCamera* camera, const PbrtRenderParams* params,
                                       float* d_film, PbrtRenderStats* stats) {
     if (!s || !camera || !params || !d_film) return PBRT_HIP_ERR_INVALID;
+    PB_LOCK(s->ctx);
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     return wavefront_render(s, *camera, *params, d_film, stats);
 }
@@ -1008,6 +1019,7 @@ extern "C" int pbrt_hip_render(PbrtHipScene* s, const PbrtCamera* camera, const 
                                float* film_xyzw, PbrtRenderStats* stats) {
     if (!s || !camera || !params || !film_xyzw) return PBRT_HIP_ERR_INVALID;
     PbrtHipContext* ctx = s->ctx;
+    PB_LOCK(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (params->width <= 0 || params->height <= 0) return PBRT_HIP_ERR_INVALID;
     size_t bytes = (size_t)params->width * params->height * 4 * sizeof(float);
@@ -1146,6 +1158,7 @@ extern "C" int pbrt_hip_scene_set_shading_data(PbrtHipScene* s, const float* pos
                                                const float* tangents, const float* uvs) {
     if (!s) return PBRT_HIP_ERR_INVALID;
     PbrtHipContext* ctx = s->ctx;
+    PB_LOCK(ctx);
     auto fail = [&](const char* msg) {
         ctx->last_error = msg;
         return PBRT_HIP_ERR_INVALID;

@@ -8,13 +8,19 @@
 
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/pbrt_hip.h"
 #include "trace.h"
 
+// Calls that reach the device through one context are serialised: the reference's Primitive is Sync + Send and li() is
+// re-entrant (src/core/primitive.rs:179, integrator.rs:412-452), so a drop-in may be entered from several host threads.
+#define PB_LOCK(ctx) std::lock_guard<std::recursive_mutex> pb_lock_((ctx)->mu)
+
 struct PbrtHipContext {
+    std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

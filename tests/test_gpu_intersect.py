@@ -396,3 +396,47 @@ def test_error_behaviour_of_the_c_abi(hip_ctx):
     hits = g.intersect(rays)
     assert np.all(hits["prim_id"][:48] == -1)
     g.close()
+
+
+def test_handles_shared_between_host_threads(hip_ctx):
+    """The reference's Primitive is Sync + Send and li() is entered from many rayon tasks at once
+    (src/core/primitive.rs:179, integrator.rs:412-452): several host threads call intersect / intersect_p / render on
+    ONE scene (and a second scene of the same context) concurrently; every result equals the single-threaded one."""
+    import threading
+    sc_a = scenes.random_triangles(30_000, seq=4, size=0.03)
+    sc_b = scenes.cornell_box()
+    ga, gb = pbrt_hip.Scene(hip_ctx, sc_a), pbrt_hip.Scene(hip_ctx, sc_b)
+    batches = [scenes.random_rays(20_000 + 1000 * k, 40 + k, origin_extent=1.5) for k in range(6)]
+    want_hits = [ga.intersect(r) for r in batches]
+    want_any = [ga.intersect_p(r) for r in batches]
+    cam = scenes.cornell_camera(48, 32)
+    want_film, _ = gb.render(cam, 48, 32, 4, max_depth=3, seed=9)
+    errors, results = [], {}
+
+    def worker(k):
+        try:
+            for rep in range(3):
+                if k < 6:
+                    results[("hit", k, rep)] = ga.intersect(batches[k])
+                    results[("any", k, rep)] = ga.intersect_p(batches[k])
+                else:
+                    results[("film", k, rep)] = gb.render(cam, 48, 32, 4, max_depth=3, seed=9)[0]
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert len(results) == 6 * 3 * 2 + 2 * 3
+    for (kind, k, rep), got in results.items():
+        if kind == "hit":
+            assert got.tobytes() == want_hits[k].tobytes()
+        elif kind == "any":
+            assert np.array_equal(got, want_any[k])
+        else:
+            assert np.array_equal(got, want_film)
+    ga.close()
+    gb.close()
