@@ -332,6 +332,8 @@ int pbrt_hip_sample_bounds(int32_t width, int32_t height, float radius_x, float 
 int pbrt_hip_write_pfm(const char* path, const float* rgb, int32_t width, int32_t height);
 /* The same image as an 8-bit sRGB PNG (pbrt-v3's WriteImage for ".png": gamma-corrected, 255 v + 0.5 clamped). */
 int pbrt_hip_write_png(const char* path, const float* rgb, int32_t width, int32_t height);
+/* ... and as OpenEXR, pbrt-v3's default (".exr"): scanline file, float32 B / G / R channels, uncompressed, linear. */
+int pbrt_hip_write_exr(const char* path, const float* rgb, int32_t width, int32_t height);
 
 /* Film::write_image's per-pixel arithmetic (src/core/film.rs:153-178, without the file
  * writer, which is todo!() in the reference): rgb = max(0, xyz_to_rgb(xyz) / filter_weight_sum). Host. */

@@ -902,6 +902,85 @@ extern "C" int pbrt_hip_write_pfm(const char* path, const float* rgb, int32_t wi
     return ok ? PBRT_HIP_OK : PBRT_HIP_ERR_INVALID;
 }
 
+// OpenEXR, the format pbrt-v3 writes by default: single-part scanline file, three 32-bit float channels (stored in
+// alphabetical order B, G, R), no compression, one scanline per chunk. Linear values, nothing clamped.
+namespace {
+struct ExrBuf {
+    std::vector<unsigned char> b;
+    void bytes(const void* p, size_t n) { b.insert(b.end(), (const unsigned char*)p, (const unsigned char*)p + n); }
+    void str(const char* s) { bytes(s, std::strlen(s) + 1); }
+    void i32(int32_t v) { bytes(&v, 4); }  // little-endian host (x86-64)
+    void f32(float v) { bytes(&v, 4); }
+    void u8(unsigned char v) { b.push_back(v); }
+    void attr(const char* name, const char* type, int32_t size) {
+        str(name);
+        str(type);
+        i32(size);
+    }
+};
+}  // namespace
+
+extern "C" int pbrt_hip_write_exr(const char* path, const float* rgb, int32_t width, int32_t height) {
+    if (!path || !rgb || width <= 0 || height <= 0) return PBRT_HIP_ERR_INVALID;
+    ExrBuf h;
+    h.i32(20000630);  // magic 0x76 0x2f 0x31 0x01
+    h.i32(2);         // version 2, no flags: single-part scanline
+    h.attr("channels", "chlist", 3 * (2 + 4 + 4 + 4 + 4) + 1);
+    for (const char* c : {"B", "G", "R"}) {
+        h.str(c);
+        h.i32(2);  // FLOAT
+        h.u8(0);   // pLinear
+        h.u8(0);
+        h.u8(0);
+        h.u8(0);
+        h.i32(1);  // xSampling
+        h.i32(1);  // ySampling
+    }
+    h.u8(0);
+    h.attr("compression", "compression", 1);
+    h.u8(0);  // NO_COMPRESSION
+    for (const char* name : {"dataWindow", "displayWindow"}) {
+        h.attr(name, "box2i", 16);
+        h.i32(0);
+        h.i32(0);
+        h.i32(width - 1);
+        h.i32(height - 1);
+    }
+    h.attr("lineOrder", "lineOrder", 1);
+    h.u8(0);  // INCREASING_Y
+    h.attr("pixelAspectRatio", "float", 4);
+    h.f32(1.0f);
+    h.attr("screenWindowCenter", "v2f", 8);
+    h.f32(0.0f);
+    h.f32(0.0f);
+    h.attr("screenWindowWidth", "float", 4);
+    h.f32(1.0f);
+    h.u8(0);  // end of header
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return PBRT_HIP_ERR_INVALID;
+    const uint64_t row_bytes = (uint64_t)width * 3 * sizeof(float), chunk = 8 + row_bytes;
+    const uint64_t first = h.b.size() + (uint64_t)height * 8;
+    std::fwrite(h.b.data(), 1, h.b.size(), f);
+    for (int32_t y = 0; y < height; ++y) {  // offset table
+        uint64_t off = first + (uint64_t)y * chunk;
+        std::fwrite(&off, 8, 1, f);
+    }
+    std::vector<float> line((size_t)width * 3);
+    for (int32_t y = 0; y < height; ++y) {
+        const float* src = rgb + (size_t)y * width * 3;
+        for (int32_t x = 0; x < width; ++x) {
+            line[x] = src[3 * x + 2];                      // B
+            line[(size_t)width + x] = src[3 * x + 1];      // G
+            line[2 * (size_t)width + x] = src[3 * x];      // R
+        }
+        int32_t head[2] = {y, (int32_t)row_bytes};
+        std::fwrite(head, 4, 2, f);
+        std::fwrite(line.data(), sizeof(float), line.size(), f);
+    }
+    bool ok = std::fclose(f) == 0;
+    return ok ? PBRT_HIP_OK : PBRT_HIP_ERR_INVALID;
+}
+
 // 8-bit sRGB PNG (what pbrt-v3's WriteImage does for ".png": gamma_correct, 255 * v + 0.5 clamped to [0, 255]);
 // the reference's own writer is todo!() (src/core/imageio.rs:3-5). zlib stream of stored (uncompressed) deflate
 // blocks: no dependency, every PNG reader accepts it.

@@ -29,7 +29,7 @@ EXPORTS = [
     "pbrt_hip_scene_create_instanced", "pbrt_hip_scene_create_with_spheres", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
     "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
-    "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png",
+    "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png", "pbrt_hip_write_exr",
     "pbrt_hip_comm_unique_id", "pbrt_hip_comm_create", "pbrt_hip_comm_destroy", "pbrt_hip_film_reduce",
     "pbrt_hip_comm_last_error",
 ]
@@ -115,6 +115,7 @@ def lib():
         L.pbrt_hip_sample_bounds.argtypes = [i32, i32, ctypes.c_float, ctypes.c_float, vp]
         L.pbrt_hip_write_pfm.argtypes = [ctypes.c_char_p, vp, i32, i32]
         L.pbrt_hip_write_png.argtypes = [ctypes.c_char_p, vp, i32, i32]
+        L.pbrt_hip_write_exr.argtypes = [ctypes.c_char_p, vp, i32, i32]
         L.pbrt_hip_film_to_rgb.argtypes = [vp, i64, vp]
         L.pbrt_hip_film_to_rgb.restype = None
         _lib = L
@@ -534,6 +535,14 @@ def write_pfm(path, rgb):
     rc = lib().pbrt_hip_write_pfm(str(path).encode(), _p(rgb), rgb.shape[1], rgb.shape[0])
     if rc != 0:
         raise PbrtHipError(f"pbrt_hip_write_pfm failed ({rc})")
+
+
+def write_exr(path, rgb):
+    """Uncompressed float32 OpenEXR of an RGB float image (h, w, 3), linear values. Host only."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    rc = lib().pbrt_hip_write_exr(str(path).encode(), _p(rgb), rgb.shape[1], rgb.shape[0])
+    if rc != 0:
+        raise PbrtHipError(f"pbrt_hip_write_exr failed ({rc})")
 
 
 def write_png(path, rgb):

@@ -163,6 +163,65 @@ def test_write_pfm_roundtrip(tmp_path):
     assert np.array_equal(back, rgb)
 
 
+def _read_exr(raw):
+    """Minimal reader of a single-part uncompressed scanline OpenEXR file -> (attributes, {channel: [h, w] float32})."""
+    import struct
+    assert struct.unpack("<iI", raw[:8]) == (20000630, 2)
+    pos, attrs = 8, {}
+
+    def cstr(p):
+        e = raw.index(b"\0", p)
+        return raw[p:e].decode(), e + 1
+
+    while raw[pos] != 0:
+        name, pos = cstr(pos)
+        typ, pos = cstr(pos)
+        (size,) = struct.unpack("<i", raw[pos:pos + 4])
+        attrs[name] = (typ, raw[pos + 4:pos + 4 + size])
+        pos += 4 + size
+    pos += 1
+    chans, p, blob = [], 0, attrs["channels"][1]
+    while blob[p] != 0:
+        e = blob.index(b"\0", p)
+        name = blob[p:e].decode()
+        ptype, plinear, xs, ys = struct.unpack("<iB3xii", blob[e + 1:e + 17])
+        chans.append((name, ptype, xs, ys))
+        p = e + 17
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    offsets = struct.unpack(f"<{h}Q", raw[pos:pos + 8 * h])
+    out = {c[0]: np.zeros((h, w), dtype=np.float32) for c in chans}
+    for row, off in enumerate(offsets):
+        y, nbytes = struct.unpack("<ii", raw[off:off + 8])
+        assert y == y0 + row and nbytes == 4 * w * len(chans)
+        data = np.frombuffer(raw[off + 8:off + 8 + nbytes], dtype="<f4").reshape(len(chans), w)
+        for k, c in enumerate(chans):
+            out[c[0]][row] = data[k]
+    assert offsets[-1] + 8 + 4 * w * len(chans) == len(raw)
+    return attrs, chans, out
+
+
+def test_write_exr_reads_back(tmp_path):
+    """pbrt_hip_write_exr: the OpenEXR layout (magic / version, the eight required attributes, alphabetical float
+    channels, offset table, one scanline per chunk) and the exact linear values, negative and > 1 included."""
+    import struct
+    w, h = 37, 23
+    rgb = (scenes.pcg32_float(8, w * h * 3).reshape(h, w, 3) * 40.0 - 2.0).astype(np.float32)
+    path = tmp_path / "img.exr"
+    pbrt_hip.write_exr(path, rgb)
+    attrs, chans, planes = _read_exr(open(path, "rb").read())
+    assert set(attrs) == {"channels", "compression", "dataWindow", "displayWindow", "lineOrder", "pixelAspectRatio",
+                          "screenWindowCenter", "screenWindowWidth"}
+    assert chans == [("B", 2, 1, 1), ("G", 2, 1, 1), ("R", 2, 1, 1)]                 # FLOAT, alphabetical
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    assert struct.unpack("<4i", attrs["displayWindow"][1]) == (0, 0, w - 1, h - 1)
+    assert struct.unpack("<f", attrs["pixelAspectRatio"][1]) == (1.0,)
+    assert np.array_equal(planes["R"], rgb[..., 0]) and np.array_equal(planes["G"], rgb[..., 1])
+    assert np.array_equal(planes["B"], rgb[..., 2])
+    L = pbrt_hip.lib()
+    assert L.pbrt_hip_write_exr(None, None, 1, 1) == 1 and L.pbrt_hip_write_exr(b"/nonexistent/x.exr", rgb.ctypes.data, w, h) == 1
+
+
 def test_write_png_decodes_back(tmp_path):
     """pbrt_hip_write_png: a valid PNG (signature, chunk CRCs, zlib stream with Adler-32) whose pixels are the
     sRGB-encoded image; decoded here with zlib and checked against the transfer curve."""
