@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--cpu-crop", type=int, nargs=2, default=[320, 180], help="crop rendered by the CPU oracle")
     ap.add_argument("--cpu-spp", type=int, default=16)
     ap.add_argument("--spp-per-pass", type=int, default=0)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: the frame has spp x N samples per pixel (per-GPU work fixed); strong: spp in total, "
+                         "the tiles of the one frame are split over the GPUs (BASELINE config 4 style)")
     ap.add_argument("--abi-reduce-check", action="store_true",
                     help="run the C-ABI film-reduce check even with one rank (needs torch.distributed.run)")
     return ap.parse_args()
@@ -125,7 +128,7 @@ def main():
             dist.barrier()
 
     W, H = args.width, args.height
-    spp_total = args.spp * world
+    spp_total = args.spp * world if args.scaling == "weak" else args.spp
     sc = scenes.random_triangles(args.tris, seq=1)
     cam = scenes.random_triangles_camera(W, H)
     t0 = time.time()
@@ -231,13 +234,14 @@ def main():
                           f"({st_o['rays']} rays in {st_o['seconds']:.1f} s)",
             }
             osc.close()
+        split = f"{args.spp} spp per GPU" if args.scaling == "weak" else "tiles of one frame split over the GPUs"
         out = {
             "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"config3: {args.tris} random triangles + constant env light, PathIntegrator "
-                            f"max_depth {args.max_depth}, {W}x{H}x{spp_total}spp ({args.spp} spp per GPU), "
+                            f"max_depth {args.max_depth}, {W}x{H}x{spp_total}spp ({split}), "
                             f"SAH BVH <=4 prims/leaf, seed 0",
                 "parallelism": f"tiles16x16 round-robin over {world} GPU(s); RCCL film reduce" if world > 1
                                else "1 GPU",
