@@ -454,6 +454,11 @@ def test_ray_queue_sorting_does_not_change_the_film(hip_ctx, monkeypatch):
     b, st_b = g.render(cam, w, h, 16, max_depth=5, seed=9)
     assert a.tobytes() == b.tobytes()
     assert (st_a["rays_closest"], st_a["rays_shadow"]) == (st_b["rays_closest"], st_b["rays_shadow"])
+    monkeypatch.setenv("PBRT_HIP_SORT_RAYS", "1")
+    monkeypatch.setenv("PBRT_HIP_SORT_FUSED", "0")          # keys from the stand-alone pass instead of k_shade
+    c, st_c = g.render(cam, w, h, 16, max_depth=5, seed=9)
+    assert a.tobytes() == c.tobytes()
+    assert (st_a["rays_closest"], st_a["rays_shadow"]) == (st_c["rays_closest"], st_c["rays_shadow"])
     g.close()
 
 
