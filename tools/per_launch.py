@@ -15,7 +15,8 @@ if sys.argv[1] == "render":
         if it == 1:
             os.environ["PBRT_HIP_TRACE_LOG"] = "1"
             print("FRAME", flush=True)
-        _, st = g.render(cam, W, H, 64, max_depth=5, rr_threshold=1.0, light_strategy=1, seed=0)
+        _, st = g.render(cam, W, H, 64, max_depth=5, rr_threshold=1.0, light_strategy=1, seed=0,
+                         tile_rank=0, tile_world=int(os.environ.get("TILE_WORLD", "1")))
     print(st, flush=True)
 else:
     f = sorted(glob.glob(os.path.join(sys.argv[2], "**", "*kernel_trace.csv"), recursive=True))[-1]
@@ -27,5 +28,5 @@ else:
         name = r["Kernel_Name"]
         name = name.split("(")[0].replace("void ", "")[:60]
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-        if e - s > 50_000:
+        if e - s > int(os.environ.get("MIN_NS", "50000")):
             print(f"{(s - t0) / 1e6:9.2f} ms  +{(e - s) / 1e6:8.3f} ms  {name}")
