@@ -1,0 +1,168 @@
+// wf_generate_trace.h — k_generate (camera rays), the wavefront's ray IO for trace_persistent, sort keys, k_trace (part of wavefront.h)
+#pragma once
+#include "wf_sampler.h"
+
+namespace pb {
+
+__global__ void k_generate(PathState ps, Queues q, PassParams pp, DevCamera cam, TileList tiles) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = (uint32_t)pp.n_pix * pp.n_samples;
+    if (p >= n) return;
+    int s_local = p / pp.n_pix, pix = p % pp.n_pix;
+    int tile = pix >> 8, within = pix & 255;
+    int2 org = tiles.origin[tile];
+    int x = org.x + (within & 15), y = org.y + (within >> 4);
+    bool valid = x >= pp.x0 && x < pp.x1 && y >= pp.y0 && y < pp.y1;
+    int flags = 0;
+    if (valid) {
+        int s = pp.sample0 + s_local;
+        Samp sm;
+        rng_set_sequence(sm.rng, sample_sequence(pp, x, y, s));
+        sm.pix = pix;
+        sm.s = s;
+        sm.dim1 = sm.dim2 = sm.arr = 0;
+        sm.h_offset = pp.smp.kind == PBRT_SAMPLER_HALTON ? halton_pixel_offset(pp.smp, x, y) : 0;
+        // Sampler::get_camera_sample (sampler.rs:27-33): 2D film, 1D time, 2D lens
+        float u0, u1, l0, l1;
+        samp_2d(pp, sm, &u0, &u1);
+        float pfx = (float)x + u0, pfy = (float)y + u1;
+        float time_u = samp_1d(pp, sm);
+        samp_2d(pp, sm, &l0, &l1);
+        V3 o = V3{0.0f, 0.0f, 0.0f}, d;
+        if (cam.kind == PBRT_CAMERA_ENVIRONMENT) {
+            // EnvironmentCamera::generate_ray (cameras/environment.rs:37-56)
+            float theta = kPi * pfy / (float)pp.height;
+            float phi = 2.0f * kPi * pfx / (float)pp.width;
+            float st, ct, sp, cp;
+            det_sincos(theta, &st, &ct);
+            det_sincos(phi, &sp, &cp);
+            d = V3{st * cp, ct, st * sp};
+        } else if (cam.kind == PBRT_CAMERA_ORTHOGRAPHIC) {
+            // OrthographicCamera::generate_ray (cameras/orthographic.rs:82-104; D58: the lens point is added to the origin)
+            o = xform_point(cam.r2c, V3{pfx, pfy, 0.0f});
+            d = V3{0.0f, 0.0f, 1.0f};
+            if (cam.lens_radius > 0.0f) {
+                float lx, ly;
+                concentric_sample_disk(l0, l1, &lx, &ly);
+                lx *= cam.lens_radius;
+                ly *= cam.lens_radius;
+                float ft = cam.focal_distance / d.z;
+                V3 p_focus = o + d * ft;
+                o.x += lx;
+                o.y += ly;
+                d = normalize(p_focus - o);
+            }
+        } else {
+            V3 p_camera = xform_point(cam.r2c, V3{pfx, pfy, 0.0f});
+            d = normalize(p_camera);
+            if (cam.lens_radius > 0.0f) {
+                float lx, ly;
+                concentric_sample_disk(l0, l1, &lx, &ly);
+                lx *= cam.lens_radius;
+                ly *= cam.lens_radius;
+                float ft = cam.focal_distance / d.z;
+                V3 p_focus = o + d * ft;
+                o = V3{lx, ly, 0.0f};
+                d = normalize(p_focus - o);
+            }
+        }
+        (void)time_u;  // ray.time only feeds animated transforms / media (out of scope)
+        // Ray through camera_to_world with origin error (geometry.rs:865-881, 898-935)
+        const float* m = cam.c2w;
+        V3 ow = xform_point(m, o);
+        float xa = __builtin_fabsf(m[0] * o.x) + __builtin_fabsf(m[1] * o.y) + __builtin_fabsf(m[2] * o.z) + __builtin_fabsf(m[3]);
+        float ya = __builtin_fabsf(m[4] * o.x) + __builtin_fabsf(m[5] * o.y) + __builtin_fabsf(m[6] * o.z) + __builtin_fabsf(m[7]);
+        float za = __builtin_fabsf(m[8] * o.x) + __builtin_fabsf(m[9] * o.y) + __builtin_fabsf(m[10] * o.z) + __builtin_fabsf(m[11]);
+        V3 o_err = V3{xa, ya, za} * kGamma3;
+        V3 dw = xform_vector(m, d);
+        float l2 = len2(dw);
+        float tmax = kInf;
+        if (l2 > 0.0f) {
+            float dt = dot(vabs(dw), o_err) / l2;
+            ow = ow + dw * dt;
+            tmax -= dt;
+        }
+        store_ray(ps, p, RS_CONT, ow, dw, tmax);
+        samp_store(ps, p, sm);
+        ps.pfilm[p] = make_float2(pfx, pfy);
+        flags = PF_VALID | PF_ALIVE;
+    } else {
+        ps.pfilm[p] = make_float2(0.0f, 0.0f);
+    }
+    ps.L[p] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    ps.beta[p] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(flags));
+    // The first wavefront is every path in order: identity queues, no atomics. Paths of pixels
+    // outside pixel_bounds (partial border tiles) carry a ray that misses at once (t_max < 0).
+    if (!valid) store_ray(ps, p, RS_CONT, V3{0.0f, 0.0f, 0.0f}, V3{0.0f, 0.0f, 1.0f}, -1.0f);
+    q.trace[p] = p * 4u + RS_CONT;
+    q.shade[p] = p;
+}
+
+// ---- trace: every pending ray of the wavefront (trace_persistent.h) ----
+struct WavefrontRayIO {
+    PathState ps;
+    const uint32_t* __restrict__ queue;
+    uint32_t count;
+    int n_segments;
+    PB_DEV uint32_t n() const { return count; }
+    PB_DEV int segments() const { return n_segments; }
+    PB_DEV bool load(uint32_t i, TravRay* r, bool* any) const {
+        uint32_t e = queue[i];
+        uint32_t p = e >> 2, slot = e & 3u;
+        size_t ri = ray_index(ps, p, slot);
+        float4 a = ps.ray[ri], b = ps.ray[ri + 1];
+        *r = TravRay{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+        *any = slot == RS_SHADOW;
+        // t_max < 0 marks the placeholder ray of a path outside pixel_bounds (k_generate): not a ray of the frame
+        return !(b.z < 0.0f);
+    }
+    PB_DEV void store(uint32_t i, bool any, bool found, float t, float b0, float b1, float b2, int slot, int inst) const {
+        uint32_t e = queue[i];
+        uint32_t p = e >> 2, rs = e & 3u;
+        size_t ri = hit_index(ps, p, rs);
+        if (any) {
+            ps.hit[ri] = make_float4(found ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
+        } else {
+            ps.hit[ri] = make_float4(t, b0, b1, b2);
+            ps.hit[ri + 1] = make_float4(__int_as_float(found ? slot : -1), __int_as_float(inst), 0.0f, 0.0f);
+        }
+    }
+};
+// Sort key of a queued ray: any-hit flag, then a 15-bit Morton code of the origin inside the scene bounds. Rays that
+// start close together walk the same part of the tree: in cache order the traversal kernel runs 20 % faster on
+// incoherent bounce rays (tools/probe_sorting.py), which pays for the two 8-bit radix passes.
+// The stand-alone form of the key (the fused one is written by k_shade's block_append): PBRT_HIP_SORT_FUSED=0, and
+// the builds with direction-octant bits.
+__global__ void k_ray_sort_keys(PathState ps, const uint32_t* __restrict__ queue, uint32_t n, float3 lo, float3 inv_extent,
+                                uint32_t* __restrict__ keys) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t e = queue[i];
+    uint32_t p = e >> 2, slot = e & 3u;
+    float4 a = ps.ray[ray_index(ps, p, slot)];
+    const float l[3] = {lo.x, lo.y, lo.z}, iv[3] = {inv_extent.x, inv_extent.y, inv_extent.z};
+    uint32_t code = ray_sort_cell(a.x, a.y, a.z, l, iv);
+#if PB_SORT_OCTANT
+    float4 d = ps.ray[ray_index(ps, p, slot) + 1];  // (d.y, d.z, t_max, -); d.x rides in a.w
+    code = (code << 3) | (a.w < 0.0f ? 1u : 0u) | (d.x < 0.0f ? 2u : 0u) | (d.y < 0.0f ? 4u : 0u);
+#endif
+    keys[i] = code | ((slot == RS_SHADOW ? 1u : 0u) << (kSortKeyBits - 1));
+}
+
+#ifndef PB_TRACE_WAVES
+#define PB_TRACE_WAVES 6
+#endif
+#ifndef PB_INST_WAVES
+#define PB_INST_WAVES 5
+#endif
+template <bool COUNT, bool INST, bool SPH = false>
+__global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_INST_WAVES : PB_TRACE_WAVES))
+    k_trace(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
+            unsigned long long* counters, int segments) {
+    __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
+    WavefrontRayIO io{ps, queue, n, segments};
+    trace_persistent<WavefrontRayIO, COUNT, INST, SPH>(bvh, io, work_counter, lds_stack + threadIdx.x,
+                                                  blockIdx.x * kTraceBlock + threadIdx.x, counters);
+}
+
+}  // namespace pb

@@ -1,0 +1,156 @@
+// wf_path.h — k_shade: PathIntegrator::li, one bounce per launch (part of wavefront.h)
+#pragma once
+#include "wf_lights.h"
+
+namespace pb {
+
+__global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Queues qin, Queues qout, PassParams pp,
+                                                 TileList tiles, uint32_t n_in) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = i < n_in;
+    uint32_t p = active ? qin.shade[i] : 0u;
+    bool emit_cont = false, emit_mis = false, emit_shadow = false;
+
+    uint32_t cell = 0;  // sort cell of the rays this path emits
+    if (active) {
+        float4 Lq = ps.L[p], bq = ps.beta[p];
+        V3 L = V3{Lq.x, Lq.y, Lq.z};
+        float eta_scale = Lq.w;
+        V3 beta = V3{bq.x, bq.y, bq.z};
+        int fb = __float_as_int(bq.w);
+        int flags = fb & 0xff, bounces = fb >> 8;
+        size_t rbase = ray_index(ps, p, RS_CONT), hbase = hit_index(ps, p, RS_CONT);
+
+        // ---- (1) resolve the pending direct-lighting estimate (integrator.rs:136-266) ----
+        if (flags & (PF_NEE_SHADOW | PF_NEE_MIS)) {
+            float pick_pdf;
+            V3 beta_v;
+            V3 ld = estimate_direct_resolve(sc, ps, p, flags, &pick_pdf, &beta_v);
+            ld = ld / pick_pdf;                 // integrator.rs:133
+            L = L + mulv(beta_v, ld);           // path.rs:113-120
+            flags &= ~(PF_NEE_SHADOW | PF_NEE_MIS);
+        }
+
+        // ---- (2) the continuation hit ----
+        if (flags & PF_ALIVE) {
+            flags &= ~PF_ALIVE;
+            float4 r0 = ps.ray[rbase], r1 = ps.ray[rbase + 1];
+            V3 rd = V3{r0.w, r1.x, r1.y};
+            float4 h0 = ps.hit[hbase];
+            float4 h1 = ps.hit[hbase + 1];
+            int hslot = __float_as_int(h1.x);
+            bool found = hslot >= 0;
+            Surf sf;
+            if (found) {
+                sf = surface_from_hit(sc.bvh, hslot, __float_as_int(h1.y), h0.y, h0.z, h0.w, rd);
+                if (qout.keys) cell = ray_sort_cell(sf.p.x, sf.p.y, sf.p.z, qout.key_lo, qout.key_inv);
+            }
+            // path.rs:80-88
+            if (bounces == 0 || (flags & PF_SPECULAR_BOUNCE)) {
+                if (found) {
+                    L = L + mulv(beta, surface_le(sc, sf, -rd));
+                } else {
+                    for (int k = 0; k < sc.n_infinite; ++k) {
+                        DevLight lt = sc.lights[sc.infinite_ids[k]];
+                        L = L + mulv(beta, V3{lt.L[0], lt.L[1], lt.L[2]});
+                    }
+                }
+            }
+            if (found && bounces < pp.max_depth) {  // path.rs:90
+                DevMaterial mat = sc.materials[sf.material];
+                Samp sm = path_sampler(ps, pp, tiles, p);
+                if (mat.type == PBRT_MAT_NONE) {
+                    // path.rs:95-98: no BSDF -> continue through the surface, bounces unchanged
+                    V3 o = offset_ray_origin(sf.p, sf.p_error, sf.n, rd);
+                    store_ray(ps, p, RS_CONT, o, rd, kInf);
+                    flags |= PF_ALIVE;
+                    emit_cont = true;
+                } else {
+                    Frame fr = make_frame(sf);
+                    V3 kd = V3{mat.kd[0], mat.kd[1], mat.kd[2]};
+                    V3 kt = V3{mat.kt[0], mat.kt[1], mat.kt[2]};
+                    V3 wo = -rd;  // path.rs:122 `let wo = -ray.d` (estimate_direct uses isect.wo = sf.wo)
+                    bool has_lobe;  // which BxDFs the material adds: pbrt-v3 rules (matte / mirror / glass)
+                    if (mat.type == PBRT_MAT_GLASS) has_lobe = !(is_black(kd) && is_black(kt));
+                    else has_lobe = !is_black(kd);
+                    bool nonspecular = (mat.type == PBRT_MAT_MATTE) && has_lobe;
+
+                    // ---- uniform_sample_one_light (integrator.rs:92-134) ----
+                    if (nonspecular && sc.n_lights > 0) {
+                        float u_pick = samp_1d(pp, sm);
+                        DevDistribution1D distrib = light_distribution_lookup(sc, sf.p);  // path.rs:115
+                        int light_num = find_interval_cdf(distrib.cdf, distrib.n + 1, u_pick);
+                        float pick_pdf = distrib.func_int > 0.0f ? distrib.func[light_num] / (distrib.func_int * (float)distrib.n)
+                                                                 : 0.0f;
+                        if (pick_pdf != 0.0f) {
+                            float ul0, ul1, us0, us1;
+                            samp_2d(pp, sm, &ul0, &ul1);
+                            samp_2d(pp, sm, &us0, &us1);
+                            int nee_flags = estimate_direct_emit(sc, ps, p, sf, fr, true, kd, light_num, ul0, ul1, us0, us1,
+                                                                 pick_pdf, beta);
+                            flags |= nee_flags;
+                            emit_shadow = (nee_flags & PF_NEE_SHADOW) != 0;
+                            emit_mis = (nee_flags & PF_NEE_MIS) != 0;
+                        }
+                    }
+
+                    // ---- BSDF sampling for the next vertex (path.rs:123-152) ----
+                    float u0, u1;
+                    samp_2d(pp, sm, &u0, &u1);
+                    V3 wi = V3{0.0f, 0.0f, 0.0f}, f = V3{0.0f, 0.0f, 0.0f};
+                    float pdf = 0.0f;
+                    bool sampled_specular = false, sampled_transmission = false;
+                    if (has_lobe) {
+                        if (mat.type == PBRT_MAT_MATTE) {
+                            bool ok;
+                            f = matte_sample_f(fr, kd, wo, u0, u1, &wi, &pdf, &ok);
+                            if (!ok) pdf = 0.0f;
+                        } else {
+                            V3 wol = to_local(fr, wo);
+                            float ur = fminr(u0 * 1.0f - 0.0f, kOneMinusEpsilon);
+                            if (wol.z != 0.0f) {
+                                V3 wil = V3{0.0f, 0.0f, 0.0f};
+                                f = sample_specular_local(mat, kd, kt, wol, ur, 0, &wil, &pdf, &sampled_transmission);
+                                sampled_specular = pdf != 0.0f;
+                                if (pdf != 0.0f) wi = to_world(fr, wil);
+                                else f = V3{0.0f, 0.0f, 0.0f};
+                            }
+                        }
+                    }
+                    if (!(is_black(f) || pdf == 0.0f)) {  // path.rs:136
+                        beta = mulv(beta, f * (absdot(wi, fr.ns) / pdf));
+                        flags = (flags & ~PF_SPECULAR_BOUNCE) | (sampled_specular ? PF_SPECULAR_BOUNCE : 0);
+                        if (sampled_specular && sampled_transmission) {
+                            float eta = mat.eta;
+                            eta_scale *= (dot(wo, sf.n) > 0.0f) ? (eta * eta) : 1.0f / (eta * eta);
+                        }
+                        V3 o = offset_ray_origin(sf.p, sf.p_error, sf.n, wi);
+                        bool alive = true;
+                        // path.rs:200-207 Russian roulette (D27 intended)
+                        V3 rr_beta = beta * eta_scale;
+                        if (max_comp(rr_beta) < pp.rr_threshold && bounces > 3) {
+                            float qq = fmaxr(0.05f, 1.0f - max_comp(rr_beta));
+                            if (samp_1d(pp, sm) < qq) alive = false;
+                            else beta = beta / (1.0f - qq);
+                        }
+                        if (alive) {
+                            store_ray(ps, p, RS_CONT, o, wi, kInf);
+                            flags |= PF_ALIVE;
+                            emit_cont = true;
+                            bounces += 1;
+                        }
+                    }
+                }
+                samp_store(ps, p, sm);
+            }
+        }
+        ps.L[p] = make_float4(L.x, L.y, L.z, eta_scale);
+        ps.beta[p] = make_float4(beta.x, beta.y, beta.z, __int_as_float((bounces << 8) | flags));
+    }
+
+    // ---- queue appends (block-aggregated) ----
+    __shared__ BlockAppend sh;
+    block_append(sh, qout, p, emit_cont, emit_mis, emit_shadow, emit_cont || emit_mis || emit_shadow, cell);
+}
+
+}  // namespace pb
