@@ -1,0 +1,769 @@
+// render.hip — Integrator::render behind the C ABI: pbrt_hip_render / pbrt_hip_render_device
+// (SamplerIntegrator::render, src/core/integrator.rs:399-480) = wavefront_render, the host driver of the kernels in
+// wavefront.h; the per-vertex shading data of the TriangleMesh (pbrt_hip_scene_set_shading_data); the host side of the
+// HaltonSampler tables.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "scene.h"
+#include "trace.h"
+#include "wavefront.h"
+
+using namespace pb;
+
+// ------------------------------------------------------------------------------------
+// render: see wavefront.h
+// ------------------------------------------------------------------------------------
+extern "C" int pbrt_hip_render_device(PbrtHipScene* s, const PbrtCamera* camera, const PbrtRenderParams* params,
+                                      float* d_film, PbrtRenderStats* stats) {
+    if (!s || !camera || !params || !d_film) return PBRT_HIP_ERR_INVALID;
+    PB_LOCK(s->ctx);
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    return wavefront_render(s, *camera, *params, d_film, stats);
+}
+
+extern "C" int pbrt_hip_render(PbrtHipScene* s, const PbrtCamera* camera, const PbrtRenderParams* params,
+                               float* film_xyzw, PbrtRenderStats* stats) {
+    if (!s || !camera || !params || !film_xyzw) return PBRT_HIP_ERR_INVALID;
+    PbrtHipContext* ctx = s->ctx;
+    PB_LOCK(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (params->width <= 0 || params->height <= 0) return PBRT_HIP_ERR_INVALID;
+    size_t bytes = (size_t)params->width * params->height * 4 * sizeof(float);
+    float* d_film = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_film, bytes));
+    int rc = wavefront_render(s, *camera, *params, d_film, stats);
+    if (rc == PBRT_HIP_OK && !hip_ok(ctx, hipMemcpy(film_xyzw, d_film, bytes, hipMemcpyDeviceToHost), "film D2H"))
+        rc = PBRT_HIP_ERR_DEVICE;
+    (void)hipFree(d_film);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------
+// wavefront_render — host driver of the kernels in wavefront.h
+// ------------------------------------------------------------------------------------
+namespace {
+// Device buffers of one call. Blocks come from (and return to) the context's cache, so that repeated renders of the
+// same size do not pay hipMalloc / hipFree again.
+struct DevBuf {
+    std::vector<size_t> taken;  // indices into ctx->block_cache
+    PbrtHipContext* ctx;
+    explicit DevBuf(PbrtHipContext* c) : ctx(c) {}
+    ~DevBuf() {
+        for (size_t i : taken) ctx->block_cache[i].in_use = false;
+        size_t idle = 0;
+        for (const auto& b : ctx->block_cache)
+            if (!b.in_use) idle += b.bytes;
+        if (idle > ((size_t)160 << 30)) trim(ctx);  // renders of many different sizes: do not sit on most of the HBM
+    }
+    static void trim(PbrtHipContext* ctx) {  // release every block no call is using (slots stay, indices are stable)
+        for (auto& b : ctx->block_cache)
+            if (!b.in_use && b.ptr) {
+                (void)hipFree(b.ptr);
+                b.ptr = nullptr;
+                b.bytes = 0;
+            }
+    }
+    template <class T>
+    T* alloc(size_t n, bool* ok) {
+        const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        // best fit among the free cached blocks that are not wastefully large
+        size_t best = SIZE_MAX;
+        for (size_t i = 0; i < ctx->block_cache.size(); ++i) {
+            const auto& b = ctx->block_cache[i];
+            if (!b.in_use && b.ptr && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 + 4096 &&
+                (best == SIZE_MAX || b.bytes < ctx->block_cache[best].bytes))
+                best = i;
+        }
+        if (best != SIZE_MAX) {
+            ctx->block_cache[best].in_use = true;
+            taken.push_back(best);
+            return (T*)ctx->block_cache[best].ptr;
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {  // out of memory with idle cached blocks around: drop them and retry once
+            (void)hipGetLastError();
+            trim(ctx);
+            e = hipMalloc(&p, bytes);
+        }
+        if (!hip_ok(ctx, e, "hipMalloc (path state)")) {
+            *ok = false;
+            return nullptr;
+        }
+        size_t slot = ctx->block_cache.size();
+        for (size_t i = 0; i < ctx->block_cache.size(); ++i)
+            if (!ctx->block_cache[i].ptr && !ctx->block_cache[i].in_use) {
+                slot = i;
+                break;
+            }
+        if (slot == ctx->block_cache.size()) ctx->block_cache.push_back({nullptr, 0, false});
+        ctx->block_cache[slot] = {p, bytes, true};
+        taken.push_back(slot);
+        return (T*)p;
+    }
+};
+}  // namespace
+
+// ---- optional per-vertex normals / uvs of the TriangleMesh (triangle.rs:17-26, used at :60-72, 252-312, 337-341) ----
+__global__ void k_set_shading(const int* __restrict__ slot_prim, const int* __restrict__ idx, const float* __restrict__ pos,
+                              const float* __restrict__ normals, const float* __restrict__ tangents,
+                              const float* __restrict__ uvs, int n, float4* __restrict__ out, float4* __restrict__ tris) {
+    int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n) return;
+    int prim = slot_prim[slot];
+    int v[3] = {idx[3 * (size_t)prim], idx[3 * (size_t)prim + 1], idx[3 * (size_t)prim + 2]};
+    float nn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, uv[6] = {0.0f, 0.0f, 1.0f, 0.0f, 1.0f, 1.0f};
+    for (int k = 0; k < 3; ++k) {
+        if (normals)
+            for (int c = 0; c < 3; ++c) nn[3 * k + c] = normals[3 * (size_t)v[k] + c];
+        if (tangents)
+            for (int c = 0; c < 3; ++c) tt[3 * k + c] = tangents[3 * (size_t)v[k] + c];
+        if (uvs)
+            for (int c = 0; c < 2; ++c) uv[2 * k + c] = uvs[2 * (size_t)v[k] + c];
+    }
+    float4* o = out + 6 * (size_t)slot;
+    o[0] = make_float4(nn[0], nn[1], nn[2], nn[3]);
+    o[1] = make_float4(nn[4], nn[5], nn[6], nn[7]);
+    o[2] = make_float4(nn[8], tt[0], tt[1], tt[2]);
+    o[3] = make_float4(tt[3], tt[4], tt[5], tt[6]);
+    o[4] = make_float4(tt[7], tt[8], uv[0], uv[1]);
+    o[5] = make_float4(uv[2], uv[3], uv[4], uv[5]);
+    // "Triangle::intersect returns false" depends on the uvs (triangle.rs:197-216): refresh the flag
+    float a[3], b[3], c[3];
+    for (int k = 0; k < 3; ++k) {
+        a[k] = pos[3 * (size_t)v[0] + k];
+        b[k] = pos[3 * (size_t)v[1] + k];
+        c[k] = pos[3 * (size_t)v[2] + k];
+    }
+    float4 t2 = tris[3 * (size_t)slot + 2];
+    int w = __float_as_int(t2.w) & ~kTriDegenerate;
+    if (triangle_rejected_by_intersect(a, b, c, uv)) w |= kTriDegenerate;
+    t2.w = __int_as_float(w);
+    tris[3 * (size_t)slot + 2] = t2;
+}
+
+extern "C" int pbrt_hip_scene_set_shading_data(PbrtHipScene* s, const float* positions, int32_t n_verts,
+                                               const int32_t* indices, int32_t n_tris, const float* normals,
+                                               const float* tangents, const float* uvs) {
+    if (!s) return PBRT_HIP_ERR_INVALID;
+    PbrtHipContext* ctx = s->ctx;
+    PB_LOCK(ctx);
+    auto fail = [&](const char* msg) {
+        ctx->last_error = msg;
+        return PBRT_HIP_ERR_INVALID;
+    };
+    if (!positions || !indices || n_tris != s->n_tris || n_verts <= 0) return fail("mesh does not match the scene");
+    if (!normals && !tangents && !uvs) return fail("no normals, tangents or uvs given");
+    if (s->d.bvh.tri_shading) return fail("shading data already set");
+    if (s->d.bvh.has_spheres) return fail("per-vertex shading data is not supported for scenes with spheres");
+    for (int64_t i = 0; i < 3 * (int64_t)n_tris; ++i)
+        if (indices[i] < 0 || indices[i] >= n_verts) return fail("vertex index out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf tmp(ctx);
+    bool ok = true;
+    int* d_idx = tmp.alloc<int>(3 * (size_t)n_tris, &ok);
+    float* d_pos = tmp.alloc<float>(3 * (size_t)n_verts, &ok);
+    float* d_n = normals ? tmp.alloc<float>(3 * (size_t)n_verts, &ok) : nullptr;
+    float* d_t = tangents ? tmp.alloc<float>(3 * (size_t)n_verts, &ok) : nullptr;
+    float* d_uv = uvs ? tmp.alloc<float>(2 * (size_t)n_verts, &ok) : nullptr;
+    void* out = nullptr;
+    if (!ok || !hip_ok(ctx, hipMalloc(&out, (size_t)n_tris * 96), "hipMalloc shading data")) return PBRT_HIP_ERR_OOM;
+    s->allocs.push_back(out);
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(d_idx, indices, 3 * (size_t)n_tris * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_pos, positions, 3 * (size_t)n_verts * sizeof(float), hipMemcpyHostToDevice, st));
+    if (d_n) HIP_TRY(ctx, hipMemcpyAsync(d_n, normals, 3 * (size_t)n_verts * sizeof(float), hipMemcpyHostToDevice, st));
+    if (d_t) HIP_TRY(ctx, hipMemcpyAsync(d_t, tangents, 3 * (size_t)n_verts * sizeof(float), hipMemcpyHostToDevice, st));
+    if (d_uv) HIP_TRY(ctx, hipMemcpyAsync(d_uv, uvs, 2 * (size_t)n_verts * sizeof(float), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_set_shading, dim3((n_tris + 255) / 256), dim3(256), 0, st, s->d.slot_prim, d_idx, d_pos, d_n, d_t, d_uv,
+                       n_tris, (float4*)out, const_cast<float4*>(s->d.bvh.tris));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    s->d.bvh.tri_shading = (const float4*)out;
+    s->d.bvh.has_normals = normals ? 1 : 0;
+    s->d.bvh.has_tangents = tangents ? 1 : 0;
+    s->d.bvh.has_uvs = uvs ? 1 : 0;
+    return PBRT_HIP_OK;
+}
+
+namespace pb {
+int sort_pairs_u32(hipStream_t st, void* temp, size_t* temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                   const uint32_t* vals_in, uint32_t* vals_out, size_t n, int bits);
+}
+
+// ---- HaltonSampler host side: prime tables and compute_radical_inverse_permutations (lowdiscrepancy.rs:11-170,
+// 333-349: RNG::default + shuffle per prime), HaltonSampler::new constants (halton.rs:40-98) ----
+namespace {
+struct HostPcg {  // rng.rs
+    uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
+    uint32_t u32() {
+        uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27), rot = (uint32_t)(old >> 59);
+        return (xs >> rot) | (xs << ((~rot + 1u) & 31u));
+    }
+    uint32_t bounded(uint32_t b) {
+        uint32_t threshold = (~b + 1u) % b;
+        for (;;) {
+            uint32_t r = u32();
+            if (r >= threshold) return r % b;
+        }
+    }
+};
+void halton_host_tables(std::vector<uint32_t>* primes_and_sums, std::vector<uint16_t>* perms) {
+    std::vector<uint32_t> primes;
+    for (uint32_t v = 2; primes.size() < 1000; ++v) {
+        bool is_prime = true;
+        for (uint32_t q : primes) {
+            if (q * q > v) break;
+            if (v % q == 0) {
+                is_prime = false;
+                break;
+            }
+        }
+        if (is_prime) primes.push_back(v);
+    }
+    primes_and_sums->assign(2000, 0);
+    uint32_t acc = 0;
+    for (int i = 0; i < 1000; ++i) {
+        (*primes_and_sums)[i] = primes[i];
+        (*primes_and_sums)[1000 + i] = acc;
+        acc += primes[i];
+    }
+    perms->resize(acc);
+    HostPcg rng;
+    uint16_t* p = perms->data();
+    for (int i = 0; i < 1000; ++i) {
+        int count = (int)primes[i];
+        for (int j = 0; j < count; ++j) p[j] = (uint16_t)j;
+        for (int j = 0; j < count; ++j) std::swap(p[j], p[j + (int)rng.bounded((uint32_t)(count - j))]);  // sampling.rs:280-287
+        p += count;
+    }
+}
+void extended_gcd(uint64_t a, uint64_t b, int64_t* x, int64_t* y) {  // halton.rs:51-61
+    if (b == 0) {
+        *x = 1;
+        *y = 0;
+        return;
+    }
+    int64_t d = (int64_t)(a / b), xp = 0, yp = 0;
+    extended_gcd(b, a % b, &xp, &yp);
+    *x = yp;
+    *y = xp - d * yp;
+}
+uint64_t multiplicative_inverse(int64_t a, int64_t n) {  // halton.rs:40-49
+    int64_t x = 0, y = 0;
+    extended_gcd((uint64_t)a, (uint64_t)n, &x, &y);
+    int64_t r = x - (x / n) * n;
+    return (uint64_t)(r < 0 ? r + n : r);
+}
+}  // namespace
+
+static int round_up_pow2(int v) {  // pbrt.rs:174-182
+    v -= 1;
+    v |= v >> 1;
+    v |= v >> 2;
+    v |= v >> 4;
+    v |= v >> 8;
+    v |= v >> 16;
+    return v + 1;
+}
+
+int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRenderParams& rp_in, float* d_film,
+                     PbrtRenderStats* stats) {
+    PbrtHipContext* ctx = s->ctx;
+    auto invalid = [&](const char* m) {
+        ctx->last_error = m;
+        return PBRT_HIP_ERR_INVALID;
+    };
+    PbrtRenderParams rp = rp_in;
+    if (rp.width <= 0 || rp.height <= 0 || rp.spp <= 0) return invalid("width, height and spp must be positive");
+    // ---- sampler: samples per pixel and Sampler::round_count (stratified.rs:30-33, zerotwosequence.rs:20, 62-64) ----
+    if (rp.sampler < PBRT_SAMPLER_RANDOM || rp.sampler > PBRT_SAMPLER_HALTON) return invalid("unknown sampler");
+    const bool tabulated = rp.sampler != PBRT_SAMPLER_RANDOM;
+    if (tabulated && (rp.sampler_dims < 0 || rp.sampler_dims > 63)) return invalid("sampler_dims must be in [0, 63]");
+    if (rp.sampler == PBRT_SAMPLER_STRATIFIED) {
+        if (rp.sampler_x < 1 || rp.sampler_y < 1 || (int64_t)rp.sampler_x * rp.sampler_y > 65536)
+            return invalid("stratified sampler: sampler_x * sampler_y must be in [1, 65536]");
+        rp.spp = rp.sampler_x * rp.sampler_y;
+    } else if (rp.sampler == PBRT_SAMPLER_ZEROTWO) {
+        if (rp.spp > 65536) return invalid("(0,2)-sequence sampler: spp too large");
+        rp.spp = round_up_pow2(rp.spp);
+    }
+    auto round_count = [&](int n) { return rp.sampler == PBRT_SAMPLER_ZEROTWO ? round_up_pow2(n) : n; };
+    if (rp.integrator == PBRT_INTEGRATOR_AO && rp.ao_samples >= 1 && rp.ao_samples <= 65535 && tabulated)
+        rp.ao_samples = round_count(rp.ao_samples);  // ao.rs:36
+    float frx = rp.filter_radius[0] > 0.0f ? rp.filter_radius[0] : 0.5f;
+    float fry = rp.filter_radius[1] > 0.0f ? rp.filter_radius[1] : 0.5f;
+    bool box = true;  // the 0.5 box filter: exact in-order accumulation (k_film_accumulate)
+    if (rp.filter_table) {
+        if (frx != 0.5f || fry != 0.5f) box = false;
+        for (int i = 0; i < 256; ++i)
+            if (rp.filter_table[i] != 1.0f) box = false;
+    } else {
+        frx = fry = 0.5f;
+    }
+    if (frx > 64.0f || fry > 64.0f) return invalid("filter radius too large");
+    {
+        int32_t sb[4];
+        pbrt_hip_sample_bounds(rp.width, rp.height, frx, fry, sb);
+        if (rp.x0 < sb[0] || rp.y0 < sb[1] || rp.x1 > sb[2] || rp.y1 > sb[3] || rp.x0 > rp.x1 || rp.y0 > rp.y1)
+            return invalid("pixel bounds outside the film's sample bounds");
+    }
+    if (rp.integrator < PBRT_INTEGRATOR_PATH || rp.integrator > PBRT_INTEGRATOR_AO)
+        return invalid("integrator must be a PbrtIntegratorKind");
+    // DirectLighting, Whitted and AO share the per-vertex stage machine of k_shade_direct
+    const bool direct = rp.integrator != PBRT_INTEGRATOR_PATH;
+    if (direct && rp.max_depth > 64) return invalid("direct lighting / Whitted: max_depth > 64 (frame stack)");
+    if (rp.integrator == PBRT_INTEGRATOR_AO && (rp.ao_samples < 1 || rp.ao_samples > 65535))
+        return invalid("ambient occlusion: ao_samples must be in [1, 65535]");
+    if (rp.max_depth < 0 || rp.max_depth > 1 << 20) return invalid("bad max_depth");
+    int world = rp.tile_world <= 0 ? 1 : rp.tile_world;
+    int rank = rp.tile_rank;
+    if (rank < 0 || rank >= world) return invalid("tile_rank outside [0, tile_world)");
+    hipStream_t st = ctx->stream;
+
+    size_t film_bytes = (size_t)rp.width * rp.height * 4 * sizeof(float);
+    HIP_TRY(ctx, hipMemsetAsync(d_film, 0, film_bytes, st));
+
+    // tiles of the sample bounds (integrator.rs:402-409), dealt round-robin to the GPUs
+    std::vector<int2> origins;
+    {
+        int32_t n_mine = 0;
+        pbrt_hip_tile_partition(rp.x0, rp.y0, rp.x1, rp.y1, rank, world, nullptr, 0, &n_mine);
+        origins.resize(n_mine);
+        pbrt_hip_tile_partition(rp.x0, rp.y0, rp.x1, rp.y1, rank, world, (int32_t*)origins.data(), n_mine, &n_mine);
+    }
+    PbrtRenderStats local{};
+    if (origins.empty()) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (stats) *stats = local;
+        return PBRT_HIP_OK;
+    }
+    const int n_pix = (int)origins.size() * kTile * kTile;
+    int64_t valid_pixels = 0;
+    for (const int2& o : origins)
+        valid_pixels += (int64_t)(std::min(o.x + kTile, rp.x1) - o.x) * (std::min(o.y + kTile, rp.y1) - o.y);
+    int spp_pass = rp.spp_per_pass > 0 ? rp.spp_per_pass : 0;
+    if (spp_pass == 0) {
+        // As many samples of a pixel in flight as half of the free HBM holds (about 400 B of path state, queue and
+        // sort slots per path; the stage machine of the other integrators adds its frame stack): a whole 64-spp
+        // 1080p frame is 133 M paths = 50 GB of the 288 GB and runs 6 large wavefronts instead of 48 small ones
+        // (+10 % on config 3: fewer launches and host round trips, shorter tails).
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+        for (const auto& b : ctx->block_cache)
+            if (!b.in_use) free_b += b.bytes;  // blocks kept from the previous render are available to this one
+        const int64_t per_path = 400 + (rp.integrator != PBRT_INTEGRATOR_PATH ? 24 + 48ll * std::max(1, rp.max_depth) : 0);
+        const int64_t target_paths = std::max<int64_t>(1ll << 20, std::min<int64_t>(1ll << 28, (int64_t)(free_b / 2) / per_path));
+        spp_pass = (int)std::max<int64_t>(1, std::min<int64_t>(rp.spp, target_paths / n_pix));
+    }
+    spp_pass = std::min(spp_pass, rp.spp);
+    const size_t N = (size_t)n_pix * spp_pass;
+    if (N * 4 >= (1ull << 32)) return invalid("too many concurrent paths for 32-bit queue entries; lower spp_per_pass");
+
+    DevBuf buf(ctx);
+    bool ok = true;
+    PathState ps;
+    ps.n_paths = N;
+    ps.ray = buf.alloc<float4>(N * 6, &ok);
+    ps.hit = buf.alloc<float4>(N * 6, &ok);
+    ps.rng = buf.alloc<uint64_t>(N, &ok);
+    ps.L = buf.alloc<float4>(N, &ok);
+    ps.beta = buf.alloc<float4>(N, &ok);
+    ps.nee_a = buf.alloc<float4>(N, &ok);
+    ps.nee_f = buf.alloc<float4>(N, &ok);
+    ps.nee_b = buf.alloc<float4>(N, &ok);
+    ps.nee_light = buf.alloc<int>(N, &ok);
+    ps.pfilm = buf.alloc<float2>(N, &ok);
+    Queues q[2];
+    for (int k = 0; k < 2; ++k) {
+        q[k].trace = buf.alloc<uint32_t>(N * 3, &ok);
+        q[k].shade = buf.alloc<uint32_t>(N, &ok);
+        q[k].counts64 = buf.alloc<unsigned long long>(2, &ok);
+        q[k].keys = nullptr;
+        for (int a = 0; a < 3; ++a) {
+            const float lo = s->d.bvh.root_min[a], hi = s->d.bvh.root_max[a];
+            q[k].key_lo[a] = lo;
+            q[k].key_inv[a] = hi > lo ? 1.0f / (hi - lo) : 0.0f;
+        }
+    }
+    // ray-queue sort (spatial order for the bounce rays): keys in / out, sorted entries, rocPRIM scratch
+    const char* sort_env = std::getenv("PBRT_HIP_SORT_RAYS");
+    // only the path integrator's later bounces are incoherent; the stage machine of the other integrators keeps
+    // shooting from the camera rays' hit points, which are already in pixel order (AO: -6 % with the sort)
+    const bool sort_rays = !(sort_env && sort_env[0] == '0') && rp.integrator == PBRT_INTEGRATOR_PATH;
+    const char* sort_from_env = std::getenv("PBRT_HIP_SORT_FROM");  // first sorted wavefront (development knob)
+    const int sort_from = sort_from_env ? std::atoi(sort_from_env) : 2;
+    // the keys are written by k_shade together with the queue entries; PBRT_HIP_SORT_FUSED=0 (and the builds with
+    // direction-octant bits) compute them in a pass of their own
+    const char* fused_env = std::getenv("PBRT_HIP_SORT_FUSED");
+    const bool fused_keys = !(fused_env && fused_env[0] == '0') && PB_SORT_OCTANT == 0;
+    uint32_t *sort_keys[2] = {nullptr, nullptr}, *sort_vals = nullptr;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    if (sort_rays) {
+        sort_keys[0] = buf.alloc<uint32_t>(N * 3, &ok);
+        sort_keys[1] = buf.alloc<uint32_t>(N * 3, &ok);
+        sort_vals = buf.alloc<uint32_t>(N * 3, &ok);
+        if (pb::sort_pairs_u32(st, nullptr, &sort_tmp_bytes, sort_keys[0], sort_keys[1], sort_vals, sort_vals, N * 3, kSortKeyBits) != 0)
+            return invalid("rocPRIM radix sort: size query failed");
+        sort_tmp = buf.alloc<char>(sort_tmp_bytes, &ok);
+    }
+    DirectState ds{};
+    std::vector<int> prefix(s->d.n_lights + 1, 0);
+    for (int i = 0; i < s->d.n_lights; ++i)  // directlighting.rs:58-62: round_count with a tabulating sampler
+        prefix[i + 1] = prefix[i] + (tabulated ? round_count(s->light_samples[i]) : s->light_samples[i]);
+    // ---- PixelSampler tables: n_dims 1D + n_dims 2D dimensions and the requested 2D arrays, per pixel ----
+    SamplerParams smp{};
+    smp.kind = rp.sampler;
+    smp.n_dims = rp.sampler_dims;
+    smp.nx = rp.sampler_x;
+    smp.ny = rp.sampler_y;
+    smp.jitter = rp.sampler_jitter;
+    ps.samp = buf.alloc<int>(N, &ok);
+    if (rp.sampler == PBRT_SAMPLER_HALTON) {
+        smp.n_dims = 0;  // nothing is tabulated per pixel: every value is a function of (sample index, dimension)
+        if (!ctx->d_halton_primes) {
+            std::vector<uint32_t> primes;
+            std::vector<uint16_t> perms;
+            halton_host_tables(&primes, &perms);
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_halton_primes, primes.size() * sizeof(uint32_t)));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_halton_perms, perms.size() * sizeof(uint16_t)));
+            HIP_TRY(ctx, hipMemcpy(ctx->d_halton_primes, primes.data(), primes.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            HIP_TRY(ctx, hipMemcpy(ctx->d_halton_perms, perms.data(), perms.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
+        smp.primes = ctx->d_halton_primes;
+        smp.perms = ctx->d_halton_perms;
+        // HaltonSampler::new(spp, film.get_sample_bounds(), false) (halton.rs:63-98)
+        int32_t sb[4];
+        pbrt_hip_sample_bounds(rp.width, rp.height, frx, fry, sb);
+        const int res[2] = {sb[2] - sb[0], sb[3] - sb[1]};
+        for (int i = 0; i < 2; ++i) {
+            int base = i == 0 ? 2 : 3, scale = 1, exp = 0;
+            while (scale < std::min(128, res[i])) {
+                scale *= base;
+                ++exp;
+            }
+            smp.h_scale[i] = scale;
+            smp.h_exp[i] = exp;
+        }
+        smp.h_stride = smp.h_scale[0] * smp.h_scale[1];
+        smp.h_minv[0] = (unsigned int)multiplicative_inverse(smp.h_scale[1], smp.h_scale[0]);
+        smp.h_minv[1] = (unsigned int)multiplicative_inverse(smp.h_scale[0], smp.h_scale[1]);
+    }
+    if (tabulated) {
+        std::vector<int2> arrays;
+        int64_t elems = (int64_t)smp.n_dims * rp.spp * 3;
+        smp.off2 = smp.n_dims * rp.spp;
+        auto request_2d_array = [&](int n) {  // sampler.rs:41-46
+            arrays.push_back(make_int2(n, (int)elems));
+            elems += (int64_t)n * rp.spp * 2;
+        };
+        if (rp.integrator == PBRT_INTEGRATOR_DIRECT && rp.light_strategy == 0) {
+            for (int i = 0; i < rp.max_depth; ++i)  // directlighting.rs:64-75
+                for (int j = 0; j < s->d.n_lights; ++j) {
+                    request_2d_array(prefix[j + 1] - prefix[j]);
+                    request_2d_array(prefix[j + 1] - prefix[j]);
+                }
+        } else if (rp.integrator == PBRT_INTEGRATOR_AO) {
+            request_2d_array(rp.ao_samples);  // ao.rs:37
+        }
+        if (arrays.size() > 0x7fff) return invalid("too many sample arrays (max_depth x lights)");
+        if (elems * n_pix * 4 > (64ll << 30) || elems >= (1ll << 31))
+            return invalid("sampler tables exceed 64 GB: lower spp, sampler_dims or the light sample counts");
+        smp.n_arrays = (int)arrays.size();
+        smp.array_end_dim = 5 + 2 * smp.n_arrays;  // sampler.rs:344-345
+        if (rp.sampler == PBRT_SAMPLER_HALTON) {
+            if (smp.array_end_dim > 990) return invalid("Halton sampler: too many sample arrays for 1000 dimensions");
+            elems = 0;
+        }
+        smp.n_elems = (int)elems;
+        smp.tables = buf.alloc<float>((size_t)elems * n_pix, &ok);
+        int2* d_arrays = buf.alloc<int2>(arrays.size(), &ok);
+        smp.arrays = d_arrays;
+        if (ok && !arrays.empty())
+            HIP_TRY(ctx, hipMemcpyAsync(d_arrays, arrays.data(), arrays.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+        if (ok) HIP_TRY(ctx, hipStreamSynchronize(st));  // `arrays` leaves scope
+    }
+    int* d_prefix = buf.alloc<int>(prefix.size(), &ok);
+    if (direct) {
+        ds.stage = buf.alloc<int>(N, &ok);
+        ds.ld_acc = buf.alloc<float4>(N, &ok);
+        ds.frames = buf.alloc<float4>(N * (size_t)std::max(1, rp.max_depth) * 3, &ok);
+        ds.light_strategy = rp.light_strategy;
+        ds.mode = rp.integrator;
+        ds.ao_samples = rp.ao_samples;
+        ds.ao_cos_sample = rp.light_strategy != 0;
+        if (prefix.back() >= 0xfff0) return invalid("too many light samples per vertex");
+    }
+    float* d_filter = nullptr;
+    if (!box) {
+        d_filter = buf.alloc<float>(256, &ok);
+        if (ok) HIP_TRY(ctx, hipMemcpyAsync(d_filter, rp.filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    float4* accum = buf.alloc<float4>(n_pix, &ok);
+    int2* d_origins = buf.alloc<int2>(origins.size(), &ok);
+    if (!ok) return PBRT_HIP_ERR_OOM;
+    HIP_TRY(ctx, hipMemcpyAsync(d_origins, origins.data(), origins.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(accum, 0, (size_t)n_pix * sizeof(float4), st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_prefix, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    TileList tiles{d_origins, (int)origins.size()};
+
+    DevCamera cam;
+    std::memcpy(cam.c2w, camera.camera_to_world, 64);
+    std::memcpy(cam.r2c, camera.raster_to_camera, 64);
+    cam.lens_radius = camera.lens_radius;
+    cam.focal_distance = camera.focal_distance;
+    cam.shutter_open = camera.shutter_open;
+    cam.shutter_close = camera.shutter_close;
+    cam.kind = camera.kind;
+    if (camera.kind < PBRT_CAMERA_PERSPECTIVE || camera.kind > PBRT_CAMERA_ENVIRONMENT) return invalid("unknown camera kind");
+
+    ShadeConsts sc;
+    sc.bvh = s->d.bvh;
+    sc.materials = s->d.materials;
+    sc.lights = s->d.lights;
+    sc.n_lights = s->d.n_lights;
+    sc.n_infinite = s->d.n_infinite;
+    sc.infinite_ids = s->d.infinite_ids;
+    // create_light_sample_distribution (lightdistrib.rs:222-232): "uniform", or one light -> uniform
+    sc.distrib = (rp.light_strategy == 0 || s->d.n_lights == 1) ? s->d.light_distrib_uniform : s->d.light_distrib_power;
+    if (rp.integrator == PBRT_INTEGRATOR_PATH && (rp.light_strategy < 0 || rp.light_strategy > 2))
+        return invalid("path: light_strategy must be 0 (uniform), 1 (power) or 2 (spatial)");
+    std::memcpy(sc.env_cond_func, s->d.env_cond_func, sizeof(sc.env_cond_func));
+    std::memcpy(sc.env_cond_cdf, s->d.env_cond_cdf, sizeof(sc.env_cond_cdf));
+    std::memcpy(sc.env_cond_int, s->d.env_cond_int, sizeof(sc.env_cond_int));
+    std::memcpy(sc.env_marg_func, s->d.env_marg_func, sizeof(sc.env_marg_func));
+    std::memcpy(sc.env_marg_cdf, s->d.env_marg_cdf, sizeof(sc.env_marg_cdf));
+    sc.env_marg_int = s->d.env_marg_int;
+    sc.world_radius = s->d.world_radius;
+    sc.light_sample_prefix = d_prefix;
+    sc.total_light_samples = prefix.back();
+    sc.spatial = nullptr;
+    sc.n_voxel[0] = sc.n_voxel[1] = sc.n_voxel[2] = 1;
+    if (rp.integrator == PBRT_INTEGRATOR_PATH && rp.light_strategy == 2 && s->d.n_lights > 1) {
+        // create_light_sample_distribution("spatial") -> SpatialLightDistribution::new(scene, 64) (lightdistrib.rs:85-107, 228)
+        if (!s->d_spatial) {
+            const float* mn = s->d.bvh.root_min;
+            const float* mx = s->d.bvh.root_max;
+            float diag[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+            int ext = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2);
+            for (int i = 0; i < 3; ++i) s->spatial_voxels[i] = std::max(1, (int)std::round(diag[i] / diag[ext] * 64.0f));
+            size_t n_voxels = (size_t)s->spatial_voxels[0] * s->spatial_voxels[1] * s->spatial_voxels[2];
+            size_t floats = n_voxels * (size_t)(2 * s->d.n_lights + 2);
+            if (floats > (1ull << 30)) return invalid("spatial light distribution: voxels x lights exceed 4 GB; use \"power\"");
+            void* p = nullptr;
+            HIP_TRY(ctx, hipMalloc(&p, floats * sizeof(float)));
+            s->allocs.push_back(p);
+            for (int i = 0; i < 3; ++i) sc.n_voxel[i] = s->spatial_voxels[i];
+            hipLaunchKernelGGL(k_spatial_light_tables, dim3((unsigned)((n_voxels + 63) / 64)), dim3(64), 0, st, sc, (float*)p);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            s->d_spatial = (float*)p;
+        }
+        sc.spatial = s->d_spatial;
+        for (int i = 0; i < 3; ++i) sc.n_voxel[i] = s->spatial_voxels[i];
+    }
+
+    hipEvent_t e_begin, e_end, e_t0, e_t1;
+    HIP_TRY(ctx, hipEventCreate(&e_begin));
+    HIP_TRY(ctx, hipEventCreate(&e_end));
+    HIP_TRY(ctx, hipEventCreate(&e_t0));
+    HIP_TRY(ctx, hipEventCreate(&e_t1));
+    auto cleanup_events = [&]() {
+        (void)hipEventDestroy(e_begin);
+        (void)hipEventDestroy(e_end);
+        (void)hipEventDestroy(e_t0);
+        (void)hipEventDestroy(e_t1);
+    };
+    int rc = PBRT_HIP_OK;
+#define RENDER_TRY(call)                                  \
+    if (rc == PBRT_HIP_OK && !hip_ok(ctx, (call), #call)) rc = PBRT_HIP_ERR_DEVICE;
+
+    RENDER_TRY(hipEventRecord(e_begin, st));
+    bool tables_ready = !tabulated || rp.sampler == PBRT_SAMPLER_HALTON;
+    for (int s0 = 0; s0 < rp.spp && rc == PBRT_HIP_OK; s0 += spp_pass) {
+        PassParams pp;
+        pp.smp = smp;
+        pp.n_pix = n_pix;
+        pp.n_samples = std::min(spp_pass, rp.spp - s0);
+        pp.sample0 = s0;
+        pp.spp = rp.spp;
+        pp.width = rp.width;
+        pp.height = rp.height;
+        pp.x0 = rp.x0;
+        pp.y0 = rp.y0;
+        pp.x1 = rp.x1;
+        pp.y1 = rp.y1;
+        pp.seed = rp.seed;
+        pp.max_depth = rp.max_depth;
+        pp.rr_threshold = rp.rr_threshold;
+        pp.light_strategy = rp.light_strategy;
+        pp.filter_rx = frx;
+        pp.filter_ry = fry;
+        pp.filter_table = d_filter;
+        pp.max_sample_luminance = rp.max_sample_luminance > 0.0f ? rp.max_sample_luminance : INFINITY;
+        uint32_t n_paths = (uint32_t)n_pix * pp.n_samples;
+        int cur = 0;
+        if (!tables_ready) {  // Sampler::start_pixel for every pixel of this GPU, once per render
+            hipLaunchKernelGGL(k_sampler_tables, dim3((n_pix + 63) / 64), dim3(64), 0, st, pp, tiles);
+            RENDER_TRY(hipGetLastError());
+            tables_ready = true;
+        }
+        hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, st, ps, q[cur], pp, cam, tiles);
+        RENDER_TRY(hipGetLastError());
+        if (direct) {
+            RENDER_TRY(hipMemsetAsync(ds.stage, 0, (size_t)n_paths * sizeof(int), st));
+            RENDER_TRY(hipMemsetAsync(ds.ld_acc, 0, (size_t)n_paths * sizeof(float4), st));
+        }
+        // the first wavefront is the identity: every path traces its camera ray and is shaded
+        unsigned long long counts[2] = {n_paths, n_paths};
+        local.camera_samples += (uint64_t)valid_pixels * pp.n_samples;
+        local.rays_closest += (uint64_t)valid_pixels * pp.n_samples;
+        bool first = true;
+        int wavefront = 0;  // 0 = camera rays, 1 = first bounce + its shadow rays, ...
+        while (rc == PBRT_HIP_OK && counts[1] > 0) {
+            uint32_t n_trace = (uint32_t)counts[0], n_shade = (uint32_t)counts[1];
+            if (n_trace > 0) {
+                RENDER_TRY(hipMemsetAsync(ctx->d_work_counter, 0, kQueueSegments * sizeof(unsigned int), st));
+                const uint32_t* trace_queue = q[cur].trace;
+                if (sort_rays && wavefront >= sort_from && n_trace >= (1u << 20)) {
+                    // from the second bounce on the rays of a wavefront start all over the scene (the first bounce still
+                    // follows the pixel order of its camera rays): trace them in Morton order of their origins
+                    if (!fused_keys) {
+                        float3 lo = make_float3(q[cur].key_lo[0], q[cur].key_lo[1], q[cur].key_lo[2]);
+                        float3 inv = make_float3(q[cur].key_inv[0], q[cur].key_inv[1], q[cur].key_inv[2]);
+                        hipLaunchKernelGGL(k_ray_sort_keys, dim3((n_trace + 255) / 256), dim3(256), 0, st, ps, q[cur].trace, n_trace, lo,
+                                           inv, sort_keys[0]);
+                    }
+                    size_t tb = sort_tmp_bytes;
+                    if (pb::sort_pairs_u32(st, sort_tmp, &tb, sort_keys[0], sort_keys[1], q[cur].trace, sort_vals, n_trace, kSortKeyBits) != 0 &&
+                        rc == PBRT_HIP_OK) {
+                        ctx->last_error = "rocPRIM radix sort failed";
+                        rc = PBRT_HIP_ERR_DEVICE;
+                    }
+                    trace_queue = sort_vals;
+                }
+                RENDER_TRY(hipEventRecord(e_t0, st));
+                {
+                    dim3 grid(persistent_grid(s)), block(kTraceBlock);
+                    const bool inst = s->d.bvh.instanced != 0;
+                    const int segments = (wavefront == 0 && !inst) ? kQueueSegments : 1;  // see trace.h
+                    if (s->d.bvh.has_spheres) {
+                        if (ctx->count_traversal)
+                            hipLaunchKernelGGL((k_trace<true, false, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
+                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
+                        else
+                            hipLaunchKernelGGL((k_trace<false, false, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
+                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
+                    } else if (ctx->count_traversal) {
+                        if (inst)
+                            hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
+                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
+                        else
+                            hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
+                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
+                    } else {
+                        if (inst)
+                            hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
+                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
+                        else
+                            hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
+                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
+                    }
+                }
+                RENDER_TRY(hipGetLastError());
+                RENDER_TRY(hipEventRecord(e_t1, st));
+            }
+            int nxt = cur ^ 1;
+            RENDER_TRY(hipMemsetAsync(q[nxt].counts64, 0, 2 * sizeof(unsigned long long), st));
+            // the wavefront this launch of k_shade fills is traced in Morton order: have it write the keys as well
+            q[nxt].keys = (sort_rays && fused_keys && wavefront + 1 >= sort_from) ? sort_keys[0] : nullptr;
+            if (direct)
+{
+                dim3 sg((n_shade + 255) / 256), sb(256);
+                if (rp.integrator == PBRT_INTEGRATOR_DIRECT)
+                    hipLaunchKernelGGL((k_shade_direct<PBRT_INTEGRATOR_DIRECT>), sg, sb, 0, st, sc, ps, ds, q[cur], q[nxt], pp, tiles, n_shade);
+                else if (rp.integrator == PBRT_INTEGRATOR_WHITTED)
+                    hipLaunchKernelGGL((k_shade_direct<PBRT_INTEGRATOR_WHITTED>), sg, sb, 0, st, sc, ps, ds, q[cur], q[nxt], pp, tiles, n_shade);
+                else
+                    hipLaunchKernelGGL((k_shade_direct<PBRT_INTEGRATOR_AO>), sg, sb, 0, st, sc, ps, ds, q[cur], q[nxt], pp, tiles, n_shade);
+            }
+            else
+                hipLaunchKernelGGL(k_shade, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, q[cur], q[nxt], pp,
+                                   tiles, n_shade);
+            RENDER_TRY(hipGetLastError());
+            RENDER_TRY(hipMemcpyAsync(ctx->h_counts, q[nxt].counts64, sizeof(counts), hipMemcpyDeviceToHost, st));
+            RENDER_TRY(hipEventRecord(ctx->ev_sync, st));
+            if (rc == PBRT_HIP_OK) {
+                hipError_t qe;
+                while ((qe = hipEventQuery(ctx->ev_sync)) == hipErrorNotReady) {
+                }
+                RENDER_TRY(qe);
+            }
+            counts[0] = ctx->h_counts[0];
+            counts[1] = ctx->h_counts[1];
+            if (n_trace > 0 && rc == PBRT_HIP_OK) {
+                float ms = 0.0f;
+                RENDER_TRY(hipEventElapsedTime(&ms, e_t0, e_t1));
+                local.trace_ms += ms;
+                local.trace_launches += 1;
+                if (std::getenv("PBRT_HIP_TRACE_LOG"))
+                    std::fprintf(stderr, "[pbrt_hip] k_trace: %u rays %.3f ms (%.0f Mrays/s)\n", n_trace, ms, n_trace / ms * 1e-3);
+                ctx->trace_ms += ms;
+                ctx->trace_launches += 1;
+            }
+            {
+                uint64_t n_rays = counts[0] & 0xffffffffull, n_shadow = counts[0] >> 32;
+                local.rays_closest += n_rays - n_shadow;
+                local.rays_shadow += n_shadow;
+                counts[0] = n_rays;
+            }
+            (void)first;
+            first = false;
+            wavefront += 1;
+            cur = nxt;
+        }
+        if (!box) {
+            hipLaunchKernelGGL(k_film_splat, dim3((n_paths + 255) / 256), dim3(256), 0, st, ps, pp, tiles, d_film);
+            RENDER_TRY(hipGetLastError());
+            continue;
+        }
+        hipLaunchKernelGGL(k_film_accumulate, dim3((n_pix + 255) / 256), dim3(256), 0, st, ps, pp, tiles, accum, d_film);
+        RENDER_TRY(hipGetLastError());
+        if (s0 + spp_pass >= rp.spp) {
+            hipLaunchKernelGGL(k_film_merge, dim3((n_pix + 255) / 256), dim3(256), 0, st, pp, tiles, accum, d_film);
+            RENDER_TRY(hipGetLastError());
+        }
+    }
+    RENDER_TRY(hipEventRecord(e_end, st));
+    RENDER_TRY(hipStreamSynchronize(st));
+    if (rc == PBRT_HIP_OK) {
+        float ms = 0.0f;
+        RENDER_TRY(hipEventElapsedTime(&ms, e_begin, e_end));
+        local.total_ms = ms;
+    }
+#undef RENDER_TRY
+    cleanup_events();
+    if (stats) *stats = local;
+    return rc;
+}
+
+#ifdef PB_LANE_STATS
+extern "C" int pbrt_hip_debug_lane_stats(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(pb::g_lane_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pb::g_lane_stats), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif

@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -191,4 +192,15 @@ __host__ __device__ inline bool triangle_rejected_by_intersect(const float* a, c
     return false;
 }
 
+// persistent kernels: enough blocks to fill every CU (LDS: 160 KiB / (kStackLds * 2 KiB) blocks of 256, at most 8)
+inline int persistent_grid(const PbrtHipScene* s) {
+    int per_cu = std::min(PB_TRACE_WAVES, (160 * 1024) / (kStackLds * kTraceBlock * (int)sizeof(uint2)));
+    return std::min(s->ctx->n_cus * per_cu, s->spill_lanes / kTraceBlock);
+}
+
 }  // namespace pb
+
+#define HIP_TRY(ctx, call)                                                 \
+    do {                                                                   \
+        if (!pb::hip_ok((ctx), (call), #call)) return PBRT_HIP_ERR_DEVICE; \
+    } while (0)

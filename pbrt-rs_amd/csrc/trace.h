@@ -45,6 +45,13 @@ struct DevBVH {
     int has_spheres;  // some leaf slots hold spheres (kPrimSphere): the SPH kernels are launched
 };
 
+// waves per SIMD requested for the traversal kernels (occupancy sweep: DESIGN.md section 4)
+#ifndef PB_TRACE_WAVES
+#define PB_TRACE_WAVES 6
+#endif
+#ifndef PB_INST_WAVES
+#define PB_INST_WAVES 5
+#endif
 #ifndef PB_STACK_LDS
 #define PB_STACK_LDS 12
 #endif

@@ -149,12 +149,6 @@ __global__ void k_ray_sort_keys(PathState ps, const uint32_t* __restrict__ queue
     keys[i] = code | ((slot == RS_SHADOW ? 1u : 0u) << (kSortKeyBits - 1));
 }
 
-#ifndef PB_TRACE_WAVES
-#define PB_TRACE_WAVES 6
-#endif
-#ifndef PB_INST_WAVES
-#define PB_INST_WAVES 5
-#endif
 template <bool COUNT, bool INST, bool SPH = false>
 __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_INST_WAVES : PB_TRACE_WAVES))
     k_trace(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
