@@ -263,6 +263,14 @@ int pbrt_hip_scene_create_instanced(PbrtHipContext* ctx, const float* positions,
                                     const PbrtLinearBVHNode* tlas_nodes, int32_t n_tlas_nodes,
                                     const int32_t* tlas_order, PbrtHipScene** out);
 void pbrt_hip_scene_destroy(PbrtHipScene* scene);
+/* Traversal layout of a scene. Beside the 64-B child-pair records of the reference's tree a scene may carry 4-wide,
+ * 48-byte records with 8-bit conservative boxes laid over the same tree (two levels of BVHAccel's nodes per record,
+ * src/accelerators/bvh.rs:129-135): the traversal kernels then walk those and decide every leaf visit with
+ * Bounds3f::intersect_p (src/core/geometry.rs:709-751) on the exact leaf box, so results are the reference's bit for
+ * bit. n_records = number of wide records, 0 when the tree is a single leaf, -1 when the scene has none; *reason then
+ * says why (instanced scene, spheres, a leaf with more than 4 primitives, PBRT_HIP_WIDE=0 ...). The string lives as
+ * long as the scene. */
+int pbrt_hip_scene_wide_records(const PbrtHipScene* scene, int32_t* n_records, const char** reason);
 
 /* ---- batch Primitive::intersect / intersect_p (src/core/primitive.rs:17-30 via
  * Scene::intersect / intersect_p, src/core/scene.rs:40-46) ----

@@ -13,13 +13,16 @@
 #include <string>
 #include <vector>
 
+#include "host_wide.h"
 #include "scene.h"
 #include "trace.h"
 #include "trace_persistent.h"
+#include "trace_wide.h"
 
 using namespace pb;
 
 static std::string g_create_error;
+
 
 
 // ------------------------------------------------------------------------------------
@@ -54,7 +57,7 @@ extern "C" int pbrt_hip_context_create(int device_id, PbrtHipContext** out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipMalloc((void**)&ctx->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_work_counter, kQueueSegments * sizeof(unsigned int)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_work_counter, kWorkCounters * sizeof(unsigned int)) != hipSuccess ||
         hipHostMalloc((void**)&ctx->h_counts, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_sync, hipEventDisableTiming) != hipSuccess ||
         hipMemset(ctx->d_counters, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
@@ -77,6 +80,7 @@ extern "C" void pbrt_hip_context_destroy(PbrtHipContext* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
+    if (ctx->d_special_list) (void)hipFree(ctx->d_special_list);
     for (auto& b : ctx->block_cache)
         if (b.ptr) (void)hipFree(b.ptr);
     ctx->block_cache.clear();
@@ -608,14 +612,41 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         d.slot_instance = dev_upload(s, slot_inst.data(), slot_inst.size(), &ok);
         s->n_instances = ia.n_instances;
     }
-    // spill slab for the deepest 40 stack entries of every resident lane of the traversal grid
+    // ---- 4-wide quantised records over the same tree (wide_bvh.h): single-level triangle scenes whose tree came
+    // from the host; PBRT_HIP_WIDE=0 keeps the scene on the binary records ----
+    int spill_entries = kStackSpill;
+    {
+        const char* wide_env = std::getenv("PBRT_HIP_WIDE");
+        if (wide_env && wide_env[0] == '0') {
+            s->wide_reason = "disabled by PBRT_HIP_WIDE=0";
+        } else if (instanced || sa.n > 0 || dt) {
+            s->wide_reason = instanced ? "instanced scene" : (dt ? "tree built on the device" : "scene with spheres");
+        } else {
+            pb::WideTree wt;
+            const char* why = pb::build_wide_tree(nodes, n_nodes, tris.data(), n_prims, &wt);
+            if (why) {
+                s->wide_reason = why;
+            } else {
+                s->wide.nodes = (const uint4*)dev_upload(s, wt.nodes.data(), wt.nodes.size(), &ok);
+                s->wide.tris = (const float4*)dev_upload(s, wt.tris.data(), wt.tris.size(), &ok);
+                s->wide.leaf_boxes = (const float4*)dev_upload(s, wt.leaf_boxes.data(), wt.leaf_boxes.size(), &ok);
+                s->wide.root_ref = wt.root_ref;
+                s->n_wide_records = wt.n_records;
+                s->has_wide = true;
+                spill_entries = std::max(spill_entries, wt.stack_need + 1 - kWideStackLds);
+            }
+        }
+    }
+    // spill slab for the deepest stack entries of every resident lane of the traversal grid
     s->spill_lanes = ctx->n_cus * 2048;
     {
         void* p = nullptr;
-        if (!hip_ok(ctx, hipMalloc(&p, (size_t)s->spill_lanes * kStackSpill * sizeof(uint2)), "hipMalloc spill")) ok = false;
+        if (!hip_ok(ctx, hipMalloc(&p, (size_t)s->spill_lanes * spill_entries * sizeof(uint2)), "hipMalloc spill")) ok = false;
         else s->allocs.push_back(p);
         d.bvh.spill = (uint2*)p;
         d.bvh.spill_stride = s->spill_lanes;
+        s->wide.spill = (uint2*)p;
+        s->wide.spill_stride = s->spill_lanes;
     }
     if (!dt) d.slot_prim = dev_upload(s, prim_order, n_prims, &ok);
     d.materials = dev_upload(s, dm.data(), dm.size(), &ok);
@@ -680,6 +711,13 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     return PBRT_HIP_OK;
 }
 
+extern "C" int pbrt_hip_scene_wide_records(const PbrtHipScene* s, int32_t* n_records, const char** reason) {
+    if (!s) return PBRT_HIP_ERR_INVALID;
+    if (n_records) *n_records = s->has_wide ? s->n_wide_records : -1;
+    if (reason) *reason = s->wide_reason.c_str();
+    return PBRT_HIP_OK;
+}
+
 extern "C" void pbrt_hip_scene_destroy(PbrtHipScene* s) {
     if (!s) return;
     PB_LOCK(s->ctx);
@@ -731,21 +769,54 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_I
                                                         blockIdx.x * kTraceBlock + threadIdx.x, counters);
 }
 
+// the same batch over the 4-wide records (trace_wide.h), and the follow-up over the rays that kernel left out
+template <bool ANY>
+__global__ void __launch_bounds__(kTraceBlock, PB_WIDE_WAVES)
+    k_intersect_batch_wide(WideTrees wt, BatchRayIO<ANY> io, unsigned int* work_counter) {
+    __shared__ uint2 lds_stack[kWideStackLds * kTraceBlock];
+    trace_wide<BatchRayIO<ANY>>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x);
+}
+template <bool ANY>
+__global__ void __launch_bounds__(kTraceBlock, PB_TRACE_WAVES)
+    k_intersect_batch_special(DevBVH bvh, SpecialListIO<BatchRayIO<ANY>> io, unsigned int* work_counter) {
+    __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
+    trace_persistent<SpecialListIO<BatchRayIO<ANY>>, false, false, false>(bvh, io, work_counter, lds_stack + threadIdx.x,
+                                                                          blockIdx.x * kTraceBlock + threadIdx.x, nullptr);
+}
+
 template <bool ANY>
 static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtHit* d_hits, uint8_t* d_flags) {
     PbrtHipContext* ctx = s->ctx;
     if (n == 0) return PBRT_HIP_OK;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_work_counter, 0, kQueueSegments * sizeof(unsigned int), ctx->stream));
-    if (ctx->time_trace) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (n >= (1ll << 32) - kChunk * 8192ll) {
         ctx->last_error = "batch too large for one launch (split it below 2^32 rays)";
         return PBRT_HIP_ERR_INVALID;
     }
+    const bool wide = s->has_wide && !ctx->count_traversal;
+    if (wide && ctx->special_capacity < (size_t)n) {  // room for the queue positions of the rays the wide kernel leaves out
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_special_list) (void)hipFree(ctx->d_special_list);
+        ctx->d_special_list = nullptr;
+        ctx->special_capacity = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_special_list, (size_t)n * sizeof(uint32_t)));
+        ctx->special_capacity = (size_t)n;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_work_counter, 0, kWorkCounters * sizeof(unsigned int), ctx->stream));
+    if (ctx->time_trace) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     {
         BatchRayIO<ANY> io{s->d.slot_prim, s->d.slot_instance, d_rays, (uint32_t)n, d_hits, d_flags};
         dim3 grid(persistent_grid(s)), block(kTraceBlock);
         const bool inst = s->d.bvh.instanced != 0;
-        if (s->d.bvh.has_spheres) {  // single-level scenes only (checked at creation)
+        if (wide) {
+            WideTrees wt = s->wide;
+            wt.special_list = ctx->d_special_list;
+            wt.special_count = ctx->d_work_counter + kSpecialCount;
+            hipLaunchKernelGGL((k_intersect_batch_wide<ANY>), dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0, ctx->stream, wt,
+                               io, ctx->d_work_counter);
+            SpecialListIO<BatchRayIO<ANY>> sio{io, ctx->d_special_list, ctx->d_work_counter + kSpecialCount};
+            hipLaunchKernelGGL((k_intersect_batch_special<ANY>), grid, block, 0, ctx->stream, s->d.bvh, sio,
+                               ctx->d_work_counter + kFollowUpCounter);
+        } else if (s->d.bvh.has_spheres) {  // single-level scenes only (checked at creation)
             if (ctx->count_traversal)
                 hipLaunchKernelGGL((k_intersect_batch<ANY, true, false, true>), grid, block, 0, ctx->stream, s->d.bvh, io,
                                    ctx->d_work_counter, ctx->d_counters);

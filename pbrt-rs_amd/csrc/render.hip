@@ -149,6 +149,15 @@ __global__ void k_set_shading(const int* __restrict__ slot_prim, const int* __re
     tris[3 * (size_t)slot + 2] = t2;
 }
 
+// the wide-order triangle copies (wide_bvh.h) carry the kTriDegenerate flag too
+__global__ void k_wide_refresh_flags(float4* __restrict__ wtris, const float4* __restrict__ tris, int n) {
+    int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= n) return;
+    float4 c = wtris[3 * (size_t)pos + 2];
+    c.z = tris[3 * (size_t)__float_as_int(c.y) + 2].w;
+    wtris[3 * (size_t)pos + 2] = c;
+}
+
 extern "C" int pbrt_hip_scene_set_shading_data(PbrtHipScene* s, const float* positions, int32_t n_verts,
                                                const int32_t* indices, int32_t n_tris, const float* normals,
                                                const float* tangents, const float* uvs) {
@@ -184,6 +193,9 @@ extern "C" int pbrt_hip_scene_set_shading_data(PbrtHipScene* s, const float* pos
     if (d_uv) HIP_TRY(ctx, hipMemcpyAsync(d_uv, uvs, 2 * (size_t)n_verts * sizeof(float), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_set_shading, dim3((n_tris + 255) / 256), dim3(256), 0, st, s->d.slot_prim, d_idx, d_pos, d_n, d_t, d_uv,
                        n_tris, (float4*)out, const_cast<float4*>(s->d.bvh.tris));
+    if (s->has_wide)
+        hipLaunchKernelGGL(k_wide_refresh_flags, dim3((n_tris + 255) / 256), dim3(256), 0, st, const_cast<float4*>(s->wide.tris),
+                           s->d.bvh.tris, n_tris);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));
     s->d.bvh.tri_shading = (const float4*)out;
@@ -417,6 +429,9 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             return invalid("rocPRIM radix sort: size query failed");
         sort_tmp = buf.alloc<char>(sort_tmp_bytes, &ok);
     }
+    // rays the wide kernel leaves to the binary one (wide_bvh.h): room for every entry of a trace queue
+    const bool use_wide = s->has_wide && !ctx->count_traversal;
+    uint32_t* special_list = use_wide ? buf.alloc<uint32_t>(N * 3, &ok) : nullptr;
     DirectState ds{};
     std::vector<int> prefix(s->d.n_lights + 1, 0);
     for (int i = 0; i < s->d.n_lights; ++i)  // directlighting.rs:58-62: round_count with a tabulating sampler
@@ -633,7 +648,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         while (rc == PBRT_HIP_OK && counts[1] > 0) {
             uint32_t n_trace = (uint32_t)counts[0], n_shade = (uint32_t)counts[1];
             if (n_trace > 0) {
-                RENDER_TRY(hipMemsetAsync(ctx->d_work_counter, 0, kQueueSegments * sizeof(unsigned int), st));
+                RENDER_TRY(hipMemsetAsync(ctx->d_work_counter, 0, kWorkCounters * sizeof(unsigned int), st));
                 const uint32_t* trace_queue = q[cur].trace;
                 if (sort_rays && wavefront >= sort_from && n_trace >= (1u << 20)) {
                     // from the second bounce on the rays of a wavefront start all over the scene (the first bounce still
@@ -657,7 +672,15 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                     dim3 grid(persistent_grid(s)), block(kTraceBlock);
                     const bool inst = s->d.bvh.instanced != 0;
                     const int segments = (wavefront == 0 && !inst) ? kQueueSegments : 1;  // see trace.h
-                    if (s->d.bvh.has_spheres) {
+                    if (use_wide) {
+                        WideTrees wt = s->wide;
+                        wt.special_list = special_list;
+                        wt.special_count = ctx->d_work_counter + kSpecialCount;
+                        hipLaunchKernelGGL(k_trace_wide, dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0, st, wt, ps,
+                                           trace_queue, n_trace, ctx->d_work_counter, segments);
+                        hipLaunchKernelGGL(k_trace_special, grid, block, 0, st, s->d.bvh, ps, trace_queue, n_trace, special_list,
+                                           ctx->d_work_counter + kSpecialCount, ctx->d_work_counter + kFollowUpCounter);
+                    } else if (s->d.bvh.has_spheres) {
                         if (ctx->count_traversal)
                             hipLaunchKernelGGL((k_trace<true, false, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
                                                n_trace, ctx->d_work_counter, ctx->d_counters, segments);

@@ -15,6 +15,7 @@
 
 #include "../../include/pbrt_hip.h"
 #include "trace.h"
+#include "wide_bvh.h"
 
 // Calls that reach the device through one context are serialised: the reference's Primitive is Sync + Send and li() is
 // re-entrant (src/core/primitive.rs:179, integrator.rs:412-452), so a drop-in may be entered from several host threads.
@@ -35,7 +36,11 @@ struct PbrtHipContext {
     bool count_traversal = false;
     unsigned long long* d_counters = nullptr;
     uint64_t counted_rays = 0;
-    unsigned int* d_work_counter = nullptr;  // ray-queue head of the persistent traversal kernel
+    // ray-queue heads of the persistent traversal kernels: [0, kQueueSegments) the launch's segments,
+    // [kFollowUpCounter] the follow-up launch over the rays the wide kernel left out, [kSpecialCount] their number
+    unsigned int* d_work_counter = nullptr;
+    uint32_t* d_special_list = nullptr;  // batch calls: queue positions of those rays (grown on demand)
+    size_t special_capacity = 0;
     // the render loop reads the queue lengths back once per wavefront: pinned landing buffer + an event the host
     // spins on (a blocking stream sync costs a scheduler wake-up per wavefront, milliseconds on a busy host)
     unsigned long long* h_counts = nullptr;
@@ -54,6 +59,8 @@ struct PbrtHipContext {
 };
 
 namespace pb {
+
+constexpr int kWorkCounters = 16, kFollowUpCounter = 8, kSpecialCount = 12;
 
 // device-side light / material tables
 struct DevLight {
@@ -113,6 +120,11 @@ struct PbrtHipScene {
     // SpatialLightDistribution tables (lightdistrib.rs:76-220), built on first use by a render with that strategy
     float* d_spatial = nullptr;
     int spatial_voxels[3] = {0, 0, 0};
+    // 4-wide quantised records over the same tree (wide_bvh.h): the traversal kernels' fast path when present
+    bool has_wide = false;
+    pb::WideTrees wide{};
+    int n_wide_records = 0;
+    std::string wide_reason;  // why the scene has none
 };
 
 namespace pb {
@@ -193,8 +205,8 @@ __host__ __device__ inline bool triangle_rejected_by_intersect(const float* a, c
 }
 
 // persistent kernels: enough blocks to fill every CU (LDS: 160 KiB / (kStackLds * 2 KiB) blocks of 256, at most 8)
-inline int persistent_grid(const PbrtHipScene* s) {
-    int per_cu = std::min(PB_TRACE_WAVES, (160 * 1024) / (kStackLds * kTraceBlock * (int)sizeof(uint2)));
+inline int persistent_grid(const PbrtHipScene* s, int waves = PB_TRACE_WAVES, int stack_lds = kStackLds) {
+    int per_cu = std::min(waves, (160 * 1024) / (stack_lds * kTraceBlock * (int)sizeof(uint2)));
     return std::min(s->ctx->n_cus * per_cu, s->spill_lanes / kTraceBlock);
 }
 

@@ -1,0 +1,285 @@
+// trace_wide.h — closest-hit / any-hit traversal over the 4-wide quantised records (wide_bvh.h).
+//
+// Same results as trace_persistent.h, i.e. as BVHAccel::intersect / intersect_p (src/accelerators/bvh.rs:828-932)
+// with Bounds3f::intersect_p (src/core/geometry.rs:709-751) and Triangle::intersect_test (src/shapes/triangle.rs:74-158):
+// the records only decide which leaves are LOOKED AT, in the reference's near-first order; whether a leaf's
+// triangles are tested is decided by the reference's own slab test on the leaf's exact box with the ray.t_max of that
+// moment (the argument is in wide_bvh.h). Scheduling (persistent waves, per-lane ray replacement, postponed leaves)
+// is trace_persistent.h's. Per step a lane issues three 16-B loads for four boxes instead of four for two.
+//
+// Rays the filter's error bound does not cover (a reciprocal direction component that is not finite or beyond
+// 2^+-40, an origin beyond 2^24) are not traced here: their queue positions go to `special_list` and the binary
+// kernel traces them in a second, usually empty, launch.
+#pragma once
+#include "trace_persistent.h"
+#include "wide_bvh.h"
+
+namespace pb {
+
+#ifndef PB_WIDE_WAVES
+#define PB_WIDE_WAVES 5
+#endif
+#ifndef PB_WIDE_STACK_LDS
+#define PB_WIDE_STACK_LDS 12
+#endif
+#ifndef PB_WIDE_INTERIOR_THRESH
+#define PB_WIDE_INTERIOR_THRESH 32
+#endif
+#ifndef PB_WIDE_REFILL_THRESH
+#define PB_WIDE_REFILL_THRESH 8
+#endif
+constexpr int kWideStackLds = PB_WIDE_STACK_LDS;
+
+// The rays trace_wide left to the binary kernel, as an IO policy of trace_persistent: ray i of this launch is ray
+// list[i] of the original queue; their number is read from device memory (the wide launch counted them).
+template <class Inner>
+struct SpecialListIO {
+    Inner inner;
+    const uint32_t* __restrict__ list;
+    const unsigned int* __restrict__ count;
+    PB_DEV uint32_t n() const { return *count; }
+    PB_DEV int segments() const { return 1; }
+    PB_DEV bool load(uint32_t i, TravRay* r, bool* any) const { return inner.load(list[i], r, any); }
+    PB_DEV void store(uint32_t i, bool any, bool found, float t, float b0, float b1, float b2, int slot, int inst) const {
+        inner.store(list[i], any, found, t, b0, b1, b2, slot, inst);
+    }
+};
+
+
+
+template <class IO>
+PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restrict__ work_counter, uint2* lds_stack,
+                       int spill_lane) {
+    const uint32_t n = io.n();
+    const int lane = threadIdx.x & 63;
+    TravRay r;
+    float idx = 0.0f, idy = 0.0f, idz = 0.0f, tmax = 0.0f, hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
+    int hit_slot = -1, cur = 0, sp = 0;
+    uint32_t index = 0;
+    bool nx = false, ny = false, nz = false, any = false, has_work = false;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.tmax = 0.0f;
+    uint32_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false;
+    const int n_seg = io.segments();
+    int seg = (int)(blockIdx.x % (unsigned)n_seg), seg_tries = 0;
+
+    auto stack_write = [&](int pos, int ref, float entry) {
+        uint2 ent = make_uint2((uint32_t)ref, __float_as_uint(entry));
+        if (pos < kWideStackLds)
+            lds_stack[pos * kTraceBlock] = ent;
+        else
+            wt.spill[(size_t)(pos - kWideStackLds) * wt.spill_stride + spill_lane] = ent;
+    };
+    auto stack_read = [&](int pos) -> uint2 {
+        return (pos < kWideStackLds) ? lds_stack[pos * kTraceBlock]
+                                     : wt.spill[(size_t)(pos - kWideStackLds) * wt.spill_stride + spill_lane];
+    };
+    auto finish = [&](bool found) {
+        io.store(index, any, found, tmax, hb0, hb1, hb2, hit_slot, -1);
+        has_work = false;
+    };
+    // next entry whose lower bound is still in front of the hit; false when the ray is finished
+    auto advance = [&]() -> bool {
+        while (sp > 0) {
+            --sp;
+            uint2 ent = stack_read(sp);
+            if (__uint_as_float(ent.y) < tmax) {
+                cur = (int)ent.x;
+                return true;
+            }
+        }
+        return false;
+    };
+
+    for (;;) {
+        // ---------------- refill idle lanes (as trace_persistent.h) ----------------
+        unsigned long long idle_mask = __ballot(!has_work);
+        int n_idle = __popcll(idle_mask);
+        if (!exhausted && (n_idle >= PB_WIDE_REFILL_THRESH)) {
+            if (chunk_next >= chunk_end) {
+                while (seg_tries < n_seg) {
+                    uint32_t seg_begin = (uint32_t)(((unsigned long long)n * (unsigned)seg) / (unsigned)n_seg);
+                    uint32_t seg_end = (uint32_t)(((unsigned long long)n * (unsigned)(seg + 1)) / (unsigned)n_seg);
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(work_counter + seg, (unsigned int)kChunk);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane(base) + seg_begin;
+                    if (base < seg_end && base >= seg_begin) {
+                        chunk_next = base;
+                        chunk_end = (base + kChunk) < seg_end ? (base + kChunk) : seg_end;
+                        break;
+                    }
+                    seg = (seg + 1 == n_seg) ? 0 : seg + 1;
+                    seg_tries += 1;
+                }
+                if (chunk_next >= chunk_end) exhausted = true;
+            }
+            uint32_t avail = chunk_end - chunk_next;
+            uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0));
+            bool take = !has_work && prefix < avail;
+            uint32_t my = chunk_next + prefix;
+            chunk_next += ((uint32_t)n_idle < avail) ? (uint32_t)n_idle : avail;
+            bool special = false;
+            if (take) {
+                index = my;
+                bool real = io.load(my, &r, &any);
+                tmax = r.tmax;
+                hit_slot = -1;
+                hb0 = hb1 = hb2 = 0.0f;
+                sp = 0;
+                has_work = true;
+                if (!real) {
+                    finish(false);  // placeholder of a path outside pixel_bounds: not a ray of the frame
+                } else {
+                    idx = 1.0f / r.dx;  // bvh.rs:831
+                    idy = 1.0f / r.dy;
+                    idz = 1.0f / r.dz;
+                    nx = idx < 0.0f;  // bvh.rs:832-836
+                    ny = idy < 0.0f;
+                    nz = idz < 0.0f;
+                    bool covered = wide_ray_covered(r.ox, r.oy, r.oz, idx, idy, idz);
+                    special = !covered;
+                    cur = wt.root_ref;
+                    if (special) has_work = false;  // traced by the binary kernel afterwards (results written there)
+                }
+            }
+            unsigned long long sm = __ballot(special);
+            if (sm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(wt.special_count, (unsigned int)__popcll(sm));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane(base);
+                if (special)
+                    wt.special_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0))] = index;
+            }
+        }
+        if (!__any(has_work)) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---------------- records ----------------
+        for (;;) {
+            bool interior = has_work && cur >= 0;
+            int n_int = __popcll(__ballot(interior));
+            if (n_int == 0) break;
+            if (n_int < PB_WIDE_INTERIOR_THRESH) {
+                bool leaf_pending = __any(has_work && cur < 0);
+                bool can_refill = !exhausted && (__popcll(__ballot(!has_work)) >= PB_WIDE_REFILL_THRESH);
+                if (leaf_pending || can_refill) break;
+            }
+            if (interior) {
+                const uint4* nd = wt.nodes + 3 * (size_t)cur;
+                uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
+                const uint32_t dw3 = q0.w;
+                const WideSetup ws = wide_setup(q0.x, q0.y, q0.z, dw3, r.ox, r.oy, r.oz, idx, idy, idz);
+                // near / far plane bytes by the sign of the direction
+                uint32_t nqx = nx ? q1.y : q1.x, fqx = nx ? q1.x : q1.y;
+                uint32_t nqy = ny ? q1.w : q1.z, fqy = ny ? q1.z : q1.w;
+                uint32_t nqz = nz ? q2.y : q2.x, fqz = nz ? q2.x : q2.y;
+                // rank of a slot in the reference's visiting order: two levels of dir_is_neg[axis] (bvh.rs:857-865)
+                const uint32_t negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+                const uint32_t f_root = (negmask >> ((dw3 >> 18) & 3u)) & 1u;
+                const uint32_t f_c0 = (negmask >> ((dw3 >> 20) & 3u)) & 1u, f_c1 = (negmask >> ((dw3 >> 22) & 3u)) & 1u;
+                const uint32_t x01 = (f_root << 1) | f_c0, x23 = (f_root << 1) | f_c1;
+                uint32_t rank[4] = {x01, x01 ^ 1u, x23 ^ 2u, x23 ^ 3u};
+                uint32_t mb[4] = {q0.x & 0xffu, q0.y & 0xffu, q0.z & 0xffu, dw3 >> 24};
+                float tn[4];
+                uint32_t rm = 0;  // bit `rank` set for every child whose quantised box the ray may hit
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    bool h = wide_child_test(ws, nqx, nqy, nqz, fqx, fqy, fqz, s, tmax, &tn[s]) && (mb[s] != 0xffu);
+                    rm |= (h ? 1u : 0u) << rank[s];
+                }
+                if (rm == 0) {
+                    if (!advance()) finish(hit_slot >= 0);
+                } else {
+                    const int n_hit = __popc(rm);
+                    const uint32_t child_base = q2.z, ntb = q2.w;
+                    int first_ref = 0;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        if ((rm >> rank[s]) & 1u) {
+                            int ref = (mb[s] & 0x80u) ? (int)(child_base + (mb[s] & 3u)) : (int)(ntb - mb[s]);
+                            int behind = __popc(rm >> (rank[s] + 1u));  // hit children the reference visits later
+                            if (behind == n_hit - 1)
+                                first_ref = ref;
+                            else
+                                stack_write(sp + behind, ref, tn[s]);  // the child visited last lies deepest
+                        }
+                    }
+                    sp += n_hit - 1;
+                    cur = first_ref;
+                }
+            }
+        }
+
+        // ---------------- leaves: the reference's box test on the exact leaf box, then its triangles ----------------
+        if (has_work && cur < 0) {
+            const int v = ~cur;
+            const int cnt = (v & 3) + 1;
+            const int first = v >> 2;
+            float4 ta = make_float4(0.0f, 0.0f, 0.0f, 0.0f), tb = ta, tc = ta;
+            float lox, loy, loz, hix, hiy, hiz;
+            if (cnt == 1) {
+                const float4* tp = wt.tris + 3 * (size_t)first;
+                ta = tp[0];
+                tb = tp[1];
+                tc = tp[2];
+                // Triangle::world_bound (the union of the three vertices): exact, so it is the leaf node's box
+                lox = wide_fmin(ta.x, wide_fmin(ta.w, tb.z));
+                hix = wide_fmax(ta.x, wide_fmax(ta.w, tb.z));
+                loy = wide_fmin(ta.y, wide_fmin(tb.x, tb.w));
+                hiy = wide_fmax(ta.y, wide_fmax(tb.x, tb.w));
+                loz = wide_fmin(ta.z, wide_fmin(tb.y, tc.x));
+                hiz = wide_fmax(ta.z, wide_fmax(tb.y, tc.x));
+            } else {
+                const float4* bp = wt.leaf_boxes + 2 * (size_t)first;
+                float4 b0 = bp[0], b1 = bp[1];
+                lox = b0.x;
+                loy = b0.y;
+                loz = b0.z;
+                hix = b1.x;
+                hiy = b1.y;
+                hiz = b1.z;
+            }
+            float entry;
+            bool pass = slab_test(nx ? hix : lox, nx ? lox : hix, ny ? hiy : loy, ny ? loy : hiy, nz ? hiz : loz, nz ? loz : hiz, r,
+                                  idx, idy, idz, tmax, &entry);
+            bool done = false;
+            if (pass) {
+                const TriRayConst trc = tri_ray_setup(r);
+                for (int i = 0; i < cnt; ++i) {
+                    if (cnt > 1) {
+                        const float4* tp = wt.tris + 3 * (size_t)(first + i);
+                        ta = tp[0];
+                        tb = tp[1];
+                        tc = tp[2];
+                    }
+                    float b0, b1, b2, t;
+                    bool hit = triangle_test(V3{ta.x, ta.y, ta.z}, V3{ta.w, tb.x, tb.y}, V3{tb.z, tb.w, tc.x}, r, trc, tmax, &b0, &b1,
+                                             &b2, &t);
+                    if (hit) {
+                        if (any) {
+                            done = true;
+                            hit_slot = __float_as_int(tc.y);
+                            break;
+                        }
+                        if (!(__float_as_int(tc.z) & kTriDegenerate)) {
+                            tmax = t;  // primitive.rs:70
+                            hb0 = b0;
+                            hb1 = b1;
+                            hb2 = b2;
+                            hit_slot = __float_as_int(tc.y);
+                        }
+                    }
+                }
+            }
+            if (done)
+                finish(true);
+            else if (!advance())
+                finish(hit_slot >= 0);
+        }
+    }
+}
+
+}  // namespace pb

@@ -159,4 +159,22 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_I
                                                   blockIdx.x * kTraceBlock + threadIdx.x, counters);
 }
 
+// the same wavefront over the 4-wide records (trace_wide.h) ...
+__global__ void __launch_bounds__(kTraceBlock, PB_WIDE_WAVES)
+    k_trace_wide(WideTrees wt, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
+                 int segments) {
+    __shared__ uint2 lds_stack[kWideStackLds * kTraceBlock];
+    WavefrontRayIO io{ps, queue, n, segments};
+    trace_wide<WavefrontRayIO>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x);
+}
+// ... and the rays it left to the binary records (axis-parallel directions and the like; usually none)
+__global__ void __launch_bounds__(kTraceBlock, PB_TRACE_WAVES)
+    k_trace_special(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, const uint32_t* __restrict__ list,
+                    const unsigned int* __restrict__ count, unsigned int* work_counter) {
+    __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
+    SpecialListIO<WavefrontRayIO> io{WavefrontRayIO{ps, queue, n, 1}, list, count};
+    trace_persistent<SpecialListIO<WavefrontRayIO>, false, false, false>(bvh, io, work_counter, lds_stack + threadIdx.x,
+                                                                         blockIdx.x * kTraceBlock + threadIdx.x, nullptr);
+}
+
 }  // namespace pb

@@ -5,6 +5,7 @@
 #include "scene.h"
 #include "trace.h"
 #include "trace_persistent.h"
+#include "trace_wide.h"
 
 namespace pb {
 

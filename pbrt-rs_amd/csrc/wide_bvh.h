@@ -1,0 +1,129 @@
+// wide_bvh.h — 4-wide, 48-byte quantised node records laid over the reference's binary BVH (layout + the box filter).
+//
+// Why: k_trace is bound by the number of 16-B lane requests the texture-address / L1 path has to process
+// (profiles/r01_pmc_summary.txt: TA busy 91 %), four per traversal step of the 64-B child-pair records. A record that
+// holds FOUR children (two levels of the reference's tree) in 48 bytes costs three requests per step and halves the
+// steps. The boxes in it are 8-bit, conservative: they only FILTER. What the reference decides is decided exactly:
+//
+//   BVHAccel::intersect (src/accelerators/bvh.rs:828-879) visits a leaf iff the leaf's own box passes
+//   Bounds3f::intersect_p (src/core/geometry.rs:709-751) with the ray.t_max current at that moment: every ancestor
+//   box contains the leaf box and was tested earlier (t_max only shrinks), and the slab test is monotone in the box
+//   and in t_max (no 0 * inf: rays with a non-finite reciprocal direction never take this path), so the ancestors'
+//   tests add nothing. The reference is therefore "for every leaf in near-first depth-first order: if the leaf box
+//   passes with the current t_max, test its triangles". The wide traversal enumerates a SUPERSET of those leaves in
+//   the same order (children of a record are ranked by the two levels of dir_is_neg[axis] decisions, bvh.rs:857-865),
+//   applies the exact slab test to the exact leaf box, then the same Triangle::intersect_test: same sequence of
+//   triangle tests with the same t_max values, hence the same (prim, t, b0, b1, b2), ties included.
+//
+// Record (12 dwords), slots 0,1 = children of the binary node's first child, 2,3 = of its second child (a binary
+// child that is a leaf sits in the even slot, the odd one is empty):
+//   dw0..2  base.xyz: the node box's lower corner rounded DOWN to 24 significant bits; low byte = m[0..2]
+//   dw3     ex | ey << 6 | ez << 12 (cell = 2^(e - kExpBias)) | axis_root << 18 | axis_c0 << 20 | axis_c1 << 22 | m[3] << 24
+//   dw4..9  lo.x, hi.x, lo.y, hi.y, lo.z, hi.z: byte s = slot s, plane = base + q * cell (lo rounded down, hi up)
+//   dw10    index of the first interior child (the interior children of a record are contiguous)
+//   dw11    ~(first triangle of the first leaf child << 2) (the leaf children's triangles are contiguous in `wtris`)
+//   m[s]    0xFF empty | 0x80 + k: interior child k | (triangle offset << 2) | (n - 1): leaf of n <= 4 triangles
+// Child reference (stack entry / `cur`): >= 0 record index; < 0 leaf, ~ref = first_wide_triangle << 2 | (n - 1).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PB_HD __host__ __device__ __forceinline__
+#else
+#define PB_HD inline
+#endif
+
+namespace pb {
+
+constexpr int kWideNodeDwords = 12;
+constexpr int kExpBias = 50;         // stored exponent field = e + 50, e in [-50, 13]
+constexpr int kExpMax = 13;
+constexpr float kWideCoordLimit = 1048576.0f;  // |scene coordinate| <= 2^20, else the scene keeps the binary records
+// rays outside these ranges (a zero or denormal direction component, an origin far outside any scene this path
+// accepts) are traced over the binary records by the exact kernel: the bound below assumes no overflow / 0 * inf
+constexpr float kWideInvDirMin = 9.094947017729282e-13f;  // 2^-40
+constexpr float kWideInvDirMax = 1099511627776.0f;        // 2^40
+constexpr float kWideOriginLimit = 16777216.0f;           // 2^24
+
+// The filter's arithmetic, shared by the kernel and the host-side conservativeness test (tests/native/).
+// For a non-special ray and one axis:   A = (base - o) * inv_d  (two roundings),  S = inv_d * 2^e  (exact),
+// plane value  fma(q, S, A -/+ G)  with  G = 2^-19 * (|A| + 256 |S|)  of that axis.  DESIGN.md (section 4, "wide records")
+// derives  near_q <= near_exact  and  far_q >= far_exact * (1 + 2 gamma_3)  for every float box inside the quantised
+// one: the rounding of A, of the fma and of the exact formula's own two (three) roundings sum to < 14 u * M per
+// plane, G is 32 u * M.
+struct WideSetup {
+    float Sx, Sy, Sz;
+    float Anx, Afx, Any, Afy, Anz, Afz;
+};
+PB_HD float wide_abs(float x) { return __builtin_fabsf(x); }
+PB_HD float wide_fmax(float a, float b) { return __builtin_fmaxf(a, b); }
+PB_HD float wide_fmin(float a, float b) { return __builtin_fminf(a, b); }
+PB_HD float wide_as_float(uint32_t u) {
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+// per record and ray: dw0..dw3 of the record, ray origin and reciprocal direction
+PB_HD WideSetup wide_setup(uint32_t dw0, uint32_t dw1, uint32_t dw2, uint32_t dw3, float ox, float oy, float oz, float idx,
+                           float idy, float idz) {
+    WideSetup w;
+    w.Sx = __builtin_ldexpf(idx, (int)(dw3 & 63u) - kExpBias);
+    w.Sy = __builtin_ldexpf(idy, (int)((dw3 >> 6) & 63u) - kExpBias);
+    w.Sz = __builtin_ldexpf(idz, (int)((dw3 >> 12) & 63u) - kExpBias);
+    float Ax = (wide_as_float(dw0 & 0xffffff00u) - ox) * idx;
+    float Ay = (wide_as_float(dw1 & 0xffffff00u) - oy) * idy;
+    float Az = (wide_as_float(dw2 & 0xffffff00u) - oz) * idz;
+    float Mx = __builtin_fmaf(wide_abs(w.Sx), 256.0f, wide_abs(Ax));
+    float My = __builtin_fmaf(wide_abs(w.Sy), 256.0f, wide_abs(Ay));
+    float Mz = __builtin_fmaf(wide_abs(w.Sz), 256.0f, wide_abs(Az));
+    // per axis: the error of that axis' plane values scales with that axis' magnitudes only (a ray nearly parallel
+    // to a slab has huge values there, and must not blur the other two)
+    const float k = 1.9073486328125e-06f;  // 2^-19 = 32 u
+    float Gx = Mx * k, Gy = My * k, Gz = Mz * k;
+    w.Anx = Ax - Gx;
+    w.Afx = Ax + Gx;
+    w.Any = Ay - Gy;
+    w.Afy = Ay + Gy;
+    w.Anz = Az - Gz;
+    w.Afz = Az + Gz;
+    return w;
+}
+// one child: nq* / fq* = the near / far plane dwords of the three axes (chosen by the sign of the direction), slot s.
+// Returns "the ray may hit a float box inside this quantised box before t_max"; *entry <= the exact test's entry distance.
+PB_HD bool wide_child_test(const WideSetup& w, uint32_t nqx, uint32_t nqy, uint32_t nqz, uint32_t fqx, uint32_t fqy, uint32_t fqz,
+                           int s, float tmax, float* entry) {
+    float tnx = __builtin_fmaf((float)((nqx >> (8 * s)) & 0xffu), w.Sx, w.Anx);
+    float tny = __builtin_fmaf((float)((nqy >> (8 * s)) & 0xffu), w.Sy, w.Any);
+    float tnz = __builtin_fmaf((float)((nqz >> (8 * s)) & 0xffu), w.Sz, w.Anz);
+    float tfx = __builtin_fmaf((float)((fqx >> (8 * s)) & 0xffu), w.Sx, w.Afx);
+    float tfy = __builtin_fmaf((float)((fqy >> (8 * s)) & 0xffu), w.Sy, w.Afy);
+    float tfz = __builtin_fmaf((float)((fqz >> (8 * s)) & 0xffu), w.Sz, w.Afz);
+    float t0 = wide_fmax(wide_fmax(tnx, tny), tnz);
+    float t1 = wide_fmin(wide_fmin(tfx, tfy), wide_fmin(tfz, tmax));
+    *entry = t0;
+    return wide_fmax(t0, 0.0f) <= t1;  // (t0 <= far) & (t0 <= t_max) & (far >= 0) & (t_max >= 0)
+}
+// rays the bound does not cover (traced over the binary records instead)
+PB_HD bool wide_ray_covered(float ox, float oy, float oz, float idx, float idy, float idz) {
+    float ax = wide_abs(idx), ay = wide_abs(idy), az = wide_abs(idz);
+    return ax >= kWideInvDirMin && ax <= kWideInvDirMax && ay >= kWideInvDirMin && ay <= kWideInvDirMax && az >= kWideInvDirMin &&
+           az <= kWideInvDirMax && wide_abs(ox) <= kWideOriginLimit && wide_abs(oy) <= kWideOriginLimit &&
+           wide_abs(oz) <= kWideOriginLimit;
+}
+
+#if defined(__HIPCC__)
+// device arrays of one scene's wide records (built by host_wide.cpp, uploaded by pbrt_hip.hip)
+struct WideTrees {
+    const uint4* __restrict__ nodes;        // 3 x uint4 per record
+    const float4* __restrict__ tris;        // 3 x float4 per wide-order triangle: (v0.xyz v1.x) (v1.yz v2.xy) (v2.z slot flags -)
+    const float4* __restrict__ leaf_boxes;  // 2 x float4 per wide-order triangle position (leaves of n >= 2)
+    int root_ref;
+    uint2* __restrict__ spill;  // [entry][global lane]
+    int spill_stride;
+    uint32_t* __restrict__ special_list;  // queue positions of the rays left to the binary kernel
+    unsigned int* __restrict__ special_count;
+};
+#endif
+
+}  // namespace pb

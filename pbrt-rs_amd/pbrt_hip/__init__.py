@@ -31,7 +31,7 @@ EXPORTS = [
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
     "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png", "pbrt_hip_write_exr",
     "pbrt_hip_comm_unique_id", "pbrt_hip_comm_create", "pbrt_hip_comm_destroy", "pbrt_hip_film_reduce",
-    "pbrt_hip_comm_last_error",
+    "pbrt_hip_comm_last_error", "pbrt_hip_scene_wide_records",
 ]
 
 
@@ -93,6 +93,7 @@ def lib():
                                                       vp, i32, vp, ctypes.POINTER(vp)]
         L.pbrt_hip_scene_destroy.argtypes = [vp]
         L.pbrt_hip_scene_destroy.restype = None
+        L.pbrt_hip_scene_wide_records.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_char_p)]
         for name in ("pbrt_hip_intersect", "pbrt_hip_intersect_p", "pbrt_hip_intersect_device",
                      "pbrt_hip_intersect_p_device"):
             getattr(L, name).argtypes = [vp, vp, i64, vp]
@@ -321,6 +322,12 @@ class Scene:
         self.ctx.check(rc, "pbrt_hip_scene_create_with_spheres")
         self.h = h
         self.ctx._scenes.add(self)
+
+    def wide_records(self):
+        """(number of 4-wide records, reason): -1 records = the scene is traced over the binary records only."""
+        n, why = ctypes.c_int32(), ctypes.c_char_p()
+        self.ctx.check(lib().pbrt_hip_scene_wide_records(self.h, ctypes.byref(n), ctypes.byref(why)), "scene_wide_records")
+        return n.value, (why.value or b"").decode()
 
     def _set_shading_data(self, scene):
         """TriangleMesh n / uv (triangle.rs:17-26): scene["normals"] / scene["tangents"] (n_verts, 3), scene["uvs"] (n_verts, 2), optional."""

@@ -11,6 +11,7 @@ sc = scenes.random_triangles(int(os.environ.get("TRIS", "1000000")), seq=1)
 cam = scenes.random_triangles_camera(W, H)
 ctx = pbrt_hip.Context(0)
 scene = pbrt_hip.Scene(ctx, sc)
+print("wide records:", scene.wide_records())
 for it in range(3):
     film, st = scene.render(cam, W, H, spp, max_depth=5, seed=0)
 rays = st["rays_closest"] + st["rays_shadow"]
