@@ -29,12 +29,20 @@ float u2f(uint32_t u) {
     std::memcpy(&f, &u, 4);
     return f;
 }
-// largest float <= x whose low 8 mantissa bits are zero
-float round_down_24(float x) {
-    uint32_t u = f2u(x);
-    if ((u & 0xffu) == 0) return x;
-    if (x > 0.0f) return u2f(u & ~0xffu);
-    return u2f((u | 0xffu) + 1u);  // negative: magnitude up to the next multiple of 2^8 ulps
+// the largest float <= target whose low mantissa byte is `m` (the record keeps m[0..2] in the low bytes of base.xyz)
+float base_with_byte(double target, uint32_t m) {
+    float t = (float)target;
+    if ((double)t > target) t = std::nextafter(t, -HUGE_VALF);
+    uint32_t u = f2u(t);
+    if (!(u & 0x80000000u)) {  // t >= +0: float order = integer order
+        uint32_t cand = (u & ~0xffu) | m;
+        if (cand <= u) return u2f(cand);
+        if (u >= 0x100u) return u2f(cand - 0x100u);
+        return u2f(0x80000000u | m);  // below the smallest positive step: a tiny negative value (or -0)
+    }
+    uint32_t mag = u & 0x7fffffffu, cand = (mag & ~0xffu) | m;  // negative: the magnitude has to be >= |t|
+    if (cand < mag) cand += 0x100u;
+    return u2f(0x80000000u | cand);
 }
 double next_up(double x) { return std::nextafter(x, HUGE_VAL); }
 double next_down(double x) { return std::nextafter(x, -HUGE_VAL); }
@@ -121,22 +129,42 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
             }
         }
         uint32_t rec[kWideNodeDwords] = {0};
-        float base[3];
-        int e[3];
-        for (int k = 0; k < 3; ++k) {
-            base[k] = round_down_24(nd.bounds_min[k]);
-            // smallest cell 2^e with 255 cells reaching the upper corner
-            double extent = next_up((double)nd.bounds_max[k] - (double)base[k]);
-            int ek = -kExpBias;
-            while (ek <= kExpMax && std::ldexp(255.0, ek) < extent) ++ek;
-            if (ek > kExpMax) return "node extent beyond the exponent range";
-            e[k] = ek;
-        }
-        uint32_t q[6] = {0, 0, 0, 0, 0, 0};
+        // children first: the bytes m[] are part of base.xyz
         uint32_t m[4] = {0xff, 0xff, 0xff, 0xff};
         int n_interior = 0, tri_off = 0;
         const int64_t first_child = (int64_t)roots.size();
         const int64_t first_tri = tri_cursor;
+        for (int s = 0; s < 4; ++s) {
+            if (slot_node[s] < 0) continue;
+            const PbrtLinearBVHNode& ch = nodes[slot_node[s]];
+            if (ch.n_primitives > 0) {
+                emit_leaf(ch);
+                m[s] = (uint32_t)(tri_off << 2) | (uint32_t)(ch.n_primitives - 1);
+                tri_off += ch.n_primitives;
+            } else {
+                m[s] = 0x80u | (uint32_t)n_interior;
+                ++n_interior;
+                roots.push_back(slot_node[s]);
+            }
+        }
+        float base[3];
+        int e[3];
+        for (int k = 0; k < 3; ++k) {
+            // base: kWideSlack cells (and a little more) below the lower corner; cell 2^e: the smallest with 255 cells
+            // reaching kWideSlack cells beyond the upper corner. The two depend on each other: settle in a few rounds.
+            int ek = kExpMin;
+            for (int round = 0; round < 8; ++round) {
+                base[k] = base_with_byte((double)nd.bounds_min[k] - 2.0 * kWideSlack * std::ldexp(1.0, ek), k < 3 ? m[k] : 0);
+                double extent = next_up((double)nd.bounds_max[k] - (double)base[k]);
+                int need = kExpMin;
+                while (need <= kExpMax && std::ldexp(255.0 - 2.0 * kWideSlack, need) < extent) ++need;
+                if (need <= ek) break;
+                ek = need;
+            }
+            if (ek > kExpMax) return "node extent beyond the exponent range";
+            e[k] = ek;
+        }
+        uint32_t q[6] = {0, 0, 0, 0, 0, 0};
         for (int s = 0; s < 4; ++s) {
             uint32_t qlo[3] = {255, 255, 255}, qhi[3] = {0, 0, 0};  // empty slot: inverted (and masked out by m = 0xFF)
             if (slot_node[s] >= 0) {
@@ -144,21 +172,10 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
                 for (int k = 0; k < 3; ++k) {
                     double dlo = next_down((double)ch.bounds_min[k] - (double)base[k]);
                     double dhi = next_up((double)ch.bounds_max[k] - (double)base[k]);
-                    double flo = std::floor(std::ldexp(dlo, -e[k])), fhi = std::ceil(std::ldexp(dhi, -e[k]));
-                    if (flo < 0.0) flo = 0.0;  // base <= every child's lower corner: plane 0 is still below it
-                    if (fhi < 0.0) fhi = 0.0;
-                    if (flo > 255.0 || fhi > 255.0) return "quantisation overflow";  // cannot happen: e was chosen for the parent box
+                    double flo = std::floor(std::ldexp(dlo, -e[k]) - kWideSlack), fhi = std::ceil(std::ldexp(dhi, -e[k]) + kWideSlack);
+                    if (flo < 0.0 || fhi > 255.0 || flo > fhi) return "quantisation out of range";  // excluded by the choice of base and e
                     qlo[k] = (uint32_t)flo;
                     qhi[k] = (uint32_t)fhi;
-                }
-                if (ch.n_primitives > 0) {
-                    emit_leaf(ch);
-                    m[s] = (uint32_t)(tri_off << 2) | (uint32_t)(ch.n_primitives - 1);
-                    tri_off += ch.n_primitives;
-                } else {
-                    m[s] = 0x80u | (uint32_t)n_interior;
-                    ++n_interior;
-                    roots.push_back(slot_node[s]);
                 }
             }
             for (int k = 0; k < 3; ++k) {
@@ -166,8 +183,8 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
                 q[2 * k + 1] |= qhi[k] << (8 * s);
             }
         }
-        for (int k = 0; k < 3; ++k) rec[k] = f2u(base[k]) | m[k];
-        rec[3] = (uint32_t)(e[0] + kExpBias) | (uint32_t)(e[1] + kExpBias) << 6 | (uint32_t)(e[2] + kExpBias) << 12 |
+        for (int k = 0; k < 3; ++k) rec[k] = f2u(base[k]);
+        rec[3] = ((uint32_t)e[0] & 63u) | ((uint32_t)e[1] & 63u) << 6 | ((uint32_t)e[2] & 63u) << 12 |
                  (uint32_t)nd.axis << 18 | (uint32_t)axis_c[0] << 20 | (uint32_t)axis_c[1] << 22 | m[3] << 24;
         for (int k = 0; k < 6; ++k) rec[4 + k] = q[k];
         rec[10] = (uint32_t)first_child;

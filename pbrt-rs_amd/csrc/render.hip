@@ -781,6 +781,14 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
 }
 
 #ifdef PB_LANE_STATS
+extern "C" int pbrt_hip_debug_wide_stats(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pb::g_wide_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pb::g_wide_stats), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
 extern "C" int pbrt_hip_debug_lane_stats(unsigned long long* out8, int reset) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(pb::g_lane_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
     if (reset) {

@@ -30,6 +30,14 @@ namespace pb {
 #endif
 constexpr int kWideStackLds = PB_WIDE_STACK_LDS;
 
+#ifdef PB_LANE_STATS
+// development instrumentation (tools/lane_stats.py): wave-level iteration counts and lane sums of trace_wide
+__device__ unsigned long long g_wide_stats[16];
+#define PB_WSTAT(i, v) wstat[i] += (v)
+#else
+#define PB_WSTAT(i, v)
+#endif
+
 // The rays trace_wide left to the binary kernel, as an IO policy of trace_persistent: ray i of this launch is ray
 // list[i] of the original queue; their number is read from device memory (the wide launch counted them).
 template <class Inner>
@@ -57,22 +65,40 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     int hit_slot = -1, cur = 0, sp = 0;
     uint32_t index = 0;
     bool nx = false, ny = false, nz = false, any = false, has_work = false;
+    uint32_t negmask = 0;
     r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.tmax = 0.0f;
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
     const int n_seg = io.segments();
     int seg = (int)(blockIdx.x % (unsigned)n_seg), seg_tries = 0;
+#ifdef PB_LANE_STATS
+    unsigned long long wstat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave-level events (lane 0's copy is kept)
+    unsigned int wl_steps = 0, wl_children = 0, wl_cand = 0, wl_pass = 0, wl_tris = 0;  // this lane's own events
+#endif
 
+    // the LDS part of the stack through an LDS-typed pointer: with a generic one the compiler merges the two
+    // branches below into flat stores
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) uint2 LdsEntry;
+    typedef volatile __attribute__((address_space(3))) unsigned long long LdsWord;
+#else  // the host pass only parses this function
+    typedef uint2 LdsEntry;
+    typedef volatile unsigned long long LdsWord;
+#endif
+    LdsEntry* const lds = (LdsEntry*)lds_stack;
     auto stack_write = [&](int pos, int ref, float entry) {
         uint2 ent = make_uint2((uint32_t)ref, __float_as_uint(entry));
         if (pos < kWideStackLds)
-            lds_stack[pos * kTraceBlock] = ent;
+            lds[pos * kTraceBlock] = ent;
         else
             wt.spill[(size_t)(pos - kWideStackLds) * wt.spill_stride + spill_lane] = ent;
     };
     auto stack_read = [&](int pos) -> uint2 {
-        return (pos < kWideStackLds) ? lds_stack[pos * kTraceBlock]
-                                     : wt.spill[(size_t)(pos - kWideStackLds) * wt.spill_stride + spill_lane];
+        // the LDS read is unconditional (a conditional one is merged with the spill read into a flat load)
+        unsigned long long raw = *(LdsWord*)&lds[(pos < kWideStackLds ? pos : kWideStackLds - 1) * kTraceBlock];
+        uint2 ent = make_uint2((uint32_t)raw, (uint32_t)(raw >> 32));
+        if (pos >= kWideStackLds) ent = wt.spill[(size_t)(pos - kWideStackLds) * wt.spill_stride + spill_lane];
+        return ent;
     };
     auto finish = [&](bool found) {
         io.store(index, any, found, tmax, hb0, hb1, hb2, hit_slot, -1);
@@ -137,6 +163,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                     nx = idx < 0.0f;  // bvh.rs:832-836
                     ny = idy < 0.0f;
                     nz = idz < 0.0f;
+                    negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
                     bool covered = wide_ray_covered(r.ox, r.oy, r.oz, idx, idy, idz);
                     special = !covered;
                     cur = wt.root_ref;
@@ -167,6 +194,8 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 bool can_refill = !exhausted && (__popcll(__ballot(!has_work)) >= PB_WIDE_REFILL_THRESH);
                 if (leaf_pending || can_refill) break;
             }
+            PB_WSTAT(0, 1);      // record iterations of this wave
+            PB_WSTAT(1, n_int);  // lanes stepping a record
             if (interior) {
                 const uint4* nd = wt.nodes + 3 * (size_t)cur;
                 uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
@@ -176,44 +205,65 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 uint32_t nqx = nx ? q1.y : q1.x, fqx = nx ? q1.x : q1.y;
                 uint32_t nqy = ny ? q1.w : q1.z, fqy = ny ? q1.z : q1.w;
                 uint32_t nqz = nz ? q2.y : q2.x, fqz = nz ? q2.x : q2.y;
-                // rank of a slot in the reference's visiting order: two levels of dir_is_neg[axis] (bvh.rs:857-865)
-                const uint32_t negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+                // rank of a slot in the reference's visiting order: two levels of dir_is_neg[axis] (bvh.rs:857-865).
+                // slot s of the first / second binary child has rank s ^ x01 / s ^ x23.
                 const uint32_t f_root = (negmask >> ((dw3 >> 18) & 3u)) & 1u;
                 const uint32_t f_c0 = (negmask >> ((dw3 >> 20) & 3u)) & 1u, f_c1 = (negmask >> ((dw3 >> 22) & 3u)) & 1u;
                 const uint32_t x01 = (f_root << 1) | f_c0, x23 = (f_root << 1) | f_c1;
-                uint32_t rank[4] = {x01, x01 ^ 1u, x23 ^ 2u, x23 ^ 3u};
-                uint32_t mb[4] = {q0.x & 0xffu, q0.y & 0xffu, q0.z & 0xffu, dw3 >> 24};
+                const uint32_t rank[4] = {x01, x01 ^ 1u, x23 ^ 2u, x23 ^ 3u};
+                // m[0..3]: the low bytes of base.xyz and the top byte of dw3, gathered into one dword
+                const uint32_t mpack = __builtin_amdgcn_perm(q0.y, q0.x, 0x0c0c0400u) | __builtin_amdgcn_perm(dw3, q0.z, 0x07000c0cu);
                 float tn[4];
                 uint32_t rm = 0;  // bit `rank` set for every child whose quantised box the ray may hit
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    bool h = wide_child_test(ws, nqx, nqy, nqz, fqx, fqy, fqz, s, tmax, &tn[s]) && (mb[s] != 0xffu);
-                    rm |= (h ? 1u : 0u) << rank[s];
+                    bool h = wide_child_test(ws, nqx, nqy, nqz, fqx, fqy, fqz, s, tmax, &tn[s]) && (((mpack >> (8 * s)) & 0xffu) != 0xffu);
+                    rm |= h ? (1u << rank[s]) : 0u;
                 }
+#ifdef PB_LANE_STATS
+                wl_steps += 1;
+                wl_children += __popc(rm);
+#endif
                 if (rm == 0) {
                     if (!advance()) finish(hit_slot >= 0);
                 } else {
-                    const int n_hit = __popc(rm);
                     const uint32_t child_base = q2.z, ntb = q2.w;
-                    int first_ref = 0;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        if ((rm >> rank[s]) & 1u) {
-                            int ref = (mb[s] & 0x80u) ? (int)(child_base + (mb[s] & 3u)) : (int)(ntb - mb[s]);
-                            int behind = __popc(rm >> (rank[s] + 1u));  // hit children the reference visits later
-                            if (behind == n_hit - 1)
-                                first_ref = ref;
-                            else
-                                stack_write(sp + behind, ref, tn[s]);  // the child visited last lies deepest
-                        }
+                    // slot of a rank (the inverse of the map above) and that child's reference
+                    auto slot_of = [&](uint32_t rk) -> uint32_t {
+                        uint32_t hi = (rk >> 1) ^ f_root;
+                        return (hi << 1) | ((rk & 1u) ^ (hi ? f_c1 : f_c0));
+                    };
+                    auto ref_of = [&](uint32_t slot) -> int {
+                        uint32_t m = (mpack >> (8u * slot)) & 0xffu;
+                        return (m & 0x80u) ? (int)(child_base + (m & 3u)) : (int)(ntb - m);
+                    };
+                    // the children the reference visits later go on the stack, last one deepest
+                    uint32_t rest = rm & (rm - 1u);
+                    while (rest) {
+                        uint32_t rk = 31u - (uint32_t)__clz((int)rest);
+                        rest &= ~(1u << rk);
+                        uint32_t slot = slot_of(rk);
+                        float e = slot == 0 ? tn[0] : (slot == 1 ? tn[1] : (slot == 2 ? tn[2] : tn[3]));
+                        stack_write(sp, ref_of(slot), e);
+                        ++sp;
                     }
-                    sp += n_hit - 1;
-                    cur = first_ref;
+                    cur = ref_of(slot_of((uint32_t)__builtin_ctz(rm)));
                 }
             }
         }
 
         // ---------------- leaves: the reference's box test on the exact leaf box, then its triangles ----------------
+#ifdef PB_LANE_STATS
+        {
+            unsigned long long lm = __ballot(has_work && cur < 0);
+            if (lm) {
+                PB_WSTAT(2, 1);             // leaf sections
+                PB_WSTAT(3, __popcll(lm));  // lanes with a candidate leaf
+            }
+            PB_WSTAT(6, 1);  // outer iterations
+            PB_WSTAT(7, __popcll(__ballot(has_work)));
+        }
+#endif
         if (has_work && cur < 0) {
             const int v = ~cur;
             const int cnt = (v & 3) + 1;
@@ -246,6 +296,13 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             bool pass = slab_test(nx ? hix : lox, nx ? lox : hix, ny ? hiy : loy, ny ? loy : hiy, nz ? hiz : loz, nz ? loz : hiz, r,
                                   idx, idy, idz, tmax, &entry);
             bool done = false;
+#ifdef PB_LANE_STATS
+            wl_cand += 1;
+            if (pass) {
+                wl_pass += 1;
+                wl_tris += cnt;
+            }
+#endif
             if (pass) {
                 const TriRayConst trc = tri_ray_setup(r);
                 for (int i = 0; i < cnt; ++i) {
@@ -280,6 +337,20 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 finish(hit_slot >= 0);
         }
     }
+#ifdef PB_LANE_STATS
+    {
+        unsigned long long v[5] = {wl_steps, wl_children, wl_cand, wl_pass, wl_tris};
+        for (int k = 0; k < 5; ++k)
+            for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+        wstat[8] = v[1];
+        wstat[11] = v[0];
+        wstat[12] = v[2];
+        wstat[4] = v[3];
+        wstat[5] = v[4];
+        if (lane == 0)
+            for (int i = 0; i < 16; ++i) atomicAdd(&g_wide_stats[i], wstat[i]);
+    }
+#endif
 }
 
 }  // namespace pb

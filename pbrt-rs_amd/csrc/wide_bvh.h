@@ -17,9 +17,11 @@
 //
 // Record (12 dwords), slots 0,1 = children of the binary node's first child, 2,3 = of its second child (a binary
 // child that is a leaf sits in the even slot, the odd one is empty):
-//   dw0..2  base.xyz: the node box's lower corner rounded DOWN to 24 significant bits; low byte = m[0..2]
-//   dw3     ex | ey << 6 | ez << 12 (cell = 2^(e - kExpBias)) | axis_root << 18 | axis_c0 << 20 | axis_c1 << 22 | m[3] << 24
-//   dw4..9  lo.x, hi.x, lo.y, hi.y, lo.z, hi.z: byte s = slot s, plane = base + q * cell (lo rounded down, hi up)
+//   dw0..2  base.xyz as floats: a point below the node box's lower corner whose low mantissa byte IS m[0..2] (the
+//           builder picks the upper 24 bits so that the float, byte included, stays below the corner: no masking)
+//   dw3     ex | ey << 6 | ez << 12 (6-bit signed, cell = 2^e) | axis_root << 18 | axis_c0 << 20 | axis_c1 << 22 | m[3] << 24
+//   dw4..9  lo.x, hi.x, lo.y, hi.y, lo.z, hi.z: byte s = slot s, plane = base + q * cell, at least kWideSlack cells
+//           outside the child's float box (lo rounded down, hi up)
 //   dw10    index of the first interior child (the interior children of a record are contiguous)
 //   dw11    ~(first triangle of the first leaf child << 2) (the leaf children's triangles are contiguous in `wtris`)
 //   m[s]    0xFF empty | 0x80 + k: interior child k | (triangle offset << 2) | (n - 1): leaf of n <= 4 triangles
@@ -37,8 +39,8 @@
 namespace pb {
 
 constexpr int kWideNodeDwords = 12;
-constexpr int kExpBias = 50;         // stored exponent field = e + 50, e in [-50, 13]
-constexpr int kExpMax = 13;
+constexpr int kExpMin = -32, kExpMax = 13;  // cell = 2^e, stored as a 6-bit signed field
+constexpr double kWideSlack = 1.0 / 256.0;   // every quantised plane lies at least this many cells outside the float box
 constexpr float kWideCoordLimit = 1048576.0f;  // |scene coordinate| <= 2^20, else the scene keeps the binary records
 // rays outside these ranges (a zero or denormal direction component, an origin far outside any scene this path
 // accepts) are traced over the binary records by the exact kernel: the bound below assumes no overflow / 0 * inf
@@ -47,11 +49,12 @@ constexpr float kWideInvDirMax = 1099511627776.0f;        // 2^40
 constexpr float kWideOriginLimit = 16777216.0f;           // 2^24
 
 // The filter's arithmetic, shared by the kernel and the host-side conservativeness test (tests/native/).
-// For a non-special ray and one axis:   A = (base - o) * inv_d  (two roundings),  S = inv_d * 2^e  (exact),
-// plane value  fma(q, S, A -/+ G)  with  G = 2^-19 * (|A| + 256 |S|)  of that axis.  DESIGN.md (section 4, "wide records")
-// derives  near_q <= near_exact  and  far_q >= far_exact * (1 + 2 gamma_3)  for every float box inside the quantised
-// one: the rounding of A, of the fma and of the exact formula's own two (three) roundings sum to < 14 u * M per
-// plane, G is 32 u * M.
+// For a covered ray and one axis:   A = (base - o) * inv_d  (two roundings),  S = inv_d * 2^e  (exact),
+// plane value  fma(q, S, fma(-/+k, |A|, A)),  k = 2^-19 = 32 u.  For every float box inside the quantised one
+// near_q <= near_exact  and  far_q >= far_exact * (1 + 2 gamma_3): the roundings of A, of the two fmas and of the
+// exact formula's own two (three) add up to < 14 u (|A| + 256 |S|) per plane; k |A| covers the |A| part and the
+// kWideSlack cells the builder leaves between the quantised and the float plane (2^-8 |S|) cover the |S| part
+// ("wide records").
 struct WideSetup {
     float Sx, Sy, Sz;
     float Anx, Afx, Any, Afy, Anz, Afz;
@@ -68,25 +71,21 @@ PB_HD float wide_as_float(uint32_t u) {
 PB_HD WideSetup wide_setup(uint32_t dw0, uint32_t dw1, uint32_t dw2, uint32_t dw3, float ox, float oy, float oz, float idx,
                            float idy, float idz) {
     WideSetup w;
-    w.Sx = __builtin_ldexpf(idx, (int)(dw3 & 63u) - kExpBias);
-    w.Sy = __builtin_ldexpf(idy, (int)((dw3 >> 6) & 63u) - kExpBias);
-    w.Sz = __builtin_ldexpf(idz, (int)((dw3 >> 12) & 63u) - kExpBias);
-    float Ax = (wide_as_float(dw0 & 0xffffff00u) - ox) * idx;
-    float Ay = (wide_as_float(dw1 & 0xffffff00u) - oy) * idy;
-    float Az = (wide_as_float(dw2 & 0xffffff00u) - oz) * idz;
-    float Mx = __builtin_fmaf(wide_abs(w.Sx), 256.0f, wide_abs(Ax));
-    float My = __builtin_fmaf(wide_abs(w.Sy), 256.0f, wide_abs(Ay));
-    float Mz = __builtin_fmaf(wide_abs(w.Sz), 256.0f, wide_abs(Az));
-    // per axis: the error of that axis' plane values scales with that axis' magnitudes only (a ray nearly parallel
-    // to a slab has huge values there, and must not blur the other two)
+    w.Sx = __builtin_ldexpf(idx, ((int)(dw3 << 26)) >> 26);
+    w.Sy = __builtin_ldexpf(idy, ((int)(dw3 << 20)) >> 26);
+    w.Sz = __builtin_ldexpf(idz, ((int)(dw3 << 14)) >> 26);
+    float Ax = (wide_as_float(dw0) - ox) * idx;
+    float Ay = (wide_as_float(dw1) - oy) * idy;
+    float Az = (wide_as_float(dw2) - oz) * idz;
+    // per axis: the error of an axis' plane values scales with that axis' magnitudes only (a ray nearly parallel to
+    // a slab has huge values there and must not blur the other two)
     const float k = 1.9073486328125e-06f;  // 2^-19 = 32 u
-    float Gx = Mx * k, Gy = My * k, Gz = Mz * k;
-    w.Anx = Ax - Gx;
-    w.Afx = Ax + Gx;
-    w.Any = Ay - Gy;
-    w.Afy = Ay + Gy;
-    w.Anz = Az - Gz;
-    w.Afz = Az + Gz;
+    w.Anx = __builtin_fmaf(-k, wide_abs(Ax), Ax);
+    w.Afx = __builtin_fmaf(k, wide_abs(Ax), Ax);
+    w.Any = __builtin_fmaf(-k, wide_abs(Ay), Ay);
+    w.Afy = __builtin_fmaf(k, wide_abs(Ay), Ay);
+    w.Anz = __builtin_fmaf(-k, wide_abs(Az), Az);
+    w.Afz = __builtin_fmaf(k, wide_abs(Az), Az);
     return w;
 }
 // one child: nq* / fq* = the near / far plane dwords of the three axes (chosen by the sign of the direction), slot s.

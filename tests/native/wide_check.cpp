@@ -159,6 +159,53 @@ int wide_check_structure(const PbrtLinearBVHNode* nodes, int32_t n_nodes, const 
         stats[2] = (int64_t)ref_leaves.size();
         stats[3] = empties;
     }
+    // P4: every quantised plane lies at least kWideSlack cells outside the float box of its child (checked in double:
+    // base, q * cell and the coordinates are all dyadic and within 2^53 of each other here), inside [0, 255]
+    {
+        std::vector<int32_t> st{wt.root_ref};
+        std::vector<int32_t> bin{0};  // binary node of each record on the stack
+        while (!st.empty()) {
+            int32_t ref = st.back(), bnode = bin.back();
+            st.pop_back();
+            bin.pop_back();
+            if (ref < 0) continue;
+            const uint32_t* rec = &wt.nodes[(size_t)ref * pb::kWideNodeDwords];
+            const PbrtLinearBVHNode& nd = nodes[bnode];
+            const int32_t c[2] = {bnode + 1, nd.offset};
+            int32_t slot_node[4] = {-1, -1, -1, -1};
+            for (int j = 0; j < 2; ++j) {
+                if (nodes[c[j]].n_primitives > 0) {
+                    slot_node[2 * j] = c[j];
+                } else {
+                    slot_node[2 * j] = c[j] + 1;
+                    slot_node[2 * j + 1] = nodes[c[j]].offset;
+                }
+            }
+            for (int s = 0; s < 4; ++s) {
+                bool empty, interior;
+                int32_t r;
+                decode(rec, s, &empty, &interior, &r);
+                if (empty != (slot_node[s] < 0)) return -12;
+                if (empty) continue;
+                const PbrtLinearBVHNode& ch = nodes[slot_node[s]];
+                if (interior != (ch.n_primitives == 0)) return -13;
+                for (int k = 0; k < 3; ++k) {
+                    float base;
+                    std::memcpy(&base, &rec[k], 4);
+                    int e = ((int)(rec[3] << (26 - 6 * k))) >> 26;
+                    double cell = std::ldexp(1.0, e);
+                    double lo = (double)base + (double)((rec[4 + 2 * k] >> (8 * s)) & 0xffu) * cell;
+                    double hi = (double)base + (double)((rec[5 + 2 * k] >> (8 * s)) & 0xffu) * cell;
+                    if (!(lo <= (double)ch.bounds_min[k] - 0.999 * pb::kWideSlack * cell)) return -14;
+                    if (!(hi >= (double)ch.bounds_max[k] + 0.999 * pb::kWideSlack * cell)) return -15;
+                }
+                if (interior) {
+                    st.push_back(r);
+                    bin.push_back(slot_node[s]);
+                }
+            }
+        }
+    }
     // P3: exact boxes of the leaves with n >= 2
     {
         std::vector<int32_t> st{wt.root_ref};

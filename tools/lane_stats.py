@@ -16,12 +16,23 @@ g = pbrt_hip.Scene(ctx, sc)
 g.render(cam, W, H, spp, max_depth=depth, seed=0)
 L = pbrt_hip.lib()
 out = (ctypes.c_uint64 * 8)()
+wout = (ctypes.c_uint64 * 16)()
 L.pbrt_hip_debug_lane_stats(out, 1)
+L.pbrt_hip_debug_wide_stats(wout, 1)
 film, st = g.render(cam, W, H, spp, max_depth=depth, seed=0)
 L.pbrt_hip_debug_lane_stats(out, 1)
+L.pbrt_hip_debug_wide_stats(wout, 1)
 s = [int(v) for v in out]
+w = [int(v) for v in wout]
 rays = st["rays_closest"] + st["rays_shadow"]
-print(f"rays {rays/1e6:.1f} M, trace {st['trace_ms']:.1f} ms")
+print(f"rays {rays/1e6:.1f} M, trace {st['trace_ms']:.1f} ms, wide records {g.wide_records()}")
+if w[0]:
+    print(f"wide records: {w[0]/1e6:.1f} M wave iterations, {w[1]/w[0]:.1f} lanes active of 64 ({w[11]/rays:.1f} record steps per ray), "
+          f"{w[8]/max(w[11],1):.2f} children pass the filter per step")
+    print(f"wide leaves:  {w[2]/1e6:.1f} M wave sections, {w[3]/max(w[2],1):.1f} lanes with a candidate leaf ({w[12]/rays:.2f} candidates per ray), "
+          f"{w[4]/max(w[12],1):.2f} of them pass the exact box, {w[5]/rays:.2f} triangle tests per ray")
+    print(f"wide outer:   {w[6]/1e6:.1f} M iterations, {w[7]/max(w[6],1):.1f} lanes with work")
+    sys.exit(0)
 print(f"interior: {s[0]/1e6:.1f} M wave iterations, {s[1]/max(s[0],1):.1f} lanes active of 64 ({s[1]/rays:.1f} node steps per ray)")
 print(f"leaves:   {s[2]/1e6:.1f} M wave sections, {s[3]/max(s[2],1):.1f} lanes with a leaf, {s[4]/max(s[2],1):.2f} loop trips per section, "
       f"{s[5]/max(s[3],1):.2f} triangles per lane-leaf, {s[5]/rays:.2f} tri tests per ray; lane-trip utilisation {s[5]/max(s[4]*64,1):.2f}")
