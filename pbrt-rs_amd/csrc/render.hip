@@ -412,6 +412,8 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     // only the path integrator's later bounces are incoherent; the stage machine of the other integrators keeps
     // shooting from the camera rays' hit points, which are already in pixel order (AO: -6 % with the sort)
     const bool sort_rays = !(sort_env && sort_env[0] == '0') && rp.integrator == PBRT_INTEGRATOR_PATH;
+    const char* seg_env = std::getenv("PBRT_HIP_SEGMENTS_ALL");  // development knob: one queue segment per XCD for every wavefront
+    const bool seg_all = seg_env && seg_env[0] == '1';
     const char* sort_from_env = std::getenv("PBRT_HIP_SORT_FROM");  // first sorted wavefront (development knob)
     const int sort_from = sort_from_env ? std::atoi(sort_from_env) : 2;
     // the keys are written by k_shade together with the queue entries; PBRT_HIP_SORT_FUSED=0 (and the builds with
@@ -671,7 +673,8 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                 {
                     dim3 grid(persistent_grid(s)), block(kTraceBlock);
                     const bool inst = s->d.bvh.instanced != 0;
-                    const int segments = (wavefront == 0 && !inst) ? kQueueSegments : 1;  // see trace.h
+                    int segments = (wavefront == 0 && !inst) ? kQueueSegments : 1;  // see trace.h
+                    if (seg_all && !inst) segments = kQueueSegments;
                     if (use_wide) {
                         WideTrees wt = s->wide;
                         wt.special_list = special_list;
