@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py — Mrays/s of the MI355X path-tracing hot path on BASELINE.json's config 3/4:
-1 000 000 random triangles + constant env light, PathIntegrator max_depth 5, 1920x1080x64 spp.
+"""bench.py — Mrays/s of the MI355X path-tracing hot path on BASELINE.json's configs 3 and 4:
+1 000 000 random triangles + constant env light, PathIntegrator max_depth 5, 1920x1080.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus 1 --steps K --warmup W          config 3: 64 spp on one GPU
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+                                                          config 4: 256 spp in total, the 16x16 tiles of the ONE
+                                                          frame dealt round-robin to the N ranks (total work fixed:
+                                                          "scaling": "strong"), one RCCL reduce of the W*H*4 film to
+                                                          rank 0 inside the timed step. --scaling weak renders
+                                                          spp x N instead (per-GPU work fixed).
 
-A step = one frame through Integrator::render (scene + BVH resident in HBM, film left on the
-device). At N GPUs the frame is 1920x1080 x (64*N) spp with the 16x16 tiles dealt round-robin to
-the ranks (per-GPU work fixed -> weak scaling; config 4 is the N=4 point, 256 spp), followed by
-one RCCL reduce of the W*H*4 film to rank 0. One ray = one Scene::intersect / intersect_p call.
-Prints ONE JSON line on rank 0.
+A step = one frame through Integrator::render (scene + BVH resident in HBM, film left on the device).
+One ray = one Scene::intersect / intersect_p call. Prints ONE JSON line on rank 0. A rank that fails or hangs ends
+the job with a non-zero exit code (the line, when there is one, is printed first).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -23,6 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pbrt-rs_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+DEFAULTS = dict(width=1920, height=1080, tris=1_000_000, max_depth=5)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
 def parse():
@@ -30,20 +37,22 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per GPU")
-    ap.add_argument("--tris", type=int, default=1_000_000)
-    ap.add_argument("--max-depth", type=int, default=5)
+    ap.add_argument("--width", type=int, default=DEFAULTS["width"])
+    ap.add_argument("--height", type=int, default=DEFAULTS["height"])
+    ap.add_argument("--spp", type=int, default=0,
+                    help="samples per pixel of the frame (strong) or per GPU (weak); default 64 at one GPU, 256 in total at N > 1")
+    ap.add_argument("--tris", type=int, default=DEFAULTS["tris"])
+    ap.add_argument("--max-depth", type=int, default=DEFAULTS["max_depth"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-crop", type=int, nargs=2, default=[320, 180], help="crop rendered by the CPU oracle")
-    ap.add_argument("--cpu-spp", type=int, default=16)
+    ap.add_argument("--cpu-crop", type=int, nargs=2, default=[640, 360], help="crop rendered by the CPU oracle")
+    ap.add_argument("--cpu-spp", type=int, default=48)
     ap.add_argument("--spp-per-pass", type=int, default=0)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: the frame has spp x N samples per pixel (per-GPU work fixed); strong: spp in total, "
-                         "the tiles of the one frame are split over the GPUs (BASELINE config 4 style)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="strong (default): the tiles of ONE frame are split over the GPUs (BASELINE config 4); "
+                         "weak: the frame has spp x N samples per pixel (per-GPU work fixed)")
     ap.add_argument("--abi-reduce-check", action="store_true",
                     help="run the C-ABI film-reduce check even with one rank (needs torch.distributed.run)")
+    ap.add_argument("--watchdog-s", type=float, default=600.0, help="a rank stuck longer than this ends the job with exit code 3")
     return ap.parse_args()
 
 
@@ -71,35 +80,123 @@ def algorithmic_bytes(rays_closest, rays_shadow, node_tests, prim_tests):
     return 32 * (rays_closest + rays_shadow) + 32 * node_tests + 48 * prim_tests + 16 * rays_closest + 4 * rays_shadow
 
 
-def abi_film_reduce_check(pbrt_hip, dist, torch, ctx, scene, cam, W, H, spp_total, args, rank, world, local_rank):
-    """This rank's film, summed onto rank 0 twice: by torch.distributed (reference) and by pbrt_hip_film_reduce."""
+def git_commit():
     try:
-        f = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
-        scene.render(cam, W, H, spp_total, max_depth=args.max_depth, rr_threshold=1.0, light_strategy=1, seed=0,
-                     tile_rank=rank, tile_world=world, spp_per_pass=args.spp_per_pass, d_film_ptr=f.data_ptr())
-        ref = f.clone()
-        dist.reduce(ref, dst=0, op=dist.ReduceOp.SUM)
-        ids = [pbrt_hip.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0, device=torch.device("cuda", local_rank))
-        torch.cuda.synchronize()
-        comm = pbrt_hip.Comm(ctx, world, rank, ids[0])
-        comm.film_reduce(f.data_ptr(), W * H, root=0)
-        comm.close()
-        ok = torch.ones(1, device=f"cuda:{local_rank}")
-        msg = "ok"
-        if rank == 0:
-            diff = float((f - ref).abs().max())
-            scale = float(ref.abs().max())
-            msg = f"max |abi - torch| = {diff:.3g} of {scale:.3g}"
-            if not diff <= 1e-5 * scale:
-                ok.zero_()
-                msg = "MISMATCH: " + msg
-            else:
-                msg = "ok: " + msg
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        return msg
-    except Exception as e:  # reported, never fatal for the measurement
-        return f"error: {type(e).__name__}: {e}"
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
+def measured_traffic(args, world, spp_total, kernel):
+    """FETCH_SIZE + WRITE_SIZE bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes over
+    this very command (profiles/r02_traffic.json). It was measured for ONE configuration: returned only when this run is
+    that configuration, otherwise None (with the reason)."""
+    try:
+        rec = json.load(open(TRAFFIC_FILE))
+    except Exception:
+        return None, "profiles/r02_traffic.json missing"
+    mine = dict(n_gpus=world, tris=args.tris, width=args.width, height=args.height, spp=spp_total, max_depth=args.max_depth, kernel=kernel)
+    diff = {k: (v, rec["config"].get(k)) for k, v in mine.items() if rec["config"].get(k) != v}
+    if diff:
+        return None, f"measured for another configuration: {diff}"
+    return rec, None
+
+
+class Stage:
+    """Collective-safe error handling: every rank reports after each stage whether it got through; if any rank did
+    not, all of them leave together (non-zero) instead of some waiting in the next collective for a rank that is gone."""
+
+    def __init__(self, dist, torch, device, use_dist, rank):
+        self.dist, self.torch, self.device, self.use_dist, self.rank = dist, torch, device, use_dist, rank
+
+    def run(self, name, fn):
+        """fn must not contain a collective another rank could miss (a rank failing before it would leave the others
+        waiting inside): collectives go into stages of their own, or, in the measured loop, behind agree()."""
+        err, out = None, None
+        try:
+            self.inject(name)
+            out = fn()
+        except StageFailed:
+            raise
+        except BaseException as e:  # noqa: BLE001 - reported and turned into an exit code
+            err = f"{type(e).__name__}: {e}"
+        self.agree(name, err)
+        return out
+
+    def collective(self, name, fn):
+        """fn IS a collective (reduce, broadcast, communicator creation ...). A rank that fails in it cannot tell the
+        others through another collective: it leaves at once, non-zero; the peers see the broken connection (or the
+        launcher ends them, or their watchdog does)."""
+        try:
+            self.inject(name)
+            return fn()
+        except BaseException as e:  # noqa: BLE001
+            print(f"[bench rank {self.rank}] collective '{name}' failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            raise StageFailed(name, f"{type(e).__name__}: {e}")
+
+    def inject(self, name):
+        if os.environ.get("PBRT_BENCH_FAIL") == f"{name}@{self.rank}":  # test hook: this rank fails at this point
+            raise RuntimeError("injected failure (PBRT_BENCH_FAIL)")
+
+    def agree(self, name, err):
+        """Collective: every rank says whether it got through `name`; if one did not, all raise StageFailed."""
+        ok = self.torch.tensor([0.0 if err else 1.0], device=self.device)
+        if self.use_dist:
+            self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
+        if float(ok[0]) < 1.0:
+            print(f"[bench rank {self.rank}] stage '{name}' failed on {'this rank: ' + err if err else 'another rank'}",
+                  file=sys.stderr, flush=True)
+            raise StageFailed(name, err)
+
+
+class StageFailed(RuntimeError):
+    pass
+
+
+def run_steps(render_into, films, steps, warmup, dist, use_dist, sync, make_event=None, stage=None):
+    """The measured loop, shared by the GPU job below and by the two-rank CPU test (tests/test_multi_gpu_gloo.py, gloo):
+    W untimed and K timed steps, a step = render this rank's tile share of the frame into a film, then (N > 1) reduce the
+    film to rank 0 — the only collective. Films alternate so that the reduce of frame k may overlap the render of frame
+    k + 1; a film is reused only after the reduce that read it has finished (make_event() returns an object with
+    synchronize(), recorded after the reduce; None where the reduce is synchronous). Bracketed by barrier + sync on both
+    sides. In the untimed warm-up steps (and in the first one at least) the ranks agree after rendering that all of them
+    got through before any enters the reduce: a rank whose render fails is then seen, not waited for. The timed steps
+    carry no such exchange; a rank that fails there exits non-zero and the launcher ends the others (a rank that hangs:
+    the watchdog). Returns (seconds, per-step stats list, the film of the last step)."""
+    reduced = [None] * len(films)
+    frame = [0]
+
+    def step(checked=False):
+        k = frame[0] % len(films)
+        frame[0] += 1
+        if reduced[k] is not None:
+            reduced[k].synchronize()
+        if checked and stage is not None:
+            err, st = None, None
+            try:
+                stage.inject("render")
+                st = render_into(films[k])
+            except BaseException as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+            stage.agree("render", err)
+        else:
+            st = render_into(films[k])
+        if use_dist:
+            dist.reduce(films[k], dst=0, op=dist.ReduceOp.SUM)
+            reduced[k] = make_event() if make_event else None
+        return st
+
+    for _ in range(warmup):
+        step(checked=True)
+    if use_dist:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(steps)]
+    sync()
+    if use_dist:
+        dist.barrier()
+    return time.perf_counter() - t0, stats, films[(frame[0] - 1) % len(films)]
 
 
 def main():
@@ -117,175 +214,255 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU is visible (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run the RCCL path runs even with one rank
+
+    out = {}
+    printed = [False]
+
+    def emit():
+        if rank == 0 and out and not printed[0]:
+            printed[0] = True
+            print(json.dumps(out), flush=True)
+
+    # A stuck communicator (or kernel) must not look like success: the watchdog prints what there is and ends this
+    # rank with exit code 3; torch.distributed.run then tears the other ranks down.
+    def give_up():
+        print(f"[bench rank {rank}] watchdog: no progress for {args.watchdog_s:.0f} s, giving up", file=sys.stderr, flush=True)
+        if out:
+            out.setdefault("error", "watchdog timeout")
+        emit()
+        os._exit(3)
+
+    dog = threading.Timer(args.watchdog_s, give_up)
+    dog.daemon = True
+    dog.start()
+
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    stage = Stage(dist, torch, device, use_dist, rank)
 
     def barrier():
         if use_dist:
             dist.barrier()
 
     W, H = args.width, args.height
+    if args.spp <= 0:
+        args.spp = 64 if (world == 1 or args.scaling == "weak") else 256
     spp_total = args.spp * world if args.scaling == "weak" else args.spp
-    sc = scenes.random_triangles(args.tris, seq=1)
-    cam = scenes.random_triangles_camera(W, H)
-    t0 = time.time()
-    bvh = pbrt_hip.bvh_build(sc["positions"], sc["indices"], 4, pbrt_hip.SPLIT_SAH)
-    t_bvh = time.time() - t0
-    ctx = pbrt_hip.Context(local_rank)
-    scene = pbrt_hip.Scene(ctx, sc, bvh=bvh)
-    # Two films: the reduce of frame k (torch's stream) may still be reading its film while frame k+1 is rendered
-    # (the library's stream); a film is reused only after the reduce that read it has finished.
-    films = [torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(2 if use_dist else 1)]
-    reduced = [None] * len(films)
-    frame = [0]
+    config_name = "config3" if (world == 1 and spp_total == 64) else ("config4" if spp_total == 256 and args.scaling == "strong" else "config3/4 variant")
+    rc = 0
+    try:
+        def setup():
+            sc = scenes.random_triangles(args.tris, seq=1)
+            cam = scenes.random_triangles_camera(W, H)
+            t0 = time.time()
+            bvh = pbrt_hip.bvh_build(sc["positions"], sc["indices"], 4, pbrt_hip.SPLIT_SAH)
+            t_bvh = time.time() - t0
+            ctx = pbrt_hip.Context(local_rank)
+            scene = pbrt_hip.Scene(ctx, sc, bvh=bvh)
+            return sc, cam, t_bvh, ctx, scene
 
-    def step():
-        k = frame[0] % len(films)
-        frame[0] += 1
-        film = films[k]
-        if reduced[k] is not None:
-            reduced[k].synchronize()
-        _, st = scene.render(cam, W, H, spp_total, max_depth=args.max_depth, rr_threshold=1.0, light_strategy=1,
-                             seed=0, tile_rank=rank, tile_world=world, spp_per_pass=args.spp_per_pass,
-                             d_film_ptr=film.data_ptr())
+        sc, cam, t_bvh, ctx, scene = stage.run("scene", setup)
+        n_wide, wide_reason = scene.wide_records()
+        kernel = "k_trace_wide" if n_wide >= 0 else "k_trace"
+        # Two films: the reduce of frame k (torch's stream) may still be reading its film while frame k+1 is rendered
+        # (the library's stream)
+        films = [torch.zeros((H, W, 4), dtype=torch.float32, device=device) for _ in range(2 if use_dist else 1)]
+
+        def render_into(film, **kw):
+            return scene.render(cam, W, H, spp_total, max_depth=args.max_depth, rr_threshold=1.0, light_strategy=1, seed=0,
+                                tile_rank=rank, tile_world=world, spp_per_pass=args.spp_per_pass, d_film_ptr=film.data_ptr(), **kw)[1]
+
+        def record_event():
+            e = torch.cuda.Event()
+            e.record()
+            return e
+
+        def timed():
+            seconds, stats, _ = run_steps(render_into, films, args.steps, args.warmup, dist, use_dist, torch.cuda.synchronize, record_event, stage)
+            return (seconds, sum(st["rays_closest"] + st["rays_shadow"] for st in stats), sum(st["trace_ms"] for st in stats),
+                    sum(st["trace_launches"] for st in stats))
+
+        elapsed, rays, trace_ms, trace_launches = timed()   # carries its own agreement points (run_steps)
+        my_rays, my_elapsed = rays, elapsed
         if use_dist:
-            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)  # the only collective: Film reduce over xGMI
-            reduced[k] = torch.cuda.Event()
-            reduced[k].record()
-        return st
+            def gather_times():
+                tt = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=device)
+                tmax = tt.clone()
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+                return float(tmax[0]), float(tt[1])
+            elapsed, rays = stage.collective("max over ranks", gather_times)
+        value = rays / elapsed / 1e6
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rays = 0
-    trace_ms = 0.0
-    trace_launches = 0
-    for _ in range(args.steps):
-        st = step()
-        rays += st["rays_closest"] + st["rays_shadow"]
-        trace_ms += st["trace_ms"]
-        trace_launches += st["trace_launches"]
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tt = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=f"cuda:{local_rank}")
-    if use_dist:
-        tmax = tt.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        elapsed, rays = float(tmax[0]), float(tt[1])
-    value = rays / elapsed / 1e6
-
-    roofline, cpu_baseline = None, None
-    if rank == 0:
-        # ---- roofline of the dominant kernel (k_trace): algorithmic bytes / measured launch time ----
-        # Box / triangle test counts of the reference's loops for exactly this frame's rays, from
-        # one instrumented (untimed) render of this rank's tile set.
-        ctx.set_counting(True)
-        ctx.counters(reset=True)
-        st_c = step() if world == 1 else scene.render(cam, W, H, spp_total, max_depth=args.max_depth, seed=0,
-                                                       tile_rank=rank, tile_world=world,
-                                                       spp_per_pass=args.spp_per_pass, d_film_ptr=films[0].data_ptr())[1]
-        c = ctx.counters(reset=True)
-        ctx.set_counting(False)
-        frame_bytes = algorithmic_bytes(st_c["rays_closest"], st_c["rays_shadow"], c["node_tests"], c["prim_tests"])
-        launches_per_frame = trace_launches / args.steps
-        trace_s_per_frame = trace_ms / args.steps * 1e-3
-        achieved = frame_bytes / trace_s_per_frame / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get("k_trace_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "k_trace",
-            "launches_per_step": launches_per_frame,
-            "avg_launch_ms": round(trace_ms / max(trace_launches, 1), 4),
-            "algorithmic_bytes_per_launch": round(frame_bytes / max(launches_per_frame, 1)),
-            "bytes_per_ray": round(frame_bytes / max(st_c["rays_closest"] + st_c["rays_shadow"], 1), 1),
-            "node_tests_per_ray": round(c["node_tests"] / max(c["rays"], 1), 2),
-            "tri_tests_per_ray": round(c["prim_tests"] / max(c["rays"], 1), 2),
-            "trace_fraction_of_step": round(trace_s_per_frame / (elapsed / args.steps), 3),
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            # ---- CPU baseline: the oracle (C++ restatement; the Rust reference cannot be built) on a
-            # bounded crop of the same frame, all host cores ----
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import oracle
-            cores = host_cores()
-            cw, ch = args.cpu_crop
-            x0, y0 = (W - cw) // 2, (H - ch) // 2
-            osc = oracle.OracleScene(sc)
-            _, st_o = osc.render(scenes.camera_dict_to_floats(cam), W, H, args.cpu_spp, max_depth=args.max_depth,
-                                 rr_threshold=1.0, light_strategy=1, seed=0, bounds=(x0, y0, x0 + cw, y0 + ch),
-                                 n_threads=cores)
-            cpu_baseline = {
-                "value": round(st_o["rays"] / st_o["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": cores,
-                "kind": "port",
-                "sample": f"{cw}x{ch} centre crop of the {W}x{H} frame at {args.cpu_spp} spp, same scene/seed "
-                          f"({st_o['rays']} rays in {st_o['seconds']:.1f} s)",
-            }
-            osc.close()
-        split = f"{args.spp} spp per GPU" if args.scaling == "weak" else "tiles of one frame split over the GPUs"
-        out = {
-            "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": f"config3: {args.tris} random triangles + constant env light, PathIntegrator "
-                            f"max_depth {args.max_depth}, {W}x{H}x{spp_total}spp ({split}), "
-                            f"SAH BVH <=4 prims/leaf, seed 0",
-                "parallelism": f"tiles16x16 round-robin over {world} GPU(s); RCCL film reduce" if world > 1
-                               else "1 GPU",
-                "sec_per_frame": round(elapsed / args.steps, 4),
-                "rays_per_frame": int(rays / args.steps),
-                "bvh_build_s_host": round(t_bvh, 2),
-            },
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
-        }
-    printed = [False]
-
-    def emit():
-        if rank == 0 and not printed[0]:
-            printed[0] = True
-            print(json.dumps(out), flush=True)
-
-    dog = None
-    if world > 1 or (args.abi_reduce_check and use_dist):
-        # Untimed: the same film merge through the C ABI's own RCCL communicator (pbrt_hip_comm_create /
-        # pbrt_hip_film_reduce), checked against torch.distributed's reduce. Should a rank fail to bring the second
-        # communicator up, the others would wait for it: a watchdog, armed until the process ends, prints the
-        # measured line and ends the rank.
-        import threading
-
-        def give_up():
-            if rank == 0:
-                out["config"].setdefault("abi_film_reduce", "timeout")
-            emit()
-            os._exit(0)
-
-        dog = threading.Timer(150.0, give_up)
-        dog.daemon = True
-        dog.start()
-        status = abi_film_reduce_check(pbrt_hip, dist, torch, ctx, scene, cam, W, H, spp_total, args, rank, world, local_rank)
         if rank == 0:
-            out["config"]["abi_film_reduce"] = status
-    emit()
-    barrier()
-    scene.close()
-    ctx.close()
-    if use_dist:
-        dist.destroy_process_group()
-    if dog is not None:
+            launches_per_frame = trace_launches / args.steps
+            trace_s_per_launch = trace_ms * 1e-3 / max(trace_launches, 1)
+            # ---- untimed, instrumented renders of this rank's tile set ----
+            # (1) the reference's loops: box / triangle tests of BVHAccel::intersect for exactly these rays -> SURVEY 8(d)
+            ctx.set_counting(1)
+            ctx.counters(reset=True)
+            st_c = render_into(films[0])
+            c = ctx.counters(reset=True)
+            frame_rays = st_c["rays_closest"] + st_c["rays_shadow"]
+            alg_bytes = algorithmic_bytes(st_c["rays_closest"], st_c["rays_shadow"], c["node_tests"], c["prim_tests"])
+            # (2) what the kernel itself fetches: 48-B records and 48-B triangles, three 16-B lane requests each
+            wc = None
+            if n_wide >= 0:
+                ctx.set_counting(2)
+                ctx.wide_counters(reset=True)
+                render_into(films[0])
+                wc = ctx.wide_counters(reset=True)
+            ctx.set_counting(0)
+            if wc is not None:
+                rec_per_launch = (wc["records"] + wc["triangles"]) / max(launches_per_frame, 1)
+                rec_bytes, table_bytes, waves = 48, max(n_wide, 1) * 48, 5
+            else:   # binary child-pair records: one 64-B record per two box tests
+                rec_per_launch = (c["node_tests"] / 2 + c["prim_tests"]) / max(launches_per_frame, 1)
+                rec_bytes, table_bytes, waves = 64, scene_interior_bytes(scene), 6
+            achieved_rec = rec_per_launch / trace_s_per_launch / 1e9
+            # ---- measured ceilings of the fetch pattern (dependent random record fetches, nothing else to do) ----
+            ceil = {
+                "same_footprint_kernel_occupancy": ctx.probe_gather(table_bytes, rec_bytes, waves) / 1e9,
+                "same_footprint_8_waves": ctx.probe_gather(table_bytes, rec_bytes, 8) / 1e9,
+                "l2_resident_8_waves": ctx.probe_gather(2 << 20, rec_bytes, 8) / 1e9,
+                "l1_resident_8_waves": ctx.probe_gather(16 << 10, rec_bytes, 8) / 1e9,
+            }
+            peak_rec = max(ceil["same_footprint_kernel_occupancy"], ceil["same_footprint_8_waves"])
+            # ---- HBM side: compulsory bytes, and the counter bytes of the committed profile of this command ----
+            tri_bytes = args.tris * 48
+            compulsory = 32 * frame_rays + 16 * st_c["rays_closest"] + 4 * st_c["rays_shadow"] + 4 * frame_rays   # rays in, hits out, queue
+            compulsory_per_launch = compulsory / max(launches_per_frame, 1) + (table_bytes + tri_bytes)          # + the tree, once
+            rec, why_not = measured_traffic(args, world, spp_total, kernel)
+            traffic = rec["bytes_per_launch"] if rec else None
+            hbm = {
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "compulsory_bytes_per_launch": round(compulsory_per_launch),
+                "compulsory_GBps": round(compulsory_per_launch / trace_s_per_launch / 1e9, 1),
+                "counter_bytes_per_launch": traffic,
+                "achieved": round(traffic / trace_s_per_launch / 1e9, 1) if traffic else None,
+                "frac": round(traffic / trace_s_per_launch / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                "source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, commit {rec['commit']}, {rec['profile']}" if rec else why_not),
+            }
+            roofline = {
+                "kernel": kernel,
+                # the binding ceiling: how fast the chip can walk dependent 48-B record fetches from a table of this size.
+                # (The kernel is NOT HBM-bound: the tree lives in L2 / Infinity Cache, see "hbm" below.)
+                "bound": "gather", "achieved": round(achieved_rec, 2), "peak": round(peak_rec, 2), "unit": "G records/s",
+                "frac": round(achieved_rec / peak_rec, 4),
+                "traffic": traffic,
+                "record_bytes": rec_bytes, "records_per_launch": round(rec_per_launch), "table_bytes": table_bytes,
+                "ceilings_G_records_per_s": {k: round(v, 2) for k, v in ceil.items()},
+                "hbm": hbm,
+                # SURVEY 8(d)'s figure, kept as a reported quantity: the bytes the REFERENCE's loop touches for these rays
+                "algorithmic": {
+                    "bytes_per_launch": round(alg_bytes / max(launches_per_frame, 1)),
+                    "GBps": round(alg_bytes / max(launches_per_frame, 1) / trace_s_per_launch / 1e9, 1),
+                    "bytes_per_ray": round(alg_bytes / max(frame_rays, 1), 1),
+                    "node_tests_per_ray": round(c["node_tests"] / max(c["rays"], 1), 2),
+                    "tri_tests_per_ray": round(c["prim_tests"] / max(c["rays"], 1), 2),
+                    "note": "served mostly from L2 / Infinity Cache: not a fraction of HBM peak",
+                },
+                "launches_per_step": launches_per_frame, "avg_launch_ms": round(trace_s_per_launch * 1e3, 4),
+                "trace_fraction_of_step": round(trace_ms * 1e-3 / args.steps / (my_elapsed / args.steps), 3),
+            }
+            if wc is not None:
+                roofline["wide"] = {"records_per_ray": round(wc["records"] / max(frame_rays, 1), 2),
+                                    "leaf_candidates_per_ray": round(wc["leaf_candidates"] / max(frame_rays, 1), 2),
+                                    "triangles_per_ray": round(wc["triangles"] / max(frame_rays, 1), 2),
+                                    "rays_left_to_binary_kernel": wc["special_rays"], "n_records": n_wide}
+            cpu_baseline = None
+            if world == 1 and not args.no_cpu_baseline:
+                # ---- CPU baseline: the oracle (C++ restatement; the Rust reference cannot be built) on a
+                # bounded crop of the same frame, all host cores this process may use ----
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle
+                cores = host_cores()
+                cw, ch = args.cpu_crop
+                x0, y0 = (W - cw) // 2, (H - ch) // 2
+                osc = oracle.OracleScene(sc)
+                _, st_o = osc.render(scenes.camera_dict_to_floats(cam), W, H, args.cpu_spp, max_depth=args.max_depth,
+                                     rr_threshold=1.0, light_strategy=1, seed=0, bounds=(x0, y0, x0 + cw, y0 + ch),
+                                     n_threads=cores)
+                cpu_baseline = {
+                    "value": round(st_o["rays"] / st_o["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": cores,
+                    "kind": "port",
+                    "sample": f"{cw}x{ch} centre crop of the {W}x{H} frame at {args.cpu_spp} spp, same scene/seed, "
+                              f"{cores} oracle threads ({st_o['rays']} rays in {st_o['seconds']:.1f} s)",
+                }
+                osc.close()
+            split = f"{args.spp} spp per GPU" if args.scaling == "weak" else "tiles of the one frame split over the GPUs"
+            out.update({
+                "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+                "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {
+                    "workload": f"{config_name}: {args.tris} random triangles + constant env light, PathIntegrator "
+                                f"max_depth {args.max_depth}, {W}x{H}x{spp_total}spp ({split}), "
+                                f"SAH BVH <=4 prims/leaf, seed 0",
+                    "parallelism": f"tiles16x16 round-robin over {world} GPU(s); RCCL film reduce inside the step" if world > 1
+                                   else "1 GPU",
+                    "sec_per_frame": round(elapsed / args.steps, 4),
+                    "rays_per_frame": int(rays / args.steps),
+                    "bvh_build_s_host": round(t_bvh, 2),
+                    "traversal": f"{kernel}" + (f" ({n_wide} 4-wide records)" if n_wide >= 0 else f" (binary records: {wide_reason})"),
+                },
+                "roofline": roofline, "cpu_baseline": cpu_baseline,
+            })
+
+        if world > 1 or (args.abi_reduce_check and use_dist):
+            # Untimed: the same film merge through the C ABI's own RCCL communicator (pbrt_hip_comm_create /
+            # pbrt_hip_film_reduce), checked against torch.distributed's reduce. Every rank reports after each stage.
+            f = torch.zeros((H, W, 4), dtype=torch.float32, device=device)
+            stage.run("abi: render", lambda: render_into(f))
+            ref = f.clone()
+            stage.collective("abi: torch reduce", lambda: dist.reduce(ref, dst=0, op=dist.ReduceOp.SUM))
+
+            def share_id():
+                ids = [pbrt_hip.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0, device=device)
+                torch.cuda.synchronize()
+                return ids[0]
+            uid = stage.collective("abi: id broadcast", share_id)
+            comm = stage.collective("abi: comm_create", lambda: pbrt_hip.Comm(ctx, world, rank, uid))
+            stage.collective("abi: film_reduce", lambda: comm.film_reduce(f.data_ptr(), W * H, root=0))
+            stage.run("abi: comm_destroy", comm.close)
+
+            def compare():
+                if rank != 0:
+                    return "ok"
+                diff, scale = float((f - ref).abs().max()), float(ref.abs().max())
+                msg = f"max |abi - torch| = {diff:.3g} of {scale:.3g}"
+                if not diff <= 1e-5 * scale:
+                    raise RuntimeError("MISMATCH: " + msg)
+                return "ok: " + msg
+            status = stage.run("abi: compare", compare)
+            if rank == 0:
+                out["config"]["abi_film_reduce"] = status
+        emit()
+        barrier()
+        scene.close()
+        ctx.close()
+    except StageFailed as e:
+        if rank == 0 and out:
+            out["error"] = f"stage '{e.args[0]}' failed" + (f": {e.args[1]}" if e.args[1] else " on another rank")
+        emit()
+        rc = 4
+    finally:
         dog.cancel()
+    if use_dist and rc == 0:
+        dist.destroy_process_group()
+    if rc:
+        sys.stdout.flush()
+        os._exit(rc)  # a failed job must not wait in destroy_process_group for ranks that are gone
+
+
+def scene_interior_bytes(scene):
+    n = len(scene.nodes) if getattr(scene, "nodes", None) is not None else 0
+    return max(1, (n - 1) // 2) * 64
 
 
 if __name__ == "__main__":

@@ -294,6 +294,16 @@ int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* total_ms, uint
  * Slower; never enabled in a timed region. */
 int pbrt_hip_set_counting(PbrtHipContext* ctx, int enable);
 int pbrt_hip_get_counters(PbrtHipContext* ctx, int reset, uint64_t counters[4]);
+/* enable = 2: the kernels over the 4-wide records (pbrt_hip_scene_wide_records) count what THEY fetch instead:
+ * counters = {records stepped (48 B each), candidate leaves, triangles loaded (48 B each), rays left to the binary
+ * kernel}. These are the product path's own figures (bench.py's gather-rate roofline), not the reference's. */
+int pbrt_hip_get_wide_counters(PbrtHipContext* ctx, int reset, uint64_t counters[4]);
+/* Measured ceiling for that roofline: every lane of a fully resident grid (waves_per_simd = 4, 5, 6 or 8 waves per
+ * SIMD) walks `iters` dependent fetches of record_bytes-sized records (48: three 16-B loads, 64: four) from a table of
+ * table_bytes of pseudo-random data, the next index computed from the bytes just loaded, and does nothing else.
+ * Returns records per second. Measurement only. */
+int pbrt_hip_probe_gather(PbrtHipContext* ctx, int64_t table_bytes, int32_t record_bytes, int32_t waves_per_simd, int32_t iters,
+                          double* records_per_second);
 
 /* ---- Integrator::render (src/core/integrator.rs:29-42, 399-480) for this GPU's tile set ----
  * film_xyzw: width*height*4 floats {xyz[3], filter_weight_sum} = the first 16 bytes of the

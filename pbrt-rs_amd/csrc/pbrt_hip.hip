@@ -56,11 +56,11 @@ extern "C" int pbrt_hip_context_create(int device_id, PbrtHipContext** out) {
     ctx->n_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_work_counter, kWorkCounters * sizeof(unsigned int)) != hipSuccess ||
         hipHostMalloc((void**)&ctx->h_counts, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_sync, hipEventDisableTiming) != hipSuccess ||
-        hipMemset(ctx->d_counters, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMemset(ctx->d_counters, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
         g_create_error = "stream / event creation failed";
         delete ctx;
         return PBRT_HIP_ERR_DEVICE;
@@ -117,7 +117,7 @@ extern "C" int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* tot
 extern "C" int pbrt_hip_set_counting(PbrtHipContext* ctx, int enable) {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
     PB_LOCK(ctx);
-    ctx->count_traversal = enable != 0;
+    ctx->count_traversal = (enable == 1 || enable == 2) ? enable : 0;
     return PBRT_HIP_OK;
 }
 
@@ -134,6 +134,20 @@ extern "C" int pbrt_hip_get_counters(PbrtHipContext* ctx, int reset, uint64_t co
     counters[3] = h[3];
     if (reset) {
         HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, sizeof(h)));
+    }
+    return PBRT_HIP_OK;
+}
+
+extern "C" int pbrt_hip_get_wide_counters(PbrtHipContext* ctx, int reset, uint64_t counters[4]) {
+    if (!ctx || !counters) return PBRT_HIP_ERR_INVALID;
+    PB_LOCK(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpy(h, ctx->d_counters + 4, sizeof(h), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) counters[k] = h[k];
+    if (reset) {
+        HIP_TRY(ctx, hipMemset(ctx->d_counters + 4, 0, sizeof(h)));
     }
     return PBRT_HIP_OK;
 }
@@ -770,11 +784,11 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_I
 }
 
 // the same batch over the 4-wide records (trace_wide.h), and the follow-up over the rays that kernel left out
-template <bool ANY>
-__global__ void __launch_bounds__(kTraceBlock, PB_WIDE_WAVES)
-    k_intersect_batch_wide(WideTrees wt, BatchRayIO<ANY> io, unsigned int* work_counter) {
+template <bool ANY, bool COUNT>
+__global__ void __launch_bounds__(kTraceBlock, COUNT ? 4 : PB_WIDE_WAVES)
+    k_intersect_batch_wide(WideTrees wt, BatchRayIO<ANY> io, unsigned int* work_counter, unsigned long long* counters) {
     __shared__ uint2 lds_stack[kWideStackLds * kTraceBlock];
-    trace_wide<BatchRayIO<ANY>>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x);
+    trace_wide<BatchRayIO<ANY>, COUNT>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x, counters);
 }
 template <bool ANY>
 __global__ void __launch_bounds__(kTraceBlock, PB_TRACE_WAVES)
@@ -792,7 +806,7 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
         ctx->last_error = "batch too large for one launch (split it below 2^32 rays)";
         return PBRT_HIP_ERR_INVALID;
     }
-    const bool wide = s->has_wide && !ctx->count_traversal;
+    const bool wide = s->has_wide && ctx->count_traversal != 1;
     if (wide && ctx->special_capacity < (size_t)n) {  // room for the queue positions of the rays the wide kernel leaves out
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_special_list) (void)hipFree(ctx->d_special_list);
@@ -811,19 +825,23 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
             WideTrees wt = s->wide;
             wt.special_list = ctx->d_special_list;
             wt.special_count = ctx->d_work_counter + kSpecialCount;
-            hipLaunchKernelGGL((k_intersect_batch_wide<ANY>), dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0, ctx->stream, wt,
-                               io, ctx->d_work_counter);
+            if (ctx->count_traversal == 2)
+                hipLaunchKernelGGL((k_intersect_batch_wide<ANY, true>), dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0,
+                                   ctx->stream, wt, io, ctx->d_work_counter, ctx->d_counters);
+            else
+                hipLaunchKernelGGL((k_intersect_batch_wide<ANY, false>), dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0,
+                                   ctx->stream, wt, io, ctx->d_work_counter, ctx->d_counters);
             SpecialListIO<BatchRayIO<ANY>> sio{io, ctx->d_special_list, ctx->d_work_counter + kSpecialCount};
             hipLaunchKernelGGL((k_intersect_batch_special<ANY>), grid, block, 0, ctx->stream, s->d.bvh, sio,
                                ctx->d_work_counter + kFollowUpCounter);
         } else if (s->d.bvh.has_spheres) {  // single-level scenes only (checked at creation)
-            if (ctx->count_traversal)
+            if (ctx->count_traversal == 1)
                 hipLaunchKernelGGL((k_intersect_batch<ANY, true, false, true>), grid, block, 0, ctx->stream, s->d.bvh, io,
                                    ctx->d_work_counter, ctx->d_counters);
             else
                 hipLaunchKernelGGL((k_intersect_batch<ANY, false, false, true>), grid, block, 0, ctx->stream, s->d.bvh, io,
                                    ctx->d_work_counter, ctx->d_counters);
-        } else if (ctx->count_traversal) {
+        } else if (ctx->count_traversal == 1) {
             if (inst)
                 hipLaunchKernelGGL((k_intersect_batch<ANY, true, true>), grid, block, 0, ctx->stream, s->d.bvh, io,
                                    ctx->d_work_counter, ctx->d_counters);

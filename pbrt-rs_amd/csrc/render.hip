@@ -432,7 +432,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         sort_tmp = buf.alloc<char>(sort_tmp_bytes, &ok);
     }
     // rays the wide kernel leaves to the binary one (wide_bvh.h): room for every entry of a trace queue
-    const bool use_wide = s->has_wide && !ctx->count_traversal;
+    const bool use_wide = s->has_wide && ctx->count_traversal != 1;
     uint32_t* special_list = use_wide ? buf.alloc<uint32_t>(N * 3, &ok) : nullptr;
     DirectState ds{};
     std::vector<int> prefix(s->d.n_lights + 1, 0);
@@ -679,18 +679,22 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                         WideTrees wt = s->wide;
                         wt.special_list = special_list;
                         wt.special_count = ctx->d_work_counter + kSpecialCount;
-                        hipLaunchKernelGGL(k_trace_wide, dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0, st, wt, ps,
-                                           trace_queue, n_trace, ctx->d_work_counter, segments);
+                        if (ctx->count_traversal == 2)
+                            hipLaunchKernelGGL(k_trace_wide<true>, dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0, st, wt, ps,
+                                               trace_queue, n_trace, ctx->d_work_counter, segments, ctx->d_counters);
+                        else
+                            hipLaunchKernelGGL(k_trace_wide<false>, dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0, st, wt, ps,
+                                               trace_queue, n_trace, ctx->d_work_counter, segments, ctx->d_counters);
                         hipLaunchKernelGGL(k_trace_special, grid, block, 0, st, s->d.bvh, ps, trace_queue, n_trace, special_list,
                                            ctx->d_work_counter + kSpecialCount, ctx->d_work_counter + kFollowUpCounter);
                     } else if (s->d.bvh.has_spheres) {
-                        if (ctx->count_traversal)
+                        if (ctx->count_traversal == 1)
                             hipLaunchKernelGGL((k_trace<true, false, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
                                                n_trace, ctx->d_work_counter, ctx->d_counters, segments);
                         else
                             hipLaunchKernelGGL((k_trace<false, false, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
                                                n_trace, ctx->d_work_counter, ctx->d_counters, segments);
-                    } else if (ctx->count_traversal) {
+                    } else if (ctx->count_traversal == 1) {
                         if (inst)
                             hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
                                                n_trace, ctx->d_work_counter, ctx->d_counters, segments);

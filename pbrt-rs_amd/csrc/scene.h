@@ -33,8 +33,10 @@ struct PbrtHipContext {
     uint64_t trace_launches = 0;
     bool time_trace = true;
     // instrumented traversal (roofline accounting): device counters {node_tests, prim_tests}
-    bool count_traversal = false;
-    unsigned long long* d_counters = nullptr;
+    // 0 = off; 1 = the binary kernels count the reference's box / triangle tests; 2 = the wide kernels count their own
+    // record / leaf / triangle fetches (pbrt_hip_set_counting)
+    int count_traversal = 0;
+    unsigned long long* d_counters = nullptr;  // [0..3] mode 1: node, prim, rays, instance tests; [4..7] mode 2
     uint64_t counted_rays = 0;
     // ray-queue heads of the persistent traversal kernels: [0, kQueueSegments) the launch's segments,
     // [kFollowUpCounter] the follow-up launch over the rays the wide kernel left out, [kSpecialCount] their number

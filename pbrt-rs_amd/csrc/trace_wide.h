@@ -55,9 +55,11 @@ struct SpecialListIO {
 
 
 
-template <class IO>
+// COUNT: also counts what this kernel itself fetches (records stepped, candidate leaves, triangles loaded, rays left to
+// the binary kernel) into counters[4..7]: the inputs of bench.py's gather-rate roofline.
+template <class IO, bool COUNT = false>
 PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restrict__ work_counter, uint2* lds_stack,
-                       int spill_lane) {
+                       int spill_lane, unsigned long long* counters = nullptr) {
     const uint32_t n = io.n();
     const int lane = threadIdx.x & 63;
     TravRay r;
@@ -71,6 +73,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     bool exhausted = false;
     const int n_seg = io.segments();
     int seg = (int)(blockIdx.x % (unsigned)n_seg), seg_tries = 0;
+    uint32_t c_rec = 0, c_cand = 0, c_tri = 0, c_special = 0;
 #ifdef PB_LANE_STATS
     unsigned long long wstat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave-level events (lane 0's copy is kept)
     unsigned int wl_steps = 0, wl_children = 0, wl_cand = 0, wl_pass = 0, wl_tris = 0;  // this lane's own events
@@ -166,6 +169,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                     negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
                     bool covered = wide_ray_covered(r.ox, r.oy, r.oz, idx, idy, idz);
                     special = !covered;
+                    if (COUNT && special) c_special += 1;
                     cur = wt.root_ref;
                     if (special) has_work = false;  // traced by the binary kernel afterwards (results written there)
                 }
@@ -199,6 +203,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             if (interior) {
                 const uint4* nd = wt.nodes + 3 * (size_t)cur;
                 uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
+                if (COUNT) c_rec += 1;
                 const uint32_t dw3 = q0.w;
                 const WideSetup ws = wide_setup(q0.x, q0.y, q0.z, dw3, r.ox, r.oy, r.oz, idx, idy, idz);
                 // near / far plane bytes by the sign of the direction
@@ -268,9 +273,11 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             const int v = ~cur;
             const int cnt = (v & 3) + 1;
             const int first = v >> 2;
+            if (COUNT) c_cand += 1;
             float4 ta = make_float4(0.0f, 0.0f, 0.0f, 0.0f), tb = ta, tc = ta;
             float lox, loy, loz, hix, hiy, hiz;
             if (cnt == 1) {
+                if (COUNT) c_tri += 1;
                 const float4* tp = wt.tris + 3 * (size_t)first;
                 ta = tp[0];
                 tb = tp[1];
@@ -307,6 +314,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 const TriRayConst trc = tri_ray_setup(r);
                 for (int i = 0; i < cnt; ++i) {
                     if (cnt > 1) {
+                        if (COUNT) c_tri += 1;
                         const float4* tp = wt.tris + 3 * (size_t)(first + i);
                         ta = tp[0];
                         tb = tp[1];
@@ -337,6 +345,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 finish(hit_slot >= 0);
         }
     }
+    if (COUNT) count_flush(counters + 4, c_rec, c_cand, c_tri, c_special);
 #ifdef PB_LANE_STATS
     {
         unsigned long long v[5] = {wl_steps, wl_children, wl_cand, wl_pass, wl_tris};

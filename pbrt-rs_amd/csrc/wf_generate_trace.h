@@ -160,12 +160,13 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_I
 }
 
 // the same wavefront over the 4-wide records (trace_wide.h) ...
-__global__ void __launch_bounds__(kTraceBlock, PB_WIDE_WAVES)
+template <bool COUNT>
+__global__ void __launch_bounds__(kTraceBlock, COUNT ? 4 : PB_WIDE_WAVES)
     k_trace_wide(WideTrees wt, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
-                 int segments) {
+                 int segments, unsigned long long* counters) {
     __shared__ uint2 lds_stack[kWideStackLds * kTraceBlock];
     WavefrontRayIO io{ps, queue, n, segments};
-    trace_wide<WavefrontRayIO>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x);
+    trace_wide<WavefrontRayIO, COUNT>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x, counters);
 }
 // ... and the rays it left to the binary records (axis-parallel directions and the like; usually none)
 __global__ void __launch_bounds__(kTraceBlock, PB_TRACE_WAVES)

@@ -31,7 +31,7 @@ EXPORTS = [
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
     "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png", "pbrt_hip_write_exr",
     "pbrt_hip_comm_unique_id", "pbrt_hip_comm_create", "pbrt_hip_comm_destroy", "pbrt_hip_film_reduce",
-    "pbrt_hip_comm_last_error", "pbrt_hip_scene_wide_records",
+    "pbrt_hip_comm_last_error", "pbrt_hip_scene_wide_records", "pbrt_hip_get_wide_counters", "pbrt_hip_probe_gather",
 ]
 
 
@@ -109,6 +109,8 @@ def lib():
                                             ctypes.POINTER(ctypes.c_uint64)]
         L.pbrt_hip_set_counting.argtypes = [vp, ctypes.c_int]
         L.pbrt_hip_get_counters.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64 * 4)]
+        L.pbrt_hip_get_wide_counters.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64 * 4)]
+        L.pbrt_hip_probe_gather.argtypes = [vp, i64, i32, i32, i32, ctypes.POINTER(ctypes.c_double)]
         L.pbrt_hip_render.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
         L.pbrt_hip_render_device.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
         L.pbrt_hip_tile_partition.argtypes = [i32, i32, i32, i32, i32, i32, vp, i32, ctypes.POINTER(i32)]
@@ -152,8 +154,21 @@ class Context:
         return ms.value, n.value
 
     def set_counting(self, enable):
-        """Instrumented traversal (box / triangle test counts of the reference's loops). Slow."""
+        """Instrumented traversal. True / 1: box / triangle test counts of the reference's loops (binary kernels);
+        2: the wide kernels' own record / leaf / triangle fetch counts (wide_counters). Slow."""
         self.check(lib().pbrt_hip_set_counting(self.h, int(enable)), "set_counting")
+
+    def wide_counters(self, reset=False):
+        c = (ctypes.c_uint64 * 4)()
+        self.check(lib().pbrt_hip_get_wide_counters(self.h, int(reset), ctypes.byref(c)), "get_wide_counters")
+        return dict(records=int(c[0]), leaf_candidates=int(c[1]), triangles=int(c[2]), special_rays=int(c[3]))
+
+    def probe_gather(self, table_bytes, record_bytes=48, waves_per_simd=5, iters=256):
+        """Measured rate (records / s) of dependent random record fetches from a table of table_bytes."""
+        r = ctypes.c_double()
+        self.check(lib().pbrt_hip_probe_gather(self.h, int(table_bytes), int(record_bytes), int(waves_per_simd), int(iters),
+                                               ctypes.byref(r)), "probe_gather")
+        return r.value
 
     def counters(self, reset=False):
         c = (ctypes.c_uint64 * 4)()

@@ -41,6 +41,100 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
+def _bench_worker(rank, world, port, out_path, fail):
+    """bench.py's own measured loop (run_steps) and stage discipline (Stage) on two gloo ranks, the CPU oracle standing in
+    for pbrt_hip_render_device: each step renders this rank's tile share into a zeroed film and reduces it to rank 0."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "pbrt-rs_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    import bench
+    import oracle
+    import pbrt_hip
+    from pbrt_hip import scenes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if fail:
+        os.environ["PBRT_BENCH_FAIL"] = fail
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    osc = oracle.OracleScene(scenes.cornell_box())
+    cam = scenes.camera_dict_to_floats(scenes.cornell_camera(W, H))
+    tiles = pbrt_hip.tile_partition(BOUNDS, rank, world)
+
+    def render_into(film):
+        film.zero_()   # as pbrt_hip_render_device does
+        rays = 0
+        for x, y in tiles:
+            b = (int(x), int(y), min(int(x) + 16, BOUNDS[2]), min(int(y) + 16, BOUNDS[3]))
+            tile, st = osc.render(cam, W, H, SPP, max_depth=8, seed=4, bounds=b, n_threads=1)
+            film += torch.from_numpy(tile)
+            rays += st["rays"]
+        return {"rays": rays}
+
+    films = [torch.zeros((H, W, 4), dtype=torch.float32) for _ in range(2)]
+    stage = bench.Stage(dist, torch, torch.device("cpu"), True, rank)
+    try:
+        seconds, stats, last = bench.run_steps(render_into, films, 2, 1, dist, True, lambda: None, None, stage)
+        rays = stage.collective("sum over ranks", lambda: _sum(dist, torch, sum(st["rays"] for st in stats)))
+    except bench.StageFailed:
+        os._exit(4)   # what bench.py's main() does: leave, non-zero, without waiting for the others
+    if rank == 0:
+        np.save(out_path, np.concatenate([last.numpy().reshape(-1), [rays / 2, seconds]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _sum(dist, torch, v):
+    t = torch.tensor([float(v)], dtype=torch.float64)
+    dist.all_reduce(t)
+    return float(t[0])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.timeout(300)
+def test_bench_loop_on_two_ranks(tmp_path):
+    """bench.run_steps + bench.Stage with world 2: the reduced film of the last step is the one-process frame, byte for
+    byte, and the rays of the ranks add up to the frame's."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    from pbrt_hip import scenes
+    out = str(tmp_path / "bench_film.npy")
+    mp.spawn(_bench_worker, args=(2, _free_port(), out, ""), nprocs=2, join=True)
+    got = np.load(out)
+    film, rays = got[:-2].reshape(H, W, 4), got[-2]
+    osc = oracle.OracleScene(scenes.cornell_box())
+    ref, st = osc.render(scenes.camera_dict_to_floats(scenes.cornell_camera(W, H)), W, H, SPP, max_depth=8, seed=4, bounds=BOUNDS)
+    osc.close()
+    assert film.astype(np.float32).tobytes() == ref.tobytes()
+    assert rays == st["rays"]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("fail", ["render@1", "sum over ranks@0"])
+def test_bench_stage_failure_ends_every_rank_nonzero(tmp_path, fail):
+    """A rank that fails inside a stage is seen by the others at the end of that stage: nobody waits in the next
+    collective, every rank exits non-zero (a hang or mismatch must not end in rc 0)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, str(tmp_path / "x.npy"), fail)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(not p.is_alive() for p in procs), "a rank is still waiting for the one that failed"
+    assert [p.exitcode for p in procs] == [4, 4]
+
+
 @pytest.mark.timeout(300)
 def test_two_rank_tile_sharding_and_film_reduce(tmp_path):
     import torch.multiprocessing as mp

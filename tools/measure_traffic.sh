@@ -1,0 +1,56 @@
+#!/bin/bash
+# Writes profiles/r02_traffic.json (fabric-side bytes per launch of the dominant traversal kernel, for bench.py's
+# roofline.traffic) and profiles/r02_bench_kernel_stats.csv from rocprofv3 runs of the default bench.py command.
+# Three separate runs (--kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE), as gpurun requires.
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+OUT=gpurun_out/traffic
+rm -rf $OUT; mkdir -p $OUT profiles
+CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
+grep '^{' $OUT/stats.log | tail -1 > $OUT/bench_line_under_rocprof.json
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -o $C -- $CMD > $OUT/$C.log 2>&1 || { tail -5 $OUT/$C.log; exit 1; }
+done
+python3 - <<'PY'
+import csv, glob, json, os, re, subprocess
+out = "gpurun_out/traffic"
+def per_kernel(counter):
+    tot, n = {}, {}
+    for f in glob.glob(f"{out}/{counter}/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f, newline="")):
+            if row["Counter_Name"] != counter: continue
+            k = row["Kernel_Name"]
+            tot[k] = tot.get(k, 0.0) + float(row["Counter_Value"]); n[k] = n.get(k, 0) + 1
+    return tot, n
+fetch, nf = per_kernel("FETCH_SIZE"); write, nw = per_kernel("WRITE_SIZE")
+# the timed launches: k_trace_wide<false> (or k_trace<false,false,false> on a scene without wide records)
+def pick(d):
+    ks = [k for k in d if re.search(r"k_trace_wide<false>|k_trace_wide<\(bool\)0>", k)] or [k for k in d if re.search(r"k_trace<false, false, false>", k)]
+    return ks[0]
+kf, kw = pick(fetch), pick(write)
+fb, wb = fetch[kf] * 1024 / nf[kf], write[kw] * 1024 / nw[kw]
+stats = glob.glob(f"{out}/stats/**/*kernel_stats.csv", recursive=True)
+avg_ns = None
+if stats:
+    for row in csv.DictReader(open(stats[0], newline="")):
+        if row["Name"] == kf: avg_ns = float(row["AverageNs"]); calls = int(row["Calls"])
+    os.system(f"cp {stats[0]} profiles/r02_bench_kernel_stats.csv")
+commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("PB_COMMIT", "unknown")
+rec = {
+    "bytes_per_launch": round(fb + wb), "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
+    "kernel_name": kf, "launches_profiled": nf[kf], "avg_launch_ns_under_kernel_trace": avg_ns,
+    "config": {"n_gpus": 1, "tris": 1000000, "width": 1920, "height": 1080, "spp": 64, "max_depth": 5,
+               "kernel": "k_trace_wide" if "wide" in kf else "k_trace"},
+    "commit": os.environ.get("PB_COMMIT", commit),
+    "profile": "profiles/r02_bench_kernel_stats.csv + rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on "
+               "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`; FETCH_SIZE = TCC_EA0_RDREQ x 64 B (Infinity-Cache hits "
+               "included), used without the x2 of wide coalesced streams: calibrated on this gather pattern in "
+               "profiles/r01_fetch_size_calibration.txt (0.986)",
+}
+json.dump(rec, open("profiles/r02_traffic.json", "w"), indent=1)
+json.dump(rec, open(f"{out}/r02_traffic.json", "w"), indent=1)
+print(json.dumps(rec, indent=1))
+PY
+cp profiles/r02_bench_kernel_stats.csv $OUT/ 2>/dev/null
+find $OUT -name "*.csv" -size +2M -delete
