@@ -394,7 +394,7 @@ def main():
                               f"{cores} oracle threads ({st_o['rays']} rays in {st_o['seconds']:.1f} s)",
                 }
                 osc.close()
-            split = f"{args.spp} spp per GPU" if args.scaling == "weak" else "tiles of the one frame split over the GPUs"
+            split = "one GPU" if world == 1 else (f"{args.spp} spp per GPU" if args.scaling == "weak" else "tiles of the one frame split over the GPUs")
             out.update({
                 "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
