@@ -315,6 +315,37 @@ int pbrt_hip_render(PbrtHipScene* scene, const PbrtCamera* camera, const PbrtRen
 int pbrt_hip_render_device(PbrtHipScene* scene, const PbrtCamera* camera, const PbrtRenderParams* params,
                            float* d_film_xyzw, PbrtRenderStats* stats);
 
+/* ---- Integrator::li (src/core/integrator.rs:29-42) in batch form ----
+ * What SamplerIntegrator::render calls per camera sample (integrator.rs:452): `li(&mut ray, scene, sampler, 0) -> Spectrum`.
+ * The host keeps its own Camera, Sampler and Film (north_star) and hands over, per call: the camera ray and the random
+ * stream the integrator is to draw from. stream_keys[i] is the argument of RNG::set_sequence (src/core/rng.rs:21-35)
+ * of ray i's RandomSampler (the reference clones one sampler per tile, sampler.rs:452 / integrator.rs:414-415; here one
+ * stream per call keeps calls independent, as pbrt_hip_render's (pixel, sample) streams do); draws_before_li values
+ * have already been drawn from that stream by the caller when li starts (render draws the CameraSample's 5 first,
+ * integrator.rs:430: with 5 and pbrt_hip_camera_rays' rays and keys the results are pbrt_hip_render's samples bit for
+ * bit). rgb[3 i ..] = the returned Spectrum, unguarded (the NaN / negative test is render's, integrator.rs:455).
+ * Re-entrant like the reference's li: calls on one context are serialised inside. n = 0 is a no-op. */
+typedef struct PbrtLiParams {
+    int32_t integrator;     /* PbrtIntegratorKind */
+    int32_t max_depth;
+    float rr_threshold;     /* path */
+    int32_t light_strategy; /* as PbrtRenderParams.light_strategy */
+    int32_t ao_samples;     /* ao */
+    int32_t draws_before_li;
+} PbrtLiParams;
+int pbrt_hip_li(PbrtHipScene* scene, const PbrtLiParams* params, const PbrtRay* rays, const uint64_t* stream_keys, int64_t n,
+                float* rgb, PbrtRenderStats* stats);
+int pbrt_hip_li_device(PbrtHipScene* scene, const PbrtLiParams* params, const PbrtRay* d_rays, const uint64_t* d_stream_keys,
+                       int64_t n, float* d_rgb, PbrtRenderStats* stats);
+/* The camera-ray stage of pbrt_hip_render on its own: Sampler::get_camera_sample (src/core/sampler.rs:27-33) +
+ * Camera::generate_ray (src/cameras/perspective.rs:90-112 ...) for every sample of this GPU's tiles (params as for
+ * pbrt_hip_render; whole 16x16 tiles, all params->spp samples in one pass). Per path: the ray, its stream key, the
+ * film position p_film (x, y) and {pixel x, pixel y, sample index}; pixels of border tiles outside the pixel bounds
+ * carry pixel = (-1, -1) and a ray with t_max < 0. n_out = number of paths; PBRT_HIP_ERR_INVALID with n_out set if
+ * capacity is too small. A host without a Camera of its own (tests, the C example) feeds pbrt_hip_li from this. */
+int pbrt_hip_camera_rays(PbrtHipScene* scene, const PbrtCamera* camera, const PbrtRenderParams* params, int64_t capacity,
+                         PbrtRay* rays, uint64_t* stream_keys, float* p_film, int32_t* pixel_sample, int64_t* n_out);
+
 /* ---- multi-GPU film merge (replaces the cross-tile part of Film::merge_film_tile,
  * src/core/film.rs:93-123, and parallel_for_2d's join, src/core/parallel.rs:4-21) ----
  * One process per GPU. Rank 0 draws a communicator id and hands it to the other ranks out of band (the host

@@ -58,6 +58,7 @@ def lib():
                                  ctypes.c_uint64] + [ctypes.c_int] * 7 + [vp, vp]
         L.orc_render_filtered.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_uint64] + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
+        L.orc_li.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, vp, vp, ctypes.c_int64, ctypes.c_int, vp, vp]
         L.orc_filter_table.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]
         L.orc_sample_bounds.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp]
         L.orc_triangle_test.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, vp]
@@ -238,6 +239,24 @@ class OracleScene:
         if hasattr(self, "n_instances"):
             st["inst_tests"] = int(stats[5])
         return film, st
+
+
+def _li(self, rays, stream_keys, integrator=0, max_depth=5, rr_threshold=1.0, light_strategy=1, ao_samples=64, cos_sample=True,
+        draws_before_li=0):
+    """Integrator::li for caller-supplied rays (structured o, d, t_max, time records) and RandomSampler stream keys."""
+    rays = np.ascontiguousarray(rays)
+    assert rays.dtype.itemsize == 32
+    keys = np.ascontiguousarray(stream_keys, dtype=np.uint64)
+    rgb = np.zeros((len(rays), 3), dtype=np.float32)
+    stats = np.zeros(3, dtype=np.uint64)
+    if integrator == 3:
+        max_depth, light_strategy = ao_samples, int(bool(cos_sample))
+    lib().orc_li(self.h, integrator, max_depth, rr_threshold, light_strategy, _p(rays), _p(keys), len(rays),
+                 draws_before_li, _p(rgb), _p(stats))
+    return rgb, dict(rays=int(stats[0]), node_tests=int(stats[1]), prim_tests=int(stats[2]))
+
+
+OracleScene.li = _li
 
 
 def sampler_spec(sampler, max_sample_luminance=0.0):

@@ -352,6 +352,48 @@ void orc_render_filtered(void* h, const float* cam, int integrator, int max_dept
     }
 }
 
+// Integrator::li (integrator.rs:29-42) for n caller-supplied rays: rays = n x {o.xyz, d.xyz, t_max, time}, keys[i] =
+// RNG::set_sequence argument of ray i's RandomSampler (rng.rs:21-35), `skip` values already drawn from it before li
+// (render draws the CameraSample first, integrator.rs:430). rgb = n x 3, the returned Spectrum unguarded.
+// stats: {rays, node_tests, prim_tests}
+void orc_li(void* h, int integrator, int max_depth, float rr_threshold, int light_strategy, const float* rays,
+            const uint64_t* keys, int64_t n, int skip, float* rgb, uint64_t* stats) {
+    const Scene& sc = ((OracleScene*)h)->scene;
+    std::unique_ptr<Integrator> integ;
+    if (integrator == 0)
+        integ.reset(new PathIntegrator(max_depth, rr_threshold,
+                                       light_strategy == 0 ? "uniform" : (light_strategy == 1 ? "power" : "spatial")));
+    else if (integrator == 1)
+        integ.reset(new DirectLightingIntegrator((LightStrategy)light_strategy, max_depth));
+    else if (integrator == 2)
+        integ.reset(new WhittedIntegrator(max_depth));
+    else
+        integ.reset(new AOIntegrator(light_strategy != 0, max_depth));  // AO: max_depth carries n_samples
+    integ->pre_process(sc);
+    SamplerSpec spec;  // RandomSampler
+    integ->request_samples(sc, spec);
+    RenderCtx rc;
+    rc.sampler.spec = &spec;
+    for (int64_t i = 0; i < n; ++i) {
+        const float* r = rays + 8 * i;
+        Ray ray;
+        ray.o = Point3f(r[0], r[1], r[2]);
+        ray.d = Vector3f(r[3], r[4], r[5]);
+        ray.t_max = r[6];
+        ray.time = r[7];
+        // one stream per call: start_sample's set_sequence with the caller's key
+        rc.sampler.start_sample(keys[i], 0, 1, 0);
+        for (int k = 0; k < skip; ++k) (void)rc.sampler.get_1d();
+        Spectrum l = integ->li(ray, sc, rc, 0);
+        for (int k = 0; k < 3; ++k) rgb[3 * i + k] = l.c[k];
+    }
+    if (stats) {
+        stats[0] = rc.ctr.rays;
+        stats[1] = rc.ctr.node_tests;
+        stats[2] = rc.ctr.prim_tests;
+    }
+}
+
 // TriangleMesh.s (triangle.rs:21): per-vertex tangents, n_verts x 3; call before rendering
 void orc_scene_set_tangents(void* h, const float* tangents, int n_verts) {
     OracleScene* os = (OracleScene*)h;

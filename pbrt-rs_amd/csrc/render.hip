@@ -46,6 +46,110 @@ extern "C" int pbrt_hip_render(PbrtHipScene* s, const PbrtCamera* camera, const 
 }
 
 // ------------------------------------------------------------------------------------
+// Integrator::li in batch form (integrator.rs:29-42) and the camera-ray stage on its own
+// ------------------------------------------------------------------------------------
+static int li_params_to_render(const PbrtLiParams* lp, PbrtRenderParams* rp) {
+    std::memset(rp, 0, sizeof(*rp));
+    rp->integrator = lp->integrator;
+    rp->max_depth = lp->max_depth;
+    rp->rr_threshold = lp->rr_threshold;
+    rp->light_strategy = lp->light_strategy;
+    rp->ao_samples = lp->ao_samples;
+    rp->tile_world = 1;
+    return (lp->draws_before_li < 0 || lp->draws_before_li > 4096) ? PBRT_HIP_ERR_INVALID : PBRT_HIP_OK;
+}
+
+extern "C" int pbrt_hip_li_device(PbrtHipScene* s, const PbrtLiParams* lp, const PbrtRay* d_rays, const uint64_t* d_stream_keys,
+                                  int64_t n, float* d_rgb, PbrtRenderStats* stats) {
+    if (!s || !lp || n < 0 || (n > 0 && (!d_rays || !d_stream_keys || !d_rgb))) return PBRT_HIP_ERR_INVALID;
+    PbrtRenderStats zero{};
+    if (stats) *stats = zero;
+    if (n == 0) return PBRT_HIP_OK;
+    PB_LOCK(s->ctx);
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    PbrtRenderParams rp;
+    if (li_params_to_render(lp, &rp) != PBRT_HIP_OK) {
+        s->ctx->last_error = "li: draws_before_li must be in [0, 4096]";
+        return PBRT_HIP_ERR_INVALID;
+    }
+    LiBatch b;
+    b.d_rays = d_rays;
+    b.d_keys = d_stream_keys;
+    b.n = n;
+    b.skip = lp->draws_before_li;
+    b.d_rgb = d_rgb;
+    PbrtCamera cam{};
+    return wavefront_render(s, cam, rp, nullptr, stats, &b);
+}
+
+extern "C" int pbrt_hip_li(PbrtHipScene* s, const PbrtLiParams* lp, const PbrtRay* rays, const uint64_t* stream_keys, int64_t n,
+                           float* rgb, PbrtRenderStats* stats) {
+    if (!s || !lp || n < 0 || (n > 0 && (!rays || !stream_keys || !rgb))) return PBRT_HIP_ERR_INVALID;
+    PbrtRenderStats zero{};
+    if (stats) *stats = zero;
+    if (n == 0) return PBRT_HIP_OK;
+    PbrtHipContext* ctx = s->ctx;
+    PB_LOCK(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    PbrtRay* d_rays = nullptr;
+    uint64_t* d_keys = nullptr;
+    float* d_rgb = nullptr;
+    int rc = PBRT_HIP_OK;
+    if (!hip_ok(ctx, hipMalloc((void**)&d_rays, (size_t)n * sizeof(PbrtRay)), "hipMalloc") ||
+        !hip_ok(ctx, hipMalloc((void**)&d_keys, (size_t)n * sizeof(uint64_t)), "hipMalloc") ||
+        !hip_ok(ctx, hipMalloc((void**)&d_rgb, (size_t)n * 3 * sizeof(float)), "hipMalloc"))
+        rc = PBRT_HIP_ERR_OOM;
+    if (rc == PBRT_HIP_OK && (!hip_ok(ctx, hipMemcpy(d_rays, rays, (size_t)n * sizeof(PbrtRay), hipMemcpyHostToDevice), "H2D") ||
+                              !hip_ok(ctx, hipMemcpy(d_keys, stream_keys, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice), "H2D")))
+        rc = PBRT_HIP_ERR_DEVICE;
+    if (rc == PBRT_HIP_OK) rc = pbrt_hip_li_device(s, lp, d_rays, d_keys, n, d_rgb, stats);
+    if (rc == PBRT_HIP_OK && !hip_ok(ctx, hipMemcpy(rgb, d_rgb, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost), "D2H"))
+        rc = PBRT_HIP_ERR_DEVICE;
+    (void)hipFree(d_rays);
+    (void)hipFree(d_keys);
+    (void)hipFree(d_rgb);
+    return rc;
+}
+
+extern "C" int pbrt_hip_camera_rays(PbrtHipScene* s, const PbrtCamera* camera, const PbrtRenderParams* params, int64_t capacity,
+                                    PbrtRay* rays, uint64_t* stream_keys, float* p_film, int32_t* pixel_sample, int64_t* n_out) {
+    if (!s || !camera || !params || !n_out) return PBRT_HIP_ERR_INVALID;
+    PbrtHipContext* ctx = s->ctx;
+    PB_LOCK(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (params->width <= 0 || params->height <= 0 || params->spp <= 0 || params->x0 > params->x1 || params->y0 > params->y1)
+        return PBRT_HIP_ERR_INVALID;
+    int32_t n_tiles = 0;
+    const int world = params->tile_world <= 0 ? 1 : params->tile_world;
+    pbrt_hip_tile_partition(params->x0, params->y0, params->x1, params->y1, params->tile_rank, world, nullptr, 0, &n_tiles);
+    const int64_t n = (int64_t)n_tiles * kTile * kTile * params->spp;  // whole tiles: pixels outside the bounds carry pixel = (-1, -1)
+    *n_out = n;
+    if (n == 0) return PBRT_HIP_OK;
+    if (capacity < n || !rays || !stream_keys || !p_film || !pixel_sample) {
+        ctx->last_error = "camera rays: output capacity too small (n_out holds the need)";
+        return PBRT_HIP_ERR_INVALID;
+    }
+    LiBatch b;
+    int rc = PBRT_HIP_OK;
+    if (!hip_ok(ctx, hipMalloc((void**)&b.out_rays, (size_t)n * sizeof(PbrtRay)), "hipMalloc") ||
+        !hip_ok(ctx, hipMalloc((void**)&b.out_keys, (size_t)n * sizeof(uint64_t)), "hipMalloc") ||
+        !hip_ok(ctx, hipMalloc((void**)&b.out_pfilm, (size_t)n * 2 * sizeof(float)), "hipMalloc") ||
+        !hip_ok(ctx, hipMalloc((void**)&b.out_pixel_sample, (size_t)n * 3 * sizeof(int32_t)), "hipMalloc"))
+        rc = PBRT_HIP_ERR_OOM;
+    if (rc == PBRT_HIP_OK) rc = wavefront_render(s, *camera, *params, nullptr, nullptr, &b);
+    if (rc == PBRT_HIP_OK && (!hip_ok(ctx, hipMemcpy(rays, b.out_rays, (size_t)n * sizeof(PbrtRay), hipMemcpyDeviceToHost), "D2H") ||
+                              !hip_ok(ctx, hipMemcpy(stream_keys, b.out_keys, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost), "D2H") ||
+                              !hip_ok(ctx, hipMemcpy(p_film, b.out_pfilm, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost), "D2H") ||
+                              !hip_ok(ctx, hipMemcpy(pixel_sample, b.out_pixel_sample, (size_t)n * 3 * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H")))
+        rc = PBRT_HIP_ERR_DEVICE;
+    (void)hipFree(b.out_rays);
+    (void)hipFree(b.out_keys);
+    (void)hipFree(b.out_pfilm);
+    (void)hipFree(b.out_pixel_sample);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------
 // wavefront_render — host driver of the kernels in wavefront.h
 // ------------------------------------------------------------------------------------
 namespace {
@@ -289,13 +393,28 @@ static int round_up_pow2(int v) {  // pbrt.rs:174-182
 }
 
 int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRenderParams& rp_in, float* d_film,
-                     PbrtRenderStats* stats) {
+                     PbrtRenderStats* stats, const LiBatch* li) {
+    const bool li_mode = li && li->d_rays, export_mode = li && li->out_rays;
     PbrtHipContext* ctx = s->ctx;
     auto invalid = [&](const char* m) {
         ctx->last_error = m;
         return PBRT_HIP_ERR_INVALID;
     };
     PbrtRenderParams rp = rp_in;
+    if (li_mode) {  // the batch stands in for a 1-spp "frame" of n pixels in a row; nothing of the film plumbing is used
+        if (li->n <= 0 || li->n > (1ll << 28)) return invalid("li: batch size must be in [1, 2^28]");
+        rp.width = (int32_t)li->n;
+        rp.height = 1;
+        rp.spp = 1;
+        rp.x0 = rp.y0 = 0;
+        rp.x1 = rp.width;
+        rp.y1 = 1;
+        rp.tile_rank = 0;
+        rp.tile_world = 1;
+        rp.spp_per_pass = 1;
+        rp.sampler = PBRT_SAMPLER_RANDOM;  // the caller's Sampler is a RandomSampler stream per ray (sampler.rs:452, random.rs)
+        rp.filter_table = nullptr;
+    }
     if (rp.width <= 0 || rp.height <= 0 || rp.spp <= 0) return invalid("width, height and spp must be positive");
     // ---- sampler: samples per pixel and Sampler::round_count (stratified.rs:30-33, zerotwosequence.rs:20, 62-64) ----
     if (rp.sampler < PBRT_SAMPLER_RANDOM || rp.sampler > PBRT_SAMPLER_HALTON) return invalid("unknown sampler");
@@ -343,11 +462,13 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     hipStream_t st = ctx->stream;
 
     size_t film_bytes = (size_t)rp.width * rp.height * 4 * sizeof(float);
-    HIP_TRY(ctx, hipMemsetAsync(d_film, 0, film_bytes, st));
+    if (d_film) HIP_TRY(ctx, hipMemsetAsync(d_film, 0, film_bytes, st));
 
     // tiles of the sample bounds (integrator.rs:402-409), dealt round-robin to the GPUs
     std::vector<int2> origins;
-    {
+    if (li_mode) {
+        origins.assign((size_t)((li->n + kTile * kTile - 1) / (kTile * kTile)), make_int2(0, 0));  // 256 rays per "tile"
+    } else {
         int32_t n_mine = 0;
         pbrt_hip_tile_partition(rp.x0, rp.y0, rp.x1, rp.y1, rank, world, nullptr, 0, &n_mine);
         origins.resize(n_mine);
@@ -363,6 +484,8 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     int64_t valid_pixels = 0;
     for (const int2& o : origins)
         valid_pixels += (int64_t)(std::min(o.x + kTile, rp.x1) - o.x) * (std::min(o.y + kTile, rp.y1) - o.y);
+    if (li_mode) valid_pixels = li->n;
+    if (export_mode) rp.spp_per_pass = rp.spp;  // one pass: the export is indexed by the paths of that pass
     int spp_pass = rp.spp_per_pass > 0 ? rp.spp_per_pass : 0;
     if (spp_pass == 0) {
         // As many samples of a pixel in flight as half of the free HBM holds (about 400 B of path state, queue and
@@ -378,6 +501,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         spp_pass = (int)std::max<int64_t>(1, std::min<int64_t>(rp.spp, target_paths / n_pix));
     }
     spp_pass = std::min(spp_pass, rp.spp);
+    if (export_mode && spp_pass != rp.spp) return invalid("camera rays: too many samples for one pass");
     const size_t N = (size_t)n_pix * spp_pass;
     if (N * 4 >= (1ull << 32)) return invalid("too many concurrent paths for 32-bit queue entries; lower spp_per_pass");
 
@@ -628,6 +752,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         pp.filter_ry = fry;
         pp.filter_table = d_filter;
         pp.max_sample_luminance = rp.max_sample_luminance > 0.0f ? rp.max_sample_luminance : INFINITY;
+        pp.stream_keys = li_mode ? li->d_keys : nullptr;
         uint32_t n_paths = (uint32_t)n_pix * pp.n_samples;
         int cur = 0;
         if (!tables_ready) {  // Sampler::start_pixel for every pixel of this GPU, once per render
@@ -635,8 +760,18 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             RENDER_TRY(hipGetLastError());
             tables_ready = true;
         }
-        hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, st, ps, q[cur], pp, cam, tiles);
+        if (li_mode)
+            hipLaunchKernelGGL(k_li_generate, dim3((n_paths + 255) / 256), dim3(256), 0, st, ps, q[cur], li->d_rays, li->d_keys,
+                               (uint32_t)li->n, n_paths, li->skip);
+        else
+            hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, st, ps, q[cur], pp, cam, tiles);
         RENDER_TRY(hipGetLastError());
+        if (export_mode) {
+            hipLaunchKernelGGL(k_camera_rays_out, dim3((n_paths + 255) / 256), dim3(256), 0, st, ps, pp, tiles, li->out_rays, li->out_keys,
+                               li->out_pfilm, li->out_pixel_sample);
+            RENDER_TRY(hipGetLastError());
+            break;
+        }
         if (direct) {
             RENDER_TRY(hipMemsetAsync(ds.stage, 0, (size_t)n_paths * sizeof(int), st));
             RENDER_TRY(hipMemsetAsync(ds.ld_acc, 0, (size_t)n_paths * sizeof(float4), st));
@@ -761,6 +896,11 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             first = false;
             wavefront += 1;
             cur = nxt;
+        }
+        if (li_mode) {
+            hipLaunchKernelGGL(k_li_output, dim3((unsigned)((li->n + 255) / 256)), dim3(256), 0, st, ps, (uint32_t)li->n, li->d_rgb);
+            RENDER_TRY(hipGetLastError());
+            continue;
         }
         if (!box) {
             hipLaunchKernelGGL(k_film_splat, dim3((n_paths + 255) / 256), dim3(256), 0, st, ps, pp, tiles, d_film);

@@ -23,5 +23,19 @@
 #include "wf_direct.h"
 #include "wf_film.h"
 
+// The same loop driven from outside the render form:
+//   li:     a batch of Integrator::li calls on the caller's rays (pbrt_hip_li): rays / keys in, radiance out, no film;
+//   export: only the camera-ray stage of a render (pbrt_hip_camera_rays): what k_generate made, copied out.
+struct LiBatch {
+    const PbrtRay* d_rays = nullptr;   // li: n caller rays (device)
+    const uint64_t* d_keys = nullptr;  // li: RNG::set_sequence argument per ray (device)
+    int64_t n = 0;
+    int skip = 0;                      // values already drawn from each stream before li
+    float* d_rgb = nullptr;            // li: n x 3 (device)
+    PbrtRay* out_rays = nullptr;       // export (device): per path of the single pass
+    uint64_t* out_keys = nullptr;
+    float* out_pfilm = nullptr;
+    int32_t* out_pixel_sample = nullptr;
+};
 int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRenderParams& rp, float* d_film,
-                     PbrtRenderStats* stats);
+                     PbrtRenderStats* stats, const LiBatch* li = nullptr);

@@ -98,6 +98,65 @@ __global__ void k_generate(PathState ps, Queues q, PassParams pp, DevCamera cam,
     q.shade[p] = p;
 }
 
+// ---- pbrt_hip_li: a batch of Integrator::li calls (integrator.rs:29-42). The caller made the rays (its own Camera) and
+// names the random stream of each (its own Sampler's RNG::set_sequence argument, rng.rs:21-35); `skip` values were
+// already drawn from that stream before li (SamplerIntegrator::render draws the 5 of the CameraSample, integrator.rs:430). ----
+__global__ void k_li_generate(PathState ps, Queues q, const PbrtRay* __restrict__ rays, const uint64_t* __restrict__ keys, uint32_t n,
+                              uint32_t n_padded, int skip) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_padded) return;
+    int flags = 0;
+    if (p < n) {
+        Rng rng;
+        rng_set_sequence(rng, keys[p]);
+        for (int k = 0; k < skip; ++k) (void)rng_u32(rng);
+        ps.rng[p] = rng.state;
+        ps.samp[p] = 0;
+        const float4* rp = reinterpret_cast<const float4*>(rays + p);
+        float4 a = rp[0], b = rp[1];
+        store_ray(ps, p, RS_CONT, V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, b.z);
+        flags = PF_VALID | PF_ALIVE;
+    } else {
+        store_ray(ps, p, RS_CONT, V3{0.0f, 0.0f, 0.0f}, V3{0.0f, 0.0f, 1.0f}, -1.0f);  // padding: misses at once, not a ray
+    }
+    ps.pfilm[p] = make_float2(0.0f, 0.0f);
+    ps.L[p] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    ps.beta[p] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(flags));
+    q.trace[p] = p * 4u + RS_CONT;
+    q.shade[p] = p;
+}
+__global__ void k_li_output(PathState ps, uint32_t n, float* __restrict__ rgb) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float4 L = ps.L[p];  // what li returns; the NaN / negative-luminance guard is render's (integrator.rs:455), not li's
+    rgb[3 * (size_t)p] = L.x;
+    rgb[3 * (size_t)p + 1] = L.y;
+    rgb[3 * (size_t)p + 2] = L.z;
+}
+// pbrt_hip_camera_rays: what k_generate made, in the caller's record types (path order)
+__global__ void k_camera_rays_out(PathState ps, PassParams pp, TileList tiles, PbrtRay* __restrict__ rays, uint64_t* __restrict__ keys,
+                                  float* __restrict__ pfilm, int32_t* __restrict__ pixel_sample) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = (uint32_t)pp.n_pix * pp.n_samples;
+    if (p >= n) return;
+    int s_local = p / pp.n_pix, pix = p % pp.n_pix;
+    int2 org = tiles.origin[pix >> 8];
+    int x = org.x + (pix & 15), y = org.y + ((pix & 255) >> 4);
+    bool valid = (__float_as_int(ps.beta[p].w) & PF_VALID) != 0;
+    size_t ri = ray_index(ps, p, RS_CONT);
+    float4 a = ps.ray[ri], b = ps.ray[ri + 1];
+    float4* out = reinterpret_cast<float4*>(rays + p);
+    out[0] = a;
+    out[1] = make_float4(b.x, b.y, b.z, 0.0f);
+    keys[p] = sample_sequence(pp, x, y, pp.sample0 + s_local);
+    float2 pf = ps.pfilm[p];
+    pfilm[2 * (size_t)p] = pf.x;
+    pfilm[2 * (size_t)p + 1] = pf.y;
+    pixel_sample[3 * (size_t)p] = valid ? x : -1;
+    pixel_sample[3 * (size_t)p + 1] = valid ? y : -1;
+    pixel_sample[3 * (size_t)p + 2] = pp.sample0 + s_local;
+}
+
 // ---- trace: every pending ray of the wavefront (trace_persistent.h) ----
 struct WavefrontRayIO {
     PathState ps;

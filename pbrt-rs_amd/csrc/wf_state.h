@@ -85,6 +85,8 @@ struct PassParams {
     float filter_rx, filter_ry;       // reconstruction filter radius
     const float* filter_table;        // 16 x 16 table (device), nullptr = 0.5 box (exact in-order path)
     float max_sample_luminance;       // Film::max_sample_luminance (film.rs:24), +inf = no clamp
+    // pbrt_hip_li: the caller's stream key of every path (RNG::set_sequence argument); nullptr = the (pixel, sample) keys
+    const uint64_t* stream_keys;
 };
 
 struct Queues {

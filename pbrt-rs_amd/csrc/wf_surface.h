@@ -350,10 +350,19 @@ PB_DEV DevDistribution1D light_distribution_lookup(const ShadeConsts& sc, V3 p) 
 
 PB_DEV Samp path_sampler(const PathState& ps, const PassParams& pp, const TileList& tiles, uint32_t p) {
     // this path's stream: inc from the (pixel, sample) index, state and the dimension counters from memory
+    Samp sm;
+    if (pp.stream_keys) {  // a batch of Integrator::li calls: the caller's own stream per ray, RandomSampler only
+        sm.rng.inc = (pp.stream_keys[p] << 1) | 1;
+        sm.rng.state = ps.rng[p];
+        sm.pix = 0;
+        sm.s = 0;
+        sm.dim1 = sm.dim2 = sm.arr = 0;
+        sm.h_offset = 0;
+        return sm;
+    }
     int s_local = p / pp.n_pix, pix = p % pp.n_pix;
     int2 org = tiles.origin[pix >> 8];
     int x = org.x + (pix & 15), y = org.y + ((pix & 255) >> 4);
-    Samp sm;
     sm.rng.inc = (sample_sequence(pp, x, y, pp.sample0 + s_local) << 1) | 1;
     sm.rng.state = ps.rng[p];
     sm.pix = pix;

@@ -32,6 +32,7 @@ EXPORTS = [
     "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png", "pbrt_hip_write_exr",
     "pbrt_hip_comm_unique_id", "pbrt_hip_comm_create", "pbrt_hip_comm_destroy", "pbrt_hip_film_reduce",
     "pbrt_hip_comm_last_error", "pbrt_hip_scene_wide_records", "pbrt_hip_get_wide_counters", "pbrt_hip_probe_gather",
+    "pbrt_hip_li", "pbrt_hip_li_device", "pbrt_hip_camera_rays",
 ]
 
 
@@ -44,6 +45,11 @@ class RenderParams(ctypes.Structure):
                 ("filter_radius", ctypes.c_float * 2), ("filter_table", ctypes.c_void_p),
                 ("sampler", ctypes.c_int32), ("sampler_x", ctypes.c_int32), ("sampler_y", ctypes.c_int32),
                 ("sampler_jitter", ctypes.c_int32), ("sampler_dims", ctypes.c_int32), ("max_sample_luminance", ctypes.c_float)]
+
+
+class LiParams(ctypes.Structure):
+    _fields_ = [("integrator", ctypes.c_int32), ("max_depth", ctypes.c_int32), ("rr_threshold", ctypes.c_float),
+                ("light_strategy", ctypes.c_int32), ("ao_samples", ctypes.c_int32), ("draws_before_li", ctypes.c_int32)]
 
 
 class RenderStats(ctypes.Structure):
@@ -113,6 +119,9 @@ def lib():
         L.pbrt_hip_probe_gather.argtypes = [vp, i64, i32, i32, i32, ctypes.POINTER(ctypes.c_double)]
         L.pbrt_hip_render.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
         L.pbrt_hip_render_device.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
+        L.pbrt_hip_li.argtypes = [vp, ctypes.POINTER(LiParams), vp, vp, i64, vp, ctypes.POINTER(RenderStats)]
+        L.pbrt_hip_li_device.argtypes = [vp, ctypes.POINTER(LiParams), vp, vp, i64, vp, ctypes.POINTER(RenderStats)]
+        L.pbrt_hip_camera_rays.argtypes = [vp, vp, ctypes.POINTER(RenderParams), i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
         L.pbrt_hip_tile_partition.argtypes = [i32, i32, i32, i32, i32, i32, vp, i32, ctypes.POINTER(i32)]
         L.pbrt_hip_filter_table.argtypes = [i32, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]
         L.pbrt_hip_sample_bounds.argtypes = [i32, i32, ctypes.c_float, ctypes.c_float, vp]
@@ -460,6 +469,33 @@ class Scene:
         self.ctx.check(rc, "pbrt_hip_render")
         stats = {name: getattr(st, name) for name, _ in RenderStats._fields_}
         return film, stats
+
+    def li(self, rays, stream_keys, integrator=INTEGRATOR_PATH, max_depth=5, rr_threshold=1.0, light_strategy=1, ao_samples=64,
+           draws_before_li=0):
+        """Integrator::li for a batch of rays (RAY_DTYPE) with one RandomSampler stream each (uint64 keys).
+        Returns (rgb[n, 3], stats)."""
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        keys = np.ascontiguousarray(stream_keys, dtype=np.uint64)
+        assert len(rays) == len(keys)
+        rgb = np.zeros((len(rays), 3), dtype=np.float32)
+        lp = LiParams(integrator, max_depth, rr_threshold, light_strategy, ao_samples, draws_before_li)
+        st = RenderStats()
+        self.ctx.check(lib().pbrt_hip_li(self.h, ctypes.byref(lp), _p(rays), _p(keys), len(rays), _p(rgb), ctypes.byref(st)), "pbrt_hip_li")
+        return rgb, {name: getattr(st, name) for name, _ in RenderStats._fields_}
+
+    def camera_rays(self, camera, width, height, spp, seed=0, bounds=None, tile_rank=0, tile_world=1):
+        """The camera-ray stage of render(): (rays[RAY_DTYPE], stream_keys[uint64], p_film[n, 2], pixel_sample[n, 3])."""
+        camera = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
+        rp = self._params(width, height, spp, INTEGRATOR_PATH, 5, 1.0, 1, seed, bounds, tile_rank, tile_world, 0, None, 64, None, 0.0)
+        n = ctypes.c_int64()
+        lib().pbrt_hip_camera_rays(self.h, _p(camera), ctypes.byref(rp), 0, None, None, None, None, ctypes.byref(n))
+        rays = np.zeros(n.value, dtype=RAY_DTYPE)
+        keys = np.zeros(n.value, dtype=np.uint64)
+        pfilm = np.zeros((n.value, 2), dtype=np.float32)
+        pix = np.zeros((n.value, 3), dtype=np.int32)
+        self.ctx.check(lib().pbrt_hip_camera_rays(self.h, _p(camera), ctypes.byref(rp), n.value, _p(rays), _p(keys), _p(pfilm), _p(pix),
+                                                  ctypes.byref(n)), "pbrt_hip_camera_rays")
+        return rays, keys, pfilm, pix
 
     def close(self):
         if getattr(self, "h", None):
