@@ -558,6 +558,20 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     // rays the wide kernel leaves to the binary one (wide_bvh.h): room for every entry of a trace queue
     const bool use_wide = s->has_wide && ctx->count_traversal != 1;
     uint32_t* special_list = use_wide ? buf.alloc<uint32_t>(N * 3, &ok) : nullptr;
+    // sort-by-material experiment: the shade queue in material order
+    const char* sort_shade_env = std::getenv("PBRT_HIP_SORT_SHADE");
+    const bool sort_shade = sort_shade_env && sort_shade_env[0] == '1' && rp.integrator == PBRT_INTEGRATOR_PATH;
+    uint32_t *shade_keys[2] = {nullptr, nullptr}, *shade_sorted = nullptr;
+    void* shade_tmp = nullptr;
+    size_t shade_tmp_bytes = 0;
+    if (sort_shade) {
+        shade_keys[0] = buf.alloc<uint32_t>(N, &ok);
+        shade_keys[1] = buf.alloc<uint32_t>(N, &ok);
+        shade_sorted = buf.alloc<uint32_t>(N, &ok);
+        if (pb::sort_pairs_u32(st, nullptr, &shade_tmp_bytes, shade_keys[0], shade_keys[1], shade_sorted, shade_sorted, N, 3) != 0)
+            return invalid("rocPRIM radix sort: size query failed");
+        shade_tmp = buf.alloc<char>(shade_tmp_bytes, &ok);
+    }
     DirectState ds{};
     std::vector<int> prefix(s->d.n_lights + 1, 0);
     for (int i = 0; i < s->d.n_lights; ++i)  // directlighting.rs:58-62: round_count with a tabulating sampler
@@ -862,9 +876,21 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                 else
                     hipLaunchKernelGGL((k_shade_direct<PBRT_INTEGRATOR_AO>), sg, sb, 0, st, sc, ps, ds, q[cur], q[nxt], pp, tiles, n_shade);
             }
-            else
-                hipLaunchKernelGGL(k_shade, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, q[cur], q[nxt], pp,
-                                   tiles, n_shade);
+            else {
+                Queues qin = q[cur];
+                if (sort_shade && wavefront >= 1 && n_shade >= (1u << 16)) {  // the first wavefront is all camera hits in pixel order
+                    hipLaunchKernelGGL(k_shade_sort_keys, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, q[cur].shade, n_shade,
+                                       pp.max_depth, shade_keys[0]);
+                    size_t tb = shade_tmp_bytes;
+                    if (pb::sort_pairs_u32(st, shade_tmp, &tb, shade_keys[0], shade_keys[1], q[cur].shade, shade_sorted, n_shade, 3) != 0 &&
+                        rc == PBRT_HIP_OK) {
+                        ctx->last_error = "rocPRIM radix sort failed";
+                        rc = PBRT_HIP_ERR_DEVICE;
+                    }
+                    qin.shade = shade_sorted;
+                }
+                hipLaunchKernelGGL(k_shade, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, qin, q[nxt], pp, tiles, n_shade);
+            }
             RENDER_TRY(hipGetLastError());
             RENDER_TRY(hipMemcpyAsync(ctx->h_counts, q[nxt].counts64, sizeof(counts), hipMemcpyDeviceToHost, st));
             RENDER_TRY(hipEventRecord(ctx->ev_sync, st));

@@ -4,6 +4,31 @@
 
 namespace pb {
 
+// Sort-by-material experiment (north_star; the reference dispatches per hit to the material, interaction.rs:318-329):
+// key of a shade-queue entry = what k_shade will branch on: 0 no continuation hit to shade (escaped / dead path, only
+// the pending estimate is resolved), 1 + material type otherwise. PBRT_HIP_SORT_SHADE=1 sorts the queue by it.
+__global__ void k_shade_sort_keys(ShadeConsts sc, PathState ps, const uint32_t* __restrict__ shade_queue, uint32_t n, int max_depth,
+                                  uint32_t* __restrict__ keys) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t p = shade_queue[i];
+    int fb = __float_as_int(ps.beta[p].w);
+    uint32_t key = 0;
+    if ((fb & PF_ALIVE) && (fb >> 8) < max_depth) {
+        float4 h1 = ps.hit[hit_index(ps, p, RS_CONT) + 1];
+        int slot = __float_as_int(h1.x), inst = __float_as_int(h1.y);
+        if (slot >= 0) {
+            int mat = __float_as_int(sc.bvh.tris[3 * (size_t)slot + 2].z);
+            if (sc.bvh.instanced && inst >= 0) {
+                int over = __float_as_int(sc.bvh.instances[7 * (size_t)inst + 6].x);
+                if (over >= 0) mat = over;
+            }
+            key = 1u + (uint32_t)sc.materials[mat].type;
+        }
+    }
+    keys[i] = key;
+}
+
 __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Queues qin, Queues qout, PassParams pp,
                                                  TileList tiles, uint32_t n_in) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
