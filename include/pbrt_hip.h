@@ -252,9 +252,10 @@ int pbrt_hip_scene_create_with_spheres(PbrtHipContext* ctx, const float* positio
                                        int32_t n_lights, const float* spheres, const int32_t* sphere_material,
                                        const int32_t* sphere_light, int32_t n_spheres, const PbrtLinearBVHNode* nodes, int32_t n_nodes,
                                        const int32_t* prim_order, PbrtHipScene** out);
-/* Two-level scene (BASELINE config 5): `n_instances` TransformedPrimitives of ONE object-space
- * triangle aggregate. blas_* = BVHAccel over the triangles (object space); tlas_* = BVHAccel over the
- * instances' world bounds, tlas_order[slot] = instance index. Only infinite lights are accepted. */
+/* Two-level scene of BASELINE config 5's shape: `n_instances` TransformedPrimitives of ONE object-space triangle
+ * aggregate (pbrt_hip_scene_create_two_level with one object and no world-space triangles). blas_* = BVHAccel over the
+ * triangles (object space); tlas_* = BVHAccel over the instances' world bounds, tlas_order[slot] = instance index.
+ * No area lights (there is no world-space triangle to carry one). */
 int pbrt_hip_scene_create_instanced(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
                                     const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
                                     const PbrtMaterial* materials, int32_t n_materials, const PbrtLight* lights,
@@ -262,6 +263,32 @@ int pbrt_hip_scene_create_instanced(PbrtHipContext* ctx, const float* positions,
                                     const int32_t* blas_order, const PbrtInstance* instances, int32_t n_instances,
                                     const PbrtLinearBVHNode* tlas_nodes, int32_t n_tlas_nodes,
                                     const int32_t* tlas_order, PbrtHipScene** out);
+/* The general two-level scene (src/core/primitive.rs:105-159, 33-103): a top-level BVHAccel whose primitives are
+ *   0 .. n_instances - 1                 TransformedPrimitives, instance i of object aggregate instance_object[i]
+ *                                        (NULL = all of object 0), each object a triangle mesh in its own BVHAccel;
+ *   n_instances .. + n_world_tris - 1    plain GeometricPrimitive triangles in world space beside them; only these can
+ *                                        be area lights (PbrtLight.prim then counts the world triangles; pbrt-v3:
+ *                                        "area lights not supported with object instancing").
+ * tlas_nodes / tlas_order: BVHAccel over the world bounds of those primitives in that order (pbrt_hip_bvh_build_boxes
+ * over pbrt_hip_instance_bounds of each instance's object bounds, then the triangles' bounds). Hit records name a
+ * triangle by its index inside its own object (instance_id >= 0) or among the world triangles (instance_id = -1). */
+typedef struct PbrtObject {
+    const float* positions;
+    int32_t n_verts;
+    const int32_t* indices;
+    int32_t n_tris;
+    const int32_t* tri_material; /* may be NULL (material 0) */
+    const PbrtLinearBVHNode* nodes; /* BVHAccel over the object-space triangles */
+    int32_t n_nodes;
+    const int32_t* prim_order;
+} PbrtObject;
+int pbrt_hip_scene_create_two_level(PbrtHipContext* ctx, const PbrtObject* objects, int32_t n_objects,
+                                    const PbrtInstance* instances, const int32_t* instance_object, int32_t n_instances,
+                                    const float* world_positions, int32_t n_world_verts, const int32_t* world_indices,
+                                    int32_t n_world_tris, const int32_t* world_tri_material, const int32_t* world_tri_light,
+                                    const PbrtMaterial* materials, int32_t n_materials, const PbrtLight* lights, int32_t n_lights,
+                                    const PbrtLinearBVHNode* tlas_nodes, int32_t n_tlas_nodes, const int32_t* tlas_order,
+                                    PbrtHipScene** out);
 void pbrt_hip_scene_destroy(PbrtHipScene* scene);
 /* Traversal layout of a scene. Beside the 64-B child-pair records of the reference's tree a scene may carry 4-wide,
  * 48-byte records with 8-bit conservative boxes laid over the same tree (two levels of BVHAccel's nodes per record,

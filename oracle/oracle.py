@@ -46,6 +46,12 @@ def lib():
         L.orc_scene_create_instanced.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, ctypes.c_int, vp,
                                                  ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_uint32]
+        L.orc_scene_create_two_level.restype = vp
+        L.orc_scene_create_two_level.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp,
+                                                 ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_uint32]
+        L.orc_scene_num_object_nodes.argtypes = [vp, ctypes.c_int]
+        L.orc_scene_get_object.argtypes = [vp, ctypes.c_int, vp, vp]
         L.orc_scene_num_blas_nodes.argtypes = [vp]
         L.orc_scene_get_blas.argtypes = [vp, vp, vp]
         L.orc_scene_destroy.argtypes = [vp]
@@ -125,6 +131,9 @@ class OracleScene:
 
     def __init__(self, scene, max_prims_in_node=4, split_method=0, quirks=0, normals=None, uvs=None, tangents=None):
         L = lib()
+        if "objects" in scene:
+            self._init_two_level(scene, max_prims_in_node, split_method, quirks)
+            return
         if "instances" in scene:
             self._init_instanced(scene, max_prims_in_node, split_method, quirks)
             return
@@ -148,6 +157,44 @@ class OracleScene:
         if tangents is not None:
             k["tangents"] = _f32(tangents)
             L.orc_scene_set_tangents(self.h, _p(k["tangents"]), k["positions"].shape[0])
+
+    def _init_two_level(self, scene, max_prims_in_node, split_method, quirks):
+        """scenes.two_level_scene: several object aggregates, instances of them, world-space triangles beside (area lights)."""
+        from pbrt_hip import scenes as _scenes
+        pos, idx, mat, lgt, off = _scenes.combined_two_level_mesh(scene)
+        L = lib()
+        self._keep = dict(
+            positions=pos, indices=idx, tri_material=mat, tri_light=lgt, off=off,
+            instances=_f32(scene["instances"]).reshape(-1, 32),
+            instance_object=np.ascontiguousarray(scene["instance_object"], dtype=np.int32),
+            instance_material=np.ascontiguousarray(scene["instance_material"], dtype=np.int32),
+            materials=_materials_flat(scene["materials"]), lights=_lights_flat(scene["lights"]))
+        k = self._keep
+        self.n_tris = idx.shape[0]
+        self.n_instances = k["instances"].shape[0]
+        self.obj_tri_offset = off
+        self.n_world_tris = len(scene["world"]["indices"])
+        self.h = L.orc_scene_create_two_level(_p(pos), pos.shape[0], _p(idx), self.n_tris, _p(off), len(off) - 1, self.n_world_tris,
+                                              _p(mat), _p(lgt), _p(k["instances"]), _p(k["instance_object"]),
+                                              _p(k["instance_material"]), self.n_instances, _p(k["materials"]), len(k["materials"]),
+                                              _p(k["lights"]), len(k["lights"]), max_prims_in_node, split_method, quirks)
+
+    def object_tree(self, k):
+        n = lib().orc_scene_num_object_nodes(self.h, k)
+        nodes = np.zeros(n, dtype=NODE_DTYPE)
+        order = np.zeros(int(self.obj_tri_offset[k + 1] - self.obj_tri_offset[k]), dtype=np.int32)
+        lib().orc_scene_get_object(self.h, k, _p(nodes), _p(order))
+        return nodes, order   # BVHAccel's leaf order indexes the primitive list it was built over: the object's own triangles
+
+    def _local_prim_ids(self, hits):
+        """combined-mesh triangle ids -> index inside the hit instance's object / among the world triangles (PbrtHit's meaning)."""
+        if not hasattr(self, "obj_tri_offset"):
+            return hits
+        prim, inst = hits["prim_id"], hits["instance_id"]
+        obj = self._keep["instance_object"][np.maximum(inst, 0)]
+        base = np.where(inst >= 0, self.obj_tri_offset[obj], self.obj_tri_offset[-1])
+        hits["prim_id"] = np.where(prim >= 0, prim - base, -1)
+        return hits
 
     def _init_instanced(self, scene, max_prims_in_node, split_method, quirks):
         """Config 5: TransformedPrimitive instances of one base mesh (scene["instances"] = (n,2,4,4) float32
@@ -191,7 +238,8 @@ class OracleScene:
         return out
 
     def prim_order(self):
-        out = np.zeros(getattr(self, "n_instances", getattr(self, "n_prims", self.n_tris)), dtype=np.int32)
+        n = getattr(self, "n_instances", getattr(self, "n_prims", self.n_tris)) + getattr(self, "n_world_tris", 0)
+        out = np.zeros(n, dtype=np.int32)
         lib().orc_scene_get_prim_order(self.h, _p(out))
         return out
 
@@ -200,7 +248,7 @@ class OracleScene:
         out = np.zeros(len(rays), dtype=HIT_DTYPE)
         ctr = np.zeros(4, dtype=np.uint64)
         lib().orc_intersect(self.h, _p(rays), len(rays), _p(out), _p(ctr), n_threads)
-        return out, self._ctr(ctr)
+        return self._local_prim_ids(out), self._ctr(ctr)
 
     def intersect_p(self, rays, n_threads=8):
         rays = np.ascontiguousarray(rays)

@@ -52,6 +52,7 @@ struct Primitive {
     virtual Bounds3f world_bound() const = 0;
     virtual bool intersect(const Ray& r, SurfaceInteraction* si) const = 0;  // mutates r.t_max
     virtual bool intersect_p(const Ray& r) const = 0;
+    virtual bool is_instance() const { return false; }  // instrumentation only: TransformedPrimitive calls are counted apart
 };
 
 // src/core/primitive.rs:33-103 — material / area light are referenced by index into the
@@ -479,7 +480,7 @@ struct BVHAccel : Primitive {
             if (bounds_intersect_p(node.bounds, ray, inv_dir, dir_is_neg, quirks)) {
                 if (node.n_primitives > 0) {
                     for (int i = 0; i < node.n_primitives; ++i) {
-                        if (ctr) (leaves_are_instances ? ctr->inst_tests : ctr->prim_tests)++;
+                        if (ctr) ((leaves_are_instances && primitives[node.primitive_or_second_child_offset + i]->is_instance()) ? ctr->inst_tests : ctr->prim_tests)++;
                         if (primitives[node.primitive_or_second_child_offset + i]->intersect(ray, si)) hit = true;
                     }
                     if (to_visit_offset == 0) break;
@@ -515,7 +516,7 @@ struct BVHAccel : Primitive {
             if (bounds_intersect_p(node.bounds, ray, inv_dir, dir_is_neg, quirks)) {
                 if (node.n_primitives > 0) {
                     for (int i = 0; i < node.n_primitives; ++i) {
-                        if (ctr) (leaves_are_instances ? ctr->inst_tests : ctr->prim_tests)++;
+                        if (ctr) ((leaves_are_instances && primitives[node.primitive_or_second_child_offset + i]->is_instance()) ? ctr->inst_tests : ctr->prim_tests)++;
                         if (primitives[node.primitive_or_second_child_offset + i]->intersect_p(ray)) return true;
                     }
                     if (to_visit_offset == 0) break;
@@ -566,6 +567,7 @@ struct TransformedPrimitive : Primitive {
     }
     // primitive.rs:151-159
     bool intersect_p(const Ray& r) const override { return primitive->intersect_p(xform_ray(to_object, r)); }
+    bool is_instance() const override { return true; }
 };
 
 }  // namespace oracle

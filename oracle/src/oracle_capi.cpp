@@ -14,7 +14,8 @@ namespace {
 struct OracleScene {
     Scene scene;
     std::shared_ptr<TriangleMesh> mesh;
-    std::shared_ptr<BVHAccel> blas;  // instanced scenes: the shared object-space aggregate
+    std::shared_ptr<BVHAccel> blas;  // instanced scenes: the (first) object-space aggregate
+    std::vector<std::shared_ptr<BVHAccel>> blases;  // two-level scenes: every object aggregate
     std::vector<Matrix4> to_object;  // per instance
 };
 
@@ -187,6 +188,85 @@ void* orc_scene_create_instanced(const float* positions, int n_verts, const int3
     sc.aggregate->leaves_are_instances = true;
     sc.finish();
     return os;
+}
+// The general two-level scene (primitive.rs:105-159, 33-103). The mesh is the COMBINED one: every object's triangles,
+// object after object (obj_tri_offset[k] .. obj_tri_offset[k+1]), then n_world_tris world-space triangles; indices already
+// point into the combined vertex list. Top-level primitives: the instances (instance i of object inst_object[i]), then the
+// world-space triangles; only those may carry area lights (tri_light). prim ids are combined-mesh triangle indices.
+void* orc_scene_create_two_level(const float* positions, int n_verts, const int32_t* indices, int n_tris,
+                                 const int32_t* obj_tri_offset, int n_objects, int n_world_tris, const int32_t* tri_material,
+                                 const int32_t* tri_light, const float* instances, const int32_t* inst_object,
+                                 const int32_t* inst_material, int n_inst, const float* materials, int n_mat, const float* lights,
+                                 int n_light, int max_prims_in_node, int split_method, uint32_t quirks) {
+    OracleScene* os = new OracleScene();
+    auto mesh = std::make_shared<TriangleMesh>();
+    mesh->n_vertices = n_verts;
+    mesh->n_triangles = n_tris;
+    mesh->p.resize(n_verts);
+    for (int i = 0; i < n_verts; ++i) mesh->p[i] = Point3f(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]);
+    mesh->vertex_indices.assign(indices, indices + 3 * (size_t)n_tris);
+    os->mesh = mesh;
+    Scene& sc = os->scene;
+    sc.quirks = quirks;
+    for (int i = 0; i < n_mat; ++i) {
+        const float* m = materials + 8 * i;
+        MaterialDesc d;
+        d.type = (int)m[0];
+        d.kd = Spectrum(m[1], m[2], m[3]);
+        d.kt = Spectrum(m[4], m[5], m[6]);
+        d.eta = m[7];
+        sc.materials.push_back(d);
+    }
+    const int world0 = obj_tri_offset[n_objects];
+    sc.prim_material.assign(n_tris, 0);
+    sc.prim_light.assign(n_tris, -1);
+    std::vector<std::shared_ptr<Shape>> shapes(n_tris);
+    for (int i = 0; i < n_tris; ++i) {
+        shapes[i] = std::make_shared<Triangle>(mesh, i, false, quirks);
+        sc.prim_material[i] = tri_material ? tri_material[i] : 0;
+        if (i >= world0 && tri_light) sc.prim_light[i] = tri_light[i];
+    }
+    for (int i = 0; i < n_light; ++i) {
+        const float* l = lights + kLightStride * i;
+        if ((int)l[0] == 0) {  // DiffuseAreaLight on world triangle l.prim
+            int prim = world0 + (int)l[4];
+            sc.lights.push_back(std::make_shared<DiffuseAreaLight>(Spectrum(l[1], l[2], l[3]), (int)l[6], shapes[prim], l[5] != 0.0f));
+        } else {
+            sc.lights.push_back(make_non_area_light(l));
+        }
+    }
+    os->blases.resize(n_objects);
+    for (int k = 0; k < n_objects; ++k) {
+        std::vector<std::shared_ptr<Primitive>> prims;
+        for (int i = obj_tri_offset[k]; i < obj_tri_offset[k + 1]; ++i)
+            prims.push_back(std::make_shared<GeometricPrimitive>(shapes[i], sc.prim_material[i], -1, i));
+        os->blases[k] = std::make_shared<BVHAccel>(prims, max_prims_in_node, (SplitMethod)split_method, quirks);
+        os->blases[k]->counts_rays = false;
+    }
+    os->blas = os->blases[0];
+    std::vector<std::shared_ptr<Primitive>> top;
+    sc.instance_material.resize(n_inst);
+    os->to_object.resize(n_inst);
+    for (int i = 0; i < n_inst; ++i) {
+        Matrix4 tw, to;
+        std::memcpy(tw.m, instances + 32 * (size_t)i, 64);
+        std::memcpy(to.m, instances + 32 * (size_t)i + 16, 64);
+        os->to_object[i] = to;
+        top.push_back(std::make_shared<TransformedPrimitive>(os->blases[inst_object ? inst_object[i] : 0], tw, to, i));
+        sc.instance_material[i] = inst_material ? inst_material[i] : -1;
+    }
+    for (int i = world0; i < n_tris; ++i)
+        top.push_back(std::make_shared<GeometricPrimitive>(shapes[i], sc.prim_material[i], sc.prim_light[i], i));
+    sc.aggregate = std::make_shared<BVHAccel>(top, max_prims_in_node, (SplitMethod)split_method, quirks);
+    sc.aggregate->leaves_are_instances = true;  // per primitive: TransformedPrimitives count as instance tests
+    sc.finish();
+    return os;
+}
+int orc_scene_num_object_nodes(void* h, int k) { return (int)((OracleScene*)h)->blases[k]->nodes.size(); }
+void orc_scene_get_object(void* h, int k, void* nodes_out, int32_t* order_out) {
+    auto& b = ((OracleScene*)h)->blases[k];
+    std::memcpy(nodes_out, b->nodes.data(), b->nodes.size() * sizeof(LinearBVHNode));
+    std::memcpy(order_out, b->ordered_prims.data(), b->ordered_prims.size() * sizeof(int32_t));
 }
 int orc_scene_num_blas_nodes(void* h) {
     OracleScene* os = (OracleScene*)h;

@@ -202,11 +202,13 @@ static float host_det_sin(float x) {
 // (trace.h): interior nodes get indices base + 0.. in DFS order, leaves are encoded with count_bits.
 struct TreeLayout {
     std::vector<float> inodes;   // 16 floats per interior node
-    int n_interior = 0, count_bits = 0, depth = 0;
+    int n_interior = 0, count_bits = 0, depth = 0, max_count = 1;
     int32_t root_ref = 0;
 };
+// slot_base: leaf slot of the tree's first primitive in the scene's slot numbering; force_count_bits >= 0: the width
+// of (n_primitives - 1) in the leaf references (several object trees share one width).
 static const char* convert_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, int32_t n_prims, int32_t base,
-                                TreeLayout* out) {
+                                TreeLayout* out, int32_t slot_base = 0, int force_count_bits = -1, int64_t n_slots_total = -1) {
     std::vector<int32_t> interior_index(n_nodes, -1);
     int n_interior = 0, max_count = 1;
     int64_t leaf_prims = 0;
@@ -245,10 +247,15 @@ static const char* convert_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes,
     if (n_interior != (n_nodes - 1) / 2 || (n_nodes & 1) == 0) return "node array is not a full binary tree";
     int count_bits = 0;
     while ((1 << count_bits) < max_count) ++count_bits;
-    if (((int64_t)n_prims << count_bits) >= (1ll << 31)) return "scene too large for 31-bit leaf references";
+    if (force_count_bits >= 0) {
+        if (force_count_bits < count_bits) return "leaf larger than the shared leaf-reference width";
+        count_bits = force_count_bits;
+    }
+    if (((n_slots_total >= 0 ? n_slots_total : (int64_t)n_prims) << count_bits) >= (1ll << 31)) return "scene too large for 31-bit leaf references";
     auto child_ref = [&](int32_t node) -> int32_t {
         const PbrtLinearBVHNode& nd = nodes[node];
-        if (nd.n_primitives > 0) return ~(int32_t)(((uint32_t)nd.offset << count_bits) | (uint32_t)(nd.n_primitives - 1));
+        if (nd.n_primitives > 0)
+            return ~(int32_t)(((uint32_t)(nd.offset + slot_base) << count_bits) | (uint32_t)(nd.n_primitives - 1));
         return base + interior_index[node];
     };
     out->inodes.assign((size_t)n_interior * 16, 0.0f);
@@ -266,6 +273,7 @@ static const char* convert_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes,
     }
     out->n_interior = n_interior;
     out->count_bits = count_bits;
+    out->max_count = max_count;
     out->root_ref = child_ref(0);
     return nullptr;
 }
@@ -278,12 +286,20 @@ struct SphereArgs {
     const int32_t* light = nullptr;  // per sphere: index of its DiffuseAreaLight or -1
     int32_t n = 0;
 };
+// Two-level scenes: the main geometry arguments of scene_create_impl are then the COMBINED mesh (every object's
+// triangles, object after object, then the world-space triangles) and prim_order the combined leaf order
+// (object k's leaf order at obj_tri_offset[k], world triangles in caller order at world_tri_offset).
 struct InstancingArgs {
     const PbrtInstance* instances = nullptr;
     int32_t n_instances = 0;
     const PbrtLinearBVHNode* tlas_nodes = nullptr;
     int32_t n_tlas_nodes = 0;
     const int32_t* tlas_order = nullptr;
+    const PbrtObject* objects = nullptr;
+    int32_t n_objects = 0;
+    const int32_t* instance_object = nullptr;  // nullptr = all instances of object 0
+    std::vector<int32_t> obj_tri_offset;       // n_objects + 1
+    int32_t n_world_tris = 0, world_tri_offset = 0;
 };
 
 static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_t n_verts, const int32_t* indices,
@@ -363,6 +379,86 @@ extern "C" int pbrt_hip_scene_create_with_spheres(PbrtHipContext* ctx, const flo
                              lights, n_lights, nodes, n_nodes, prim_order, InstancingArgs(), out, nullptr, sa);
 }
 
+extern "C" int pbrt_hip_scene_create_two_level(PbrtHipContext* ctx, const PbrtObject* objects, int32_t n_objects,
+                                               const PbrtInstance* instances, const int32_t* instance_object, int32_t n_instances,
+                                               const float* world_positions, int32_t n_world_verts, const int32_t* world_indices,
+                                               int32_t n_world_tris, const int32_t* world_tri_material,
+                                               const int32_t* world_tri_light, const PbrtMaterial* materials, int32_t n_materials,
+                                               const PbrtLight* lights, int32_t n_lights, const PbrtLinearBVHNode* tlas_nodes,
+                                               int32_t n_tlas_nodes, const int32_t* tlas_order, PbrtHipScene** out) {
+    if (!ctx || !out) return PBRT_HIP_ERR_INVALID;
+    auto fail = [&](const char* msg) {
+        ctx->last_error = msg;
+        return PBRT_HIP_ERR_INVALID;
+    };
+    if (!objects || n_objects <= 0 || !instances || n_instances <= 0 || !tlas_nodes || n_tlas_nodes <= 0 || !tlas_order)
+        return fail("two-level scene needs objects, instances and a top-level node array");
+    if (n_world_tris < 0 || n_world_verts < 0 || (n_world_tris > 0 && (!world_positions || !world_indices || n_world_verts <= 0)))
+        return fail("bad world-space triangle arguments");
+    // ---- the combined mesh: object after object, then the world-space triangles ----
+    InstancingArgs ia;
+    ia.instances = instances;
+    ia.n_instances = n_instances;
+    ia.tlas_nodes = tlas_nodes;
+    ia.n_tlas_nodes = n_tlas_nodes;
+    ia.tlas_order = tlas_order;
+    ia.objects = objects;
+    ia.n_objects = n_objects;
+    ia.instance_object = instance_object;
+    ia.n_world_tris = n_world_tris;
+    int64_t n_verts = 0, n_tris = 0, n_nodes = 0;
+    ia.obj_tri_offset.assign(n_objects + 1, 0);
+    for (int32_t k = 0; k < n_objects; ++k) {
+        const PbrtObject& o = objects[k];
+        if (!o.positions || !o.indices || !o.nodes || !o.prim_order || o.n_verts <= 0 || o.n_tris <= 0 || o.n_nodes <= 0)
+            return fail("object aggregate with a null pointer or an empty mesh / tree");
+        for (int64_t i = 0; i < 3 * (int64_t)o.n_tris; ++i)
+            if (o.indices[i] < 0 || o.indices[i] >= o.n_verts) return fail("object vertex index out of range");
+        for (int32_t i = 0; i < o.n_tris; ++i)
+            if (o.prim_order[i] < 0 || o.prim_order[i] >= o.n_tris) return fail("object prim_order entry out of range");
+        n_verts += o.n_verts;
+        n_tris += o.n_tris;
+        n_nodes += o.n_nodes;
+        ia.obj_tri_offset[k + 1] = (int32_t)n_tris;
+    }
+    ia.world_tri_offset = (int32_t)n_tris;
+    for (int64_t i = 0; i < 3 * (int64_t)n_world_tris; ++i)
+        if (world_indices[i] < 0 || world_indices[i] >= n_world_verts) return fail("world triangle vertex index out of range");
+    n_verts += n_world_verts;
+    n_tris += n_world_tris;
+    if (n_tris >= (1ll << 30) || n_verts >= (1ll << 31)) return fail("two-level scene too large");
+    for (int32_t i = 0; i < n_instances; ++i)
+        if (instance_object && (instance_object[i] < 0 || instance_object[i] >= n_objects)) return fail("instance_object out of range");
+    for (int32_t i = 0; i < n_lights; ++i)
+        if (lights[i].type == PBRT_LIGHT_DIFFUSE_AREA && (lights[i].prim < 0 || lights[i].prim >= n_world_tris))
+            return fail("area lights sit on world-space triangles (instanced primitives cannot be area lights): prim out of range");
+    std::vector<float> pos((size_t)n_verts * 3);
+    std::vector<int32_t> idx((size_t)n_tris * 3), mat((size_t)n_tris, 0), lgt((size_t)n_tris, -1), order((size_t)n_tris);
+    int64_t v0 = 0, t0 = 0;
+    for (int32_t k = 0; k < n_objects; ++k) {
+        const PbrtObject& o = objects[k];
+        std::memcpy(&pos[(size_t)v0 * 3], o.positions, (size_t)o.n_verts * 12);
+        for (int64_t i = 0; i < 3 * (int64_t)o.n_tris; ++i) idx[(size_t)t0 * 3 + i] = o.indices[i] + (int32_t)v0;
+        for (int32_t i = 0; i < o.n_tris; ++i) {
+            mat[(size_t)t0 + i] = o.tri_material ? o.tri_material[i] : 0;
+            order[(size_t)t0 + i] = o.prim_order[i] + (int32_t)t0;
+        }
+        v0 += o.n_verts;
+        t0 += o.n_tris;
+    }
+    if (n_world_tris > 0) {
+        std::memcpy(&pos[(size_t)v0 * 3], world_positions, (size_t)n_world_verts * 12);
+        for (int64_t i = 0; i < 3 * (int64_t)n_world_tris; ++i) idx[(size_t)t0 * 3 + i] = world_indices[i] + (int32_t)v0;
+        for (int32_t i = 0; i < n_world_tris; ++i) {
+            mat[(size_t)t0 + i] = world_tri_material ? world_tri_material[i] : 0;
+            lgt[(size_t)t0 + i] = world_tri_light ? world_tri_light[i] : -1;
+            order[(size_t)t0 + i] = (int32_t)t0 + i;
+        }
+    }
+    return scene_create_impl(ctx, pos.data(), (int32_t)n_verts, idx.data(), (int32_t)n_tris, mat.data(), materials, n_materials,
+                             lgt.data(), lights, n_lights, nullptr, (int32_t)n_nodes, order.data(), ia, out);
+}
+
 extern "C" int pbrt_hip_scene_create_instanced(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
                                                const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
                                                const PbrtMaterial* materials, int32_t n_materials,
@@ -372,23 +468,17 @@ extern "C" int pbrt_hip_scene_create_instanced(PbrtHipContext* ctx, const float*
                                                int32_t n_instances, const PbrtLinearBVHNode* tlas_nodes,
                                                int32_t n_tlas_nodes, const int32_t* tlas_order, PbrtHipScene** out) {
     if (!ctx || !out) return PBRT_HIP_ERR_INVALID;
-    if (!instances || n_instances <= 0 || !tlas_nodes || n_tlas_nodes <= 0 || !tlas_order) {
-        ctx->last_error = "instanced scene needs instances and a top-level node array";
-        return PBRT_HIP_ERR_INVALID;
-    }
-    for (int32_t i = 0; i < n_lights; ++i)
-        if (lights[i].type == PBRT_LIGHT_DIFFUSE_AREA) {
-            ctx->last_error = "instanced primitives cannot be area lights: only infinite and delta lights are accepted";
-            return PBRT_HIP_ERR_INVALID;
-        }
-    InstancingArgs ia;
-    ia.instances = instances;
-    ia.n_instances = n_instances;
-    ia.tlas_nodes = tlas_nodes;
-    ia.n_tlas_nodes = n_tlas_nodes;
-    ia.tlas_order = tlas_order;
-    return scene_create_impl(ctx, positions, n_verts, indices, n_tris, tri_material, materials, n_materials, nullptr,
-                             lights, n_lights, blas_nodes, n_blas_nodes, blas_order, ia, out);
+    PbrtObject obj;
+    obj.positions = positions;
+    obj.n_verts = n_verts;
+    obj.indices = indices;
+    obj.n_tris = n_tris;
+    obj.tri_material = tri_material;
+    obj.nodes = blas_nodes;
+    obj.n_nodes = n_blas_nodes;
+    obj.prim_order = blas_order;
+    return pbrt_hip_scene_create_two_level(ctx, &obj, 1, instances, nullptr, n_instances, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                                           materials, n_materials, lights, n_lights, tlas_nodes, n_tlas_nodes, tlas_order, out);
 }
 
 static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_t n_verts, const int32_t* indices,
@@ -407,7 +497,7 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         return PBRT_HIP_ERR_INVALID;
     };
     if (n_tris <= 0 || n_verts <= 0 || n_nodes <= 0) return fail("empty scene: n_tris, n_verts and n_nodes must be > 0");
-    if (!positions || !indices || (!dt && (!nodes || !prim_order))) return fail("null geometry / BVH pointer");
+    if (!positions || !indices || (!dt && ((!nodes && ia.n_instances == 0) || !prim_order))) return fail("null geometry / BVH pointer");
     if (n_materials <= 0 || !materials) return fail("at least one material is required");
     if (n_lights < 0 || (n_lights > 0 && !lights)) return fail("bad light table");
     for (int64_t i = 0; i < 3 * (int64_t)n_tris; ++i)
@@ -431,7 +521,8 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     }
     for (int32_t i = 0; i < n_lights; ++i) {
         if (lights[i].type < PBRT_LIGHT_DIFFUSE_AREA || lights[i].type > PBRT_LIGHT_DISTANT) return fail("unknown light type");
-        if (lights[i].type == PBRT_LIGHT_DIFFUSE_AREA && (lights[i].prim < 0 || lights[i].prim >= n_tris + sa.n))
+        if (lights[i].type == PBRT_LIGHT_DIFFUSE_AREA &&
+            (lights[i].prim < 0 || lights[i].prim >= (ia.n_instances > 0 ? ia.n_world_tris : n_tris + sa.n)))
             return fail("area light primitive out of range");
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -440,10 +531,13 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     // single level: one tree over the triangles. Two levels (instancing): top-level tree over the
     // instances first, then the object-level tree over the triangles, in one record array.
     const bool instanced = ia.n_instances > 0;
+    const int32_t n_top = ia.n_instances + ia.n_world_tris;  // primitives of the top-level aggregate
     TreeLayout top, obj;
+    std::vector<TreeLayout> obj_trees;
     if (instanced) {
+        for (int32_t i = 0; i < n_top; ++i)
+            if (ia.tlas_order[i] < 0 || ia.tlas_order[i] >= n_top) return fail("tlas_order entry out of range");
         for (int32_t i = 0; i < ia.n_instances; ++i) {
-            if (ia.tlas_order[i] < 0 || ia.tlas_order[i] >= ia.n_instances) return fail("tlas_order entry out of range");
             const float* m = ia.instances[i].to_world;
             const float* mi = ia.instances[i].to_object;
             if (m[12] != 0.0f || m[13] != 0.0f || m[14] != 0.0f || m[15] != 1.0f || mi[12] != 0.0f || mi[13] != 0.0f ||
@@ -451,8 +545,25 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
                 return fail("instance transforms must be affine (last row 0 0 0 1)");
             if (ia.instances[i].material >= n_materials) return fail("instance material out of range");
         }
-        if (const char* e = convert_tree(ia.tlas_nodes, ia.n_tlas_nodes, ia.n_instances, 0, &top)) return fail(e);
-        if (const char* e = convert_tree(nodes, n_nodes, n_tris, top.n_interior, &obj)) return fail(e);
+        if (const char* e = convert_tree(ia.tlas_nodes, ia.n_tlas_nodes, n_top, 0, &top)) return fail(e);
+        // the object-level trees behind it in one record array; one leaf-reference width for all of them
+        int max_count = 1;
+        for (int32_t k = 0; k < ia.n_objects; ++k)
+            for (int32_t i = 0; i < ia.objects[k].n_nodes; ++i) max_count = std::max<int>(max_count, ia.objects[k].nodes[i].n_primitives);
+        int bits = 0;
+        while ((1 << bits) < max_count) ++bits;
+        int base = top.n_interior, deepest = 0;
+        obj_trees.resize(ia.n_objects);
+        for (int32_t k = 0; k < ia.n_objects; ++k) {
+            const PbrtObject& o = ia.objects[k];
+            if (const char* e = convert_tree(o.nodes, o.n_nodes, o.n_tris, base, &obj_trees[k], ia.obj_tri_offset[k], bits, n_tris)) return fail(e);
+            base += obj_trees[k].n_interior;
+            deepest = std::max(deepest, obj_trees[k].depth);
+            obj.inodes.insert(obj.inodes.end(), obj_trees[k].inodes.begin(), obj_trees[k].inodes.end());
+        }
+        obj.n_interior = base - top.n_interior;
+        obj.count_bits = bits;
+        obj.depth = deepest;
     } else if (dt) {
         top.n_interior = dt->n_interior;
         top.root_ref = dt->root_ref;
@@ -539,7 +650,7 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         std::memcpy(l.w2l, lights[i].world_to_light, 36);
         l.delta = (l.type == PBRT_LIGHT_POINT || l.type == PBRT_LIGHT_SPOT || l.type == PBRT_LIGHT_DISTANT) ? 1 : 0;
         if (l.type == PBRT_LIGHT_DIFFUSE_AREA) {
-            int32_t prim = lights[i].prim;
+            int32_t prim = lights[i].prim + (instanced ? ia.world_tri_offset : 0);  // two-level: prim counts the world-space triangles
             l.slot = dt ? dt->light_slot[i] : prim_slot[prim];
             if (prim >= n_tris) {
                 float r = sa.spheres[4 * (size_t)(prim - n_tris) + 3];
@@ -602,24 +713,38 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     d.bvh.has_spheres = sa.n > 0 ? 1 : 0;
     d.bvh.instanced = instanced ? 1 : 0;
     if (instanced) {
-        std::memcpy(d.bvh.blas_root_min, nodes[0].bounds_min, 12);
-        std::memcpy(d.bvh.blas_root_max, nodes[0].bounds_max, 12);
-        d.bvh.blas_root_ref = obj.root_ref;
         d.bvh.blas_count_bits = obj.count_bits;
-        // instance records in top-level leaf order: to_object rows 0-2, to_world rows 0-2, (material, id)
-        std::vector<float> inst((size_t)ia.n_instances * 28, 0.0f);
-        std::vector<int32_t> slot_inst(ia.n_instances);
-        std::vector<char> seen(ia.n_instances, 0);
-        for (int32_t slot = 0; slot < ia.n_instances; ++slot) {
+        // object table: (root box min, root reference) (root box max, -)
+        std::vector<float> objs((size_t)ia.n_objects * 8, 0.0f);
+        for (int32_t k = 0; k < ia.n_objects; ++k) {
+            const PbrtLinearBVHNode& root = ia.objects[k].nodes[0];
+            float* r = &objs[(size_t)k * 8];
+            std::memcpy(r, root.bounds_min, 12);
+            std::memcpy(r + 3, &obj_trees[k].root_ref, 4);
+            std::memcpy(r + 4, root.bounds_max, 12);
+        }
+        d.bvh.objects = (const float4*)dev_upload(s, objs.data(), objs.size(), &ok);
+        // records of the top-level leaf slots: to_object rows 0-2, to_world rows 0-2, (material, instance id, object, kind);
+        // a world-space triangle beside the instances: kind 1, its leaf slot in the third field
+        std::vector<float> inst((size_t)n_top * 28, 0.0f);
+        std::vector<int32_t> slot_inst(n_top);
+        std::vector<char> seen(n_top, 0);
+        for (int32_t slot = 0; slot < n_top; ++slot) {
             int32_t id = ia.tlas_order[slot];
             if (seen[id]) ok = false;
             seen[id] = 1;
-            slot_inst[slot] = id;
             float* r = &inst[(size_t)slot * 28];
-            std::memcpy(r, ia.instances[id].to_object, 48);
-            std::memcpy(r + 12, ia.instances[id].to_world, 48);
-            int32_t meta[4] = {ia.instances[id].material, id, 0, 0};
-            std::memcpy(r + 24, meta, 16);
+            if (id < ia.n_instances) {
+                slot_inst[slot] = id;
+                std::memcpy(r, ia.instances[id].to_object, 48);
+                std::memcpy(r + 12, ia.instances[id].to_world, 48);
+                int32_t meta[4] = {ia.instances[id].material, id, ia.instance_object ? ia.instance_object[id] : 0, 0};
+                std::memcpy(r + 24, meta, 16);
+            } else {
+                slot_inst[slot] = -1;
+                int32_t meta[4] = {-1, -1, prim_slot[ia.world_tri_offset + (id - ia.n_instances)], 1};
+                std::memcpy(r + 24, meta, 16);
+            }
         }
         if (!ok) ctx->last_error = "tlas_order is not a permutation";
         d.bvh.instances = (const float4*)dev_upload(s, inst.data(), inst.size(), &ok);
@@ -662,7 +787,16 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         s->wide.spill = (uint2*)p;
         s->wide.spill_stride = s->spill_lanes;
     }
-    if (!dt) d.slot_prim = dev_upload(s, prim_order, n_prims, &ok);
+    if (!dt && !instanced) d.slot_prim = dev_upload(s, prim_order, n_prims, &ok);
+    if (instanced) {  // hit records name a triangle by its index inside its own object (world triangles: their own list)
+        std::vector<int32_t> local(n_prims);
+        int32_t k = 0;
+        for (int32_t slot = 0; slot < n_prims; ++slot) {
+            while (k < ia.n_objects && slot >= ia.obj_tri_offset[k + 1]) ++k;
+            local[slot] = prim_order[slot] - (k < ia.n_objects ? ia.obj_tri_offset[k] : ia.world_tri_offset);
+        }
+        d.slot_prim = dev_upload(s, local.data(), local.size(), &ok);
+    }
     d.materials = dev_upload(s, dm.data(), dm.size(), &ok);
     d.lights = dev_upload(s, dl.data(), dl.size(), &ok);
     d.n_lights = n_lights;

@@ -31,13 +31,15 @@ struct DevBVH {
     int n_slots;
     uint2* __restrict__ spill;  // [entry][global lane] overflow stack
     int spill_stride;           // number of lanes the slab was sized for
-    // two-level scenes (TransformedPrimitive instances of one object-space aggregate): the fields
-    // above describe the top level (leaves = instance slots); these describe the object level.
+    // two-level scenes (src/core/primitive.rs:105-159): the fields above describe the top level, whose leaf slots hold
+    // TransformedPrimitives of object-space aggregates and, beside them, plain world-space triangles.
     int instanced;
-    const float4* __restrict__ instances;  // 7 x float4 per instance slot: to_object rows 0-2, to_world rows 0-2, (material, id, -, -)
-    int blas_root_ref;
-    int blas_count_bits;
-    float blas_root_min[3], blas_root_max[3];
+    // 7 x float4 per top-level leaf slot: to_object rows 0-2, to_world rows 0-2, (material, instance id, object, kind);
+    // kind 1 = a world-space triangle, its leaf slot in `tris` in the third field
+    const float4* __restrict__ instances;
+    // 2 x float4 per object aggregate: (root box min, root reference) (root box max, -)
+    const float4* __restrict__ objects;
+    int blas_count_bits;  // of the object-level leaf references (one width for all objects)
     // optional per-vertex shading data of TriangleMesh (triangle.rs:17-26: n, s, uv), 6 x float4 per leaf slot:
     // (n0.xyz, n1.x) (n1.yz, n2.xy) (n2.z, s0.xyz) (s1.xyz, s2.x) (s2.yz, uv0.xy) (uv1.xy, uv2.xy); null = none
     const float4* __restrict__ tri_shading;

@@ -166,8 +166,11 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
             n_inst += 1;
             n_node += 1;  // the object aggregate tests its root box (bvh.rs:841-842)
         }
-        if (!root_box_test(s, bvh.blas_root_min, bvh.blas_root_max)) return false;
-        s.cur = bvh.blas_root_ref;
+        const float4* ob = bvh.objects + 2 * (size_t)__float_as_int(m[6].z);
+        const float4 o0 = ob[0], o1 = ob[1];
+        const float mn[3] = {o0.x, o0.y, o0.z}, mx[3] = {o1.x, o1.y, o1.z};
+        if (!root_box_test(s, mn, mx)) return false;
+        s.cur = __float_as_int(o0.w);
         return true;
     };
     // second half (primitive.rs:140-143): r.t_max = ray.t_max on a hit; back to the world ray
@@ -356,14 +359,42 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
                     w.leaf_first = ref >> bvh.count_bits;
                     w.leaf_next = 0;
                 }
-                bool entered = false;
-                while (w.leaf_next < w.leaf_cnt && !entered) {
+                bool entered = false, done = false;
+                while (w.leaf_next < w.leaf_cnt && !entered && !done) {
                     int slot = w.leaf_first + w.leaf_next;
                     w.leaf_next += 1;
+                    const float4 kind = bvh.instances[7 * (size_t)slot + 6];
+                    if (__float_as_int(kind.w) == 1) {
+                        // a GeometricPrimitive beside the instances (primitive.rs:65-78): the world ray against its triangle
+                        const int tslot = __float_as_int(kind.z);
+                        V3 p0, p1, p2;
+                        int flags;
+                        load_tri(bvh.tris, tslot, &p0, &p1, &p2, &flags);
+                        if (COUNT) n_prim += 1;
+                        float b0, b1, b2, t;
+                        const TriRayConst c = tri_ray_setup(s.r);
+                        if (triangle_test(p0, p1, p2, s.r, c, s.tmax, &b0, &b1, &b2, &t)) {
+                            if (s.any) {
+                                done = true;
+                            } else if (!(flags & kTriDegenerate)) {
+                                s.tmax = t;
+                                w.tmax_world = t;
+                                s.b0 = b0;
+                                s.b1 = b1;
+                                s.b2 = b2;
+                                s.hit_slot = tslot;
+                                w.hit_inst = -1;
+                            }
+                        }
+                        continue;
+                    }
                     entered = enter_instance(slot);
                     if (!entered) exit_instance();
                 }
-                if (!entered && !advance()) finish(s.hit_slot >= 0);
+                if (done)
+                    finish(true);
+                else if (!entered && !advance())
+                    finish(s.hit_slot >= 0);
             } else {
                 int ref = ~s.cur;
                 int cnt = (ref & tri_count_mask) + 1;

@@ -32,7 +32,7 @@ EXPORTS = [
     "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png", "pbrt_hip_write_exr",
     "pbrt_hip_comm_unique_id", "pbrt_hip_comm_create", "pbrt_hip_comm_destroy", "pbrt_hip_film_reduce",
     "pbrt_hip_comm_last_error", "pbrt_hip_scene_wide_records", "pbrt_hip_get_wide_counters", "pbrt_hip_probe_gather",
-    "pbrt_hip_li", "pbrt_hip_li_device", "pbrt_hip_camera_rays",
+    "pbrt_hip_li", "pbrt_hip_li_device", "pbrt_hip_camera_rays", "pbrt_hip_scene_create_two_level",
 ]
 
 
@@ -45,6 +45,11 @@ class RenderParams(ctypes.Structure):
                 ("filter_radius", ctypes.c_float * 2), ("filter_table", ctypes.c_void_p),
                 ("sampler", ctypes.c_int32), ("sampler_x", ctypes.c_int32), ("sampler_y", ctypes.c_int32),
                 ("sampler_jitter", ctypes.c_int32), ("sampler_dims", ctypes.c_int32), ("max_sample_luminance", ctypes.c_float)]
+
+
+class PbrtObject(ctypes.Structure):
+    _fields_ = [("positions", ctypes.c_void_p), ("n_verts", ctypes.c_int32), ("indices", ctypes.c_void_p), ("n_tris", ctypes.c_int32),
+                ("tri_material", ctypes.c_void_p), ("nodes", ctypes.c_void_p), ("n_nodes", ctypes.c_int32), ("prim_order", ctypes.c_void_p)]
 
 
 class LiParams(ctypes.Structure):
@@ -97,6 +102,8 @@ def lib():
         L.pbrt_hip_instance_bounds.argtypes = [vp, vp, vp, i32, vp, vp]
         L.pbrt_hip_scene_create_instanced.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, vp, i32,
                                                       vp, i32, vp, ctypes.POINTER(vp)]
+        L.pbrt_hip_scene_create_two_level.argtypes = [vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, vp,
+                                                      ctypes.POINTER(vp)]
         L.pbrt_hip_scene_destroy.argtypes = [vp]
         L.pbrt_hip_scene_destroy.restype = None
         L.pbrt_hip_scene_wide_records.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_char_p)]
@@ -278,6 +285,26 @@ def instance_bounds(object_min, object_max, instances):
     return lo, hi
 
 
+def build_general_two_level(scene, max_prims_in_node=4, split_method=SPLIT_SAH):
+    """Host BVH builds for scenes.two_level_scene-style scenes: one tree per object, the top-level tree over the instances'
+    world bounds followed by the world triangles' bounds. Returns (object trees [(nodes, order)], instances, tlas_nodes, tlas_order)."""
+    trees = [bvh_build(o["positions"], o["indices"], max_prims_in_node, split_method) for o in scene["objects"]]
+    inst = make_instances(scene)
+    io = np.asarray(scene["instance_object"], dtype=np.int32)
+    lo, hi = np.zeros((len(inst), 3), dtype=np.float32), np.zeros((len(inst), 3), dtype=np.float32)
+    for k, (nodes, _) in enumerate(trees):
+        sel = np.flatnonzero(io == k)
+        if len(sel):
+            a, b = instance_bounds(nodes[0]["bmin"], nodes[0]["bmax"], np.ascontiguousarray(inst[sel]))
+            lo[sel], hi[sel] = a, b
+    w = scene["world"]
+    if len(w["indices"]):
+        tri = np.asarray(w["positions"], dtype=np.float32)[np.asarray(w["indices"], dtype=np.int32)]
+        lo, hi = np.concatenate([lo, tri.min(axis=1)]), np.concatenate([hi, tri.max(axis=1)])
+    tlas_nodes, tlas_order = bvh_build_boxes(lo, hi, max_prims_in_node, split_method)
+    return trees, inst, tlas_nodes, tlas_order
+
+
 def build_two_level(scene, max_prims_in_node=4, split_method=SPLIT_SAH):
     """Host BVH builds for an instanced scene: object-level tree over the triangles, top-level tree over
     the instances' world bounds. Returns (blas_nodes, blas_order, instances, tlas_nodes, tlas_order)."""
@@ -296,6 +323,9 @@ class Scene:
         """device_build=True: BVHAccel::new(HLBVH) built and laid out on the GPU (pbrt_hip_scene_create_hlbvh);
         self.build_ms / self.layout_ms then hold the HIP-event times and self.nodes is None."""
         self.ctx = ctx
+        if "objects" in scene:
+            self._init_two_level(scene, max_prims_in_node, split_method, bvh)
+            return
         if "instances" in scene:
             self._init_instanced(scene, max_prims_in_node, split_method, bvh)
             return
@@ -403,6 +433,39 @@ class Scene:
         self.h = h
         self.ctx._scenes.add(self)
         self._set_shading_data(scene)
+
+    def _init_two_level(self, scene, max_prims_in_node, split_method, bvh):
+        """scenes.two_level_scene: several object aggregates, instances of them, world-space triangles (area lights) beside."""
+        if bvh is None:
+            bvh = build_general_two_level(scene, max_prims_in_node, split_method)
+        self.object_trees, self.instances, self.tlas_nodes, self.tlas_order = bvh
+        keep = []
+        objs = (PbrtObject * len(scene["objects"]))()
+        for k, (o, (nodes, order)) in enumerate(zip(scene["objects"], self.object_trees)):
+            pos = np.ascontiguousarray(o["positions"], dtype=np.float32)
+            idx = np.ascontiguousarray(o["indices"], dtype=np.int32)
+            mat = np.ascontiguousarray(o["tri_material"], dtype=np.int32)
+            keep += [pos, idx, mat, nodes, order]
+            objs[k] = PbrtObject(pos.ctypes.data, len(pos), idx.ctypes.data, len(idx), mat.ctypes.data, nodes.ctypes.data, len(nodes),
+                                 order.ctypes.data)
+        io = np.ascontiguousarray(scene["instance_object"], dtype=np.int32)
+        w = scene["world"]
+        wp = np.ascontiguousarray(w["positions"], dtype=np.float32)
+        wi = np.ascontiguousarray(w["indices"], dtype=np.int32)
+        wm = np.ascontiguousarray(w["tri_material"], dtype=np.int32)
+        wl = np.ascontiguousarray(w["tri_light"], dtype=np.int32)
+        materials = np.ascontiguousarray(scene["materials"], dtype=MATERIAL_DTYPE)
+        lights = np.ascontiguousarray(scene["lights"], dtype=LIGHT_DTYPE)
+        h = ctypes.c_void_p()
+        rc = lib().pbrt_hip_scene_create_two_level(
+            self.ctx.h, ctypes.addressof(objs), len(objs), _p(self.instances), _p(io), len(self.instances),
+            _p(wp) if len(wi) else None, len(wp) if len(wi) else 0, _p(wi) if len(wi) else None, len(wi),
+            _p(wm) if len(wi) else None, _p(wl) if len(wi) else None, _p(materials), len(materials),
+            _p(lights) if len(lights) else None, len(lights), _p(self.tlas_nodes), len(self.tlas_nodes), _p(self.tlas_order),
+            ctypes.byref(h))
+        self.ctx.check(rc, "pbrt_hip_scene_create_two_level")
+        self.h = h
+        self.ctx._scenes.add(self)
 
     def intersect(self, rays):
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)

@@ -320,6 +320,70 @@ def instanced_scene(n_base_tris=10_000, n_instances=1000, seq_mesh=2, seq_xf=3, 
                 tri_material=base["tri_material"], tri_light=base["tri_light"])
 
 
+def two_level_scene(n_instances=90, seq_xf=13, extent=2.0, env_L=(0.2, 0.25, 0.3)):
+    """A general two-level scene (primitive.rs:105-159): three different object aggregates (triangle clouds of different
+    size and density), instances of them cycling 0, 1, 2 with matte / mirror / glass by instance, and world-space
+    geometry beside them: a floor quad and an emitting quad (one-sided DiffuseAreaLight, two triangles) above the cloud,
+    plus a dim constant environment. scene["objects"]: list of {positions, indices, tri_material}; scene["instance_object"];
+    scene["world"]: {positions, indices, tri_material, tri_light} (lights' `prim` counts the world triangles)."""
+    objs = []
+    for k, (n, ext, size, sq) in enumerate([(1500, 0.25, 0.05, 21), (600, 0.18, 0.09, 22), (2500, 0.3, 0.03, 23)]):
+        b = random_triangles(n, seq=sq, extent=ext, size=size)
+        objs.append(dict(positions=b["positions"], indices=b["indices"], tri_material=np.full(n, k % 3, dtype=np.int32)))
+    u = pcg32_float(seq_xf, n_instances * 6).astype(np.float64).reshape(n_instances, 6)
+    inst = np.zeros((n_instances, 2, 4, 4), dtype=np.float32)
+    for i in range(n_instances):
+        m = _random_rigid(u[i, :3])
+        m[:3, 3] = (u[i, 3:] * 2 - 1) * extent
+        inst[i, 0] = m.astype(np.float32)
+        inst[i, 1] = np.linalg.inv(m).astype(np.float32)
+    inst[:, :, 3, :] = (0, 0, 0, 1)
+    e = extent * 1.6
+    fy, ly, lw = -extent * 1.3, extent * 1.4, extent * 0.5
+    wp = np.array([[-e, fy, -e], [e, fy, -e], [e, fy, e], [-e, fy, e],
+                   [-lw, ly, -lw], [lw, ly, -lw], [lw, ly, lw], [-lw, ly, lw]], dtype=np.float32)
+    wi = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7]], dtype=np.int32)   # floor faces +y, light faces -y
+    materials = _materials([
+        (MAT_MATTE, (0.5, 0.5, 0.5), (0, 0, 0), 1.0),
+        (MAT_MIRROR, (0.9, 0.9, 0.9), (0, 0, 0), 1.0),
+        (MAT_GLASS, (1.0, 1.0, 1.0), (1.0, 1.0, 1.0), 1.5),
+        (MAT_MATTE, (0.7, 0.6, 0.5), (0, 0, 0), 1.0),
+    ])
+    lights = _lights([(LIGHT_DIFFUSE_AREA, (12.0, 11.0, 9.0), 2, 0, 1), (LIGHT_DIFFUSE_AREA, (12.0, 11.0, 9.0), 3, 0, 1),
+                      (LIGHT_INFINITE, env_L, -1, 0, 1)])
+    return dict(objects=objs, instances=inst, instance_object=(np.arange(n_instances) % 3).astype(np.int32),
+                instance_material=np.where(np.arange(n_instances) % 4 == 3, -1, np.arange(n_instances) % 3).astype(np.int32),
+                world=dict(positions=wp, indices=wi, tri_material=np.array([3, 3, 0, 0], dtype=np.int32),
+                           tri_light=np.array([-1, -1, 0, 1], dtype=np.int32)),
+                materials=materials, lights=lights)
+
+
+def two_level_camera(width, height, extent=2.0):
+    return perspective_camera((0.3 * extent, 0.4 * extent, 3.4 * extent), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 42.0, width, height)
+
+
+def combined_two_level_mesh(scene):
+    """Every object's triangles, object after object, then the world triangles: (positions, indices, tri_material,
+    tri_light, obj_tri_offset[n_objects + 1]); what the oracle's and the library's two-level creation work on."""
+    pos, idx, mat, lgt, off = [], [], [], [], [0]
+    v0 = 0
+    for o in scene["objects"]:
+        pos.append(np.asarray(o["positions"], dtype=np.float32))
+        idx.append(np.asarray(o["indices"], dtype=np.int32) + v0)
+        mat.append(np.asarray(o["tri_material"], dtype=np.int32))
+        lgt.append(np.full(len(o["indices"]), -1, dtype=np.int32))
+        v0 += len(o["positions"])
+        off.append(off[-1] + len(o["indices"]))
+    w = scene["world"]
+    if len(w["indices"]):
+        pos.append(np.asarray(w["positions"], dtype=np.float32))
+        idx.append(np.asarray(w["indices"], dtype=np.int32) + v0)
+        mat.append(np.asarray(w["tri_material"], dtype=np.int32))
+        lgt.append(np.asarray(w["tri_light"], dtype=np.int32))
+    return (np.ascontiguousarray(np.concatenate(pos)), np.ascontiguousarray(np.concatenate(idx)),
+            np.ascontiguousarray(np.concatenate(mat)), np.ascontiguousarray(np.concatenate(lgt)), np.array(off, dtype=np.int32))
+
+
 def world_space_instances(scene):
     """The same geometry without TransformedPrimitives: one world-space TriangleMesh per instance, vertices put
     through `Transform * Point3f` (transform.rs:351-370, float32, the operation order of the reference) as

@@ -272,3 +272,19 @@ def test_too_deep_tree_is_refused_without_a_gpu_fault():
         if nodes["n_primitives"][i] == 0:
             stack += [(i + 1, d + 1), (int(nodes["offset"][i]), d + 1)]
     assert depth > 64                      # the scene below must be refused (checked on the GPU box in test_gpu_intersect)
+
+
+def test_general_two_level_host_trees_equal_oracle():
+    """Host builds for the general two-level scene (one tree per object aggregate, the top-level tree over the instances'
+    world bounds followed by the world triangles') against the oracle's BVHAccel::new on the same primitives. No GPU."""
+    import oracle
+    from pbrt_hip import scenes
+    sc = scenes.two_level_scene(n_instances=40)
+    osc = oracle.OracleScene(sc)
+    trees, inst, tlas_nodes, tlas_order = pbrt_hip.build_general_two_level(sc)
+    assert tlas_nodes.tobytes() == osc.nodes().tobytes() and np.array_equal(tlas_order, osc.prim_order())
+    assert len(tlas_order) == 40 + 4
+    for k, (nodes, order) in enumerate(trees):
+        on, oo = osc.object_tree(k)
+        assert nodes.tobytes() == on.tobytes() and np.array_equal(order, oo)
+    osc.close()

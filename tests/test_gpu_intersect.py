@@ -122,6 +122,46 @@ def test_instrumented_counts_match_reference_loops(hip_ctx):
     osc.close()
 
 
+def test_general_two_level_scene_parity(hip_ctx):
+    """The general TransformedPrimitive scene (src/core/primitive.rs:105-159): three different object aggregates,
+    instances cycling through them, and world-space GeometricPrimitives (a floor and an emitting quad) beside the instances
+    in the same top-level BVHAccel. Bit-exact hits (triangle index inside its object, instance id, -1 for the world
+    triangles), any-hit flags and the reference-loop counters, top-level triangle tests included."""
+    sc = scenes.two_level_scene()
+    osc = oracle.OracleScene(sc)
+    gsc = pbrt_hip.Scene(hip_ctx, sc)
+    assert gsc.tlas_nodes.tobytes() == osc.nodes().tobytes() and np.array_equal(gsc.tlas_order, osc.prim_order())
+    for k, (nodes, order) in enumerate(gsc.object_trees):
+        on, oo = osc.object_tree(k)
+        assert nodes.tobytes() == on.tobytes() and np.array_equal(order, oo)
+    rays = _scene_rays(sc, 120_000, 41, 3.0)
+    rays["t_max"][::4] = np.float32(2.5)
+    cpu, ctr = osc.intersect(rays)
+    cpu_p, ctr_p = osc.intersect_p(rays)
+    gpu = gsc.intersect(rays)
+    _assert_hits_equal(gpu, cpu)
+    assert np.array_equal(gpu["instance_id"], cpu["instance_id"])
+    hit = cpu["prim_id"] >= 0
+    inst = sc["instance_object"][np.maximum(cpu["instance_id"], 0)]
+    for k in range(3):          # every object aggregate is hit, and so are the world-space triangles
+        assert (hit & (cpu["instance_id"] >= 0) & (inst == k)).sum() > 2000
+    world = hit & (cpu["instance_id"] < 0)
+    assert world.sum() > 5000 and set(np.unique(cpu["prim_id"][world])) == {0, 1, 2, 3}
+    assert np.array_equal(gsc.intersect_p(rays), cpu_p)
+    hip_ctx.set_counting(True)
+    try:
+        hip_ctx.counters(reset=True)
+        gsc.intersect(rays)
+        c = hip_ctx.counters(reset=True)
+        gsc.intersect_p(rays)
+        c_p = hip_ctx.counters(reset=True)
+    finally:
+        hip_ctx.set_counting(False)
+    assert c == ctr and c_p == ctr_p
+    gsc.close()
+    osc.close()
+
+
 def test_instanced_scene_parity(hip_ctx):
     """Two-level traversal (TransformedPrimitive instances, src/core/primitive.rs:136-159) vs the oracle:
     bit-exact hits incl. the instance id, any-hit flags, and the reference-loop counters."""

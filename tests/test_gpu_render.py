@@ -579,3 +579,19 @@ def test_sphere_area_lights(hip_ctx, integrator, kw):
                                               seed=101, **kw)
     _compare(film_g, film_c)
     assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+
+
+@pytest.mark.parametrize("integrator,kw", [(pbrt_hip.INTEGRATOR_PATH, dict(max_depth=8, light_strategy=1)),
+                                            (pbrt_hip.INTEGRATOR_PATH, dict(max_depth=5, light_strategy=0)),
+                                            (pbrt_hip.INTEGRATOR_DIRECT, dict(max_depth=3, light_strategy=0))])
+def test_general_two_level_scene_with_area_light(hip_ctx, integrator, kw):
+    """Instances of three object aggregates (matte / mirror / glass) lit by an emitting world-space quad beside them
+    (primitive.rs:105-159 + 33-103; pbrt-v3: only non-instanced primitives can be area lights) plus a dim environment:
+    light sampling, MIS hits on the emitter through the two-level traversal, shadow rays through instances."""
+    w, h = 112, 80
+    sc = scenes.two_level_scene()
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, scenes.two_level_camera(w, h), w, h, 8, integrator=integrator, seed=6, **kw)
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    rgb = oracle.film_to_rgb(film_c)
+    assert rgb.mean() > 0.05 and rgb.max() > 5.0       # the emitter itself is in view
