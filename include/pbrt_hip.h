@@ -151,7 +151,8 @@ typedef struct PbrtRenderParams {
     int32_t spp;            /* RandomSampler samples per pixel */
     int32_t width, height;  /* film full_resolution */
     int32_t x0, y0, x1, y1; /* pixel_bounds [x0,x1) x [y0,y1) */
-    uint64_t seed;          /* stream of (pixel, sample) = seed ^ ((y*width + x)*spp + s) */
+    uint64_t seed;          /* stream of (pixel, sample) = seed ^ (pixel_number * spp + s), pixel_number = the pixel's
+                             * row-major number over the film's sample bounds: y * width + x with the 0.5 box filter */
     int32_t tile_rank;      /* this GPU renders the 16x16 tiles whose index % tile_world == tile_rank */
     int32_t tile_world;     /* 1 = all tiles */
     int32_t spp_per_pass;   /* 0 = library default; samples of one pixel traced concurrently */

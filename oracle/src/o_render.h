@@ -941,6 +941,8 @@ inline void render(const Scene& scene, const PerspectiveCamera& camera, Integrat
     // get_sample_bounds with a 0.5 box filter = the pixel rectangle itself (film.rs:76-81, D42)
     int sx0 = rp.x0, sy0 = rp.y0, sx1 = rp.x1, sy1 = rp.y1;
     int ntx = (sx1 - sx0 + TILE_SIZE - 1) / TILE_SIZE, nty = (sy1 - sy0 + TILE_SIZE - 1) / TILE_SIZE;
+    int fsb[4];
+    film.sample_bounds(&fsb[0], &fsb[1], &fsb[2], &fsb[3]);
     std::atomic<int> next_tile(0);
     std::mutex film_mutex;
     int n_threads = std::max(1, rp.n_threads);
@@ -963,9 +965,13 @@ inline void render(const Scene& scene, const PerspectiveCamera& camera, Integrat
             FilmTile film_tile(film, std::max(tx0, 0), std::max(ty0, 0), std::min(tx1, film.width), std::min(ty1, film.height));
             for (int py = y0; py < y1; ++py)
                 for (int px = x0; px < x1; ++px) {
-                    rc.sampler.start_pixel(rp.seed, (int64_t)py * film.width + px, rp.spp, px, py);
+                    // the pixel's number over the film's SAMPLE bounds (film.rs:76-81): with a filter wider than the 0.5
+                    // box, pixels left of / above the film are sampled too and must not share a stream with a film pixel
+                    // (y * width + x would give (width, y) and (0, y + 1) the same one)
+                    const int64_t pixel_index = (int64_t)(py - fsb[1]) * (fsb[2] - fsb[0]) + (px - fsb[0]);
+                    rc.sampler.start_pixel(rp.seed, pixel_index, rp.spp, px, py);
                     for (int s = 0; s < rp.spp; ++s) {
-                        rc.sampler.start_sample(rp.seed, (int64_t)py * film.width + px, rp.spp, s);
+                        rc.sampler.start_sample(rp.seed, pixel_index, rp.spp, s);
                         CameraSample cs = rc.sampler.get_camera_sample(px, py);
                         Ray ray;
                         Float ray_weight = camera.generate_ray(cs, &ray);

@@ -27,7 +27,14 @@ struct Rccl {
 };
 Rccl g_rccl;
 std::mutex g_rccl_mutex;
-std::string g_comm_error;
+// Last error of the communicator entry points. Written from any thread under g_error_mutex; pbrt_hip_comm_last_error
+// hands out a copy owned by the calling thread, so a concurrent writer cannot pull the buffer from under a reader.
+std::mutex g_error_mutex;
+std::string g_comm_error_text;
+void set_comm_error(const std::string& text) {
+    std::lock_guard<std::mutex> lock(g_error_mutex);
+    g_comm_error_text = text;
+}
 
 template <class F>
 bool bind(void* h, const char* name, F* fn) {
@@ -43,8 +50,14 @@ Rccl* rccl() {
     // Python host with PyTorch's bundled one besides /opt/rocm's), and RCCL on top of the other stack's runtime
     // fails in ncclCommInitRank. Look next to the loaded libamdhip64 first.
     void* h = nullptr;
+    // a copy the process has already loaded (PyTorch's, the host renderer's) comes first: two RCCLs in one process
+    // would each set up their own transport state
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+        if (h) break;
+    }
     Dl_info info;
-    if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+    if (!h && dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
         std::string dir(info.dli_fname);
         size_t slash = dir.rfind('/');
         if (slash != std::string::npos) {
@@ -84,24 +97,29 @@ struct PbrtHipComm {
 
 static_assert(sizeof(ncclUniqueId) == PBRT_HIP_COMM_ID_BYTES, "communicator id size");
 
-extern "C" const char* pbrt_hip_comm_last_error(void) { return g_comm_error.c_str(); }
+extern "C" const char* pbrt_hip_comm_last_error(void) {
+    static thread_local std::string mine;
+    std::lock_guard<std::mutex> lock(g_error_mutex);
+    mine = g_comm_error_text;
+    return mine.c_str();
+}
 
 extern "C" int pbrt_hip_comm_unique_id(uint8_t id[PBRT_HIP_COMM_ID_BYTES]) {
     if (!id) return PBRT_HIP_ERR_INVALID;
     Rccl* r = rccl();
     if (!r) {
-        g_comm_error = g_rccl.error;
+        set_comm_error(g_rccl.error);
         return PBRT_HIP_ERR_DEVICE;
     }
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
-        g_comm_error = "no HIP device visible: RCCL communicators need one GPU per process";
+        set_comm_error("no HIP device visible: RCCL communicators need one GPU per process");
         return PBRT_HIP_ERR_NO_DEVICE;
     }
     ncclUniqueId uid;
     ncclResult_t e = r->GetUniqueId(&uid);
     if (e != ncclSuccess) {
-        g_comm_error = std::string("ncclGetUniqueId: ") + r->GetErrorString(e);
+        set_comm_error(std::string("ncclGetUniqueId: ") + r->GetErrorString(e));
         return PBRT_HIP_ERR_DEVICE;
     }
     std::memcpy(id, &uid, sizeof(uid));
@@ -112,17 +130,17 @@ extern "C" int pbrt_hip_comm_create(PbrtHipContext* ctx, int32_t world, int32_t 
                                     PbrtHipComm** out) {
     if (out) *out = nullptr;
     if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) {
-        g_comm_error = "pbrt_hip_comm_create: bad argument";
+        set_comm_error("pbrt_hip_comm_create: bad argument");
         return PBRT_HIP_ERR_INVALID;
     }
     PB_LOCK(ctx);
     Rccl* r = rccl();
     if (!r) {
-        g_comm_error = ctx->last_error = g_rccl.error;
+        set_comm_error(ctx->last_error = g_rccl.error);
         return PBRT_HIP_ERR_DEVICE;
     }
     if (hipSetDevice(ctx->device) != hipSuccess) {
-        g_comm_error = ctx->last_error = "hipSetDevice failed";
+        set_comm_error(ctx->last_error = "hipSetDevice failed");
         return PBRT_HIP_ERR_DEVICE;
     }
     ncclUniqueId uid;
@@ -130,7 +148,7 @@ extern "C" int pbrt_hip_comm_create(PbrtHipContext* ctx, int32_t world, int32_t 
     ncclComm_t comm = nullptr;
     ncclResult_t e = r->CommInitRank(&comm, world, uid, rank);
     if (e != ncclSuccess) {
-        g_comm_error = ctx->last_error = std::string("ncclCommInitRank: ") + r->GetErrorString(e);
+        set_comm_error(ctx->last_error = std::string("ncclCommInitRank: ") + r->GetErrorString(e));
         return PBRT_HIP_ERR_DEVICE;
     }
     PbrtHipComm* c = new PbrtHipComm;
@@ -145,7 +163,11 @@ extern "C" int pbrt_hip_comm_create(PbrtHipContext* ctx, int32_t world, int32_t 
 extern "C" void pbrt_hip_comm_destroy(PbrtHipComm* comm) {
     if (!comm) return;
     Rccl* r = rccl();
-    if (r && comm->comm) (void)r->CommDestroy(comm->comm);
+    {
+        PB_LOCK(comm->ctx);  // not while a reduce of this context is in flight, and on the context's device
+        (void)hipSetDevice(comm->ctx->device);
+        if (r && comm->comm) (void)r->CommDestroy(comm->comm);
+    }
     delete comm;
 }
 
@@ -153,7 +175,7 @@ extern "C" void pbrt_hip_comm_destroy(PbrtHipComm* comm) {
 // afterwards (ncclReduce), root < 0: every rank's does (ncclAllReduce). Returns after the stream has drained.
 extern "C" int pbrt_hip_film_reduce(PbrtHipComm* comm, float* d_film_xyzw, int64_t n_pixels, int32_t root) {
     if (!comm || !d_film_xyzw || n_pixels < 0 || root >= comm->world) {
-        g_comm_error = "pbrt_hip_film_reduce: bad argument";
+        set_comm_error("pbrt_hip_film_reduce: bad argument");
         return PBRT_HIP_ERR_INVALID;
     }
     Rccl* r = rccl();
@@ -166,12 +188,12 @@ extern "C" int pbrt_hip_film_reduce(PbrtHipComm* comm, float* d_film_xyzw, int64
     ncclResult_t e = root >= 0 ? r->Reduce(d_film_xyzw, d_film_xyzw, count, ncclFloat32, ncclSum, root, comm->comm, ctx->stream)
                                : r->AllReduce(d_film_xyzw, d_film_xyzw, count, ncclFloat32, ncclSum, comm->comm, ctx->stream);
     if (e != ncclSuccess) {
-        g_comm_error = ctx->last_error = std::string(root >= 0 ? "ncclReduce: " : "ncclAllReduce: ") + r->GetErrorString(e);
+        set_comm_error(ctx->last_error = std::string(root >= 0 ? "ncclReduce: " : "ncclAllReduce: ") + r->GetErrorString(e));
         return PBRT_HIP_ERR_DEVICE;
     }
     hipError_t he = hipStreamSynchronize(ctx->stream);
     if (he != hipSuccess) {
-        g_comm_error = ctx->last_error = std::string("hipStreamSynchronize after the film reduce: ") + hipGetErrorString(he);
+        set_comm_error(ctx->last_error = std::string("hipStreamSynchronize after the film reduce: ") + hipGetErrorString(he));
         return PBRT_HIP_ERR_DEVICE;
     }
     return PBRT_HIP_OK;

@@ -5,15 +5,19 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "scene.h"
 #include "trace.h"
 #include "wavefront.h"
+
+static constexpr double kWavefrontDeadlineSeconds = 120.0;  // no wavefront of a render takes this long
 
 using namespace pb;
 
@@ -728,17 +732,16 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         for (int i = 0; i < 3; ++i) sc.n_voxel[i] = s->spatial_voxels[i];
     }
 
-    hipEvent_t e_begin, e_end, e_t0, e_t1;
-    HIP_TRY(ctx, hipEventCreate(&e_begin));
-    HIP_TRY(ctx, hipEventCreate(&e_end));
-    HIP_TRY(ctx, hipEventCreate(&e_t0));
-    HIP_TRY(ctx, hipEventCreate(&e_t1));
+    hipEvent_t e_begin = nullptr, e_end = nullptr, e_t0 = nullptr, e_t1 = nullptr;
     auto cleanup_events = [&]() {
-        (void)hipEventDestroy(e_begin);
-        (void)hipEventDestroy(e_end);
-        (void)hipEventDestroy(e_t0);
-        (void)hipEventDestroy(e_t1);
+        for (hipEvent_t e : {e_begin, e_end, e_t0, e_t1})
+            if (e) (void)hipEventDestroy(e);
     };
+    if (!hip_ok(ctx, hipEventCreate(&e_begin), "hipEventCreate") || !hip_ok(ctx, hipEventCreate(&e_end), "hipEventCreate") ||
+        !hip_ok(ctx, hipEventCreate(&e_t0), "hipEventCreate") || !hip_ok(ctx, hipEventCreate(&e_t1), "hipEventCreate")) {
+        cleanup_events();
+        return PBRT_HIP_ERR_DEVICE;
+    }
     int rc = PBRT_HIP_OK;
 #define RENDER_TRY(call)                                  \
     if (rc == PBRT_HIP_OK && !hip_ok(ctx, (call), #call)) rc = PBRT_HIP_ERR_DEVICE;
@@ -758,6 +761,13 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         pp.y0 = rp.y0;
         pp.x1 = rp.x1;
         pp.y1 = rp.y1;
+        {
+            int32_t sb[4];
+            pbrt_hip_sample_bounds(rp.width, rp.height, frx, fry, sb);
+            pp.sb_x0 = sb[0];
+            pp.sb_y0 = sb[1];
+            pp.sb_w = sb[2] - sb[0];
+        }
         pp.seed = rp.seed;
         pp.max_depth = rp.max_depth;
         pp.rr_threshold = rp.rr_threshold;
@@ -895,10 +905,23 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             RENDER_TRY(hipMemcpyAsync(ctx->h_counts, q[nxt].counts64, sizeof(counts), hipMemcpyDeviceToHost, st));
             RENDER_TRY(hipEventRecord(ctx->ev_sync, st));
             if (rc == PBRT_HIP_OK) {
+                // spin on the event (a blocking sync costs a scheduler wake-up per wavefront), but not for ever: a kernel
+                // that never finishes must surface as an error of this call, with the context's lock released
                 hipError_t qe;
+                const auto spin_start = std::chrono::steady_clock::now();
+                uint32_t polls = 0;
                 while ((qe = hipEventQuery(ctx->ev_sync)) == hipErrorNotReady) {
+                    if ((++polls & 0xfffu) == 0) {
+                        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - spin_start).count();
+                        if (waited > kWavefrontDeadlineSeconds) {
+                            ctx->last_error = "a wavefront did not finish within the deadline (hung kernel?)";
+                            rc = PBRT_HIP_ERR_DEVICE;
+                            break;
+                        }
+                        if (waited > 0.05) std::this_thread::yield();  // long wavefronts: stop burning a core
+                    }
                 }
-                RENDER_TRY(qe);
+                if (rc == PBRT_HIP_OK) RENDER_TRY(qe);
             }
             counts[0] = ctx->h_counts[0];
             counts[1] = ctx->h_counts[1];
@@ -941,7 +964,9 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         }
     }
     RENDER_TRY(hipEventRecord(e_end, st));
-    RENDER_TRY(hipStreamSynchronize(st));
+    if (rc == PBRT_HIP_OK || ctx->last_error.find("deadline") == std::string::npos)
+        (void)hipStreamSynchronize(st);  // also after an error: nothing of this call may still run when its buffers go back
+                                         // to the cache (after the deadline the stream is presumed hung: do not wait on it)
     if (rc == PBRT_HIP_OK) {
         float ms = 0.0f;
         RENDER_TRY(hipEventElapsedTime(&ms, e_begin, e_end));

@@ -171,7 +171,7 @@ __global__ void k_sampler_tables(PassParams pp, TileList tiles) {
     const SamplerParams& sp = pp.smp;
     PixelColumn c{sp.tables + pix, (size_t)pp.n_pix};
     Rng rng;
-    rng_set_sequence(rng, pp.seed ^ (0x4000000000000000ULL | (uint64_t)((int64_t)y * pp.width + x)));
+    rng_set_sequence(rng, pp.seed ^ (0x4000000000000000ULL | (uint64_t)pixel_number(pp, x, y)));
     const int n = pp.spp;
     if (sp.kind == PBRT_SAMPLER_STRATIFIED) {
         for (int d = 0; d < sp.n_dims; ++d) {  // stratified_sample_1d (sampling.rs:11-17) + shuffle

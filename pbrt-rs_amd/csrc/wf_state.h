@@ -78,6 +78,7 @@ struct PassParams {
     int spp;           // total samples per pixel (RNG keying)
     int width, height;
     int x0, y0, x1, y1;
+    int sb_x0, sb_y0, sb_w;  // Film::get_sample_bounds of the whole film: origin and width (pixel_number)
     uint64_t seed;
     int max_depth;
     float rr_threshold;
@@ -120,8 +121,14 @@ PB_DEV uint32_t ray_sort_cell(float ox, float oy, float oz, const float* lo, con
     return code;
 }
 
+// The pixel's number over the film's sample bounds (film.rs:76-81): with the 0.5 box filter that is y * width + x;
+// with a wider filter the pixels sampled left of / above the film get numbers of their own ((width, y) and (0, y + 1)
+// would share y * width + x, and with it their random streams).
+PB_DEV int64_t pixel_number(const PassParams& pp, int x, int y) {
+    return (int64_t)(y - pp.sb_y0) * pp.sb_w + (x - pp.sb_x0);
+}
 PB_DEV uint64_t sample_sequence(const PassParams& pp, int x, int y, int s) {
-    return pp.seed ^ (uint64_t)(((int64_t)y * pp.width + x) * (int64_t)pp.spp + s);
+    return pp.seed ^ (uint64_t)(pixel_number(pp, x, y) * (int64_t)pp.spp + s);
 }
 
 // Block-aggregated queue append. Same-address atomics saturate near 10^2 per microsecond on the
