@@ -347,6 +347,16 @@ def main():
                 "frac": round(traffic / trace_s_per_launch / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, commit {rec['commit']}, {rec['profile']}" if rec else why_not),
             }
+            # the issue side, from the same committed profile: vector wave-instructions per launch against one per two
+            # cycles per SIMD (a wave64 instruction occupies a SIMD-32 for two cycles), 1024 SIMDs at 2.4 GHz
+            valu = None
+            if rec and rec.get("valu_insts_per_launch"):
+                peak_ips = 256 * 4 * 2.4e9 / 2
+                ips = rec["valu_insts_per_launch"] / trace_s_per_launch
+                valu = {"wave_insts_per_launch": round(rec["valu_insts_per_launch"]), "achieved_G_insts_per_s": round(ips / 1e9, 1),
+                        "peak_G_insts_per_s": round(peak_ips / 1e9, 1), "frac": round(ips / peak_ips, 4),
+                        "lane_utilisation": round(rec["valu_lane_utilisation"], 3) if rec.get("valu_lane_utilisation") else None,
+                        "source": f"rocprofv3 --pmc SQ_INSTS_VALU ..., commit {rec['commit']}"}
             roofline = {
                 "kernel": kernel,
                 # the binding ceiling: how fast the chip can walk dependent 48-B record fetches from a table of this size.
@@ -357,6 +367,7 @@ def main():
                 "record_bytes": rec_bytes, "records_per_launch": round(rec_per_launch), "table_bytes": table_bytes,
                 "ceilings_G_records_per_s": {k: round(v, 2) for k, v in ceil.items()},
                 "hbm": hbm,
+                "valu": valu,
                 # SURVEY 8(d)'s figure, kept as a reported quantity: the bytes the REFERENCE's loop touches for these rays
                 "algorithmic": {
                     "bytes_per_launch": round(alg_bytes / max(launches_per_frame, 1)),

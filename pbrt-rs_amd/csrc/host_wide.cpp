@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -111,9 +112,23 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
     }
     if ((int64_t)n_slots >= (1ll << 29)) return "too many triangles for 30-bit wide references";
     // records in breadth-first order: the interior children of a record are consecutive
+    // A record's index is fixed when its parent is laid out (the parent's interior children take the next free indices,
+    // contiguously); the ORDER in which records are laid out decides which records and triangles end up near each other:
+    // first-in-first-out = breadth-first (levels contiguous), last-in-first-out = depth-first (subtrees nearly contiguous).
+    const char* order_env = std::getenv("PBRT_HIP_WIDE_ORDER");
+    const bool depth_first = order_env && order_env[0] == 'd';
     std::vector<int32_t> roots;  // binary node of every record
     roots.push_back(0);
-    for (size_t w = 0; w < roots.size(); ++w) {
+    std::vector<size_t> work{0};
+    size_t work_head = 0;
+    while (work_head < work.size()) {
+        size_t w;
+        if (depth_first) {
+            w = work.back();
+            work.pop_back();
+        } else {
+            w = work[work_head++];
+        }
         const int32_t i = roots[w];
         const PbrtLinearBVHNode& nd = nodes[i];
         int32_t slot_node[4] = {-1, -1, -1, -1};
@@ -145,6 +160,7 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
                 m[s] = 0x80u | (uint32_t)n_interior;
                 ++n_interior;
                 roots.push_back(slot_node[s]);
+                work.push_back(roots.size() - 1);
             }
         }
         float base[3];
@@ -189,7 +205,10 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
         for (int k = 0; k < 6; ++k) rec[4 + k] = q[k];
         rec[10] = (uint32_t)first_child;
         rec[11] = ~(uint32_t)(first_tri << 2);
-        out->nodes.insert(out->nodes.end(), rec, rec + kWideNodeDwords);
+        if (depth_first && n_interior > 1)  // walk the first interior child first, as BVHAccel's flattening does
+            std::reverse(work.end() - n_interior, work.end());
+        if (out->nodes.size() < roots.size() * kWideNodeDwords) out->nodes.resize(roots.size() * kWideNodeDwords, 0u);
+        std::memcpy(&out->nodes[w * kWideNodeDwords], rec, sizeof(rec));
         if (roots.size() >= (1u << 31)) return "too many records";
     }
     out->root_ref = 0;

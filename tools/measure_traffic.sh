@@ -12,12 +12,22 @@ grep '^{' $OUT/stats.log | tail -1 > $OUT/bench_line_under_rocprof.json
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -o $C -- $CMD > $OUT/$C.log 2>&1 || { tail -5 $OUT/$C.log; exit 1; }
 done
+# the issue side of the same launches: vector instructions, the lane-cycles they kept busy, wave residency
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/SQ -o SQ -- $CMD > $OUT/SQ.log 2>&1 || { tail -5 $OUT/SQ.log; exit 1; }
 python3 - <<'PY'
 import csv, glob, json, os, re, subprocess
 out = "gpurun_out/traffic"
 def per_kernel(counter):
     tot, n = {}, {}
     for f in glob.glob(f"{out}/{counter}/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f, newline="")):
+            if row["Counter_Name"] != counter: continue
+            k = row["Kernel_Name"]
+            tot[k] = tot.get(k, 0.0) + float(row["Counter_Value"]); n[k] = n.get(k, 0) + 1
+    return tot, n
+def per_kernel_in(sub, counter):
+    tot, n = {}, {}
+    for f in glob.glob(f"{out}/{sub}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f, newline="")):
             if row["Counter_Name"] != counter: continue
             k = row["Kernel_Name"]
@@ -37,7 +47,15 @@ if stats:
         if row["Name"] == kf: avg_ns = float(row["AverageNs"]); calls = int(row["Calls"])
     os.system(f"cp {stats[0]} profiles/r02_bench_kernel_stats.csv")
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("PB_COMMIT", "unknown")
+sq = {}
+for c in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"):
+    t, n = per_kernel_in("SQ", c)
+    if kf in t: sq[c] = t[kf] / n[kf]
 rec = {
+    "valu_insts_per_launch": sq.get("SQ_INSTS_VALU"), "salu_insts_per_launch": sq.get("SQ_INSTS_SALU"),
+    "valu_lane_utilisation": (sq["SQ_THREAD_CYCLES_VALU"] / (sq["SQ_INSTS_VALU"] * 64)) if sq.get("SQ_INSTS_VALU") else None,
+    "wave_cycles_waiting_fraction": (sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAVE_CYCLES") else None,
+    "gpu_cycles_per_launch": (sq["GRBM_GUI_ACTIVE"] / 8) if sq.get("GRBM_GUI_ACTIVE") else None,
     "bytes_per_launch": round(fb + wb), "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
     "kernel_name": kf, "launches_profiled": nf[kf], "avg_launch_ns_under_kernel_trace": avg_ns,
     "config": {"n_gpus": 1, "tris": 1000000, "width": 1920, "height": 1080, "spp": 64, "max_depth": 5,
