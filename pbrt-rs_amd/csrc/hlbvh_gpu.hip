@@ -768,6 +768,24 @@ int hlbvh_build_scene_tree(PbrtHipContext* ctx, const float* positions, int32_t 
         (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
         out->convert_ms = ms;
     }
+    {
+        // The wide records are laid out on the host (host_wide.cpp): bring the flat tree and the triangle records back.
+        // Costs a D2H copy (80 B per triangle) and ~0.1 s per million triangles of host work on top of the device build;
+        // PBRT_HIP_WIDE_DEVICE_TREES=0 keeps scene setup at the device build's few milliseconds (binary records only).
+        const char* w1 = std::getenv("PBRT_HIP_WIDE");
+        const char* w2 = std::getenv("PBRT_HIP_WIDE_DEVICE_TREES");
+        if (!(w1 && w1[0] == '0') && !(w2 && w2[0] == '0')) {
+            out->h_nodes.resize(n_nodes);
+            out->h_tris.resize((size_t)n * 12);
+            e = hipMemcpy(out->h_nodes.data(), d_nodes, (size_t)n_nodes * sizeof(PbrtLinearBVHNode), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(out->h_tris.data(), p_tris, (size_t)n * 48, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) {
+                release();
+                pb::hip_ok(ctx, e, "hlbvh: copy of the tree for the wide records");
+                return PBRT_HIP_ERR_DEVICE;
+            }
+        }
+    }
     out->inodes = (float4*)p_inodes;
     out->tris = (float4*)p_tris;
     out->slot_prim = (int*)p_slot_prim;

@@ -51,8 +51,9 @@ double next_down(double x) { return std::nextafter(x, -HUGE_VAL); }
 }  // namespace
 
 const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, const float* tris, int32_t n_slots,
-                            WideTree* out) {
+                            WideTree* out, const WideBase& base_of) {
     if (n_nodes <= 0 || n_slots <= 0) return "empty tree";
+    const bool opaque = tris == nullptr;
     // ---- the properties the exactness argument needs: checked, not assumed ----
     for (int32_t i = 0; i < n_nodes; ++i) {
         const PbrtLinearBVHNode& nd = nodes[i];
@@ -63,7 +64,7 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
         }
         if (nd.n_primitives > 0) {
             if (nd.n_primitives > 4) return "leaf with more than 4 primitives";
-            if (nd.n_primitives == 1) {
+            if (nd.n_primitives == 1 && !opaque) {
                 // the single-triangle leaf box is recomputed from the vertices by the kernel: it has to BE the tight box
                 const float* t = tris + 12 * (size_t)nd.offset;
                 for (int k = 0; k < 3; ++k) {
@@ -80,24 +81,30 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
                         return "child box not inside its parent's";
         }
     }
-    auto leaf_ref = [](int64_t first_wide, int n) -> int32_t { return ~(int32_t)((first_wide << 2) | (int64_t)(n - 1)); };
-    out->tris.assign((size_t)n_slots * 12, 0.0f);
+    auto leaf_ref = [&](int64_t first_wide, int n) -> int32_t { return ~(int32_t)(((first_wide + base_of.tri) << 2) | (int64_t)(n - 1)); };
+    if (!opaque) out->tris.assign((size_t)n_slots * 12, 0.0f);
+    if (opaque) out->order.assign((size_t)n_slots, -1);
     out->leaf_boxes.assign((size_t)n_slots * 8, 0.0f);
     int64_t tri_cursor = 0;
     auto emit_leaf = [&](const PbrtLinearBVHNode& lf) -> int64_t {  // copies the leaf's triangles, returns their first wide position
         int64_t first = tri_cursor;
         for (int j = 0; j < lf.n_primitives; ++j) {
+            if (opaque) {
+                out->order[(size_t)tri_cursor] = lf.offset + j + base_of.slot;
+                ++tri_cursor;
+                continue;
+            }
             const float* src = tris + 12 * (size_t)(lf.offset + j);
             float* dst = &out->tris[12 * (size_t)tri_cursor];
             std::memcpy(dst, src, 36);
-            int32_t slot = lf.offset + j;
+            int32_t slot = lf.offset + j + base_of.slot;
             int32_t flags;
             std::memcpy(&flags, src + 11, 4);
             std::memcpy(dst + 9, &slot, 4);
             std::memcpy(dst + 10, &flags, 4);
             ++tri_cursor;
         }
-        if (lf.n_primitives >= 2) {
+        if (lf.n_primitives >= 2 || opaque) {
             float* b = &out->leaf_boxes[8 * (size_t)first];
             std::memcpy(b, lf.bounds_min, 12);
             std::memcpy(b + 4, lf.bounds_max, 12);
@@ -105,12 +112,15 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
         return first;
     };
     if (nodes[0].n_primitives > 0) {  // the whole tree is one leaf
-        out->root_ref = leaf_ref(emit_leaf(nodes[0]), nodes[0].n_primitives);
+        {
+            const int64_t first = emit_leaf(nodes[0]);
+            out->root_ref = leaf_ref(first, nodes[0].n_primitives);
+        }
         out->nodes.assign(kWideNodeDwords, 0u);
         out->n_records = 0;
         return nullptr;
     }
-    if ((int64_t)n_slots >= (1ll << 29)) return "too many triangles for 30-bit wide references";
+    if ((int64_t)n_slots + base_of.tri >= (1ll << 29)) return "too many triangles for 30-bit wide references";
     // records in breadth-first order: the interior children of a record are consecutive
     // A record's index is fixed when its parent is laid out (the parent's interior children take the next free indices,
     // contiguously); the ORDER in which records are laid out decides which records and triangles end up near each other:
@@ -203,15 +213,15 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
         rec[3] = ((uint32_t)e[0] & 63u) | ((uint32_t)e[1] & 63u) << 6 | ((uint32_t)e[2] & 63u) << 12 |
                  (uint32_t)nd.axis << 18 | (uint32_t)axis_c[0] << 20 | (uint32_t)axis_c[1] << 22 | m[3] << 24;
         for (int k = 0; k < 6; ++k) rec[4 + k] = q[k];
-        rec[10] = (uint32_t)first_child;
-        rec[11] = ~(uint32_t)(first_tri << 2);
+        rec[10] = (uint32_t)(first_child + base_of.record);
+        rec[11] = ~(uint32_t)((first_tri + base_of.tri) << 2);
         if (depth_first && n_interior > 1)  // walk the first interior child first, as BVHAccel's flattening does
             std::reverse(work.end() - n_interior, work.end());
         if (out->nodes.size() < roots.size() * kWideNodeDwords) out->nodes.resize(roots.size() * kWideNodeDwords, 0u);
         std::memcpy(&out->nodes[w * kWideNodeDwords], rec, sizeof(rec));
         if (roots.size() >= (1u << 31)) return "too many records";
     }
-    out->root_ref = 0;
+    out->root_ref = base_of.record;
     out->n_records = (int)roots.size();
     {
         // a record with k children leaves at most k - 1 of them on the stack while the first is being walked
@@ -223,7 +233,7 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
             for (int s = 0; s < 4; ++s) {
                 if (m[s] == 0xffu) continue;
                 ++k;
-                if (m[s] & 0x80u) deepest = std::max(deepest, need[rec[10] + (m[s] & 3u)]);
+                if (m[s] & 0x80u) deepest = std::max(deepest, need[rec[10] - (uint32_t)base_of.record + (m[s] & 3u)]);
             }
             need[w] = k - 1 + deepest;
         }

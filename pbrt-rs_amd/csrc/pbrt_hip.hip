@@ -689,6 +689,7 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
 
     DevSceneData& d = s->d;
     std::memset(&d, 0, sizeof(d));
+    std::vector<float> top_slot_records;  // two-level scenes: the 112-B records of the top-level leaf slots
     if (dt) {
         d.bvh.inodes = dt->inodes;
         d.bvh.tris = dt->tris;
@@ -714,6 +715,10 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     d.bvh.instanced = instanced ? 1 : 0;
     if (instanced) {
         d.bvh.blas_count_bits = obj.count_bits;
+        d.bvh.general_top = (ia.n_objects > 1 || ia.n_world_tris > 0) ? 1 : 0;
+        d.bvh.blas_root_ref = obj_trees[0].root_ref;
+        std::memcpy(d.bvh.blas_root_min, ia.objects[0].nodes[0].bounds_min, 12);
+        std::memcpy(d.bvh.blas_root_max, ia.objects[0].nodes[0].bounds_max, 12);
         // object table: (root box min, root reference) (root box max, -)
         std::vector<float> objs((size_t)ia.n_objects * 8, 0.0f);
         for (int32_t k = 0; k < ia.n_objects; ++k) {
@@ -726,7 +731,8 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         d.bvh.objects = (const float4*)dev_upload(s, objs.data(), objs.size(), &ok);
         // records of the top-level leaf slots: to_object rows 0-2, to_world rows 0-2, (material, instance id, object, kind);
         // a world-space triangle beside the instances: kind 1, its leaf slot in the third field
-        std::vector<float> inst((size_t)n_top * 28, 0.0f);
+        std::vector<float>& inst = top_slot_records;
+        inst.assign((size_t)n_top * 28, 0.0f);
         std::vector<int32_t> slot_inst(n_top);
         std::vector<char> seen(n_top, 0);
         for (int32_t slot = 0; slot < n_top; ++slot) {
@@ -758,11 +764,65 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         const char* wide_env = std::getenv("PBRT_HIP_WIDE");
         if (wide_env && wide_env[0] == '0') {
             s->wide_reason = "disabled by PBRT_HIP_WIDE=0";
-        } else if (instanced || sa.n > 0 || dt) {
-            s->wide_reason = instanced ? "instanced scene" : (dt ? "tree built on the device" : "scene with spheres");
+        } else if (sa.n > 0 || (dt && dt->h_nodes.empty())) {
+            s->wide_reason = dt ? "tree built on the device (PBRT_HIP_WIDE_DEVICE_TREES=0)" : "scene with spheres";
+        } else if (instanced) {
+            // two levels: the top-level tree's records first (its leaves keep their exact boxes and name top-level
+            // primitives in wide order), then every object aggregate's; one triangle / leaf-box array for all objects
+            pb::WideTree top;
+            const char* why = pb::build_wide_tree(ia.tlas_nodes, ia.n_tlas_nodes, nullptr, n_top, &top);
+            std::vector<pb::WideTree> wobj(ia.n_objects);
+            int record_base = why ? 0 : top.n_records, deepest = 0;
+            for (int32_t k = 0; k < ia.n_objects && !why; ++k) {
+                pb::WideBase b;
+                b.record = record_base;
+                b.tri = b.slot = ia.obj_tri_offset[k];
+                why = pb::build_wide_tree(ia.objects[k].nodes, ia.objects[k].n_nodes, tris.data() + 12 * (size_t)ia.obj_tri_offset[k],
+                                          ia.objects[k].n_tris, &wobj[k], b);
+                if (!why) {
+                    record_base += wobj[k].n_records;
+                    deepest = std::max(deepest, wobj[k].stack_need);
+                }
+            }
+            if (why) {
+                s->wide_reason = why;
+            } else {
+                std::vector<uint32_t> wn;
+                wn.insert(wn.end(), top.nodes.begin(), top.nodes.begin() + (size_t)top.n_records * kWideNodeDwords);
+                std::vector<float> wt((size_t)n_prims * 12, 0.0f), wb((size_t)n_prims * 8, 0.0f), wo((size_t)ia.n_objects * 8, 0.0f);
+                for (int32_t k = 0; k < ia.n_objects; ++k) {
+                    wn.insert(wn.end(), wobj[k].nodes.begin(), wobj[k].nodes.begin() + (size_t)wobj[k].n_records * kWideNodeDwords);
+                    std::memcpy(&wt[12 * (size_t)ia.obj_tri_offset[k]], wobj[k].tris.data(), wobj[k].tris.size() * 4);
+                    std::memcpy(&wb[8 * (size_t)ia.obj_tri_offset[k]], wobj[k].leaf_boxes.data(), wobj[k].leaf_boxes.size() * 4);
+                    const PbrtLinearBVHNode& root = ia.objects[k].nodes[0];
+                    float* r = &wo[(size_t)k * 8];
+                    std::memcpy(r, root.bounds_min, 12);
+                    std::memcpy(r + 3, &wobj[k].root_ref, 4);
+                    std::memcpy(r + 4, root.bounds_max, 12);
+                }
+                if (wn.empty()) wn.assign(kWideNodeDwords, 0u);
+                std::vector<float> ws((size_t)n_top * 28);
+                for (int32_t pos = 0; pos < n_top; ++pos) {
+                    const int32_t slot = top.order[pos];
+                    std::memcpy(&ws[(size_t)pos * 28], &top_slot_records[(size_t)slot * 28], 112);
+                    std::memcpy(&ws[(size_t)pos * 28 + 25], &slot, 4);  // second meta field: the binary-layout top slot (hit records name it)
+                }
+                s->wide.nodes = (const uint4*)dev_upload(s, wn.data(), wn.size(), &ok);
+                s->wide.tris = (const float4*)dev_upload(s, wt.data(), wt.size(), &ok);
+                s->wide.leaf_boxes = (const float4*)dev_upload(s, wb.data(), wb.size(), &ok);
+                s->wide.top_slots = (const float4*)dev_upload(s, ws.data(), ws.size(), &ok);
+                s->wide.top_boxes = (const float4*)dev_upload(s, top.leaf_boxes.data(), top.leaf_boxes.size(), &ok);
+                s->wide.objects = (const float4*)dev_upload(s, wo.data(), wo.size(), &ok);
+                s->wide.slot_tris = d.bvh.tris;
+                s->wide.root_ref = top.root_ref;
+                s->n_wide_records = record_base;
+                s->has_wide = true;
+                spill_entries = std::max(spill_entries, top.stack_need + deepest + 2 - kWideStackLds);
+            }
         } else {
             pb::WideTree wt;
-            const char* why = pb::build_wide_tree(nodes, n_nodes, tris.data(), n_prims, &wt);
+            const char* why = dt ? pb::build_wide_tree(dt->h_nodes.data(), n_nodes, dt->h_tris.data(), n_prims, &wt)
+                                 : pb::build_wide_tree(nodes, n_nodes, tris.data(), n_prims, &wt);
             if (why) {
                 s->wide_reason = why;
             } else {
@@ -918,18 +978,19 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_I
 }
 
 // the same batch over the 4-wide records (trace_wide.h), and the follow-up over the rays that kernel left out
-template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock, COUNT ? 4 : PB_WIDE_WAVES)
+template <bool ANY, bool COUNT, bool INST = false>
+__global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES)
     k_intersect_batch_wide(WideTrees wt, BatchRayIO<ANY> io, unsigned int* work_counter, unsigned long long* counters) {
     __shared__ uint2 lds_stack[kWideStackLds * kTraceBlock];
-    trace_wide<BatchRayIO<ANY>, COUNT>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x, counters);
+    trace_wide<BatchRayIO<ANY>, COUNT, INST>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x,
+                                             counters);
 }
-template <bool ANY>
-__global__ void __launch_bounds__(kTraceBlock, PB_TRACE_WAVES)
+template <bool ANY, bool INST = false>
+__global__ void __launch_bounds__(kTraceBlock, INST ? PB_INST_WAVES : PB_TRACE_WAVES)
     k_intersect_batch_special(DevBVH bvh, SpecialListIO<BatchRayIO<ANY>> io, unsigned int* work_counter) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
-    trace_persistent<SpecialListIO<BatchRayIO<ANY>>, false, false, false>(bvh, io, work_counter, lds_stack + threadIdx.x,
-                                                                          blockIdx.x * kTraceBlock + threadIdx.x, nullptr);
+    trace_persistent<SpecialListIO<BatchRayIO<ANY>>, false, INST, false>(bvh, io, work_counter, lds_stack + threadIdx.x,
+                                                                         blockIdx.x * kTraceBlock + threadIdx.x, nullptr);
 }
 
 template <bool ANY>
@@ -959,15 +1020,22 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
             WideTrees wt = s->wide;
             wt.special_list = ctx->d_special_list;
             wt.special_count = ctx->d_work_counter + kSpecialCount;
-            if (ctx->count_traversal == 2)
-                hipLaunchKernelGGL((k_intersect_batch_wide<ANY, true>), dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0,
-                                   ctx->stream, wt, io, ctx->d_work_counter, ctx->d_counters);
-            else
-                hipLaunchKernelGGL((k_intersect_batch_wide<ANY, false>), dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0,
-                                   ctx->stream, wt, io, ctx->d_work_counter, ctx->d_counters);
             SpecialListIO<BatchRayIO<ANY>> sio{io, ctx->d_special_list, ctx->d_work_counter + kSpecialCount};
-            hipLaunchKernelGGL((k_intersect_batch_special<ANY>), grid, block, 0, ctx->stream, s->d.bvh, sio,
-                               ctx->d_work_counter + kFollowUpCounter);
+            if (inst) {
+                hipLaunchKernelGGL((k_intersect_batch_wide<ANY, false, true>), dim3(persistent_grid(s, PB_WIDE_INST_WAVES, kWideStackLds)),
+                                   block, 0, ctx->stream, wt, io, ctx->d_work_counter, ctx->d_counters);
+                hipLaunchKernelGGL((k_intersect_batch_special<ANY, true>), grid, block, 0, ctx->stream, s->d.bvh, sio,
+                                   ctx->d_work_counter + kFollowUpCounter);
+            } else {
+                if (ctx->count_traversal == 2)
+                    hipLaunchKernelGGL((k_intersect_batch_wide<ANY, true>), dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0,
+                                       ctx->stream, wt, io, ctx->d_work_counter, ctx->d_counters);
+                else
+                    hipLaunchKernelGGL((k_intersect_batch_wide<ANY, false>), dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0,
+                                       ctx->stream, wt, io, ctx->d_work_counter, ctx->d_counters);
+                hipLaunchKernelGGL((k_intersect_batch_special<ANY>), grid, block, 0, ctx->stream, s->d.bvh, sio,
+                                   ctx->d_work_counter + kFollowUpCounter);
+            }
         } else if (s->d.bvh.has_spheres) {  // single-level scenes only (checked at creation)
             if (ctx->count_traversal == 1)
                 hipLaunchKernelGGL((k_intersect_batch<ANY, true, false, true>), grid, block, 0, ctx->stream, s->d.bvh, io,

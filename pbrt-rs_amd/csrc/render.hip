@@ -838,14 +838,21 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                         WideTrees wt = s->wide;
                         wt.special_list = special_list;
                         wt.special_count = ctx->d_work_counter + kSpecialCount;
-                        if (ctx->count_traversal == 2)
-                            hipLaunchKernelGGL(k_trace_wide<true>, dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0, st, wt, ps,
-                                               trace_queue, n_trace, ctx->d_work_counter, segments, ctx->d_counters);
-                        else
-                            hipLaunchKernelGGL(k_trace_wide<false>, dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0, st, wt, ps,
-                                               trace_queue, n_trace, ctx->d_work_counter, segments, ctx->d_counters);
-                        hipLaunchKernelGGL(k_trace_special, grid, block, 0, st, s->d.bvh, ps, trace_queue, n_trace, special_list,
-                                           ctx->d_work_counter + kSpecialCount, ctx->d_work_counter + kFollowUpCounter);
+                        if (inst) {
+                            hipLaunchKernelGGL((k_trace_wide<false, true>), dim3(persistent_grid(s, PB_WIDE_INST_WAVES, kWideStackLds)), block, 0,
+                                               st, wt, ps, trace_queue, n_trace, ctx->d_work_counter, segments, ctx->d_counters);
+                            hipLaunchKernelGGL(k_trace_special<true>, grid, block, 0, st, s->d.bvh, ps, trace_queue, n_trace, special_list,
+                                               ctx->d_work_counter + kSpecialCount, ctx->d_work_counter + kFollowUpCounter);
+                        } else {
+                            if (ctx->count_traversal == 2)
+                                hipLaunchKernelGGL(k_trace_wide<true>, dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0, st, wt,
+                                                   ps, trace_queue, n_trace, ctx->d_work_counter, segments, ctx->d_counters);
+                            else
+                                hipLaunchKernelGGL(k_trace_wide<false>, dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0, st, wt,
+                                                   ps, trace_queue, n_trace, ctx->d_work_counter, segments, ctx->d_counters);
+                            hipLaunchKernelGGL(k_trace_special<false>, grid, block, 0, st, s->d.bvh, ps, trace_queue, n_trace, special_list,
+                                               ctx->d_work_counter + kSpecialCount, ctx->d_work_counter + kFollowUpCounter);
+                        }
                     } else if (s->d.bvh.has_spheres) {
                         if (ctx->count_traversal == 1)
                             hipLaunchKernelGGL((k_trace<true, false, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,

@@ -159,6 +159,10 @@ struct DeviceTree {
     float root_min[3], root_max[3];
     int root_ref = 0, count_bits = 0, n_interior = 0, n_nodes = 0;
     std::vector<int32_t> light_slot;  // per light: leaf slot of an area light's triangle, -1 otherwise
+    // host copies of the flat node array and the triangle records, for laying the 4-wide records (wide_bvh.h) over the
+    // device-built tree as well; empty when that is switched off (PBRT_HIP_WIDE=0 / PBRT_HIP_WIDE_DEVICE_TREES=0)
+    std::vector<PbrtLinearBVHNode> h_nodes;
+    std::vector<float> h_tris;
     double build_ms = 0.0;            // tree build; convert_ms: re-layout into the traversal format
     double convert_ms = 0.0;
 };

@@ -166,6 +166,11 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
             n_inst += 1;
             n_node += 1;  // the object aggregate tests its root box (bvh.rs:841-842)
         }
+        if (!bvh.general_top) {
+            if (!root_box_test(s, bvh.blas_root_min, bvh.blas_root_max)) return false;
+            s.cur = bvh.blas_root_ref;
+            return true;
+        }
         const float4* ob = bvh.objects + 2 * (size_t)__float_as_int(m[6].z);
         const float4 o0 = ob[0], o1 = ob[1];
         const float mn[3] = {o0.x, o0.y, o0.z}, mx[3] = {o1.x, o1.y, o1.z};
@@ -363,7 +368,8 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
                 while (w.leaf_next < w.leaf_cnt && !entered && !done) {
                     int slot = w.leaf_first + w.leaf_next;
                     w.leaf_next += 1;
-                    const float4 kind = bvh.instances[7 * (size_t)slot + 6];
+                    float4 kind = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (bvh.general_top) kind = bvh.instances[7 * (size_t)slot + 6];
                     if (__float_as_int(kind.w) == 1) {
                         // a GeometricPrimitive beside the instances (primitive.rs:65-78): the world ray against its triangle
                         const int tslot = __float_as_int(kind.z);

@@ -19,6 +19,9 @@ namespace pb {
 #ifndef PB_WIDE_WAVES
 #define PB_WIDE_WAVES 5
 #endif
+#ifndef PB_WIDE_INST_WAVES
+#define PB_WIDE_INST_WAVES 4
+#endif
 #ifndef PB_WIDE_STACK_LDS
 #define PB_WIDE_STACK_LDS 12
 #endif
@@ -57,7 +60,12 @@ struct SpecialListIO {
 
 // COUNT: also counts what this kernel itself fetches (records stepped, candidate leaves, triangles loaded, rays left to
 // the binary kernel) into counters[4..7]: the inputs of bench.py's gather-rate roofline.
-template <class IO, bool COUNT = false>
+// INST: two-level scenes (primitive.rs:105-159), as trace_persistent's INST: the world ray walks the top-level records; a
+// candidate top-level leaf is confirmed with the reference's slab test on its exact box, its entries are taken in leaf
+// order: a TransformedPrimitive transforms the ray (geometry.rs:865-881) and walks its object's records with a stack
+// floor, a plain triangle is tested in place. An object-space ray the filter's bound does not cover ends the wide
+// traversal of that ray: it goes to the binary kernel like an uncovered world ray.
+template <class IO, bool COUNT = false, bool INST = false>
 PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restrict__ work_counter, uint2* lds_stack,
                        int spill_lane, unsigned long long* counters = nullptr) {
     const uint32_t n = io.n();
@@ -74,6 +82,11 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     const int n_seg = io.segments();
     int seg = (int)(blockIdx.x % (unsigned)n_seg), seg_tries = 0;
     uint32_t c_rec = 0, c_cand = 0, c_tri = 0, c_special = 0;
+    // two-level state (INST)
+    float wox = 0.0f, woy = 0.0f, woz = 0.0f, wdx = 0.0f, wdy = 0.0f, wdz = 0.0f, tmax_world = 0.0f;
+    int leaf_first = 0, leaf_cnt = 0, leaf_next = 0, cur_top_slot = -1, hit_inst = -1, base_sp = 0;
+    bool in_instance = false, hit_here = false;
+    constexpr int kLeaveInstance = (int)0x80000000;
 #ifdef PB_LANE_STATS
     unsigned long long wstat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave-level events (lane 0's copy is kept)
     unsigned int wl_steps = 0, wl_children = 0, wl_cand = 0, wl_pass = 0, wl_tris = 0;  // this lane's own events
@@ -104,12 +117,19 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         return ent;
     };
     auto finish = [&](bool found) {
-        io.store(index, any, found, tmax, hb0, hb1, hb2, hit_slot, -1);
+        io.store(index, any, found, tmax, hb0, hb1, hb2, hit_slot, INST ? hit_inst : -1);
         has_work = false;
     };
-    // next entry whose lower bound is still in front of the hit; false when the ray is finished
+    // next entry whose lower bound is still in front of the hit; false when the ray is finished. Inside an instance
+    // the stack ends at the floor laid down on entry: the lane then parks on kLeaveInstance and leaves the instance in
+    // the leaf phase (primitive.rs:140-143), where the rest of the top-level leaf is taken up again.
     auto advance = [&]() -> bool {
-        while (sp > 0) {
+        for (;;) {
+            if (INST && in_instance && sp <= base_sp) {
+                cur = kLeaveInstance;
+                return true;
+            }
+            if (sp == 0) return false;
             --sp;
             uint2 ent = stack_read(sp);
             if (__uint_as_float(ent.y) < tmax) {
@@ -117,7 +137,66 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 return true;
             }
         }
-        return false;
+    };
+    auto set_ray_constants = [&]() {
+        idx = 1.0f / r.dx;  // bvh.rs:831
+        idy = 1.0f / r.dy;
+        idz = 1.0f / r.dz;
+        nx = idx < 0.0f;  // bvh.rs:832-836
+        ny = idy < 0.0f;
+        nz = idz < 0.0f;
+        negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+    };
+    // TransformedPrimitive::intersect, first half (primitive.rs:136-139). 0 = the ray misses the object's root box,
+    // 1 = entered, 2 = the object-space ray is outside what the filter's bound covers (the ray leaves the wide path)
+    auto enter_instance = [&](int pos) -> int {
+        const float4* m = wt.top_slots + 7 * (size_t)pos;
+        float4 r0 = m[0], r1 = m[1], r2 = m[2], meta = m[6];
+        float x = wox, y = woy, z = woz;
+        float ox = r0.x * x + r0.y * y + r0.z * z + r0.w;
+        float oy = r1.x * x + r1.y * y + r1.z * z + r1.w;
+        float oz = r2.x * x + r2.y * y + r2.z * z + r2.w;
+        float xa = __builtin_fabsf(r0.x * x) + __builtin_fabsf(r0.y * y) + __builtin_fabsf(r0.z * z) + __builtin_fabsf(r0.w);
+        float ya = __builtin_fabsf(r1.x * x) + __builtin_fabsf(r1.y * y) + __builtin_fabsf(r1.z * z) + __builtin_fabsf(r1.w);
+        float za = __builtin_fabsf(r2.x * x) + __builtin_fabsf(r2.y * y) + __builtin_fabsf(r2.z * z) + __builtin_fabsf(r2.w);
+        float ex = xa * kGamma3, ey = ya * kGamma3, ez = za * kGamma3;
+        float dx = r0.x * wdx + r0.y * wdy + r0.z * wdz;
+        float dy = r1.x * wdx + r1.y * wdy + r1.z * wdz;
+        float dz = r2.x * wdx + r2.y * wdy + r2.z * wdz;
+        float l2 = dx * dx + dy * dy + dz * dz;
+        float tm = tmax_world;
+        if (l2 > 0.0f) {
+            float dt = (__builtin_fabsf(dx) * ex + __builtin_fabsf(dy) * ey + __builtin_fabsf(dz) * ez) / l2;
+            ox = ox + dx * dt;
+            oy = oy + dy * dt;
+            oz = oz + dz * dt;
+            tm -= dt;
+        }
+        r = TravRay{ox, oy, oz, dx, dy, dz, tm};
+        tmax = tm;
+        set_ray_constants();
+        if (!wide_ray_covered(r.ox, r.oy, r.oz, idx, idy, idz)) return 2;
+        in_instance = true;
+        hit_here = false;
+        cur_top_slot = __float_as_int(meta.y);
+        base_sp = sp;
+        const float4* ob = wt.objects + 2 * (size_t)__float_as_int(meta.z);
+        const float4 o0 = ob[0], o1 = ob[1];
+        float e;
+        // the object aggregate's own root box (bvh.rs:841-842): a leaf box passing implies it passes, so failing it ends the visit
+        if (!slab_test(nx ? o1.x : o0.x, nx ? o0.x : o1.x, ny ? o1.y : o0.y, ny ? o0.y : o1.y, nz ? o1.z : o0.z, nz ? o0.z : o1.z, r,
+                       idx, idy, idz, tmax, &e))
+            return 0;
+        cur = __float_as_int(o0.w);
+        return 1;
+    };
+    // second half (primitive.rs:140-143): r.t_max = ray.t_max on a hit; back to the world ray
+    auto exit_instance = [&]() {
+        if (hit_here) tmax_world = tmax;
+        r = TravRay{wox, woy, woz, wdx, wdy, wdz, tmax_world};
+        tmax = tmax_world;
+        set_ray_constants();
+        in_instance = false;
     };
 
     for (;;) {
@@ -160,13 +239,19 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 if (!real) {
                     finish(false);  // placeholder of a path outside pixel_bounds: not a ray of the frame
                 } else {
-                    idx = 1.0f / r.dx;  // bvh.rs:831
-                    idy = 1.0f / r.dy;
-                    idz = 1.0f / r.dz;
-                    nx = idx < 0.0f;  // bvh.rs:832-836
-                    ny = idy < 0.0f;
-                    nz = idz < 0.0f;
-                    negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+                    set_ray_constants();
+                    if (INST) {
+                        wox = r.ox;
+                        woy = r.oy;
+                        woz = r.oz;
+                        wdx = r.dx;
+                        wdy = r.dy;
+                        wdz = r.dz;
+                        tmax_world = r.tmax;
+                        in_instance = false;
+                        hit_inst = -1;
+                        leaf_cnt = leaf_next = 0;
+                    }
                     bool covered = wide_ray_covered(r.ox, r.oy, r.oz, idx, idy, idz);
                     special = !covered;
                     if (COUNT && special) c_special += 1;
@@ -269,7 +354,64 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             PB_WSTAT(7, __popcll(__ballot(has_work)));
         }
 #endif
-        if (has_work && cur < 0) {
+        if (INST && has_work && cur < 0 && (!in_instance || cur == kLeaveInstance)) {
+            bool walk = true;
+            if (in_instance) {
+                exit_instance();  // the rest of the top-level leaf follows
+            } else {
+                // a candidate top-level leaf: the reference's test on its exact box with the world ray and the current t_max
+                const int v = ~cur;
+                leaf_cnt = (v & 3) + 1;
+                leaf_first = v >> 2;
+                leaf_next = 0;
+                const float4* bp = wt.top_boxes + 2 * (size_t)leaf_first;
+                const float4 b0 = bp[0], b1 = bp[1];
+                float e;
+                walk = slab_test(nx ? b1.x : b0.x, nx ? b0.x : b1.x, ny ? b1.y : b0.y, ny ? b0.y : b1.y, nz ? b1.z : b0.z,
+                                 nz ? b0.z : b1.z, r, idx, idy, idz, tmax, &e);
+            }
+            bool entered = false, done = false, abandon = false;
+            while (walk && leaf_next < leaf_cnt && !entered && !done && !abandon) {
+                const int pos = leaf_first + leaf_next;
+                leaf_next += 1;
+                const float4 meta = wt.top_slots[7 * (size_t)pos + 6];
+                if (__float_as_int(meta.w) == 1) {
+                    // a GeometricPrimitive beside the instances (primitive.rs:65-78): the world ray against its triangle
+                    const int tslot = __float_as_int(meta.z);
+                    const float4* tp = wt.slot_tris + 3 * (size_t)tslot;
+                    const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                    float b0, b1, b2, t;
+                    const TriRayConst c = tri_ray_setup(r);
+                    if (triangle_test(V3{ta.x, ta.y, ta.z}, V3{ta.w, tb.x, tb.y}, V3{tb.z, tb.w, tc.x}, r, c, tmax, &b0, &b1, &b2, &t)) {
+                        if (any) {
+                            done = true;
+                        } else if (!(__float_as_int(tc.w) & kTriDegenerate)) {
+                            tmax = t;
+                            tmax_world = t;
+                            hb0 = b0;
+                            hb1 = b1;
+                            hb2 = b2;
+                            hit_slot = tslot;
+                            hit_inst = -1;
+                        }
+                    }
+                    continue;
+                }
+                const int how = enter_instance(pos);
+                entered = how == 1;
+                abandon = how == 2;
+                if (how == 0) exit_instance();
+            }
+            if (abandon) {
+                // left to the binary kernel, which traces the ray from scratch (rare: one list append per such ray)
+                wt.special_list[atomicAdd(wt.special_count, 1u)] = index;
+                has_work = false;
+            } else if (done) {
+                finish(true);
+            } else if (!entered && !advance()) {
+                finish(hit_slot >= 0);
+            }
+        } else if (has_work && cur < 0) {
             const int v = ~cur;
             const int cnt = (v & 3) + 1;
             const int first = v >> 2;
@@ -335,6 +477,10 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                             hb1 = b1;
                             hb2 = b2;
                             hit_slot = __float_as_int(tc.y);
+                            if (INST) {
+                                hit_here = true;
+                                hit_inst = cur_top_slot;
+                            }
                         }
                     }
                 }

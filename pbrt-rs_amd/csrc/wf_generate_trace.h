@@ -219,22 +219,24 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_I
 }
 
 // the same wavefront over the 4-wide records (trace_wide.h) ...
-template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock, COUNT ? 4 : PB_WIDE_WAVES)
+template <bool COUNT, bool INST = false>
+__global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES)
     k_trace_wide(WideTrees wt, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
                  int segments, unsigned long long* counters) {
     __shared__ uint2 lds_stack[kWideStackLds * kTraceBlock];
     WavefrontRayIO io{ps, queue, n, segments};
-    trace_wide<WavefrontRayIO, COUNT>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x, counters);
+    trace_wide<WavefrontRayIO, COUNT, INST>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x,
+                                            counters);
 }
 // ... and the rays it left to the binary records (axis-parallel directions and the like; usually none)
-__global__ void __launch_bounds__(kTraceBlock, PB_TRACE_WAVES)
+template <bool INST = false>
+__global__ void __launch_bounds__(kTraceBlock, INST ? PB_INST_WAVES : PB_TRACE_WAVES)
     k_trace_special(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, const uint32_t* __restrict__ list,
                     const unsigned int* __restrict__ count, unsigned int* work_counter) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
     SpecialListIO<WavefrontRayIO> io{WavefrontRayIO{ps, queue, n, 1}, list, count};
-    trace_persistent<SpecialListIO<WavefrontRayIO>, false, false, false>(bvh, io, work_counter, lds_stack + threadIdx.x,
-                                                                         blockIdx.x * kTraceBlock + threadIdx.x, nullptr);
+    trace_persistent<SpecialListIO<WavefrontRayIO>, false, INST, false>(bvh, io, work_counter, lds_stack + threadIdx.x,
+                                                                        blockIdx.x * kTraceBlock + threadIdx.x, nullptr);
 }
 
 }  // namespace pb

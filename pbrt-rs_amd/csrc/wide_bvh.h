@@ -122,6 +122,12 @@ struct WideTrees {
     int spill_stride;
     uint32_t* __restrict__ special_list;  // queue positions of the rays left to the binary kernel
     unsigned int* __restrict__ special_count;
+    // two-level scenes: `nodes` holds the top-level tree's records, then every object aggregate's; the leaves of the
+    // top-level tree hold top-level primitives in wide order:
+    const float4* __restrict__ top_slots;  // 7 x float4 per position: DevBVH::instances' record, its second meta field = the binary-layout top slot
+    const float4* __restrict__ top_boxes;  // 2 x float4 per position: the exact box of the top-level leaf that starts there
+    const float4* __restrict__ objects;    // 2 x float4 per object aggregate: (root box min, wide root reference) (root box max, -)
+    const float4* __restrict__ slot_tris;  // DevBVH::tris (the world-space triangles of top-level leaves are read by leaf slot)
 };
 #endif
 

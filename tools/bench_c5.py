@@ -14,6 +14,7 @@ print(f"scene + host BVHs {time.time()-t:.2f} s; tlas nodes {len(bvh[3])} blas n
 cam = scenes.instanced_camera(W, H)
 ctx = pbrt_hip.Context(0)
 scene = pbrt_hip.Scene(ctx, sc, bvh=bvh)
+print("wide records:", scene.wide_records())
 for it in range(2):
     film, st = scene.render(cam, W, H, spp, max_depth=16, seed=0)
 rays = st["rays_closest"] + st["rays_shadow"]
