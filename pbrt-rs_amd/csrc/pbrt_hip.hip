@@ -815,6 +815,10 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
                 s->wide.objects = (const float4*)dev_upload(s, wo.data(), wo.size(), &ok);
                 s->wide.slot_tris = d.bvh.tris;
                 s->wide.root_ref = top.root_ref;
+                s->wide.general_top = d.bvh.general_top;
+                s->wide.obj0_root = wobj[0].root_ref;
+                std::memcpy(s->wide.obj0_min, ia.objects[0].nodes[0].bounds_min, 12);
+                std::memcpy(s->wide.obj0_max, ia.objects[0].nodes[0].bounds_max, 12);
                 s->n_wide_records = record_base;
                 s->has_wide = true;
                 spill_entries = std::max(spill_entries, top.stack_need + deepest + 2 - kWideStackLds);
@@ -969,7 +973,7 @@ struct BatchRayIO {
         }
     }
 };
-template <bool ANY, bool COUNT, bool INST, bool SPH = false>
+template <bool ANY, bool COUNT, int INST, bool SPH = false>
 __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_INST_WAVES : PB_TRACE_WAVES))
     k_intersect_batch(DevBVH bvh, BatchRayIO<ANY> io, unsigned int* work_counter, unsigned long long* counters) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
@@ -978,14 +982,14 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_I
 }
 
 // the same batch over the 4-wide records (trace_wide.h), and the follow-up over the rays that kernel left out
-template <bool ANY, bool COUNT, bool INST = false>
+template <bool ANY, bool COUNT, int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES)
     k_intersect_batch_wide(WideTrees wt, BatchRayIO<ANY> io, unsigned int* work_counter, unsigned long long* counters) {
     __shared__ uint2 lds_stack[kWideStackLds * kTraceBlock];
     trace_wide<BatchRayIO<ANY>, COUNT, INST>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x,
                                              counters);
 }
-template <bool ANY, bool INST = false>
+template <bool ANY, int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, INST ? PB_INST_WAVES : PB_TRACE_WAVES)
     k_intersect_batch_special(DevBVH bvh, SpecialListIO<BatchRayIO<ANY>> io, unsigned int* work_counter) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
@@ -1015,49 +1019,43 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
     {
         BatchRayIO<ANY> io{s->d.slot_prim, s->d.slot_instance, d_rays, (uint32_t)n, d_hits, d_flags};
         dim3 grid(persistent_grid(s)), block(kTraceBlock);
-        const bool inst = s->d.bvh.instanced != 0;
+        const int inst = s->d.bvh.instanced ? (s->d.bvh.general_top ? 2 : 1) : 0;  // trace_persistent.h: INST
+        const bool count_ref = ctx->count_traversal == 1, count_wide = ctx->count_traversal == 2;
+#define PB_LAUNCH_BINARY(COUNT, INST, SPH) \
+    hipLaunchKernelGGL((k_intersect_batch<ANY, COUNT, INST, SPH>), grid, block, 0, ctx->stream, s->d.bvh, io, ctx->d_work_counter, ctx->d_counters)
+#define PB_LAUNCH_WIDE(COUNT, INST)                                                                                                  \
+    hipLaunchKernelGGL((k_intersect_batch_wide<ANY, COUNT, INST>),                                                                   \
+                       dim3(persistent_grid(s, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES, kWideStackLds)), block, 0, ctx->stream, \
+                       wt, io, ctx->d_work_counter, ctx->d_counters)
+#define PB_LAUNCH_SPECIAL(INST) \
+    hipLaunchKernelGGL((k_intersect_batch_special<ANY, INST>), grid, block, 0, ctx->stream, s->d.bvh, sio, ctx->d_work_counter + kFollowUpCounter)
         if (wide) {
             WideTrees wt = s->wide;
             wt.special_list = ctx->d_special_list;
             wt.special_count = ctx->d_work_counter + kSpecialCount;
             SpecialListIO<BatchRayIO<ANY>> sio{io, ctx->d_special_list, ctx->d_work_counter + kSpecialCount};
-            if (inst) {
-                hipLaunchKernelGGL((k_intersect_batch_wide<ANY, false, true>), dim3(persistent_grid(s, PB_WIDE_INST_WAVES, kWideStackLds)),
-                                   block, 0, ctx->stream, wt, io, ctx->d_work_counter, ctx->d_counters);
-                hipLaunchKernelGGL((k_intersect_batch_special<ANY, true>), grid, block, 0, ctx->stream, s->d.bvh, sio,
-                                   ctx->d_work_counter + kFollowUpCounter);
+            if (inst == 2) {
+                if (count_wide) PB_LAUNCH_WIDE(true, 2); else PB_LAUNCH_WIDE(false, 2);
+                PB_LAUNCH_SPECIAL(2);
+            } else if (inst == 1) {
+                if (count_wide) PB_LAUNCH_WIDE(true, 1); else PB_LAUNCH_WIDE(false, 1);
+                PB_LAUNCH_SPECIAL(1);
             } else {
-                if (ctx->count_traversal == 2)
-                    hipLaunchKernelGGL((k_intersect_batch_wide<ANY, true>), dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0,
-                                       ctx->stream, wt, io, ctx->d_work_counter, ctx->d_counters);
-                else
-                    hipLaunchKernelGGL((k_intersect_batch_wide<ANY, false>), dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0,
-                                       ctx->stream, wt, io, ctx->d_work_counter, ctx->d_counters);
-                hipLaunchKernelGGL((k_intersect_batch_special<ANY>), grid, block, 0, ctx->stream, s->d.bvh, sio,
-                                   ctx->d_work_counter + kFollowUpCounter);
+                if (count_wide) PB_LAUNCH_WIDE(true, 0); else PB_LAUNCH_WIDE(false, 0);
+                PB_LAUNCH_SPECIAL(0);
             }
         } else if (s->d.bvh.has_spheres) {  // single-level scenes only (checked at creation)
-            if (ctx->count_traversal == 1)
-                hipLaunchKernelGGL((k_intersect_batch<ANY, true, false, true>), grid, block, 0, ctx->stream, s->d.bvh, io,
-                                   ctx->d_work_counter, ctx->d_counters);
-            else
-                hipLaunchKernelGGL((k_intersect_batch<ANY, false, false, true>), grid, block, 0, ctx->stream, s->d.bvh, io,
-                                   ctx->d_work_counter, ctx->d_counters);
-        } else if (ctx->count_traversal == 1) {
-            if (inst)
-                hipLaunchKernelGGL((k_intersect_batch<ANY, true, true>), grid, block, 0, ctx->stream, s->d.bvh, io,
-                                   ctx->d_work_counter, ctx->d_counters);
-            else
-                hipLaunchKernelGGL((k_intersect_batch<ANY, true, false>), grid, block, 0, ctx->stream, s->d.bvh, io,
-                                   ctx->d_work_counter, ctx->d_counters);
+            if (count_ref) PB_LAUNCH_BINARY(true, 0, true); else PB_LAUNCH_BINARY(false, 0, true);
+        } else if (inst == 2) {
+            if (count_ref) PB_LAUNCH_BINARY(true, 2, false); else PB_LAUNCH_BINARY(false, 2, false);
+        } else if (inst == 1) {
+            if (count_ref) PB_LAUNCH_BINARY(true, 1, false); else PB_LAUNCH_BINARY(false, 1, false);
         } else {
-            if (inst)
-                hipLaunchKernelGGL((k_intersect_batch<ANY, false, true>), grid, block, 0, ctx->stream, s->d.bvh, io,
-                                   ctx->d_work_counter, ctx->d_counters);
-            else
-                hipLaunchKernelGGL((k_intersect_batch<ANY, false, false>), grid, block, 0, ctx->stream, s->d.bvh, io,
-                                   ctx->d_work_counter, ctx->d_counters);
+            if (count_ref) PB_LAUNCH_BINARY(true, 0, false); else PB_LAUNCH_BINARY(false, 0, false);
         }
+#undef PB_LAUNCH_BINARY
+#undef PB_LAUNCH_WIDE
+#undef PB_LAUNCH_SPECIAL
     }
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->time_trace) {

@@ -831,50 +831,44 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                 RENDER_TRY(hipEventRecord(e_t0, st));
                 {
                     dim3 grid(persistent_grid(s)), block(kTraceBlock);
-                    const bool inst = s->d.bvh.instanced != 0;
+                    const int inst = s->d.bvh.instanced ? (s->d.bvh.general_top ? 2 : 1) : 0;  // trace_persistent.h: INST
                     int segments = (wavefront == 0 && !inst) ? kQueueSegments : 1;  // see trace.h
                     if (seg_all && !inst) segments = kQueueSegments;
+                    const bool count_ref = ctx->count_traversal == 1, count_wide = ctx->count_traversal == 2;
+#define PB_LAUNCH_BINARY(COUNT, INST, SPH) \
+    hipLaunchKernelGGL((k_trace<COUNT, INST, SPH>), grid, block, 0, st, s->d.bvh, ps, trace_queue, n_trace, ctx->d_work_counter, ctx->d_counters, segments)
+#define PB_LAUNCH_WIDE(COUNT, INST)                                                                                                        \
+    hipLaunchKernelGGL((k_trace_wide<COUNT, INST>), dim3(persistent_grid(s, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES, kWideStackLds)), \
+                       block, 0, st, wt, ps, trace_queue, n_trace, ctx->d_work_counter, segments, ctx->d_counters)
+#define PB_LAUNCH_SPECIAL(INST)                                                                                   \
+    hipLaunchKernelGGL(k_trace_special<INST>, grid, block, 0, st, s->d.bvh, ps, trace_queue, n_trace, special_list, \
+                       ctx->d_work_counter + kSpecialCount, ctx->d_work_counter + kFollowUpCounter)
                     if (use_wide) {
                         WideTrees wt = s->wide;
                         wt.special_list = special_list;
                         wt.special_count = ctx->d_work_counter + kSpecialCount;
-                        if (inst) {
-                            hipLaunchKernelGGL((k_trace_wide<false, true>), dim3(persistent_grid(s, PB_WIDE_INST_WAVES, kWideStackLds)), block, 0,
-                                               st, wt, ps, trace_queue, n_trace, ctx->d_work_counter, segments, ctx->d_counters);
-                            hipLaunchKernelGGL(k_trace_special<true>, grid, block, 0, st, s->d.bvh, ps, trace_queue, n_trace, special_list,
-                                               ctx->d_work_counter + kSpecialCount, ctx->d_work_counter + kFollowUpCounter);
+                        if (inst == 2) {
+                            if (count_wide) PB_LAUNCH_WIDE(true, 2); else PB_LAUNCH_WIDE(false, 2);
+                            PB_LAUNCH_SPECIAL(2);
+                        } else if (inst == 1) {
+                            if (count_wide) PB_LAUNCH_WIDE(true, 1); else PB_LAUNCH_WIDE(false, 1);
+                            PB_LAUNCH_SPECIAL(1);
                         } else {
-                            if (ctx->count_traversal == 2)
-                                hipLaunchKernelGGL(k_trace_wide<true>, dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0, st, wt,
-                                                   ps, trace_queue, n_trace, ctx->d_work_counter, segments, ctx->d_counters);
-                            else
-                                hipLaunchKernelGGL(k_trace_wide<false>, dim3(persistent_grid(s, PB_WIDE_WAVES, kWideStackLds)), block, 0, st, wt,
-                                                   ps, trace_queue, n_trace, ctx->d_work_counter, segments, ctx->d_counters);
-                            hipLaunchKernelGGL(k_trace_special<false>, grid, block, 0, st, s->d.bvh, ps, trace_queue, n_trace, special_list,
-                                               ctx->d_work_counter + kSpecialCount, ctx->d_work_counter + kFollowUpCounter);
+                            if (count_wide) PB_LAUNCH_WIDE(true, 0); else PB_LAUNCH_WIDE(false, 0);
+                            PB_LAUNCH_SPECIAL(0);
                         }
                     } else if (s->d.bvh.has_spheres) {
-                        if (ctx->count_traversal == 1)
-                            hipLaunchKernelGGL((k_trace<true, false, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
-                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
-                        else
-                            hipLaunchKernelGGL((k_trace<false, false, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
-                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
-                    } else if (ctx->count_traversal == 1) {
-                        if (inst)
-                            hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
-                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
-                        else
-                            hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
-                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
+                        if (count_ref) PB_LAUNCH_BINARY(true, 0, true); else PB_LAUNCH_BINARY(false, 0, true);
+                    } else if (inst == 2) {
+                        if (count_ref) PB_LAUNCH_BINARY(true, 2, false); else PB_LAUNCH_BINARY(false, 2, false);
+                    } else if (inst == 1) {
+                        if (count_ref) PB_LAUNCH_BINARY(true, 1, false); else PB_LAUNCH_BINARY(false, 1, false);
                     } else {
-                        if (inst)
-                            hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
-                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
-                        else
-                            hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, st, s->d.bvh, ps, trace_queue,
-                                               n_trace, ctx->d_work_counter, ctx->d_counters, segments);
+                        if (count_ref) PB_LAUNCH_BINARY(true, 0, false); else PB_LAUNCH_BINARY(false, 0, false);
                     }
+#undef PB_LAUNCH_BINARY
+#undef PB_LAUNCH_WIDE
+#undef PB_LAUNCH_SPECIAL
                 }
                 RENDER_TRY(hipGetLastError());
                 RENDER_TRY(hipEventRecord(e_t1, st));

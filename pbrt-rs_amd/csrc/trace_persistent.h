@@ -97,7 +97,11 @@ PB_DEV bool root_box_test(const LaneState& s, const float* mn, const float* mx) 
 }
 
 // IO policy: n(), segments(), load(i, &ray, &any) -> bool real ray, store(i, any, found, t, b0, b1, b2, slot, instance)
-template <class IO, bool COUNT, bool INST, bool SPH = false>
+// INST: 0 = one level; 1 = instances of ONE object aggregate and nothing beside them (config 5's shape: the object's root
+// rides in the kernel arguments); 2 = the general top level (several objects, world-space triangles beside the instances).
+// A template value rather than a run-time flag: with the general code compiled in, the 96-register build of the
+// single-object kernel spilled 100 B instead of 56 B and config 5 lost 15 %.
+template <class IO, bool COUNT, int INST, bool SPH = false>
 PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __restrict__ work_counter,
                              uint2* lds_stack, int spill_lane, unsigned long long* counters) {
     const uint32_t n = io.n();
@@ -166,7 +170,7 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
             n_inst += 1;
             n_node += 1;  // the object aggregate tests its root box (bvh.rs:841-842)
         }
-        if (!bvh.general_top) {
+        if (INST != 2) {
             if (!root_box_test(s, bvh.blas_root_min, bvh.blas_root_max)) return false;
             s.cur = bvh.blas_root_ref;
             return true;
@@ -369,8 +373,8 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
                     int slot = w.leaf_first + w.leaf_next;
                     w.leaf_next += 1;
                     float4 kind = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if (bvh.general_top) kind = bvh.instances[7 * (size_t)slot + 6];
-                    if (__float_as_int(kind.w) == 1) {
+                    if (INST == 2) kind = bvh.instances[7 * (size_t)slot + 6];
+                    if (INST == 2 && __float_as_int(kind.w) == 1) {
                         // a GeometricPrimitive beside the instances (primitive.rs:65-78): the world ray against its triangle
                         const int tslot = __float_as_int(kind.z);
                         V3 p0, p1, p2;

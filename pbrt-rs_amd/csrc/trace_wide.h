@@ -20,7 +20,7 @@ namespace pb {
 #define PB_WIDE_WAVES 5
 #endif
 #ifndef PB_WIDE_INST_WAVES
-#define PB_WIDE_INST_WAVES 4
+#define PB_WIDE_INST_WAVES 5
 #endif
 #ifndef PB_WIDE_STACK_LDS
 #define PB_WIDE_STACK_LDS 12
@@ -64,8 +64,12 @@ struct SpecialListIO {
 // candidate top-level leaf is confirmed with the reference's slab test on its exact box, its entries are taken in leaf
 // order: a TransformedPrimitive transforms the ray (geometry.rs:865-881) and walks its object's records with a stack
 // floor, a plain triangle is tested in place. An object-space ray the filter's bound does not cover ends the wide
-// traversal of that ray: it goes to the binary kernel like an uncovered world ray.
-template <class IO, bool COUNT = false, bool INST = false>
+// traversal of that ray: it goes to the binary kernel like an uncovered world ray. INST == 1: instances of one object
+// aggregate and nothing beside them (its root in the kernel arguments, no per-entry kind / object lookups); 2: general.
+// The world ray is not kept while a lane is inside an instance: leaving one reads it again through io.load (two
+// loads per visit against six registers for the whole traversal), and an entry whose object root box the ray misses
+// never replaces the lane's ray in the first place.
+template <class IO, bool COUNT = false, int INST = 0>
 PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restrict__ work_counter, uint2* lds_stack,
                        int spill_lane, unsigned long long* counters = nullptr) {
     const uint32_t n = io.n();
@@ -83,7 +87,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     int seg = (int)(blockIdx.x % (unsigned)n_seg), seg_tries = 0;
     uint32_t c_rec = 0, c_cand = 0, c_tri = 0, c_special = 0;
     // two-level state (INST)
-    float wox = 0.0f, woy = 0.0f, woz = 0.0f, wdx = 0.0f, wdy = 0.0f, wdz = 0.0f, tmax_world = 0.0f;
+    float tmax_world = 0.0f;
     int leaf_first = 0, leaf_cnt = 0, leaf_next = 0, cur_top_slot = -1, hit_inst = -1, base_sp = 0;
     bool in_instance = false, hit_here = false;
     constexpr int kLeaveInstance = (int)0x80000000;
@@ -149,10 +153,10 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     };
     // TransformedPrimitive::intersect, first half (primitive.rs:136-139). 0 = the ray misses the object's root box,
     // 1 = entered, 2 = the object-space ray is outside what the filter's bound covers (the ray leaves the wide path)
-    auto enter_instance = [&](int pos) -> int {
+    auto enter_instance = [&](int pos, const float4 meta) -> int {
         const float4* m = wt.top_slots + 7 * (size_t)pos;
-        float4 r0 = m[0], r1 = m[1], r2 = m[2], meta = m[6];
-        float x = wox, y = woy, z = woz;
+        float4 r0 = m[0], r1 = m[1], r2 = m[2];
+        const float x = r.ox, y = r.oy, z = r.oz, wdx = r.dx, wdy = r.dy, wdz = r.dz;  // the lane holds the world ray here
         float ox = r0.x * x + r0.y * y + r0.z * z + r0.w;
         float oy = r1.x * x + r1.y * y + r1.z * z + r1.w;
         float oz = r2.x * x + r2.y * y + r2.z * z + r2.w;
@@ -172,28 +176,49 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             oz = oz + dz * dt;
             tm -= dt;
         }
-        r = TravRay{ox, oy, oz, dx, dy, dz, tm};
+        const TravRay ro{ox, oy, oz, dx, dy, dz, tm};
+        const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;  // bvh.rs:831
+        if (!wide_ray_covered(ox, oy, oz, ix, iy, iz)) return 2;
+        const bool bx = ix < 0.0f, by = iy < 0.0f, bz = iz < 0.0f;
+        float mnx, mny, mnz, mxx, mxy, mxz;
+        int root;
+        if (INST == 2) {
+            const float4* ob = wt.objects + 2 * (size_t)__float_as_int(meta.z);
+            const float4 o0 = ob[0], o1 = ob[1];
+            mnx = o0.x, mny = o0.y, mnz = o0.z, mxx = o1.x, mxy = o1.y, mxz = o1.z;
+            root = __float_as_int(o0.w);
+        } else {
+            mnx = wt.obj0_min[0], mny = wt.obj0_min[1], mnz = wt.obj0_min[2];
+            mxx = wt.obj0_max[0], mxy = wt.obj0_max[1], mxz = wt.obj0_max[2];
+            root = wt.obj0_root;
+        }
+        float e;
+        // the object aggregate's own root box (bvh.rs:841-842): a leaf box passing implies it passes, so failing it ends
+        // the visit, and the lane keeps the world ray it holds
+        if (!slab_test(bx ? mxx : mnx, bx ? mnx : mxx, by ? mxy : mny, by ? mny : mxy, bz ? mxz : mnz, bz ? mnz : mxz, ro, ix, iy, iz, tm, &e))
+            return 0;
+        r = ro;
         tmax = tm;
-        set_ray_constants();
-        if (!wide_ray_covered(r.ox, r.oy, r.oz, idx, idy, idz)) return 2;
+        idx = ix;
+        idy = iy;
+        idz = iz;
+        nx = bx;
+        ny = by;
+        nz = bz;
+        negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
         in_instance = true;
         hit_here = false;
         cur_top_slot = __float_as_int(meta.y);
         base_sp = sp;
-        const float4* ob = wt.objects + 2 * (size_t)__float_as_int(meta.z);
-        const float4 o0 = ob[0], o1 = ob[1];
-        float e;
-        // the object aggregate's own root box (bvh.rs:841-842): a leaf box passing implies it passes, so failing it ends the visit
-        if (!slab_test(nx ? o1.x : o0.x, nx ? o0.x : o1.x, ny ? o1.y : o0.y, ny ? o0.y : o1.y, nz ? o1.z : o0.z, nz ? o0.z : o1.z, r,
-                       idx, idy, idz, tmax, &e))
-            return 0;
-        cur = __float_as_int(o0.w);
+        cur = root;
         return 1;
     };
     // second half (primitive.rs:140-143): r.t_max = ray.t_max on a hit; back to the world ray
     auto exit_instance = [&]() {
         if (hit_here) tmax_world = tmax;
-        r = TravRay{wox, woy, woz, wdx, wdy, wdz, tmax_world};
+        bool any_again;
+        (void)io.load(index, &r, &any_again);
+        r.tmax = tmax_world;
         tmax = tmax_world;
         set_ray_constants();
         in_instance = false;
@@ -241,12 +266,6 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 } else {
                     set_ray_constants();
                     if (INST) {
-                        wox = r.ox;
-                        woy = r.oy;
-                        woz = r.oz;
-                        wdx = r.dx;
-                        wdy = r.dy;
-                        wdz = r.dz;
                         tmax_world = r.tmax;
                         in_instance = false;
                         hit_inst = -1;
@@ -291,53 +310,52 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 if (COUNT) c_rec += 1;
                 const uint32_t dw3 = q0.w;
                 const WideSetup ws = wide_setup(q0.x, q0.y, q0.z, dw3, r.ox, r.oy, r.oz, idx, idy, idz);
-                // near / far plane bytes by the sign of the direction
-                uint32_t nqx = nx ? q1.y : q1.x, fqx = nx ? q1.x : q1.y;
-                uint32_t nqy = ny ? q1.w : q1.z, fqy = ny ? q1.z : q1.w;
-                uint32_t nqz = nz ? q2.y : q2.x, fqz = nz ? q2.x : q2.y;
-                // rank of a slot in the reference's visiting order: two levels of dir_is_neg[axis] (bvh.rs:857-865).
-                // slot s of the first / second binary child has rank s ^ x01 / s ^ x23.
+                // The reference's visiting order of the four slots is two levels of dir_is_neg[axis] (bvh.rs:857-865): the
+                // first binary child's slots (0, 1) before the second's (2, 3) unless the root axis is negative, and the
+                // like inside each pair. `sel` holds, per byte, the slot visited k-th; the plane bytes and the descriptor
+                // bytes are put into that order once (v_perm_b32), so that everything below is indexed by rank.
                 const uint32_t f_root = (negmask >> ((dw3 >> 18) & 3u)) & 1u;
                 const uint32_t f_c0 = (negmask >> ((dw3 >> 20) & 3u)) & 1u, f_c1 = (negmask >> ((dw3 >> 22) & 3u)) & 1u;
-                const uint32_t x01 = (f_root << 1) | f_c0, x23 = (f_root << 1) | f_c1;
-                const uint32_t rank[4] = {x01, x01 ^ 1u, x23 ^ 2u, x23 ^ 3u};
-                // m[0..3]: the low bytes of base.xyz and the top byte of dw3, gathered into one dword
-                const uint32_t mpack = __builtin_amdgcn_perm(q0.y, q0.x, 0x0c0c0400u) | __builtin_amdgcn_perm(dw3, q0.z, 0x07000c0cu);
+                uint32_t sel = 0x03020100u ^ (f_c0 ? 0x00000101u : 0u) ^ (f_c1 ? 0x01010000u : 0u);
+                sel = __builtin_amdgcn_alignbit(sel, sel, f_root << 4);
+                const uint32_t nqx = __builtin_amdgcn_perm(0u, nx ? q1.y : q1.x, sel), fqx = __builtin_amdgcn_perm(0u, nx ? q1.x : q1.y, sel);
+                const uint32_t nqy = __builtin_amdgcn_perm(0u, ny ? q1.w : q1.z, sel), fqy = __builtin_amdgcn_perm(0u, ny ? q1.z : q1.w, sel);
+                const uint32_t nqz = __builtin_amdgcn_perm(0u, nz ? q2.y : q2.x, sel), fqz = __builtin_amdgcn_perm(0u, nz ? q2.x : q2.y, sel);
+                // m[0..3]: the low bytes of base.xyz and the top byte of dw3, gathered into one dword, in visiting order
+                const uint32_t mslot = __builtin_amdgcn_perm(q0.y, q0.x, 0x0c0c0400u) | __builtin_amdgcn_perm(dw3, q0.z, 0x07000c0cu);
+                const uint32_t mpack = __builtin_amdgcn_perm(0u, mslot, sel);
+                const uint32_t child_base = q2.z, ntb = q2.w;
                 float tn[4];
-                uint32_t rm = 0;  // bit `rank` set for every child whose quantised box the ray may hit
+                bool h[4];
+                int ref[4];
+                // (two children per v_pk_fma_f32 was tried: 12 fewer VALU instructions per step, 1.5 % slower)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    bool h = wide_child_test(ws, nqx, nqy, nqz, fqx, fqy, fqz, s, tmax, &tn[s]) && (((mpack >> (8 * s)) & 0xffu) != 0xffu);
-                    rm |= h ? (1u << rank[s]) : 0u;
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t m = (mpack >> (8 * k)) & 0xffu;
+                    h[k] = wide_child_test(ws, nqx, nqy, nqz, fqx, fqy, fqz, k, tmax, &tn[k]) && (m != 0xffu);
+                    ref[k] = (m & 0x80u) ? (int)(child_base + (m & 3u)) : (int)(ntb - m);
                 }
 #ifdef PB_LANE_STATS
                 wl_steps += 1;
-                wl_children += __popc(rm);
+                wl_children += (h[0] ? 1 : 0) + (h[1] ? 1 : 0) + (h[2] ? 1 : 0) + (h[3] ? 1 : 0);
 #endif
-                if (rm == 0) {
-                    if (!advance()) finish(hit_slot >= 0);
-                } else {
-                    const uint32_t child_base = q2.z, ntb = q2.w;
-                    // slot of a rank (the inverse of the map above) and that child's reference
-                    auto slot_of = [&](uint32_t rk) -> uint32_t {
-                        uint32_t hi = (rk >> 1) ^ f_root;
-                        return (hi << 1) | ((rk & 1u) ^ (hi ? f_c1 : f_c0));
-                    };
-                    auto ref_of = [&](uint32_t slot) -> int {
-                        uint32_t m = (mpack >> (8u * slot)) & 0xffu;
-                        return (m & 0x80u) ? (int)(child_base + (m & 3u)) : (int)(ntb - m);
-                    };
-                    // the children the reference visits later go on the stack, last one deepest
-                    uint32_t rest = rm & (rm - 1u);
-                    while (rest) {
-                        uint32_t rk = 31u - (uint32_t)__clz((int)rest);
-                        rest &= ~(1u << rk);
-                        uint32_t slot = slot_of(rk);
-                        float e = slot == 0 ? tn[0] : (slot == 1 ? tn[1] : (slot == 2 ? tn[2] : tn[3]));
-                        stack_write(sp, ref_of(slot), e);
-                        ++sp;
-                    }
-                    cur = ref_of(slot_of((uint32_t)__builtin_ctz(rm)));
+                // the children the reference visits later go on the stack, last one deepest
+                if (h[3] && (h[0] || h[1] || h[2])) {
+                    stack_write(sp, ref[3], tn[3]);
+                    ++sp;
+                }
+                if (h[2] && (h[0] || h[1])) {
+                    stack_write(sp, ref[2], tn[2]);
+                    ++sp;
+                }
+                if (h[1] && h[0]) {
+                    stack_write(sp, ref[1], tn[1]);
+                    ++sp;
+                }
+                if (h[0] || h[1] || h[2] || h[3]) {
+                    cur = h[0] ? ref[0] : (h[1] ? ref[1] : (h[2] ? ref[2] : ref[3]));
+                } else if (!advance()) {
+                    finish(hit_slot >= 0);
                 }
             }
         }
@@ -375,7 +393,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 const int pos = leaf_first + leaf_next;
                 leaf_next += 1;
                 const float4 meta = wt.top_slots[7 * (size_t)pos + 6];
-                if (__float_as_int(meta.w) == 1) {
+                if (INST == 2 && __float_as_int(meta.w) == 1) {
                     // a GeometricPrimitive beside the instances (primitive.rs:65-78): the world ray against its triangle
                     const int tslot = __float_as_int(meta.z);
                     const float4* tp = wt.slot_tris + 3 * (size_t)tslot;
@@ -397,10 +415,9 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                     }
                     continue;
                 }
-                const int how = enter_instance(pos);
+                const int how = enter_instance(pos, meta);
                 entered = how == 1;
                 abandon = how == 2;
-                if (how == 0) exit_instance();
             }
             if (abandon) {
                 // left to the binary kernel, which traces the ray from scratch (rare: one list append per such ray)

@@ -208,7 +208,7 @@ __global__ void k_ray_sort_keys(PathState ps, const uint32_t* __restrict__ queue
     keys[i] = code | ((slot == RS_SHADOW ? 1u : 0u) << (kSortKeyBits - 1));
 }
 
-template <bool COUNT, bool INST, bool SPH = false>
+template <bool COUNT, int INST, bool SPH = false>
 __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_INST_WAVES : PB_TRACE_WAVES))
     k_trace(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
             unsigned long long* counters, int segments) {
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_I
 }
 
 // the same wavefront over the 4-wide records (trace_wide.h) ...
-template <bool COUNT, bool INST = false>
+template <bool COUNT, int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES)
     k_trace_wide(WideTrees wt, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
                  int segments, unsigned long long* counters) {
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WA
                                             counters);
 }
 // ... and the rays it left to the binary records (axis-parallel directions and the like; usually none)
-template <bool INST = false>
+template <int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, INST ? PB_INST_WAVES : PB_TRACE_WAVES)
     k_trace_special(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, const uint32_t* __restrict__ list,
                     const unsigned int* __restrict__ count, unsigned int* work_counter) {

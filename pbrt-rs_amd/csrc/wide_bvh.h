@@ -128,6 +128,11 @@ struct WideTrees {
     const float4* __restrict__ top_boxes;  // 2 x float4 per position: the exact box of the top-level leaf that starts there
     const float4* __restrict__ objects;    // 2 x float4 per object aggregate: (root box min, wide root reference) (root box max, -)
     const float4* __restrict__ slot_tris;  // DevBVH::tris (the world-space triangles of top-level leaves are read by leaf slot)
+    // instances of ONE object aggregate with nothing beside them (config 5's shape, the kernels' INST == 1): that object's
+    // root box and wide root reference ride in the kernel arguments
+    int general_top;
+    int obj0_root;
+    float obj0_min[3], obj0_max[3];
 };
 #endif
 

@@ -114,6 +114,12 @@ int wide_check_structure(const PbrtLinearBVHNode* nodes, int32_t n_nodes, const 
                 if (ref < 0) {
                     int v = ~ref, n = (v & 3) + 1, first = v >> 2;
                     if (first < 0 || first + n > n_slots) return -2;
+                    if (!tris) {  // opaque primitives: order[] maps the wide-order position back to the leaf slot
+                        for (int j = 0; j < n; ++j)
+                            if (wt.order[(size_t)first + j] != wt.order[(size_t)first] + j) return -3;
+                        wide_leaves.push_back(wt.order[(size_t)first] * 8 + n);
+                        continue;
+                    }
                     int32_t slot0;
                     std::memcpy(&slot0, &wt.tris[12 * (size_t)first + 9], 4);
                     for (int j = 0; j < n; ++j) {  // P3: triangles copied in leaf order, slot ids consecutive
@@ -219,10 +225,11 @@ int wide_check_structure(const PbrtLinearBVHNode* nodes, int32_t n_nodes, const 
             if (ref < 0) {
                 int v = ~ref, n = (v & 3) + 1, first = v >> 2;
                 int32_t slot0;
-                std::memcpy(&slot0, &wt.tris[12 * (size_t)first + 9], 4);
+                if (tris) std::memcpy(&slot0, &wt.tris[12 * (size_t)first + 9], 4);
+                else slot0 = wt.order[(size_t)first];
                 const PbrtLinearBVHNode& lf = nodes[leaf_node[slot0]];
                 if (lf.n_primitives != n) return -10;
-                if (n >= 2 && (std::memcmp(&wt.leaf_boxes[8 * (size_t)first], lf.bounds_min, 12) != 0 ||
+                if ((n >= 2 || !tris) && (std::memcmp(&wt.leaf_boxes[8 * (size_t)first], lf.bounds_min, 12) != 0 ||
                                std::memcmp(&wt.leaf_boxes[8 * (size_t)first + 4], lf.bounds_max, 12) != 0))
                     return -11;
                 continue;
@@ -264,7 +271,8 @@ struct FilterWalk {
         if (ref < 0) {
             int v = ~ref, first = v >> 2;
             int32_t slot0;
-            std::memcpy(&slot0, &wt->tris[12 * (size_t)first + 9], 4);
+            if (wt->order.empty()) std::memcpy(&slot0, &wt->tris[12 * (size_t)first + 9], 4);
+            else slot0 = wt->order[(size_t)first];  // opaque primitives
             const PbrtLinearBVHNode& lf = nodes[(*leaf_node)[slot0]];
             float entry_inf;
             bool pass_inf = slab(lf.bounds_min, lf.bounds_max, o, id, INFINITY, &entry_inf);

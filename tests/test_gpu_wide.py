@@ -1,0 +1,158 @@
+"""The 4-wide quantised records are the traversal that runs (not a silent use of the binary records), on every kind of
+scene the library builds them for, and the three kernels agree: wide records (default), binary records (the
+instrumented reference-count kernel, set_counting(1)) and the oracle's BVHAccel::intersect / intersect_p
+(src/accelerators/bvh.rs:812-945) give the same hits bit for bit. Rays outside the range the filter's error bound covers
+(wide_bvh.h: wide_ray_covered) are traced by the binary kernel in a follow-up launch, and are counted.
+"""
+import numpy as np
+import pytest
+
+import oracle
+import pbrt_hip
+from pbrt_hip import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _rays_into(lo, hi, n, seq):
+    u = scenes.pcg32_float(seq, n * 6).reshape(n, 6)
+    ext = (hi - lo).astype(np.float32)
+    r = scenes.random_rays(n, seq + 1)
+    r["o"] = (lo + (u[:, :3] * 1.6 - 0.3) * ext).astype(np.float32)
+    aim = (lo + u[:, 3:6] * ext).astype(np.float32)
+    d = aim - r["o"]
+    d[np.all(d == 0, axis=1)] = (0.1, 0.2, 0.3)
+    r["d"] = d.astype(np.float32)
+    r["t_max"][::5] = np.float32(0.6)
+    return r
+
+
+def _three_way(ctx, gsc, osc, rays):
+    """(wide hits, wide occlusion, wide counters) after asserting wide == binary == oracle."""
+    ctx.set_counting(2)
+    try:
+        ctx.wide_counters(reset=True)
+        hw, pw = gsc.intersect(rays), gsc.intersect_p(rays)
+        wc = ctx.wide_counters(reset=True)
+        ctx.set_counting(1)
+        ctx.counters(reset=True)
+        hb, pb = gsc.intersect(rays), gsc.intersect_p(rays)
+    finally:
+        ctx.set_counting(0)
+    hd, pd = gsc.intersect(rays), gsc.intersect_p(rays)          # the uninstrumented wide kernels
+    assert hw.tobytes() == hb.tobytes() == hd.tobytes()
+    assert np.array_equal(pw, pb) and np.array_equal(pw, pd)
+    cpu, _ = osc.intersect(rays)
+    for f in ("prim_id", "t", "b0", "b1", "b2"):
+        assert np.array_equal(hw[f], cpu[f]), f
+    assert np.array_equal(pw, osc.intersect_p(rays)[0])
+    return hw, pw, wc
+
+
+@pytest.mark.parametrize("which", ["cloud", "cornell", "mixed", "instanced", "two_level", "device_built"])
+def test_wide_records_are_what_runs(hip_ctx, which):
+    kw = {}
+    if which == "cloud":
+        sc = scenes.random_triangles(60_000, seq=4, size=0.04)
+    elif which == "cornell":
+        sc = scenes.cornell_box()
+    elif which == "mixed":
+        sc = scenes.mixed_materials_scene()
+    elif which == "instanced":
+        sc = scenes.instanced_scene(n_base_tris=3000, n_instances=300)
+    elif which == "two_level":
+        sc = scenes.two_level_scene(n_instances=70)
+    else:
+        sc, kw = scenes.random_triangles(60_000, seq=4, size=0.04), dict(device_build=True)
+    gsc = pbrt_hip.Scene(hip_ctx, sc, **kw)
+    n_rec, why = gsc.wide_records()
+    assert n_rec > 0, why
+    if which == "device_built":
+        osc = oracle.OracleScene(sc, split_method=pbrt_hip.SPLIT_HLBVH)
+    else:
+        osc = oracle.OracleScene(sc)
+    root = osc.nodes()[0]
+    rays = _rays_into(root["bmin"], root["bmax"], 80_000, 41)
+    hits, occl, wc = _three_way(hip_ctx, gsc, osc, rays)
+    assert (hits["prim_id"] >= 0).sum() > 2000 and occl.sum() > 2000
+    assert wc["records"] > len(rays) and wc["triangles"] > 0        # the wide kernels did the work ...
+    assert wc["special_rays"] < len(rays) // 50                     # ... for all but a few rays
+    gsc.close()
+    osc.close()
+
+
+def test_rays_outside_the_filters_range_take_the_binary_records(hip_ctx):
+    """Axis-parallel directions (infinite reciprocals), denormal-small components, far origins: the wide kernel lists them,
+    a follow-up launch of the binary kernel traces them; the count is exactly the number wide_ray_covered rejects."""
+    sc = scenes.random_triangles(20_000, seq=3, size=0.05)
+    gsc = pbrt_hip.Scene(hip_ctx, sc)
+    osc = oracle.OracleScene(sc)
+    n = 40_000
+    rays = _rays_into(np.float32([-1, -1, -1]), np.float32([1, 1, 1]), n, 57)
+    k = np.arange(n)
+    a = k % 3
+    par = k % 4 == 0
+    rays["d"][par, a[par]] = 0.0                                   # 1/0 = inf
+    tiny = k % 4 == 1
+    rays["d"][tiny, a[tiny]] = np.float32(1e-30)                   # |1/d| > 2^40
+    far = k % 16 == 2
+    rays["o"][far, a[far]] = np.float32(-3e7)                      # |o| > 2^24, aimed back at the scene
+    rays["d"][far] = -rays["o"][far] + rays["d"][far] * np.float32(0.1)
+    huge = k % 16 == 3
+    rays["d"][huge] *= np.float32(1e15)                            # |1/d| < 2^-40 on every axis
+    with np.errstate(divide="ignore"):
+        inv = np.abs(np.float32(1) / rays["d"])
+    covered = (np.all((inv >= np.float32(2.0 ** -40)) & (inv <= np.float32(2.0 ** 40)), axis=1)
+               & np.all(np.abs(rays["o"]) <= np.float32(2.0 ** 24), axis=1))
+    assert 0.3 * n < (~covered).sum() < 0.7 * n
+    hits, occl, wc = _three_way(hip_ctx, gsc, osc, rays)
+    assert wc["special_rays"] == 2 * int((~covered).sum())         # once per launch: intersect and intersect_p
+    assert (hits["prim_id"][~covered] >= 0).sum() > 500 and (hits["prim_id"][covered] >= 0).sum() > 500
+    gsc.close()
+    osc.close()
+
+
+def test_wide_traversal_fetches_fewer_records_than_the_reference_loop_tests_boxes(hip_ctx):
+    """What the wide records are for: per ray, records fetched (48 B each) against the reference loop's box tests (32 B
+    nodes). The ratio on the bench's kind of scene is what DESIGN.md's request count rests on."""
+    sc = scenes.random_triangles(200_000, seq=1, size=0.02)
+    gsc = pbrt_hip.Scene(hip_ctx, sc)
+    rays = scenes.random_rays(200_000, 5, origin_extent=1.2)
+    hip_ctx.set_counting(2)
+    try:
+        hip_ctx.wide_counters(reset=True)
+        gsc.intersect(rays)
+        wc = hip_ctx.wide_counters(reset=True)
+        hip_ctx.set_counting(1)
+        hip_ctx.counters(reset=True)
+        gsc.intersect(rays)
+        bc = hip_ctx.counters(reset=True)
+    finally:
+        hip_ctx.set_counting(0)
+    assert wc["records"] * 2.2 < bc["node_tests"]
+    assert wc["triangles"] <= bc["prim_tests"] * 1.1 + 100     # leaves pass the exact box first, so few extra triangles
+    gsc.close()
+
+
+@pytest.mark.parametrize("split,max_prims", [(pbrt_hip.SPLIT_SAH, 4), (pbrt_hip.SPLIT_MIDDLE, 1), (pbrt_hip.SPLIT_EQUAL_COUNTS, 2), (pbrt_hip.SPLIT_HLBVH, 4)])
+def test_visiting_order_decides_ties(hip_ctx, split, max_prims):
+    """Every triangle three times, under different primitive numbers: all copies give the same t, and the reference keeps
+    the one its traversal reaches first (Triangle::intersect_test needs t < t_max, triangle.rs:127-131). The primitive
+    number returned is therefore a direct read-out of the visiting order of leaves and of triangles inside them."""
+    base = scenes.random_triangles(4000, seq=12, size=0.15)
+    n = len(base["indices"])
+    perm = np.argsort(scenes.pcg32_float(3, 3 * n), kind="stable").astype(np.int64)   # the copies are not neighbours in the input
+    sc = dict(base, indices=np.ascontiguousarray(np.tile(base["indices"], (3, 1))[perm]),
+              tri_material=np.ascontiguousarray(np.tile(base["tri_material"], 3)[perm]),
+              tri_light=np.ascontiguousarray(np.tile(base["tri_light"], 3)[perm]))
+    gsc = pbrt_hip.Scene(hip_ctx, sc, max_prims_in_node=max_prims, split_method=split)
+    assert gsc.wide_records()[0] > 0
+    osc = oracle.OracleScene(sc, max_prims_in_node=max_prims, split_method=split)
+    rays = scenes.random_rays(60_000, 8, origin_extent=1.3)
+    hits, occl, wc = _three_way(hip_ctx, gsc, osc, rays)
+    hit = hits["prim_id"] >= 0
+    assert hit.sum() > 10_000
+    copies = perm[hits["prim_id"][hit]] // n        # which of the three copies won: all three occur
+    assert len(np.unique(copies)) == 3
+    gsc.close()
+    osc.close()

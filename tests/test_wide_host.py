@@ -203,3 +203,26 @@ def test_filter_on_an_axis_aligned_scene_with_rays_on_its_planes(chk):
     counts = np.zeros(4, dtype=np.int64)
     bad = chk.wide_check_filter(nodes.ctypes.data, len(nodes), tris.ctypes.data, len(tris), rays.ctypes.data, n, counts.ctypes.data)
     assert bad == 0 and counts[1] > n
+
+
+def test_top_level_tree_over_opaque_primitives(chk):
+    """A two-level scene's top-level aggregate (src/core/api.rs:1481-1520: TransformedPrimitives beside world triangles):
+    the builder gets no triangle records (tris == NULL), keeps every leaf's exact box and reports the wide-order ->
+    leaf-slot map; same P1-P4."""
+    sc = scenes.two_level_scene(n_instances=60)
+    trees, inst, tlas_nodes, tlas_order = pbrt_hip.build_general_two_level(sc)
+    n_slots = len(tlas_order)
+    stats = np.zeros(4, dtype=np.int64)
+    why = ctypes.create_string_buffer(200)
+    rc = chk.wide_check_structure(tlas_nodes.ctypes.data, len(tlas_nodes), None, n_slots, stats.ctypes.data, why, 200)
+    assert rc == 0, (rc, why.value)
+    assert stats[2] == int((tlas_nodes["n_primitives"] > 0).sum())
+    rays = _adversarial_rays(tlas_nodes, 3000, 17)
+    counts = np.zeros(4, dtype=np.int64)
+    bad = chk.wide_check_filter(tlas_nodes.ctypes.data, len(tlas_nodes), None, n_slots, rays.ctypes.data, len(rays), counts.ctypes.data)
+    assert bad == 0 and counts[1] > 1000, (bad, counts)
+    # ... and each object aggregate is an ordinary triangle tree
+    for o, (nodes, order) in zip(sc["objects"], trees):
+        tris = _tri_records(np.asarray(o["positions"], dtype=np.float32), np.asarray(o["indices"], dtype=np.int32), order)
+        rc, st, w = _structure(chk, nodes, tris)
+        assert rc == 0, (rc, w)

@@ -20,6 +20,12 @@ for it in range(2):
 rays = st["rays_closest"] + st["rays_shadow"]
 print(f"{W}x{H}x{spp}: total {st['total_ms']:.1f} ms trace {st['trace_ms']:.1f} ms ({st['trace_launches']} launches) "
       f"rays {rays/1e6:.1f}M -> {rays/st['total_ms']/1e3:.0f} Mrays/s")
+if os.environ.get("NO_COUNT"): sys.exit(0)
+if scene.wide_records()[0] > 0:
+    ctx.set_counting(2); ctx.wide_counters(reset=True)
+    scene.render(cam, W, H, spp, max_depth=16, seed=0)
+    wc = ctx.wide_counters(reset=True)
+    print("wide per ray: " + " ".join(f"{k} {v/rays:.2f}" for k, v in wc.items()))
 ctx.set_counting(True); ctx.counters(reset=True)
 film, st2 = scene.render(cam, W, H, spp, max_depth=16, seed=0)
 c = ctx.counters(reset=True); ctx.set_counting(False)
