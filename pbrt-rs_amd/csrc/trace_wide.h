@@ -76,9 +76,9 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     const int lane = threadIdx.x & 63;
     TravRay r;
     float idx = 0.0f, idy = 0.0f, idz = 0.0f, tmax = 0.0f, hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
-    int hit_slot = -1, cur = 0, sp = 0;
+    int hit_slot = -1, sp = 0;
     uint32_t index = 0;
-    bool nx = false, ny = false, nz = false, any = false, has_work = false;
+    bool nx = false, ny = false, nz = false, any = false;
     uint32_t negmask = 0;
     r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.tmax = 0.0f;
     uint32_t chunk_next = 0, chunk_end = 0;
@@ -90,7 +90,17 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     float tmax_world = 0.0f;
     int leaf_first = 0, leaf_cnt = 0, leaf_next = 0, cur_top_slot = -1, hit_inst = -1, base_sp = 0;
     bool in_instance = false, hit_here = false;
-    constexpr int kLeaveInstance = (int)0x80000000;
+    // What a lane is doing is all in `cur`: a record index (>= 0), a leaf reference (< 0, above the five codes below), or
+    // one of the codes. Flags kept as separate booleans cost scalar mask bookkeeping in every iteration of the loops
+    // that change them; one integer costs a vector compare where it is asked.
+    constexpr int kLeaveInstance = (int)0x80000000;  // INST: the instance's stack floor was reached, leave it in the leaf phase
+    constexpr int kNeedPop = (int)0x80000001;         // out of children: take a stack entry at the next record iteration
+    constexpr int kIdle = (int)0x80000002;            // no ray
+    constexpr int kDoneHit = (int)0x80000003;         // ray finished, its result is still in the registers ...
+    constexpr int kDoneMiss = (int)0x80000004;        // ... (found / not found), stored at the next refill
+    int cur = kIdle;
+    auto is_idle = [&]() -> bool { return ((uint32_t)cur - (uint32_t)kIdle) <= 2u; };
+    auto is_leaf_ref = [&]() -> bool { return cur < 0 && cur > kDoneMiss; };
 #ifdef PB_LANE_STATS
     unsigned long long wstat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave-level events (lane 0's copy is kept)
     unsigned int wl_steps = 0, wl_children = 0, wl_cand = 0, wl_pass = 0, wl_tris = 0;  // this lane's own events
@@ -120,26 +130,33 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         if (pos >= kWideStackLds) ent = wt.spill[(size_t)(pos - kWideStackLds) * wt.spill_stride + spill_lane];
         return ent;
     };
+    // A finished ray's result stays in the lane's registers (the lane is idle) until the wave next refills, and is
+    // stored then, by all the lanes that finished meanwhile at once: with 64 rays per wave some lane finishes in most
+    // record steps, and storing there cost every step the store sequence at one or two lanes.
     auto finish = [&](bool found) {
-        io.store(index, any, found, tmax, hb0, hb1, hb2, hit_slot, INST ? hit_inst : -1);
-        has_work = false;
+        cur = found ? kDoneHit : kDoneMiss;
     };
-    // next entry whose lower bound is still in front of the hit; false when the ray is finished. Inside an instance
-    // the stack ends at the floor laid down on entry: the lane then parks on kLeaveInstance and leaves the instance in
-    // the leaf phase (primitive.rs:140-143), where the rest of the top-level leaf is taken up again.
-    auto advance = [&]() -> bool {
-        for (;;) {
-            if (INST && in_instance && sp <= base_sp) {
-                cur = kLeaveInstance;
-                return true;
-            }
-            if (sp == 0) return false;
+    auto flush_result = [&]() {
+        if (cur == kDoneHit || cur == kDoneMiss) {
+            io.store(index, any, cur == kDoneHit, tmax, hb0, hb1, hb2, hit_slot, INST ? hit_inst : -1);
+            cur = kIdle;
+        }
+    };
+    // A lane that ran out of children (need_pop) takes ONE stack entry at the top of the next record iteration, together
+    // with the other such lanes: the next entry whose lower bound is still in front of the hit becomes `cur`; an entry
+    // behind the hit costs the lane that iteration. Inside an instance the stack ends at the floor laid down on entry:
+    // the lane then parks on kLeaveInstance and leaves the instance in the leaf phase (primitive.rs:140-143), where the
+    // rest of the top-level leaf is taken up again. (The loop this replaces popped until it found a live entry, at one
+    // or two lanes per iteration, with the exec-mask bookkeeping of a divergent loop in every record step.)
+    auto pop_one = [&]() {
+        if (INST && in_instance && sp <= base_sp) {
+            cur = kLeaveInstance;
+        } else if (sp == 0) {
+            finish(hit_slot >= 0);
+        } else {
             --sp;
             uint2 ent = stack_read(sp);
-            if (__uint_as_float(ent.y) < tmax) {
-                cur = (int)ent.x;
-                return true;
-            }
+            if (__uint_as_float(ent.y) < tmax) cur = (int)ent.x;
         }
     };
     auto set_ray_constants = [&]() {
@@ -226,7 +243,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
 
     for (;;) {
         // ---------------- refill idle lanes (as trace_persistent.h) ----------------
-        unsigned long long idle_mask = __ballot(!has_work);
+        unsigned long long idle_mask = __ballot(is_idle());
         int n_idle = __popcll(idle_mask);
         if (!exhausted && (n_idle >= PB_WIDE_REFILL_THRESH)) {
             if (chunk_next >= chunk_end) {
@@ -249,7 +266,8 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             uint32_t avail = chunk_end - chunk_next;
             uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0));
-            bool take = !has_work && prefix < avail;
+            flush_result();
+            bool take = is_idle() && prefix < avail;
             uint32_t my = chunk_next + prefix;
             chunk_next += ((uint32_t)n_idle < avail) ? (uint32_t)n_idle : avail;
             bool special = false;
@@ -260,7 +278,6 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 hit_slot = -1;
                 hb0 = hb1 = hb2 = 0.0f;
                 sp = 0;
-                has_work = true;
                 if (!real) {
                     finish(false);  // placeholder of a path outside pixel_bounds: not a ray of the frame
                 } else {
@@ -275,7 +292,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                     special = !covered;
                     if (COUNT && special) c_special += 1;
                     cur = wt.root_ref;
-                    if (special) has_work = false;  // traced by the binary kernel afterwards (results written there)
+                    if (special) cur = kIdle;  // traced by the binary kernel afterwards (results written there)
                 }
             }
             unsigned long long sm = __ballot(special);
@@ -287,23 +304,24 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                     wt.special_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0))] = index;
             }
         }
-        if (!__any(has_work)) {
+        if (!__any(!is_idle())) {
             if (exhausted) break;
             continue;
         }
 
         // ---------------- records ----------------
         for (;;) {
-            bool interior = has_work && cur >= 0;
-            int n_int = __popcll(__ballot(interior));
+            if (cur == kNeedPop) pop_one();
+            bool interior = cur >= 0;
+            int n_int = __popcll(__ballot(cur >= 0 || cur == kNeedPop));
             if (n_int == 0) break;
             if (n_int < PB_WIDE_INTERIOR_THRESH) {
-                bool leaf_pending = __any(has_work && cur < 0);
-                bool can_refill = !exhausted && (__popcll(__ballot(!has_work)) >= PB_WIDE_REFILL_THRESH);
+                bool leaf_pending = __any(is_leaf_ref() || (INST && cur == kLeaveInstance));
+                bool can_refill = !exhausted && (__popcll(__ballot(is_idle())) >= PB_WIDE_REFILL_THRESH);
                 if (leaf_pending || can_refill) break;
             }
             PB_WSTAT(0, 1);      // record iterations of this wave
-            PB_WSTAT(1, n_int);  // lanes stepping a record
+            PB_WSTAT(1, __popcll(__ballot(interior)));  // lanes stepping a record
             if (interior) {
                 const uint4* nd = wt.nodes + 3 * (size_t)cur;
                 uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
@@ -340,22 +358,36 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 wl_children += (h[0] ? 1 : 0) + (h[1] ? 1 : 0) + (h[2] ? 1 : 0) + (h[3] ? 1 : 0);
 #endif
                 // the children the reference visits later go on the stack, last one deepest
-                if (h[3] && (h[0] || h[1] || h[2])) {
-                    stack_write(sp, ref[3], tn[3]);
-                    ++sp;
-                }
-                if (h[2] && (h[0] || h[1])) {
-                    stack_write(sp, ref[2], tn[2]);
-                    ++sp;
-                }
-                if (h[1] && h[0]) {
-                    stack_write(sp, ref[1], tn[1]);
-                    ++sp;
+                const bool p3 = h[3] && (h[0] || h[1] || h[2]), p2 = h[2] && (h[0] || h[1]), p1 = h[1] && h[0];
+                if (!__any(sp > kWideStackLds - 3)) {
+                    // all three fit the LDS part for every lane of the wave (nearly always): store unconditionally, a
+                    // lane that does not push just leaves its stack pointer where it was (the entry above the top of a
+                    // stack is never read). No exec-mask bookkeeping: the three predicated pushes below cost about as
+                    // many scalar instructions as vector ones.
+                    lds[sp * kTraceBlock] = make_uint2((uint32_t)ref[3], __float_as_uint(tn[3]));
+                    sp += p3 ? 1 : 0;
+                    lds[sp * kTraceBlock] = make_uint2((uint32_t)ref[2], __float_as_uint(tn[2]));
+                    sp += p2 ? 1 : 0;
+                    lds[sp * kTraceBlock] = make_uint2((uint32_t)ref[1], __float_as_uint(tn[1]));
+                    sp += p1 ? 1 : 0;
+                } else {
+                    if (p3) {
+                        stack_write(sp, ref[3], tn[3]);
+                        ++sp;
+                    }
+                    if (p2) {
+                        stack_write(sp, ref[2], tn[2]);
+                        ++sp;
+                    }
+                    if (p1) {
+                        stack_write(sp, ref[1], tn[1]);
+                        ++sp;
+                    }
                 }
                 if (h[0] || h[1] || h[2] || h[3]) {
                     cur = h[0] ? ref[0] : (h[1] ? ref[1] : (h[2] ? ref[2] : ref[3]));
-                } else if (!advance()) {
-                    finish(hit_slot >= 0);
+                } else {
+                    cur = kNeedPop;
                 }
             }
         }
@@ -363,16 +395,16 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         // ---------------- leaves: the reference's box test on the exact leaf box, then its triangles ----------------
 #ifdef PB_LANE_STATS
         {
-            unsigned long long lm = __ballot(has_work && cur < 0);
+            unsigned long long lm = __ballot(is_leaf_ref() || (INST && cur == kLeaveInstance));
             if (lm) {
                 PB_WSTAT(2, 1);             // leaf sections
                 PB_WSTAT(3, __popcll(lm));  // lanes with a candidate leaf
             }
             PB_WSTAT(6, 1);  // outer iterations
-            PB_WSTAT(7, __popcll(__ballot(has_work)));
+            PB_WSTAT(7, __popcll(__ballot(!is_idle())));
         }
 #endif
-        if (INST && has_work && cur < 0 && (!in_instance || cur == kLeaveInstance)) {
+        if (INST && (cur == kLeaveInstance || (is_leaf_ref() && !in_instance))) {
             bool walk = true;
             if (in_instance) {
                 exit_instance();  // the rest of the top-level leaf follows
@@ -422,13 +454,13 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             if (abandon) {
                 // left to the binary kernel, which traces the ray from scratch (rare: one list append per such ray)
                 wt.special_list[atomicAdd(wt.special_count, 1u)] = index;
-                has_work = false;
+                cur = kIdle;
             } else if (done) {
                 finish(true);
-            } else if (!entered && !advance()) {
-                finish(hit_slot >= 0);
+            } else if (!entered) {
+                cur = kNeedPop;
             }
-        } else if (has_work && cur < 0) {
+        } else if (is_leaf_ref()) {
             const int v = ~cur;
             const int cnt = (v & 3) + 1;
             const int first = v >> 2;
@@ -504,10 +536,11 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             }
             if (done)
                 finish(true);
-            else if (!advance())
-                finish(hit_slot >= 0);
+            else
+                cur = kNeedPop;
         }
     }
+    flush_result();
     if (COUNT) count_flush(counters + 4, c_rec, c_cand, c_tri, c_special);
 #ifdef PB_LANE_STATS
     {

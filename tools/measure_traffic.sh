@@ -36,7 +36,7 @@ def per_kernel_in(sub, counter):
 fetch, nf = per_kernel("FETCH_SIZE"); write, nw = per_kernel("WRITE_SIZE")
 # the timed launches: k_trace_wide<false> (or k_trace<false,false,false> on a scene without wide records)
 def pick(d):
-    ks = [k for k in d if re.search(r"k_trace_wide<false>|k_trace_wide<\(bool\)0>", k)] or [k for k in d if re.search(r"k_trace<false, false, false>", k)]
+    ks = [k for k in d if re.search(r"k_trace_wide<false(, 0)?>|k_trace_wide<\(bool\)0", k)] or [k for k in d if re.search(r"k_trace<false, (false|0), false>", k)]
     return ks[0]
 kf, kw = pick(fetch), pick(write)
 fb, wb = fetch[kf] * 1024 / nf[kf], write[kw] * 1024 / nw[kw]
