@@ -14,6 +14,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 # the issue side of the same launches: vector instructions, the lane-cycles they kept busy, wave residency
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/SQ -o SQ -- $CMD > $OUT/SQ.log 2>&1 || { tail -5 $OUT/SQ.log; exit 1; }
+# ... and how busy the texture addressers were (the unit that turns lane requests into cache accesses)
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/TA -o TA -- $CMD > $OUT/TA.log 2>&1 || { tail -5 $OUT/TA.log; exit 1; }
 python3 - <<'PY'
 import csv, glob, json, os, re, subprocess
 out = "gpurun_out/traffic"
@@ -51,7 +53,12 @@ sq = {}
 for c in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"):
     t, n = per_kernel_in("SQ", c)
     if kf in t: sq[c] = t[kf] / n[kf]
+ta = {}
+for c in ("TA_TA_BUSY_sum", "GRBM_GUI_ACTIVE"):
+    t, n = per_kernel_in("TA", c)
+    if kf in t: ta[c] = t[kf] / n[kf]
 rec = {
+    "ta_busy_fraction": (ta["TA_TA_BUSY_sum"] / 256 / (ta["GRBM_GUI_ACTIVE"] / 8)) if ta.get("GRBM_GUI_ACTIVE") else None,
     "valu_insts_per_launch": sq.get("SQ_INSTS_VALU"), "salu_insts_per_launch": sq.get("SQ_INSTS_SALU"),
     "valu_lane_utilisation": (sq["SQ_THREAD_CYCLES_VALU"] / (sq["SQ_INSTS_VALU"] * 64)) if sq.get("SQ_INSTS_VALU") else None,
     "wave_cycles_waiting_fraction": (sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAVE_CYCLES") else None,
