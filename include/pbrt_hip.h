@@ -295,9 +295,10 @@ void pbrt_hip_scene_destroy(PbrtHipScene* scene);
  * 48-byte records with 8-bit conservative boxes laid over the same tree (two levels of BVHAccel's nodes per record,
  * src/accelerators/bvh.rs:129-135): the traversal kernels then walk those and decide every leaf visit with
  * Bounds3f::intersect_p (src/core/geometry.rs:709-751) on the exact leaf box, so results are the reference's bit for
- * bit. n_records = number of wide records, 0 when the tree is a single leaf, -1 when the scene has none; *reason then
- * says why (instanced scene, spheres, a leaf with more than 4 primitives, PBRT_HIP_WIDE=0 ...). The string lives as
- * long as the scene. */
+ * bit. Two-level scenes carry them for the top-level tree and for every object aggregate. n_records = number of wide
+ * records (all trees of the scene), 0 when the tree is a single leaf, -1 when the scene has none; *reason then says why
+ * (spheres, a leaf with more than 4 primitives, coordinates beyond 2^20, PBRT_HIP_WIDE=0 ...). The string lives as long
+ * as the scene. */
 int pbrt_hip_scene_wide_records(const PbrtHipScene* scene, int32_t* n_records, const char** reason);
 
 /* ---- batch Primitive::intersect / intersect_p (src/core/primitive.rs:17-30 via
