@@ -155,7 +155,9 @@ typedef struct PbrtRenderParams {
                              * row-major number over the film's sample bounds: y * width + x with the 0.5 box filter */
     int32_t tile_rank;      /* this GPU renders the 16x16 tiles whose index % tile_world == tile_rank */
     int32_t tile_world;     /* 1 = all tiles */
-    int32_t spp_per_pass;   /* 0 = library default; samples of one pixel traced concurrently */
+    int32_t spp_per_pass;   /* 0 = library default; samples of one pixel traced concurrently. Queue entries are 32 bits
+                             * (path << 2 | ray slot): pixels x spp_per_pass of one pass must stay below 2^30, larger values
+                             * are refused with PBRT_HIP_ERR_INVALID (the default never gets there: it is sized from free HBM) */
     int32_t ao_samples;     /* AOIntegrator::n_samples (ao.rs:21); other integrators ignore it */
     /* Reconstruction filter (src/core/filter.rs:10-15, src/filters/): radius in pixels and Film's 16x16
      * table of filter.evaluate over the positive quadrant (src/core/film.rs:52-63; build it with

@@ -44,6 +44,11 @@ __device__ unsigned long long g_wide_stats[16];
 #define PB_WSTAT(i, v)
 #endif
 
+// 64-bit population count as a 32-bit scalar (with __popcll the compare that follows is made in 64 bits, on the vector unit)
+__device__ __forceinline__ int popc64(unsigned long long m) {
+    return __builtin_popcount((uint32_t)m) + __builtin_popcount((uint32_t)(m >> 32));
+}
+
 // The rays trace_wide left to the binary kernel, as an IO policy of trace_persistent: ray i of this launch is ray
 // list[i] of the original queue; their number is read from device memory (the wide launch counted them).
 template <class Inner>
@@ -247,7 +252,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     for (;;) {
         // ---------------- refill idle lanes (as trace_persistent.h) ----------------
         unsigned long long idle_mask = __ballot(is_idle());
-        int n_idle = __popcll(idle_mask);
+        int n_idle = popc64(idle_mask);
         if (!exhausted && (n_idle >= PB_WIDE_REFILL_THRESH)) {
             if (chunk_next >= chunk_end) {
                 while (seg_tries < n_seg) {
@@ -301,7 +306,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             unsigned long long sm = __ballot(special);
             if (sm) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(wt.special_count, (unsigned int)__popcll(sm));
+                if (lane == 0) base = atomicAdd(wt.special_count, (unsigned int)popc64(sm));
                 base = (uint32_t)__builtin_amdgcn_readfirstlane(base);
                 if (special)
                     wt.special_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0))] = index;
@@ -316,15 +321,15 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         for (;;) {
             if (cur == kNeedPop) pop_one();
             bool interior = cur >= 0;
-            int n_int = __popcll(__ballot(cur >= 0 || cur == kNeedPop));
+            int n_int = popc64(__ballot(cur >= 0) | __ballot(cur == kNeedPop));  // two compare masks OR-ed on the scalar unit
             if (n_int == 0) break;
             if (n_int < (INST ? PB_WIDE_INST_INTERIOR_THRESH : PB_WIDE_INTERIOR_THRESH)) {
                 bool leaf_pending = __any(is_leaf_ref() || (INST && cur == kLeaveInstance));
-                bool can_refill = !exhausted && (__popcll(__ballot(is_idle())) >= PB_WIDE_REFILL_THRESH);
+                bool can_refill = !exhausted && (popc64(__ballot(is_idle())) >= PB_WIDE_REFILL_THRESH);
                 if (leaf_pending || can_refill) break;
             }
             PB_WSTAT(0, 1);      // record iterations of this wave
-            PB_WSTAT(1, __popcll(__ballot(interior)));  // lanes stepping a record
+            PB_WSTAT(1, popc64(__ballot(interior)));  // lanes stepping a record
             if (interior) {
                 const uint4* nd = wt.nodes + 3 * (size_t)cur;
                 uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
@@ -401,10 +406,10 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             unsigned long long lm = __ballot(is_leaf_ref() || (INST && cur == kLeaveInstance));
             if (lm) {
                 PB_WSTAT(2, 1);             // leaf sections
-                PB_WSTAT(3, __popcll(lm));  // lanes with a candidate leaf
+                PB_WSTAT(3, popc64(lm));  // lanes with a candidate leaf
             }
             PB_WSTAT(6, 1);  // outer iterations
-            PB_WSTAT(7, __popcll(__ballot(!is_idle())));
+            PB_WSTAT(7, popc64(__ballot(!is_idle())));
         }
 #endif
         if (INST && (cur == kLeaveInstance || (is_leaf_ref() && !in_instance))) {
