@@ -96,8 +96,10 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     uint32_t c_rec = 0, c_cand = 0, c_tri = 0, c_special = 0;
     // two-level state (INST)
     float tmax_world = 0.0f;
-    int leaf_first = 0, leaf_cnt = 0, leaf_next = 0, cur_top_slot = -1, hit_inst = -1, base_sp = 0;
-    bool in_instance = false, hit_here = false;
+    // base_sp >= 0: the lane is inside an instance whose stack floor is base_sp (-1 outside); the instance that holds the
+    // current hit is hit_inst (a top-level slot is visited at most once per ray, so hit_inst == cur_top_slot says "hit
+    // inside the instance being left"). No flags: see the lane codes above.
+    int leaf_first = 0, leaf_cnt = 0, leaf_next = 0, cur_top_slot = -1, hit_inst = -1, base_sp = -1;
     // What a lane is doing is all in `cur`: a record index (>= 0), a leaf reference (< 0, above the five codes below), or
     // one of the codes. Flags kept as separate booleans cost scalar mask bookkeeping in every iteration of the loops
     // that change them; one integer costs a vector compare where it is asked.
@@ -157,7 +159,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     // rest of the top-level leaf is taken up again. (The loop this replaces popped until it found a live entry, at one
     // or two lanes per iteration, with the exec-mask bookkeeping of a divergent loop in every record step.)
     auto pop_one = [&]() {
-        if (INST && in_instance && sp <= base_sp) {
+        if (INST && sp <= base_sp) {
             cur = kLeaveInstance;
         } else if (sp == 0) {
             finish(hit_slot >= 0);
@@ -231,8 +233,6 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         ny = by;
         nz = bz;
         negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
-        in_instance = true;
-        hit_here = false;
         cur_top_slot = __float_as_int(meta.y);
         base_sp = sp;
         cur = root;
@@ -240,13 +240,13 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     };
     // second half (primitive.rs:140-143): r.t_max = ray.t_max on a hit; back to the world ray
     auto exit_instance = [&]() {
-        if (hit_here) tmax_world = tmax;
+        if (hit_inst == cur_top_slot) tmax_world = tmax;
         bool any_again;
         (void)io.load(index, &r, &any_again);
         r.tmax = tmax_world;
         tmax = tmax_world;
         set_ray_constants();
-        in_instance = false;
+        base_sp = -1;
     };
 
     for (;;) {
@@ -292,7 +292,8 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                     set_ray_constants();
                     if (INST) {
                         tmax_world = r.tmax;
-                        in_instance = false;
+                        base_sp = -1;
+                        cur_top_slot = -2;
                         hit_inst = -1;
                         leaf_cnt = leaf_next = 0;
                     }
@@ -412,9 +413,9 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             PB_WSTAT(7, popc64(__ballot(!is_idle())));
         }
 #endif
-        if (INST && (cur == kLeaveInstance || (is_leaf_ref() && !in_instance))) {
+        if (INST && (cur == kLeaveInstance || (is_leaf_ref() && base_sp < 0))) {
             bool walk = true;
-            if (in_instance) {
+            if (base_sp >= 0) {
                 exit_instance();  // the rest of the top-level leaf follows
             } else {
                 // a candidate top-level leaf: the reference's test on its exact box with the world ray and the current t_max
@@ -535,7 +536,6 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                             hb2 = b2;
                             hit_slot = __float_as_int(tc.y);
                             if (INST) {
-                                hit_here = true;
                                 hit_inst = cur_top_slot;
                             }
                         }
