@@ -769,12 +769,22 @@ int hlbvh_build_scene_tree(PbrtHipContext* ctx, const float* positions, int32_t 
         out->convert_ms = ms;
     }
     {
-        // The wide records are laid out on the host (host_wide.cpp): bring the flat tree and the triangle records back.
-        // Costs a D2H copy (80 B per triangle) and ~0.1 s per million triangles of host work on top of the device build;
-        // PBRT_HIP_WIDE_DEVICE_TREES=0 keeps scene setup at the device build's few milliseconds (binary records only).
+        // The wide records are laid over the flat tree while it is still on the device (wide_gpu.hip: a few ms per 10 M
+        // triangles). PBRT_HIP_WIDE_BUILD=host brings the flat tree and the triangle records back instead and lets the host
+        // builder do it (host_wide.cpp; 80 B per triangle over PCIe + tens of ms per million triangles): same bytes, kept
+        // for the test of exactly that. PBRT_HIP_WIDE_DEVICE_TREES=0: binary records only.
         const char* w1 = std::getenv("PBRT_HIP_WIDE");
         const char* w2 = std::getenv("PBRT_HIP_WIDE_DEVICE_TREES");
-        if (!(w1 && w1[0] == '0') && !(w2 && w2[0] == '0')) {
+        const char* w3 = std::getenv("PBRT_HIP_WIDE_BUILD");
+        const bool want_wide = !(w1 && w1[0] == '0') && !(w2 && w2[0] == '0');
+        if (!want_wide) {
+            out->wide_reason = (w1 && w1[0] == '0') ? "disabled by PBRT_HIP_WIDE=0" : "tree built on the device (PBRT_HIP_WIDE_DEVICE_TREES=0)";
+        } else if (!(w3 && w3[0] == 'h')) {
+            if (!pb::build_wide_tree_device(ctx, d_nodes, n_nodes, (const float*)p_tris, n, root, &out->wide, &out->wide_reason)) {
+                release();
+                return PBRT_HIP_ERR_DEVICE;
+            }
+        } else {
             out->h_nodes.resize(n_nodes);
             out->h_tris.resize((size_t)n * 12);
             e = hipMemcpy(out->h_nodes.data(), d_nodes, (size_t)n_nodes * sizeof(PbrtLinearBVHNode), hipMemcpyDeviceToHost);

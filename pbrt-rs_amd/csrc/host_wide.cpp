@@ -10,127 +10,94 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "host_wide.h"
-#include "wide_bvh.h"
+#include "wide_build.h"
 
 namespace pb {
 
 
 namespace {
 
-uint32_t f2u(float f) {
-    uint32_t u;
-    std::memcpy(&u, &f, 4);
-    return u;
+// runs fn(begin, end) over [0, n) on the host threads this process may use (PBRT_HIP_HOST_THREADS, at most 16);
+// fn returns an error text or nullptr, the first error in index order wins
+template <class F>
+const char* parallel_chunks(size_t n, size_t min_chunk, F fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("PBRT_HIP_HOST_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));
+    size_t n_threads = std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 16u), std::max<size_t>(1, n / std::max<size_t>(1, min_chunk)));
+    if (n_threads <= 1) return fn((size_t)0, n);
+    std::vector<const char*> err(n_threads, nullptr);
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < n_threads; ++t)
+        pool.emplace_back([&, t] { err[t] = fn(n * t / n_threads, n * (t + 1) / n_threads); });
+    for (auto& th : pool) th.join();
+    for (const char* e : err)
+        if (e) return e;
+    return nullptr;
 }
-float u2f(uint32_t u) {
-    float f;
-    std::memcpy(&f, &u, 4);
-    return f;
-}
-// the largest float <= target whose low mantissa byte is `m` (the record keeps m[0..2] in the low bytes of base.xyz)
-float base_with_byte(double target, uint32_t m) {
-    float t = (float)target;
-    if ((double)t > target) t = std::nextafter(t, -HUGE_VALF);
-    uint32_t u = f2u(t);
-    if (!(u & 0x80000000u)) {  // t >= +0: float order = integer order
-        uint32_t cand = (u & ~0xffu) | m;
-        if (cand <= u) return u2f(cand);
-        if (u >= 0x100u) return u2f(cand - 0x100u);
-        return u2f(0x80000000u | m);  // below the smallest positive step: a tiny negative value (or -0)
-    }
-    uint32_t mag = u & 0x7fffffffu, cand = (mag & ~0xffu) | m;  // negative: the magnitude has to be >= |t|
-    if (cand < mag) cand += 0x100u;
-    return u2f(0x80000000u | cand);
-}
-double next_up(double x) { return std::nextafter(x, HUGE_VAL); }
-double next_down(double x) { return std::nextafter(x, -HUGE_VAL); }
 
 }  // namespace
 
+// Three passes. (1) the properties the exactness argument needs, checked per node (parallel). (2) the structure, one
+// sequential walk over node headers: which binary node every record stands for, where its interior children and its leaf
+// children's triangles start (the interior children of a record are consecutive records, the triangles of its leaf
+// children consecutive wide-order positions). (3) the records themselves — bases, exponents, the 24 planes — and the
+// triangle copies, independent per record (parallel). 1 M triangles: 230 ms -> a few tens of ms on 16 threads.
 const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, const float* tris, int32_t n_slots,
                             WideTree* out, const WideBase& base_of) {
     if (n_nodes <= 0 || n_slots <= 0) return "empty tree";
     const bool opaque = tris == nullptr;
-    // ---- the properties the exactness argument needs: checked, not assumed ----
-    for (int32_t i = 0; i < n_nodes; ++i) {
-        const PbrtLinearBVHNode& nd = nodes[i];
-        for (int k = 0; k < 3; ++k) {
-            if (!(std::fabs(nd.bounds_min[k]) <= kWideCoordLimit) || !(std::fabs(nd.bounds_max[k]) <= kWideCoordLimit))
-                return "coordinates beyond 2^20";
-            if (!(nd.bounds_min[k] <= nd.bounds_max[k])) return "inverted node box";
-        }
-        if (nd.n_primitives > 0) {
-            if (nd.n_primitives > 4) return "leaf with more than 4 primitives";
-            if (nd.n_primitives == 1 && !opaque) {
-                // the single-triangle leaf box is recomputed from the vertices by the kernel: it has to BE the tight box
-                const float* t = tris + 12 * (size_t)nd.offset;
-                for (int k = 0; k < 3; ++k) {
-                    float lo = std::fmin(t[k], std::fmin(t[3 + k], t[6 + k]));
-                    float hi = std::fmax(t[k], std::fmax(t[3 + k], t[6 + k]));
-                    if (lo != nd.bounds_min[k] || hi != nd.bounds_max[k]) return "single-triangle leaf box is not the triangle's bounds";
-                }
-            }
-        } else {
-            const PbrtLinearBVHNode* ch[2] = {&nodes[i + 1], &nodes[nd.offset]};
-            for (int c = 0; c < 2; ++c)
-                for (int k = 0; k < 3; ++k)
-                    if (ch[c]->bounds_min[k] < nd.bounds_min[k] || ch[c]->bounds_max[k] > nd.bounds_max[k])
-                        return "child box not inside its parent's";
-        }
-    }
+    // ---- (1) checked, not assumed ----
+    if (const char* why = parallel_chunks((size_t)n_nodes, 1 << 15, [&](size_t i0, size_t i1) -> const char* {
+            for (size_t i = i0; i < i1; ++i)
+                if (int code = wide_check_node(nodes, (int32_t)i, tris)) return wide_error_text(code);
+            return nullptr;
+        }))
+        return why;
     auto leaf_ref = [&](int64_t first_wide, int n) -> int32_t { return ~(int32_t)(((first_wide + base_of.tri) << 2) | (int64_t)(n - 1)); };
     if (!opaque) out->tris.assign((size_t)n_slots * 12, 0.0f);
     if (opaque) out->order.assign((size_t)n_slots, -1);
     out->leaf_boxes.assign((size_t)n_slots * 8, 0.0f);
-    int64_t tri_cursor = 0;
-    auto emit_leaf = [&](const PbrtLinearBVHNode& lf) -> int64_t {  // copies the leaf's triangles, returns their first wide position
-        int64_t first = tri_cursor;
-        for (int j = 0; j < lf.n_primitives; ++j) {
-            if (opaque) {
-                out->order[(size_t)tri_cursor] = lf.offset + j + base_of.slot;
-                ++tri_cursor;
-                continue;
-            }
-            const float* src = tris + 12 * (size_t)(lf.offset + j);
-            float* dst = &out->tris[12 * (size_t)tri_cursor];
-            std::memcpy(dst, src, 36);
-            int32_t slot = lf.offset + j + base_of.slot;
-            int32_t flags;
-            std::memcpy(&flags, src + 11, 4);
-            std::memcpy(dst + 9, &slot, 4);
-            std::memcpy(dst + 10, &flags, 4);
-            ++tri_cursor;
-        }
-        if (lf.n_primitives >= 2 || opaque) {
+    // copies a leaf's triangles to wide-order position `first` (and its exact box, where the kernel reads one)
+    auto emit_leaf = [&](const PbrtLinearBVHNode& lf, int64_t first) {
+        if (opaque) {
+            for (int j = 0; j < lf.n_primitives; ++j) out->order[(size_t)(first + j)] = lf.offset + j + base_of.slot;
             float* b = &out->leaf_boxes[8 * (size_t)first];
             std::memcpy(b, lf.bounds_min, 12);
             std::memcpy(b + 4, lf.bounds_max, 12);
+            return;
         }
-        return first;
+        wide_emit_leaf(lf, tris, base_of.slot, (size_t)first, out->tris.data(), out->leaf_boxes.data());
     };
     if (nodes[0].n_primitives > 0) {  // the whole tree is one leaf
-        {
-            const int64_t first = emit_leaf(nodes[0]);
-            out->root_ref = leaf_ref(first, nodes[0].n_primitives);
-        }
+        emit_leaf(nodes[0], 0);
+        out->root_ref = leaf_ref(0, nodes[0].n_primitives);
         out->nodes.assign(kWideNodeDwords, 0u);
         out->n_records = 0;
         return nullptr;
     }
     if ((int64_t)n_slots + base_of.tri >= (1ll << 29)) return "too many triangles for 30-bit wide references";
-    // records in breadth-first order: the interior children of a record are consecutive
+    // ---- (2) structure ----
     // A record's index is fixed when its parent is laid out (the parent's interior children take the next free indices,
     // contiguously); the ORDER in which records are laid out decides which records and triangles end up near each other:
     // first-in-first-out = breadth-first (levels contiguous), last-in-first-out = depth-first (subtrees nearly contiguous).
+    // (Measured: no difference for the traversal, profiles/r02_scene_rates.txt.)
     const char* order_env = std::getenv("PBRT_HIP_WIDE_ORDER");
     const bool depth_first = order_env && order_env[0] == 'd';
-    std::vector<int32_t> roots;  // binary node of every record
-    roots.push_back(0);
+    struct Rec {
+        int32_t node;         // the binary node this record stands for
+        int32_t first_child;  // record index of its first interior child
+        int64_t first_tri;    // wide-order position of its first leaf child's first triangle
+    };
+    std::vector<Rec> recs;
+    recs.reserve((size_t)n_nodes / 3 + 16);
+    recs.push_back(Rec{0, 0, 0});
     std::vector<size_t> work{0};
     size_t work_head = 0;
+    int64_t tri_cursor = 0;
     while (work_head < work.size()) {
         size_t w;
         if (depth_first) {
@@ -139,94 +106,53 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
         } else {
             w = work[work_head++];
         }
-        const int32_t i = roots[w];
-        const PbrtLinearBVHNode& nd = nodes[i];
-        int32_t slot_node[4] = {-1, -1, -1, -1};
-        const int32_t c[2] = {i + 1, nd.offset};
-        int axis_c[2] = {0, 0};
-        for (int j = 0; j < 2; ++j) {
-            if (nodes[c[j]].n_primitives > 0) {
-                slot_node[2 * j] = c[j];
-            } else {
-                slot_node[2 * j] = c[j] + 1;
-                slot_node[2 * j + 1] = nodes[c[j]].offset;
-                axis_c[j] = nodes[c[j]].axis;
-            }
-        }
-        uint32_t rec[kWideNodeDwords] = {0};
-        // children first: the bytes m[] are part of base.xyz
-        uint32_t m[4] = {0xff, 0xff, 0xff, 0xff};
-        int n_interior = 0, tri_off = 0;
-        const int64_t first_child = (int64_t)roots.size();
-        const int64_t first_tri = tri_cursor;
+        int32_t slot_node[4];
+        int axis_c[2];
+        wide_slots_of(nodes, recs[w].node, slot_node, axis_c);
+        recs[w].first_child = (int32_t)recs.size();
+        recs[w].first_tri = tri_cursor;
+        int n_interior = 0;
         for (int s = 0; s < 4; ++s) {
             if (slot_node[s] < 0) continue;
             const PbrtLinearBVHNode& ch = nodes[slot_node[s]];
             if (ch.n_primitives > 0) {
-                emit_leaf(ch);
-                m[s] = (uint32_t)(tri_off << 2) | (uint32_t)(ch.n_primitives - 1);
-                tri_off += ch.n_primitives;
+                tri_cursor += ch.n_primitives;
             } else {
-                m[s] = 0x80u | (uint32_t)n_interior;
                 ++n_interior;
-                roots.push_back(slot_node[s]);
-                work.push_back(roots.size() - 1);
+                recs.push_back(Rec{slot_node[s], 0, 0});
+                work.push_back(recs.size() - 1);
             }
         }
-        float base[3];
-        int e[3];
-        for (int k = 0; k < 3; ++k) {
-            // base: kWideSlack cells (and a little more) below the lower corner; cell 2^e: the smallest with 255 cells
-            // reaching kWideSlack cells beyond the upper corner. The two depend on each other: settle in a few rounds.
-            int ek = kExpMin;
-            for (int round = 0; round < 8; ++round) {
-                base[k] = base_with_byte((double)nd.bounds_min[k] - 2.0 * kWideSlack * std::ldexp(1.0, ek), k < 3 ? m[k] : 0);
-                double extent = next_up((double)nd.bounds_max[k] - (double)base[k]);
-                int need = kExpMin;
-                while (need <= kExpMax && std::ldexp(255.0 - 2.0 * kWideSlack, need) < extent) ++need;
-                if (need <= ek) break;
-                ek = need;
-            }
-            if (ek > kExpMax) return "node extent beyond the exponent range";
-            e[k] = ek;
-        }
-        uint32_t q[6] = {0, 0, 0, 0, 0, 0};
-        for (int s = 0; s < 4; ++s) {
-            uint32_t qlo[3] = {255, 255, 255}, qhi[3] = {0, 0, 0};  // empty slot: inverted (and masked out by m = 0xFF)
-            if (slot_node[s] >= 0) {
-                const PbrtLinearBVHNode& ch = nodes[slot_node[s]];
-                for (int k = 0; k < 3; ++k) {
-                    double dlo = next_down((double)ch.bounds_min[k] - (double)base[k]);
-                    double dhi = next_up((double)ch.bounds_max[k] - (double)base[k]);
-                    double flo = std::floor(std::ldexp(dlo, -e[k]) - kWideSlack), fhi = std::ceil(std::ldexp(dhi, -e[k]) + kWideSlack);
-                    if (flo < 0.0 || fhi > 255.0 || flo > fhi) return "quantisation out of range";  // excluded by the choice of base and e
-                    qlo[k] = (uint32_t)flo;
-                    qhi[k] = (uint32_t)fhi;
-                }
-            }
-            for (int k = 0; k < 3; ++k) {
-                q[2 * k] |= qlo[k] << (8 * s);
-                q[2 * k + 1] |= qhi[k] << (8 * s);
-            }
-        }
-        for (int k = 0; k < 3; ++k) rec[k] = f2u(base[k]);
-        rec[3] = ((uint32_t)e[0] & 63u) | ((uint32_t)e[1] & 63u) << 6 | ((uint32_t)e[2] & 63u) << 12 |
-                 (uint32_t)nd.axis << 18 | (uint32_t)axis_c[0] << 20 | (uint32_t)axis_c[1] << 22 | m[3] << 24;
-        for (int k = 0; k < 6; ++k) rec[4 + k] = q[k];
-        rec[10] = (uint32_t)(first_child + base_of.record);
-        rec[11] = ~(uint32_t)((first_tri + base_of.tri) << 2);
         if (depth_first && n_interior > 1)  // walk the first interior child first, as BVHAccel's flattening does
             std::reverse(work.end() - n_interior, work.end());
-        if (out->nodes.size() < roots.size() * kWideNodeDwords) out->nodes.resize(roots.size() * kWideNodeDwords, 0u);
-        std::memcpy(&out->nodes[w * kWideNodeDwords], rec, sizeof(rec));
-        if (roots.size() >= (1u << 31)) return "too many records";
+        if (recs.size() >= (1u << 31)) return "too many records";
     }
+    if (tri_cursor != n_slots) return "leaves do not cover the triangle list";
+    out->nodes.assign(recs.size() * kWideNodeDwords, 0u);
+    // ---- (3) the records ----
+    if (const char* why = parallel_chunks(recs.size(), 1 << 13, [&](size_t w0, size_t w1) -> const char* {
+            for (size_t w = w0; w < w1; ++w) {
+                const int32_t i = recs[w].node;
+                int32_t slot_node[4];
+                int axis_c[2], tri_off[4];
+                wide_slots_of(nodes, i, slot_node, axis_c);
+                uint32_t rec[kWideNodeDwords] = {0};
+                if (int code = wide_make_record(nodes, i, slot_node, axis_c, (uint32_t)((int64_t)recs[w].first_child + base_of.record),
+                                                (uint32_t)(recs[w].first_tri + base_of.tri), rec, tri_off))
+                    return wide_error_text(code);
+                for (int s = 0; s < 4; ++s)
+                    if (slot_node[s] >= 0 && nodes[slot_node[s]].n_primitives > 0) emit_leaf(nodes[slot_node[s]], recs[w].first_tri + tri_off[s]);
+                std::memcpy(&out->nodes[w * kWideNodeDwords], rec, sizeof(rec));
+            }
+            return nullptr;
+        }))
+        return why;
     out->root_ref = base_of.record;
-    out->n_records = (int)roots.size();
+    out->n_records = (int)recs.size();
     {
         // a record with k children leaves at most k - 1 of them on the stack while the first is being walked
-        std::vector<int> need(roots.size(), 0);
-        for (size_t w = roots.size(); w-- > 0;) {
+        std::vector<int> need(recs.size(), 0);
+        for (size_t w = recs.size(); w-- > 0;) {
             const uint32_t* rec = &out->nodes[w * kWideNodeDwords];
             const uint32_t m[4] = {rec[0] & 0xffu, rec[1] & 0xffu, rec[2] & 0xffu, rec[3] >> 24};
             int k = 0, deepest = 0;
@@ -239,7 +165,6 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
         }
         out->stack_need = need[0];
     }
-    if (tri_cursor != n_slots) return "leaves do not cover the triangle list";
     return nullptr;
 }
 

@@ -360,6 +360,11 @@ extern "C" int pbrt_hip_scene_create_hlbvh(PbrtHipContext* ctx, const float* pos
         (void)hipFree(dt.tris);
         (void)hipFree(dt.slot_prim);
     }
+    if (dt.wide.nodes) {
+        (void)hipFree(dt.wide.nodes);
+        (void)hipFree(dt.wide.tris);
+        (void)hipFree(dt.wide.leaf_boxes);
+    }
     return rc;
 }
 
@@ -764,8 +769,24 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         const char* wide_env = std::getenv("PBRT_HIP_WIDE");
         if (wide_env && wide_env[0] == '0') {
             s->wide_reason = "disabled by PBRT_HIP_WIDE=0";
-        } else if (sa.n > 0 || (dt && dt->h_nodes.empty())) {
-            s->wide_reason = dt ? "tree built on the device (PBRT_HIP_WIDE_DEVICE_TREES=0)" : "scene with spheres";
+        } else if (sa.n > 0) {
+            s->wide_reason = "scene with spheres";
+        } else if (dt && dt->wide.n_records >= 0) {
+            // laid out on the device beside the tree (wide_gpu.hip): the scene takes the arrays over
+            s->wide.nodes = (const uint4*)dt->wide.nodes;
+            s->wide.tris = (const float4*)dt->wide.tris;
+            s->wide.leaf_boxes = (const float4*)dt->wide.leaf_boxes;
+            s->allocs.push_back(dt->wide.nodes);
+            s->allocs.push_back(dt->wide.tris);
+            s->allocs.push_back(dt->wide.leaf_boxes);
+            dt->wide.nodes = nullptr;
+            dt->wide.tris = dt->wide.leaf_boxes = nullptr;
+            s->wide.root_ref = dt->wide.root_ref;
+            s->n_wide_records = dt->wide.n_records;
+            s->has_wide = true;
+            spill_entries = std::max(spill_entries, dt->wide.stack_need + 1 - kWideStackLds);
+        } else if (dt && dt->h_nodes.empty()) {
+            s->wide_reason = dt->wide_reason ? dt->wide_reason : "tree built on the device: no wide records";
         } else if (instanced) {
             // two levels: the top-level tree's records first (its leaves keep their exact boxes and name top-level
             // primitives in wide order), then every object aggregate's; one triangle / leaf-box array for all objects
@@ -822,6 +843,34 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
                 s->n_wide_records = record_base;
                 s->has_wide = true;
                 spill_entries = std::max(spill_entries, top.stack_need + deepest + 2 - kWideStackLds);
+            }
+        } else if (!dt && ok && !(std::getenv("PBRT_HIP_WIDE_BUILD") && std::getenv("PBRT_HIP_WIDE_BUILD")[0] == 'h')) {
+            // a tree from the host: its flat nodes go up once, the records are laid out on the device from them and from
+            // the triangle records already there (wide_gpu.hip; the host builder produces the same bytes, tens of ms per
+            // million triangles slower: PBRT_HIP_WIDE_BUILD=host)
+            bool up = true;
+            PbrtLinearBVHNode* d_flat = dev_upload(s, nodes, (size_t)n_nodes, &up);
+            pb::WideDeviceTree wd;
+            const char* why = nullptr;
+            if (!up || !pb::build_wide_tree_device(ctx, d_flat, n_nodes, (const float*)d.bvh.tris, n_prims, nodes[0], &wd, &why)) {
+                ok = false;
+            } else if (why) {
+                s->wide_reason = why;
+            } else {
+                s->wide.nodes = (const uint4*)wd.nodes;
+                s->wide.tris = (const float4*)wd.tris;
+                s->wide.leaf_boxes = (const float4*)wd.leaf_boxes;
+                s->allocs.push_back(wd.nodes);
+                s->allocs.push_back(wd.tris);
+                s->allocs.push_back(wd.leaf_boxes);
+                s->wide.root_ref = wd.root_ref;
+                s->n_wide_records = wd.n_records;
+                s->has_wide = true;
+                spill_entries = std::max(spill_entries, wd.stack_need + 1 - kWideStackLds);
+            }
+            if (d_flat) {  // only the builder needed it
+                (void)hipFree(d_flat);
+                s->allocs.erase(std::remove(s->allocs.begin(), s->allocs.end(), (void*)d_flat), s->allocs.end());
             }
         } else {
             pb::WideTree wt;
@@ -927,6 +976,22 @@ extern "C" int pbrt_hip_scene_wide_records(const PbrtHipScene* s, int32_t* n_rec
     if (!s) return PBRT_HIP_ERR_INVALID;
     if (n_records) *n_records = s->has_wide ? s->n_wide_records : -1;
     if (reason) *reason = s->wide_reason.c_str();
+    return PBRT_HIP_OK;
+}
+
+// Copies a single-level scene's wide records back: n_records x 12 dwords, n_slots x 12 floats (wide-order triangles),
+// n_slots x 8 floats (leaf boxes). Not part of the boundary (not in include/pbrt_hip.h): the test that the device builder
+// (wide_gpu.hip) and the host builder (host_wide.cpp) produce the same bytes reads the arrays through it.
+extern "C" int pbrt_hip_debug_wide_export(PbrtHipScene* s, uint32_t* nodes, float* tris, float* boxes, int32_t n_slots) {
+    if (!s || !s->has_wide || s->d.bvh.instanced || n_slots != s->d.bvh.n_slots) return PBRT_HIP_ERR_INVALID;
+    PbrtHipContext* ctx = s->ctx;
+    PB_LOCK(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (nodes && s->n_wide_records > 0)
+        HIP_TRY(ctx, hipMemcpy(nodes, s->wide.nodes, (size_t)s->n_wide_records * kWideNodeDwords * 4, hipMemcpyDeviceToHost));
+    if (tris) HIP_TRY(ctx, hipMemcpy(tris, s->wide.tris, (size_t)n_slots * 48, hipMemcpyDeviceToHost));
+    if (boxes) HIP_TRY(ctx, hipMemcpy(boxes, s->wide.leaf_boxes, (size_t)n_slots * 32, hipMemcpyDeviceToHost));
     return PBRT_HIP_OK;
 }
 

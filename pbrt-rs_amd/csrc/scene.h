@@ -152,6 +152,18 @@ inline T* dev_upload(PbrtHipScene* s, const T* src, size_t n, bool* ok) {
 
 // A single-level scene tree built and re-laid out on the device (hlbvh_gpu.hip): the scene takes
 // ownership of the three device arrays.
+// device arrays of the 4-wide records of one tree, built on the device (wide_gpu.hip); the caller owns them
+struct WideDeviceTree {
+    uint32_t* nodes = nullptr;    // 12 dwords per record
+    float* tris = nullptr;        // 12 floats per wide-order triangle
+    float* leaf_boxes = nullptr;  // 8 floats per wide-order triangle position
+    int32_t root_ref = 0;
+    int n_records = -1;  // -1: not built
+    int stack_need = 0;
+};
+bool build_wide_tree_device(PbrtHipContext* ctx, const PbrtLinearBVHNode* d_nodes, int32_t n_nodes, const float* d_tris, int32_t n_slots,
+                            const PbrtLinearBVHNode& root, WideDeviceTree* out, const char** reason);
+
 struct DeviceTree {
     float4* inodes = nullptr;   // 64-B child-pair records
     float4* tris = nullptr;     // 48-B triangles in leaf order
@@ -159,8 +171,11 @@ struct DeviceTree {
     float root_min[3], root_max[3];
     int root_ref = 0, count_bits = 0, n_interior = 0, n_nodes = 0;
     std::vector<int32_t> light_slot;  // per light: leaf slot of an area light's triangle, -1 otherwise
-    // host copies of the flat node array and the triangle records, for laying the 4-wide records (wide_bvh.h) over the
-    // device-built tree as well; empty when that is switched off (PBRT_HIP_WIDE=0 / PBRT_HIP_WIDE_DEVICE_TREES=0)
+    // the 4-wide records (wide_bvh.h) laid over the device-built tree, on the device as well (wide_gpu.hip);
+    // wide.n_records < 0: not built (wide_reason says why: PBRT_HIP_WIDE=0, PBRT_HIP_WIDE_DEVICE_TREES=0, or the tree does not
+    // qualify). PBRT_HIP_WIDE_BUILD=host: the host builder instead, on copies of the tree (the test of host == device).
+    WideDeviceTree wide;
+    const char* wide_reason = nullptr;
     std::vector<PbrtLinearBVHNode> h_nodes;
     std::vector<float> h_tris;
     double build_ms = 0.0;            // tree build; convert_ms: re-layout into the traversal format

@@ -377,6 +377,19 @@ class Scene:
         self.h = h
         self.ctx._scenes.add(self)
 
+    def debug_wide_export(self, n_slots):
+        """(records (n, 12) uint32, wide-order triangles (n_slots, 12) float32, leaf boxes (n_slots, 8) float32) of a
+        single-level scene, copied back from the device (pbrt_hip_debug_wide_export: a test hook, not part of the boundary)."""
+        n, _ = self.wide_records()
+        nodes = np.zeros((max(n, 0), 12), dtype=np.uint32)
+        tris = np.zeros((n_slots, 12), dtype=np.float32)
+        boxes = np.zeros((n_slots, 8), dtype=np.float32)
+        f = lib().pbrt_hip_debug_wide_export
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+        f.restype = ctypes.c_int
+        self.ctx.check(f(self.h, nodes.ctypes.data, tris.ctypes.data, boxes.ctypes.data, int(n_slots)), "debug_wide_export")
+        return nodes, tris, boxes
+
     def wide_records(self):
         """(number of 4-wide records, reason): -1 records = the scene is traced over the binary records only."""
         n, why = ctypes.c_int32(), ctypes.c_char_p()

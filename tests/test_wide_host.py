@@ -32,7 +32,7 @@ def chk():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     deps = [SRC] + [os.path.join(HERE, "..", "pbrt-rs_amd", "csrc", f) for f in ("host_wide.cpp", "host_wide.h", "wide_bvh.h")]
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", OUT, SRC])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-o", OUT, SRC])
     L = ctypes.CDLL(OUT)
     vp, i32 = ctypes.c_void_p, ctypes.c_int32
     L.wide_check_structure.argtypes = [vp, i32, vp, i32, vp, ctypes.c_char_p, ctypes.c_int]
