@@ -79,7 +79,8 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
         out->n_records = 0;
         return nullptr;
     }
-    if ((int64_t)n_slots + base_of.tri >= (1ll << 29)) return "too many triangles for 30-bit wide references";
+    // (the five lowest integers are lane codes of the traversal kernel, trace_wide.h: leaf references stay above them)
+    if ((int64_t)n_slots + base_of.tri >= (1ll << 29) - 4) return "too many triangles for 30-bit wide references";
     // ---- (2) structure ----
     // A record's index is fixed when its parent is laid out (the parent's interior children take the next free indices,
     // contiguously); the ORDER in which records are laid out decides which records and triangles end up near each other:

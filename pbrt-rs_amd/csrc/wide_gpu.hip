@@ -113,7 +113,7 @@ bool build_wide_tree_device(PbrtHipContext* ctx, const PbrtLinearBVHNode* d_node
         *reason = "empty tree";
         return true;
     }
-    if ((int64_t)n_slots >= (1ll << 29)) {
+    if ((int64_t)n_slots >= (1ll << 29) - 4) {  // the five lowest integers are lane codes of the traversal kernel (trace_wide.h)
         *reason = "too many triangles for 30-bit wide references";
         return true;
     }
