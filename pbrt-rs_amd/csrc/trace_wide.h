@@ -40,8 +40,10 @@ constexpr int kWideStackLds = PB_WIDE_STACK_LDS;
 // development instrumentation (tools/lane_stats.py): wave-level iteration counts and lane sums of trace_wide
 __device__ unsigned long long g_wide_stats[16];
 #define PB_WSTAT(i, v) wstat[i] += (v)
+#define PB_WCLOCK(var) const unsigned long long var = __builtin_readcyclecounter()
 #else
 #define PB_WSTAT(i, v)
+#define PB_WCLOCK(var)
 #endif
 
 // 64-bit population count as a 32-bit scalar (with __popcll the compare that follows is made in 64 bits, on the vector unit)
@@ -251,9 +253,11 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
 
     for (;;) {
         // ---------------- refill idle lanes (as trace_persistent.h) ----------------
+        PB_WCLOCK(t_refill0);
         unsigned long long idle_mask = __ballot(is_idle());
         int n_idle = popc64(idle_mask);
         if (!exhausted && (n_idle >= PB_WIDE_REFILL_THRESH)) {
+            PB_WSTAT(9, 1);  // refills
             if (chunk_next >= chunk_end) {
                 while (seg_tries < n_seg) {
                     uint32_t seg_begin = (uint32_t)(((unsigned long long)n * (unsigned)seg) / (unsigned)n_seg);
@@ -276,6 +280,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0));
             flush_result();
             bool take = is_idle() && prefix < avail;
+            PB_WSTAT(10, popc64(__ballot(take)));  // rays fetched
             uint32_t my = chunk_next + prefix;
             chunk_next += ((uint32_t)n_idle < avail) ? (uint32_t)n_idle : avail;
             bool special = false;
@@ -319,6 +324,8 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         }
 
         // ---------------- records ----------------
+        PB_WCLOCK(t_rec0);
+        PB_WSTAT(13, t_rec0 - t_refill0);
         for (;;) {
             if (cur == kNeedPop) pop_one();
             bool interior = cur >= 0;
@@ -402,6 +409,8 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         }
 
         // ---------------- leaves: the reference's box test on the exact leaf box, then its triangles ----------------
+        PB_WCLOCK(t_leaf0);
+        PB_WSTAT(14, t_leaf0 - t_rec0);
 #ifdef PB_LANE_STATS
         {
             unsigned long long lm = __ballot(is_leaf_ref() || (INST && cur == kLeaveInstance));
@@ -547,6 +556,9 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             else
                 cur = kNeedPop;
         }
+#ifdef PB_LANE_STATS
+        wstat[15] += __builtin_readcyclecounter() - t_leaf0;
+#endif
     }
     flush_result();
     if (COUNT) count_flush(counters + 4, c_rec, c_cand, c_tri, c_special);

@@ -32,6 +32,10 @@ if w[0]:
     print(f"wide leaves:  {w[2]/1e6:.1f} M wave sections, {w[3]/max(w[2],1):.1f} lanes with a candidate leaf ({w[12]/rays:.2f} candidates per ray), "
           f"{w[4]/max(w[12],1):.2f} of them pass the exact box, {w[5]/rays:.2f} triangle tests per ray")
     print(f"wide outer:   {w[6]/1e6:.1f} M iterations, {w[7]/max(w[6],1):.1f} lanes with work")
+    cyc = w[13] + w[14] + w[15]
+    if cyc:
+        print(f"wide refills: {w[9]/1e6:.2f} M ({w[9]/max(w[6],1):.2f} per outer iteration), {w[10]/max(w[9],1):.1f} rays fetched per refill")
+        print(f"wave time (s_memtime between sections): refill {100*w[13]/cyc:.1f} %, record loop {100*w[14]/cyc:.1f} %, leaf phase {100*w[15]/cyc:.1f} %")
     sys.exit(0)
 print(f"interior: {s[0]/1e6:.1f} M wave iterations, {s[1]/max(s[0],1):.1f} lanes active of 64 ({s[1]/rays:.1f} node steps per ray)")
 print(f"leaves:   {s[2]/1e6:.1f} M wave sections, {s[3]/max(s[2],1):.1f} lanes with a leaf, {s[4]/max(s[2],1):.2f} loop trips per section, "
