@@ -31,6 +31,9 @@ namespace pb {
 #ifndef PB_WIDE_INST_INTERIOR_THRESH
 #define PB_WIDE_INST_INTERIOR_THRESH 24  // two-level scenes: more kinds of work wait behind the record loop (config 5: 24 +5 %, 40 -8 %)
 #endif
+#ifndef PB_WIDE_INST_GATHER
+#define PB_WIDE_INST_GATHER 1
+#endif
 #ifndef PB_WIDE_REFILL_THRESH
 #define PB_WIDE_REFILL_THRESH 8
 #endif
@@ -332,7 +335,11 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             int n_int = popc64(__ballot(cur >= 0) | __ballot(cur == kNeedPop));  // two compare masks OR-ed on the scalar unit
             if (n_int == 0) break;
             if (n_int < (INST ? PB_WIDE_INST_INTERIOR_THRESH : PB_WIDE_INTERIOR_THRESH)) {
-                bool leaf_pending = __any(is_leaf_ref() || (INST && cur == kLeaveInstance));
+                // two-level scenes: lanes waiting to enter / leave an instance (the expensive, rarely taken branch of the
+                // leaf phase) only count once PB_WIDE_INST_GATHER of them wait: the branch then runs for that many lanes
+                bool leaf_pending = INST ? (__any(is_leaf_ref() && base_sp >= 0) ||
+                                            popc64(__ballot(cur == kLeaveInstance || (is_leaf_ref() && base_sp < 0))) >= PB_WIDE_INST_GATHER)
+                                         : __any(is_leaf_ref());
                 bool can_refill = !exhausted && (popc64(__ballot(is_idle())) >= PB_WIDE_REFILL_THRESH);
                 if (leaf_pending || can_refill) break;
             }
@@ -422,7 +429,14 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             PB_WSTAT(7, popc64(__ballot(!is_idle())));
         }
 #endif
-        if (INST && (cur == kLeaveInstance || (is_leaf_ref() && base_sp < 0))) {
+        // (see the record loop: this branch waits for PB_WIDE_INST_GATHER lanes unless nothing else is left to do)
+        bool inst_turn = false;
+        if (INST) {
+            const bool waits = cur == kLeaveInstance || (is_leaf_ref() && base_sp < 0);
+            const bool others = __any(cur >= 0 || cur == kNeedPop || (is_leaf_ref() && base_sp >= 0));
+            inst_turn = waits && (!others || popc64(__ballot(waits)) >= PB_WIDE_INST_GATHER);
+        }
+        if (INST && inst_turn) {
             bool walk = true;
             if (base_sp >= 0) {
                 exit_instance();  // the rest of the top-level leaf follows
@@ -478,7 +492,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             } else if (!entered) {
                 cur = kNeedPop;
             }
-        } else if (is_leaf_ref()) {
+        } else if (is_leaf_ref() && (!INST || base_sp >= 0)) {
             const int v = ~cur;
             const int cnt = (v & 3) + 1;
             const int first = v >> 2;
