@@ -1051,8 +1051,9 @@ template <bool ANY, bool COUNT, int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES)
     k_intersect_batch_wide(WideTrees wt, BatchRayIO<ANY> io, unsigned int* work_counter, unsigned long long* counters) {
     __shared__ uint2 lds_stack[kWideStackLds * kTraceBlock];
+    __shared__ float lds_world[(INST && PB_WIDE_WORLD_LDS) ? 6 * kTraceBlock : 1];
     trace_wide<BatchRayIO<ANY>, COUNT, INST>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x,
-                                             counters);
+                                             counters, lds_world + ((INST && PB_WIDE_WORLD_LDS) ? threadIdx.x : 0));
 }
 template <bool ANY, int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, INST ? PB_INST_WAVES : PB_TRACE_WAVES)
@@ -1090,7 +1091,7 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
     hipLaunchKernelGGL((k_intersect_batch<ANY, COUNT, INST, SPH>), grid, block, 0, ctx->stream, s->d.bvh, io, ctx->d_work_counter, ctx->d_counters)
 #define PB_LAUNCH_WIDE(COUNT, INST)                                                                                                  \
     hipLaunchKernelGGL((k_intersect_batch_wide<ANY, COUNT, INST>),                                                                   \
-                       dim3(persistent_grid(s, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES, kWideStackLds)), block, 0, ctx->stream, \
+                       dim3(persistent_grid(s, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES, kWideStackLds, (INST && PB_WIDE_WORLD_LDS) ? 6 * 4 * kTraceBlock : 0)), block, 0, ctx->stream, \
                        wt, io, ctx->d_work_counter, ctx->d_counters)
 #define PB_LAUNCH_SPECIAL(INST) \
     hipLaunchKernelGGL((k_intersect_batch_special<ANY, INST>), grid, block, 0, ctx->stream, s->d.bvh, sio, ctx->d_work_counter + kFollowUpCounter)

@@ -838,7 +838,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
 #define PB_LAUNCH_BINARY(COUNT, INST, SPH) \
     hipLaunchKernelGGL((k_trace<COUNT, INST, SPH>), grid, block, 0, st, s->d.bvh, ps, trace_queue, n_trace, ctx->d_work_counter, ctx->d_counters, segments)
 #define PB_LAUNCH_WIDE(COUNT, INST)                                                                                                        \
-    hipLaunchKernelGGL((k_trace_wide<COUNT, INST>), dim3(persistent_grid(s, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES, kWideStackLds)), \
+    hipLaunchKernelGGL((k_trace_wide<COUNT, INST>), dim3(persistent_grid(s, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES, kWideStackLds, (INST && PB_WIDE_WORLD_LDS) ? 6 * 4 * kTraceBlock : 0)), \
                        block, 0, st, wt, ps, trace_queue, n_trace, ctx->d_work_counter, segments, ctx->d_counters)
 #define PB_LAUNCH_SPECIAL(INST)                                                                                   \
     hipLaunchKernelGGL(k_trace_special<INST>, grid, block, 0, st, s->d.bvh, ps, trace_queue, n_trace, special_list, \

@@ -226,8 +226,8 @@ __host__ __device__ inline bool triangle_rejected_by_intersect(const float* a, c
 }
 
 // persistent kernels: enough blocks to fill every CU (LDS: 160 KiB / (kStackLds * 2 KiB) blocks of 256, at most 8)
-inline int persistent_grid(const PbrtHipScene* s, int waves = PB_TRACE_WAVES, int stack_lds = kStackLds) {
-    int per_cu = std::min(waves, (160 * 1024) / (stack_lds * kTraceBlock * (int)sizeof(uint2)));
+inline int persistent_grid(const PbrtHipScene* s, int waves = PB_TRACE_WAVES, int stack_lds = kStackLds, int other_lds_bytes = 0) {
+    int per_cu = std::min(waves, (160 * 1024) / (stack_lds * kTraceBlock * (int)sizeof(uint2) + other_lds_bytes));
     return std::min(s->ctx->n_cus * per_cu, s->spill_lanes / kTraceBlock);
 }
 

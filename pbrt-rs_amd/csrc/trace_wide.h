@@ -31,6 +31,9 @@ namespace pb {
 #ifndef PB_WIDE_INST_INTERIOR_THRESH
 #define PB_WIDE_INST_INTERIOR_THRESH 24  // two-level scenes: more kinds of work wait behind the record loop (config 5: 24 +5 %, 40 -8 %)
 #endif
+#ifndef PB_WIDE_WORLD_LDS
+#define PB_WIDE_WORLD_LDS 1  // two-level scenes: the world ray of a lane inside an instance is kept in LDS (6 KB per block)
+#endif
 #ifndef PB_WIDE_INST_GATHER
 #define PB_WIDE_INST_GATHER 1
 #endif
@@ -84,7 +87,7 @@ struct SpecialListIO {
 // never replaces the lane's ray in the first place.
 template <class IO, bool COUNT = false, int INST = 0>
 PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restrict__ work_counter, uint2* lds_stack,
-                       int spill_lane, unsigned long long* counters = nullptr) {
+                       int spill_lane, unsigned long long* counters = nullptr, float* lds_world = nullptr) {
     const uint32_t n = io.n();
     const int lane = threadIdx.x & 63;
     TravRay r;
@@ -131,6 +134,11 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     typedef volatile unsigned long long LdsWord;
 #endif
     LdsEntry* const lds = (LdsEntry*)lds_stack;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) float LdsFloat;
+#else
+    typedef float LdsFloat;
+#endif
     auto stack_write = [&](int pos, int ref, float entry) {
         uint2 ent = make_uint2((uint32_t)ref, __float_as_uint(entry));
         if (pos < kWideStackLds)
@@ -246,8 +254,22 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     // second half (primitive.rs:140-143): r.t_max = ray.t_max on a hit; back to the world ray
     auto exit_instance = [&]() {
         if (hit_inst == cur_top_slot) tmax_world = tmax;
+#if PB_WIDE_WORLD_LDS
+        {
+            // the world ray waits in LDS, [component][lane], while the lane is inside an instance (through the queue it is
+            // two dependent global loads, 1.5 - 2 us during which the whole wave stands still, at every exit)
+            const LdsFloat* w = (const LdsFloat*)lds_world;
+            r.ox = w[0 * kTraceBlock];
+            r.oy = w[1 * kTraceBlock];
+            r.oz = w[2 * kTraceBlock];
+            r.dx = w[3 * kTraceBlock];
+            r.dy = w[4 * kTraceBlock];
+            r.dz = w[5 * kTraceBlock];
+        }
+#else
         bool any_again;
         (void)io.load(index, &r, &any_again);
+#endif
         r.tmax = tmax_world;
         tmax = tmax_world;
         set_ray_constants();
@@ -299,6 +321,15 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 } else {
                     set_ray_constants();
                     if (INST) {
+#if PB_WIDE_WORLD_LDS
+                        LdsFloat* w = (LdsFloat*)lds_world;
+                        w[0 * kTraceBlock] = r.ox;
+                        w[1 * kTraceBlock] = r.oy;
+                        w[2 * kTraceBlock] = r.oz;
+                        w[3 * kTraceBlock] = r.dx;
+                        w[4 * kTraceBlock] = r.dy;
+                        w[5 * kTraceBlock] = r.dz;
+#endif
                         tmax_world = r.tmax;
                         base_sp = -1;
                         cur_top_slot = -2;

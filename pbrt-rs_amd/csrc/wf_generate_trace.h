@@ -224,9 +224,10 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WA
     k_trace_wide(WideTrees wt, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
                  int segments, unsigned long long* counters) {
     __shared__ uint2 lds_stack[kWideStackLds * kTraceBlock];
+    __shared__ float lds_world[(INST && PB_WIDE_WORLD_LDS) ? 6 * kTraceBlock : 1];
     WavefrontRayIO io{ps, queue, n, segments};
     trace_wide<WavefrontRayIO, COUNT, INST>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x,
-                                            counters);
+                                            counters, lds_world + ((INST && PB_WIDE_WORLD_LDS) ? threadIdx.x : 0));
 }
 // ... and the rays it left to the binary records (axis-parallel directions and the like; usually none)
 template <int INST = 0>
