@@ -191,3 +191,36 @@ def test_device_builder_of_the_wide_records_equals_the_host_builder(hip_ctx, mon
     assert g_dev.intersect(rays).tobytes() == g_host.intersect(rays).tobytes()
     g_dev.close()
     g_host.close()
+
+
+@pytest.mark.parametrize("instanced", [False, True])
+def test_stacks_deeper_than_the_lds_part(hip_ctx, instanced):
+    """Large overlapping triangles, one per leaf: a ray through the middle passes nearly every box, up to three children
+    are pushed per record level, and the per-lane stack outgrows its 12 LDS entries (the spill slab in global memory and the
+    predicated push path take over from the unconditional LDS stores). Same hits as the binary kernel and the oracle."""
+    if instanced:
+        sc = scenes.instanced_scene(n_base_tris=2000, n_instances=40, tri_size=0.25, base_extent=0.3, extent=0.6)
+        kw = {}
+    else:
+        sc = scenes.random_triangles(3000, seq=5, size=0.4)
+        kw = dict(max_prims_in_node=1, split_method=pbrt_hip.SPLIT_MIDDLE)
+    gsc = pbrt_hip.Scene(hip_ctx, sc, **kw)
+    assert gsc.wide_records()[0] > 0
+    if not instanced:
+        # the builder's bound on the stack depth, recomputed from the records: k children leave k - 1 on the stack
+        rec = gsc.debug_wide_export(len(sc["indices"]))[0]
+        m = np.stack([rec[:, 0] & 0xff, rec[:, 1] & 0xff, rec[:, 2] & 0xff, rec[:, 3] >> 24], axis=1).astype(np.int64)
+        need = np.zeros(len(rec), dtype=np.int64)
+        for w in range(len(rec) - 1, -1, -1):          # children have larger indices (breadth-first layout)
+            live = m[w] != 0xff
+            kids = [int(rec[w, 10]) + int(v & 3) for v in m[w][live & ((m[w] & 0x80) != 0)]]
+            need[w] = int(live.sum()) - 1 + (max(need[k] for k in kids) if kids else 0)
+        assert need[0] > 14, need[0]
+    osc = oracle.OracleScene(sc, **kw)
+    root = osc.nodes()[0]
+    rays = _rays_into(root["bmin"], root["bmax"], 30_000, 91)
+    rays["t_max"][:] = np.inf
+    hits, occl, wc = _three_way(hip_ctx, gsc, osc, rays)
+    assert wc["records"] > 40 * len(rays)          # long walks: tens of records per ray and launch
+    gsc.close()
+    osc.close()
