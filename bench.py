@@ -51,7 +51,9 @@ def parse():
                     help="strong (default): the tiles of ONE frame are split over the GPUs (BASELINE config 4); "
                          "weak: the frame has spp x N samples per pixel (per-GPU work fixed)")
     ap.add_argument("--abi-reduce-check", action="store_true",
-                    help="run the C-ABI film-reduce check even with one rank (needs torch.distributed.run)")
+                    help="after the measurement, repeat the film merge untimed through the C ABI's own RCCL communicator "
+                         "(pbrt_hip_comm_create / pbrt_hip_film_reduce) and compare with torch.distributed's; needs "
+                         "torch.distributed.run. Not part of the default job: the measured run does not depend on a second communicator")
     ap.add_argument("--watchdog-s", type=float, default=600.0, help="a rank stuck longer than this ends the job with exit code 3")
     return ap.parse_args()
 
@@ -432,7 +434,7 @@ def main():
                 "roofline": roofline, "cpu_baseline": cpu_baseline,
             })
 
-        if world > 1 or (args.abi_reduce_check and use_dist):
+        if args.abi_reduce_check and use_dist:
             # Untimed: the same film merge through the C ABI's own RCCL communicator (pbrt_hip_comm_create /
             # pbrt_hip_film_reduce), checked against torch.distributed's reduce. Every rank reports after each stage.
             f = torch.zeros((H, W, 4), dtype=torch.float32, device=device)
