@@ -72,8 +72,6 @@ struct SpecialListIO {
     }
 };
 
-
-
 // COUNT: also counts what this kernel itself fetches (records stepped, candidate leaves, triangles loaded, rays left to
 // the binary kernel) into counters[4..7]: the inputs of bench.py's gather-rate roofline.
 // INST: two-level scenes (primitive.rs:105-159), as trace_persistent's INST: the world ray walks the top-level records; a
@@ -82,9 +80,9 @@ struct SpecialListIO {
 // floor, a plain triangle is tested in place. An object-space ray the filter's bound does not cover ends the wide
 // traversal of that ray: it goes to the binary kernel like an uncovered world ray. INST == 1: instances of one object
 // aggregate and nothing beside them (its root in the kernel arguments, no per-entry kind / object lookups); 2: general.
-// The world ray is not kept while a lane is inside an instance: leaving one reads it again through io.load (two
-// loads per visit against six registers for the whole traversal), and an entry whose object root box the ray misses
-// never replaces the lane's ray in the first place.
+// The world ray is not kept in registers while a lane is inside an instance: it waits in LDS (lds_world, [component][lane];
+// PB_WIDE_WORLD_LDS=0: re-read through io.load, two dependent global loads per exit), and an entry whose object root box the
+// ray misses never replaces the lane's ray in the first place.
 template <class IO, bool COUNT = false, int INST = 0>
 PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restrict__ work_counter, uint2* lds_stack,
                        int spill_lane, unsigned long long* counters = nullptr, float* lds_world = nullptr) {
