@@ -26,10 +26,13 @@ namespace pb {
 #define PB_WIDE_STACK_LDS 12
 #endif
 #ifndef PB_WIDE_INTERIOR_THRESH
-#define PB_WIDE_INTERIOR_THRESH 32
+#define PB_WIDE_INTERIOR_THRESH 48  // with postponed leaves (PB_WIDE_SPECULATE); 32 was the optimum without them, and is 3 % slower with
 #endif
 #ifndef PB_WIDE_INST_INTERIOR_THRESH
 #define PB_WIDE_INST_INTERIOR_THRESH 24  // two-level scenes: more kinds of work wait behind the record loop (config 5: 24 +5 %, 40 -8 %)
+#endif
+#ifndef PB_WIDE_SPECULATE
+#define PB_WIDE_SPECULATE 1  // one-level scenes: a lane keeps walking records with ONE candidate leaf postponed (see `pend`)
 #endif
 #ifndef PB_WIDE_WORLD_LDS
 #define PB_WIDE_WORLD_LDS 1  // two-level scenes: the world ray of a lane inside an instance is kept in LDS (6 KB per block)
@@ -154,8 +157,17 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     // A finished ray's result stays in the lane's registers (the lane is idle) until the wave next refills, and is
     // stored then, by all the lanes that finished meanwhile at once: with 64 rays per wave some lane finishes in most
     // record steps, and storing there cost every step the store sequence at one or two lanes.
+    // Postponed leaf (one-level scenes): a lane that reaches a candidate leaf does not stop for the wave's next leaf phase
+    // but keeps it in `pend` (< 0: a leaf reference, >= 0: none) and walks on — with the t_max it has, which the postponed
+    // leaf may yet shorten: what it walks meanwhile is a superset of what the reference walks, and every leaf is still
+    // confirmed with the t_max current when its turn comes. Turns are kept: the postponed leaf is tested before any leaf
+    // found after it; a lane that finds a second one waits, as every lane did before. More lanes step records, and the
+    // leaf phase finds more lanes with a leaf to test.
+    constexpr bool SPEC = PB_WIDE_SPECULATE && INST == 0;
+    int pend = 0;
     auto finish = [&](bool found) {
         cur = found ? kDoneHit : kDoneMiss;
+        if (SPEC) pend = 0;
     };
     auto flush_result = [&]() {
         if (cur == kDoneHit || cur == kDoneMiss) {
@@ -173,7 +185,12 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         if (INST && sp <= base_sp) {
             cur = kLeaveInstance;
         } else if (sp == 0) {
-            finish(hit_slot >= 0);
+            if (SPEC && pend < 0) {  // nothing left to walk but the postponed leaf: wait for the leaf phase with it
+                cur = pend;
+                pend = 0;
+            } else {
+                finish(hit_slot >= 0);
+            }
         } else {
             --sp;
             uint2 ent = stack_read(sp);
@@ -314,6 +331,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 hit_slot = -1;
                 hb0 = hb1 = hb2 = 0.0f;
                 sp = 0;
+                if (SPEC) pend = 0;
                 if (!real) {
                     finish(false);  // placeholder of a path outside pixel_bounds: not a ray of the frame
                 } else {
@@ -359,6 +377,10 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         PB_WCLOCK(t_rec0);
         PB_WSTAT(13, t_rec0 - t_refill0);
         for (;;) {
+            if (SPEC && pend >= 0 && is_leaf_ref()) {  // postpone the leaf, walk on
+                pend = cur;
+                cur = kNeedPop;
+            }
             if (cur == kNeedPop) pop_one();
             bool interior = cur >= 0;
             int n_int = popc64(__ballot(cur >= 0) | __ballot(cur == kNeedPop));  // two compare masks OR-ed on the scalar unit
@@ -521,8 +543,9 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             } else if (!entered) {
                 cur = kNeedPop;
             }
-        } else if (is_leaf_ref() && (!INST || base_sp >= 0)) {
-            const int v = ~cur;
+        } else if ((SPEC && pend < 0) || (is_leaf_ref() && (!INST || base_sp >= 0))) {
+            const bool from_pend = SPEC && pend < 0;  // the postponed leaf first; a leaf in `cur` then waits for the next phase
+            const int v = ~(from_pend ? pend : cur);
             const int cnt = (v & 3) + 1;
             const int first = v >> 2;
             if (COUNT) c_cand += 1;
@@ -596,6 +619,8 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             }
             if (done)
                 finish(true);
+            else if (from_pend)
+                pend = 0;
             else
                 cur = kNeedPop;
         }
