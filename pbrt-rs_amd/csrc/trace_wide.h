@@ -117,9 +117,10 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     constexpr int kIdle = (int)0x80000002;            // no ray
     constexpr int kDoneHit = (int)0x80000003;         // ray finished, its result is still in the registers ...
     constexpr int kDoneMiss = (int)0x80000004;        // ... (found / not found), stored at the next refill
+    constexpr int kWait = (int)0x80000005;            // nothing left to walk, postponed leaves still to be tested (see `pend`)
     int cur = kIdle;
     auto is_idle = [&]() -> bool { return ((uint32_t)cur - (uint32_t)kIdle) <= 2u; };
-    auto is_leaf_ref = [&]() -> bool { return cur < 0 && cur > kDoneMiss; };
+    auto is_leaf_ref = [&]() -> bool { return cur < 0 && cur > kWait; };
 #ifdef PB_LANE_STATS
     unsigned long long wstat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave-level events (lane 0's copy is kept)
     unsigned int wl_steps = 0, wl_children = 0, wl_cand = 0, wl_pass = 0, wl_tris = 0;  // this lane's own events
@@ -164,10 +165,11 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     // found after it; a lane that finds a second one waits, as every lane did before. More lanes step records, and the
     // leaf phase finds more lanes with a leaf to test.
     constexpr bool SPEC = PB_WIDE_SPECULATE && INST == 0;
-    int pend = 0;
+    constexpr bool SPEC2 = SPEC && PB_WIDE_SPECULATE >= 2;  // two postponed leaves (pend first, then pend2)
+    int pend = 0, pend2 = 0;
     auto finish = [&](bool found) {
         cur = found ? kDoneHit : kDoneMiss;
-        if (SPEC) pend = 0;
+        if (SPEC) pend = pend2 = 0;
     };
     auto flush_result = [&]() {
         if (cur == kDoneHit || cur == kDoneMiss) {
@@ -185,9 +187,8 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         if (INST && sp <= base_sp) {
             cur = kLeaveInstance;
         } else if (sp == 0) {
-            if (SPEC && pend < 0) {  // nothing left to walk but the postponed leaf: wait for the leaf phase with it
-                cur = pend;
-                pend = 0;
+            if (SPEC && pend < 0) {  // nothing left to walk but the postponed leaves: wait for the leaf phase
+                cur = kWait;
             } else {
                 finish(hit_slot >= 0);
             }
@@ -331,7 +332,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 hit_slot = -1;
                 hb0 = hb1 = hb2 = 0.0f;
                 sp = 0;
-                if (SPEC) pend = 0;
+                if (SPEC) pend = pend2 = 0;
                 if (!real) {
                     finish(false);  // placeholder of a path outside pixel_bounds: not a ray of the frame
                 } else {
@@ -377,8 +378,11 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         PB_WCLOCK(t_rec0);
         PB_WSTAT(13, t_rec0 - t_refill0);
         for (;;) {
-            if (SPEC && pend >= 0 && is_leaf_ref()) {  // postpone the leaf, walk on
-                pend = cur;
+            if (SPEC && (SPEC2 ? pend2 : pend) >= 0 && is_leaf_ref()) {  // postpone the leaf, walk on
+                if (SPEC2 && pend < 0)
+                    pend2 = cur;
+                else
+                    pend = cur;
                 cur = kNeedPop;
             }
             if (cur == kNeedPop) pop_one();
@@ -390,7 +394,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 // leaf phase) only count once PB_WIDE_INST_GATHER of them wait: the branch then runs for that many lanes
                 bool leaf_pending = INST ? (__any(is_leaf_ref() && base_sp >= 0) ||
                                             popc64(__ballot(cur == kLeaveInstance || (is_leaf_ref() && base_sp < 0))) >= PB_WIDE_INST_GATHER)
-                                         : __any(is_leaf_ref());
+                                         : __any(is_leaf_ref() || (SPEC && cur == kWait));
                 bool can_refill = !exhausted && (popc64(__ballot(is_idle())) >= PB_WIDE_REFILL_THRESH);
                 if (leaf_pending || can_refill) break;
             }
@@ -619,9 +623,11 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             }
             if (done)
                 finish(true);
-            else if (from_pend)
-                pend = 0;
-            else
+            else if (from_pend) {
+                pend = pend2;
+                pend2 = 0;
+                if (cur == kWait && pend >= 0) cur = kNeedPop;  // (the pop finds the stack empty and finishes the ray)
+            } else
                 cur = kNeedPop;
         }
 #ifdef PB_LANE_STATS
