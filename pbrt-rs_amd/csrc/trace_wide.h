@@ -34,6 +34,9 @@ namespace pb {
 #ifndef PB_WIDE_SPECULATE
 #define PB_WIDE_SPECULATE 1  // one-level scenes: a lane keeps walking records with ONE candidate leaf postponed (see `pend`)
 #endif
+#ifndef PB_WIDE_SPECULATE_INST
+#define PB_WIDE_SPECULATE_INST 0  // two-level scenes: measured slower (config 5 geometry 1147 vs 1163 Mrays/s)
+#endif
 #ifndef PB_WIDE_WORLD_LDS
 #define PB_WIDE_WORLD_LDS 1  // two-level scenes: the world ray of a lane inside an instance is kept in LDS (6 KB per block)
 #endif
@@ -164,7 +167,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     // confirmed with the t_max current when its turn comes. Turns are kept: the postponed leaf is tested before any leaf
     // found after it; a lane that finds a second one waits, as every lane did before. More lanes step records, and the
     // leaf phase finds more lanes with a leaf to test.
-    constexpr bool SPEC = PB_WIDE_SPECULATE && INST == 0;
+    constexpr bool SPEC = PB_WIDE_SPECULATE && (INST == 0 || PB_WIDE_SPECULATE_INST);  // two levels: triangle leaves inside an instance
     constexpr bool SPEC2 = SPEC && PB_WIDE_SPECULATE >= 2;  // two postponed leaves (pend first, then pend2)
     int pend = 0, pend2 = 0;
     auto finish = [&](bool found) {
@@ -185,7 +188,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     // or two lanes per iteration, with the exec-mask bookkeeping of a divergent loop in every record step.)
     auto pop_one = [&]() {
         if (INST && sp <= base_sp) {
-            cur = kLeaveInstance;
+            cur = (SPEC && pend < 0) ? kWait : kLeaveInstance;  // the postponed leaf belongs to this instance: test it first
         } else if (sp == 0) {
             if (SPEC && pend < 0) {  // nothing left to walk but the postponed leaves: wait for the leaf phase
                 cur = kWait;
@@ -378,7 +381,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         PB_WCLOCK(t_rec0);
         PB_WSTAT(13, t_rec0 - t_refill0);
         for (;;) {
-            if (SPEC && (SPEC2 ? pend2 : pend) >= 0 && is_leaf_ref()) {  // postpone the leaf, walk on
+            if (SPEC && (SPEC2 ? pend2 : pend) >= 0 && is_leaf_ref() && (!INST || base_sp >= 0)) {  // postpone the leaf, walk on
                 if (SPEC2 && pend < 0)
                     pend2 = cur;
                 else
@@ -392,7 +395,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             if (n_int < (INST ? PB_WIDE_INST_INTERIOR_THRESH : PB_WIDE_INTERIOR_THRESH)) {
                 // two-level scenes: lanes waiting to enter / leave an instance (the expensive, rarely taken branch of the
                 // leaf phase) only count once PB_WIDE_INST_GATHER of them wait: the branch then runs for that many lanes
-                bool leaf_pending = INST ? (__any(is_leaf_ref() && base_sp >= 0) ||
+                bool leaf_pending = INST ? (__any((is_leaf_ref() && base_sp >= 0) || (SPEC && cur == kWait)) ||
                                             popc64(__ballot(cur == kLeaveInstance || (is_leaf_ref() && base_sp < 0))) >= PB_WIDE_INST_GATHER)
                                          : __any(is_leaf_ref() || (SPEC && cur == kWait));
                 bool can_refill = !exhausted && (popc64(__ballot(is_idle())) >= PB_WIDE_REFILL_THRESH);
@@ -488,7 +491,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         bool inst_turn = false;
         if (INST) {
             const bool waits = cur == kLeaveInstance || (is_leaf_ref() && base_sp < 0);
-            const bool others = __any(cur >= 0 || cur == kNeedPop || (is_leaf_ref() && base_sp >= 0));
+            const bool others = __any(cur >= 0 || cur == kNeedPop || cur == kWait || (is_leaf_ref() && base_sp >= 0));
             inst_turn = waits && (!others || popc64(__ballot(waits)) >= PB_WIDE_INST_GATHER);
         }
         if (INST && inst_turn) {
