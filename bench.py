@@ -368,7 +368,7 @@ def main():
                 # the record-fetch path (texture addresser / L1: three 16-B lane requests per 48-B record) against the rate of
                 # dependent record fetches from an L1-resident table, measured in this run. The kernel is NOT HBM-bound: the
                 # tree lives in L2 / Infinity Cache ("hbm" below); what it does not spend fetching it spends issuing the
-                # box-filter arithmetic at 56 % lane utilisation ("valu", "ta_busy_fraction": the stamped counters).
+                # box-filter arithmetic at the lane utilisation "valu" reports ("valu", "ta_busy_fraction": the stamped counters).
                 "bound": "gather", "achieved": round(achieved_rec, 2), "peak": round(peak_rec, 2), "unit": "G records/s",
                 "frac": round(achieved_rec / peak_rec, 4),
                 "peak_is": "pbrt_hip_probe_gather: dependent 48-B record fetches from a 16 KiB (L1-resident) table, 8 waves / SIMD, this run",
