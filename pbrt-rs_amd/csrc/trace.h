@@ -128,6 +128,21 @@ PB_DEV TriRayConst tri_ray_setup(const TravRay& r) {
     c.sz = 1.0f / pz;
     return c;
 }
+// the same with the ray's reciprocal direction at hand: 1 / d[kz] IS the traversal's inv_dir component (one correctly
+// rounded division of the same operands), two divisions instead of three
+PB_DEV TriRayConst tri_ray_setup(const TravRay& r, float idx, float idy, float idz) {
+    float ax = __builtin_fabsf(r.dx), ay = __builtin_fabsf(r.dy), az = __builtin_fabsf(r.dz);
+    int kz = (ax > ay && ax > az) ? 0 : (ay > az ? 1 : 2);
+    float px = kz == 0 ? r.dy : (kz == 1 ? r.dz : r.dx);
+    float py = kz == 0 ? r.dz : (kz == 1 ? r.dx : r.dy);
+    float pz = kz == 0 ? r.dx : (kz == 1 ? r.dy : r.dz);
+    TriRayConst c;
+    c.kz = kz;
+    c.sx = -px / pz;
+    c.sy = -py / pz;
+    c.sz = kz == 0 ? idx : (kz == 1 ? idy : idz);
+    return c;
+}
 PB_DEV V3 permute_kz(V3 v, int kz) {
     return V3{kz == 0 ? v.y : (kz == 1 ? v.z : v.x), kz == 0 ? v.z : (kz == 1 ? v.x : v.y),
               kz == 0 ? v.x : (kz == 1 ? v.y : v.z)};

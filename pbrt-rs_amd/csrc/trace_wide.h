@@ -521,7 +521,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                     const float4* tp = wt.slot_tris + 3 * (size_t)tslot;
                     const float4 ta = tp[0], tb = tp[1], tc = tp[2];
                     float b0, b1, b2, t;
-                    const TriRayConst c = tri_ray_setup(r);
+                    const TriRayConst c = tri_ray_setup(r, idx, idy, idz);
                     if (triangle_test(V3{ta.x, ta.y, ta.z}, V3{ta.w, tb.x, tb.y}, V3{tb.z, tb.w, tc.x}, r, c, tmax, &b0, &b1, &b2, &t)) {
                         if (any) {
                             done = true;
@@ -593,7 +593,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             }
 #endif
             if (pass) {
-                const TriRayConst trc = tri_ray_setup(r);
+                const TriRayConst trc = tri_ray_setup(r, idx, idy, idz);
                 for (int i = 0; i < cnt; ++i) {
                     if (cnt > 1) {
                         if (COUNT) c_tri += 1;
