@@ -4,6 +4,8 @@ instrumented reference-count kernel, set_counting(1)) and the oracle's BVHAccel:
 (src/accelerators/bvh.rs:812-945) give the same hits bit for bit. Rays outside the range the filter's error bound covers
 (wide_bvh.h: wide_ray_covered) are traced by the binary kernel in a follow-up launch, and are counted.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -224,3 +226,52 @@ def test_stacks_deeper_than_the_lds_part(hip_ctx, instanced):
     assert wc["records"] > 40 * len(rays)          # long walks: tens of records per ray and launch
     gsc.close()
     osc.close()
+
+
+def test_adversarial_meshes_and_rays_through_vertices_and_edges(hip_ctx):
+    """Hypothesis-generated small meshes (coincident vertices, zero-area triangles, repeated triangles, large and tiny
+    coordinates) under every host split method, with rays aimed exactly at vertices and edge midpoints (the cases where
+    the watertight test's ties and the box planes of single-triangle leaves meet), axis-parallel rays among them (the
+    hand-over to the binary kernel). Whatever the builder decides (records, or a refusal with a reason), the answers are
+    the oracle's."""
+    from hypothesis import given, settings, strategies as st
+    from test_property_host import meshes
+
+    @settings(max_examples=int(os.environ.get("PB_HYP_EXAMPLES", "50")), deadline=None)
+    @given(mesh=meshes(), max_prims=st.sampled_from([1, 2, 4]), split=st.sampled_from([0, 1, 2, 3]))
+    def check(mesh, max_prims, split):
+        verts, idx = mesh
+        sc = dict(positions=verts, indices=idx, tri_material=np.zeros(len(idx), dtype=np.int32),
+                  materials=scenes._materials([(1, (0.5, 0.5, 0.5), (0, 0, 0), 1.0)]),
+                  tri_light=np.full(len(idx), -1, dtype=np.int32), lights=scenes._lights([]))
+        tri = verts[idx]                                                    # (n, 3, 3)
+        targets = np.concatenate([tri.reshape(-1, 3), (tri[:, 0] + tri[:, 1]) * np.float32(0.5), tri.mean(axis=1)])
+        n = 3 * len(targets)
+        rays = scenes.random_rays(n, 7, origin_extent=2.0)
+        tgt = targets[np.arange(n) % len(targets)]
+        scale = np.maximum(np.abs(tgt).max(axis=1, keepdims=True), 1.0).astype(np.float32)
+        rays["o"] = (tgt + rays["o"] * scale).astype(np.float32)           # origins around the target, at its own scale
+        rays["d"] = (tgt - rays["o"]).astype(np.float32)
+        k = np.arange(n)
+        par = k % 5 == 0
+        rays["d"][par, k[par] % 3] = 0.0                                    # axis-parallel: 1 / 0 in the slab test
+        rays["d"][np.all(rays["d"] == 0, axis=1)] = (0.0, 0.0, 1.0)
+        finite = np.isfinite(rays["o"]).all(axis=1) & np.isfinite(rays["d"]).all(axis=1)
+        rays = np.ascontiguousarray(rays[finite])
+        if len(rays) == 0:
+            return
+        osc = oracle.OracleScene(sc, max_prims, split)
+        gsc = pbrt_hip.Scene(hip_ctx, sc, max_prims_in_node=max_prims, split_method=split)
+        try:
+            n_rec, why = gsc.wide_records()
+            assert n_rec >= 0 or why                                         # records, or a stated reason
+            cpu, _ = osc.intersect(rays)
+            gpu = gsc.intersect(rays)
+            for f in ("prim_id", "t", "b0", "b1", "b2"):
+                assert np.array_equal(gpu[f], cpu[f]), (f, n_rec, why)
+            assert np.array_equal(gsc.intersect_p(rays), osc.intersect_p(rays)[0])
+        finally:
+            gsc.close()
+            osc.close()
+
+    check()
