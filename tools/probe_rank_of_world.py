@@ -7,7 +7,8 @@ import pbrt_hip
 from pbrt_hip import scenes
 
 worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
-strong = bool(os.environ.get("STRONG"))  # one 64-spp frame split over the ranks instead of 64 spp per rank
+strong = bool(os.environ.get("STRONG"))  # one frame of SPP (default 64) samples split over the ranks instead of 64 spp per rank
+spp_strong = int(os.environ.get("SPP", "64"))  # 256 = BASELINE config 4, what bench.py --gpus N (N > 1) runs
 W, H = 1920, 1080
 ctx = pbrt_hip.Context(0)
 sc = pbrt_hip.Scene(ctx, scenes.random_triangles(1_000_000, seq=1))
@@ -17,7 +18,7 @@ for world in worlds:
         best = None
         for it in range(3):
             t0 = time.perf_counter()
-            _, st = sc.render(cam, W, H, 64 if strong else 64 * world, max_depth=5, rr_threshold=1.0, light_strategy=1, seed=0,
+            _, st = sc.render(cam, W, H, spp_strong if strong else 64 * world, max_depth=5, rr_threshold=1.0, light_strategy=1, seed=0,
                               tile_rank=rank, tile_world=world)
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
