@@ -29,7 +29,8 @@ sys.path.insert(0, os.path.join(ROOT, "pbrt-rs_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 DEFAULTS = dict(width=1920, height=1080, tris=1_000_000, max_depth=5)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+KERNEL_SOURCES = ("pbrt-rs_amd/csrc", "pbrt-rs_amd/build.sh")
 
 
 def parse():
@@ -55,6 +56,13 @@ def parse():
                          "(pbrt_hip_comm_create / pbrt_hip_film_reduce) and compare with torch.distributed's; needs "
                          "torch.distributed.run. Not part of the default job: the measured run does not depend on a second communicator")
     ap.add_argument("--watchdog-s", type=float, default=600.0, help="a rank stuck longer than this ends the job with exit code 3")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="nccl (= RCCL over xGMI, the measured job) or gloo: the same job with the film reduce and the agreement "
+                         "collectives staged through host memory — the rehearsal of the N > 1 path on a box with ONE GPU, where "
+                         "RCCL refuses two ranks on one device (tests/test_gpu_two_ranks.py)")
+    ap.add_argument("--one-gpu", action="store_true", help="every rank uses device 0 (rehearsal on a one-GPU box, with --dist-backend gloo)")
+    ap.add_argument("--save-film", default="", help="rank 0 writes the reduced film of the last step here (.npy)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed config-5 block (N = 1 only)")
     return ap.parse_args()
 
 
@@ -82,26 +90,52 @@ def algorithmic_bytes(rays_closest, rays_shadow, node_tests, prim_tests):
     return 32 * (rays_closest + rays_shadow) + 32 * node_tests + 48 * prim_tests + 16 * rays_closest + 4 * rays_shadow
 
 
-def git_commit():
-    try:
-        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
-    except Exception:
-        return None
+def kernel_source_hash():
+    """sha1 over the kernel sources (pbrt-rs_amd/csrc/*, build.sh): what the stamped counter profile was measured on."""
+    import hashlib
+    h = hashlib.sha1()
+    files = []
+    for rel in KERNEL_SOURCES:
+        path = os.path.join(ROOT, rel)
+        if os.path.isdir(path):
+            files += [os.path.join(path, f) for f in os.listdir(path) if f.endswith((".h", ".hip", ".cpp"))]
+        elif os.path.exists(path):
+            files.append(path)
+    for f in sorted(files):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
 
 
 def measured_traffic(args, world, spp_total, kernel):
-    """FETCH_SIZE + WRITE_SIZE bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes over
-    this very command (profiles/r02_traffic.json). It was measured for ONE configuration: returned only when this run is
-    that configuration, otherwise None (with the reason)."""
+    """The stamped counter profile of this very command (profiles/r03_traffic.json, written by tools/measure_traffic.sh:
+    rocprofv3 --kernel-trace --stats and separate --pmc passes). It was measured for ONE configuration and ONE state of
+    the kernel sources: returned only when this run is that configuration (otherwise None and the reason); `stale` says
+    that the kernel sources have changed since (the figures are then reported as measured, flagged)."""
     try:
         rec = json.load(open(TRAFFIC_FILE))
     except Exception:
-        return None, "profiles/r02_traffic.json missing"
+        return None, "profiles/r03_traffic.json missing", False
     mine = dict(n_gpus=world, tris=args.tris, width=args.width, height=args.height, spp=spp_total, max_depth=args.max_depth, kernel=kernel)
     diff = {k: (v, rec["config"].get(k)) for k, v in mine.items() if rec["config"].get(k) != v}
     if diff:
-        return None, f"measured for another configuration: {diff}"
-    return rec, None
+        return None, f"measured for another configuration: {diff}", False
+    return rec, None, rec.get("source_hash") != kernel_source_hash()
+
+
+def loaded_runtime_libs():
+    """Which HIP runtime / RCCL this process ended up on (/proc/self/maps): a Python host holds PyTorch's bundled ROCm and
+    /opt/rocm side by side; the first to initialise owns the GPU."""
+    libs = set()
+    try:
+        for line in open("/proc/self/maps"):
+            path = line.rsplit(" ", 1)[-1].strip()
+            base = os.path.basename(path)
+            if base.startswith(("libamdhip64", "librccl", "libhsa-runtime64", "libpbrt_hip")):
+                libs.add(path)
+    except OSError:
+        pass
+    return sorted(libs)
 
 
 class Stage:
@@ -155,14 +189,15 @@ class StageFailed(RuntimeError):
     pass
 
 
-def run_steps(render_into, films, steps, warmup, dist, use_dist, sync, make_event=None, stage=None):
+def run_steps(render_into, films, steps, warmup, dist, use_dist, sync, make_event=None, stage=None, reduce_film=None):
     """The measured loop, shared by the GPU job below and by the two-rank CPU test (tests/test_multi_gpu_gloo.py, gloo):
     W untimed and K timed steps, a step = render this rank's tile share of the frame into a film, then (N > 1) reduce the
     film to rank 0 — the only collective. Films alternate so that the reduce of frame k may overlap the render of frame
     k + 1; a film is reused only after the reduce that read it has finished (make_event() returns an object with
     synchronize(), recorded after the reduce; None where the reduce is synchronous). Bracketed by barrier + sync on both
     sides. In the untimed warm-up steps (and in the first one at least) the ranks agree after rendering that all of them
-    got through before any enters the reduce: a rank whose render fails is then seen, not waited for. The timed steps
+    got through before any enters the reduce: a rank whose render fails is then seen, not waited for. reduce_film(film)
+    replaces the plain dist.reduce where the film cannot be handed to the backend as it is (gloo + device films). The timed steps
     carry no such exchange; a rank that fails there exits non-zero and the launcher ends the others (a rank that hangs:
     the watchdog). Returns (seconds, per-step stats list, the film of the last step)."""
     reduced = [None] * len(films)
@@ -184,7 +219,10 @@ def run_steps(render_into, films, steps, warmup, dist, use_dist, sync, make_even
         else:
             st = render_into(films[k])
         if use_dist:
-            dist.reduce(films[k], dst=0, op=dist.ReduceOp.SUM)
+            if reduce_film is not None:
+                reduce_film(films[k])
+            else:
+                dist.reduce(films[k], dst=0, op=dist.ReduceOp.SUM)
             reduced[k] = make_event() if make_event else None
         return st
 
@@ -215,9 +253,13 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU is visible (the HIP path has no CPU fallback)")
+    if args.one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run the RCCL path runs even with one rank
+    staged = args.dist_backend == "gloo"            # collectives on host tensors; films staged through host memory
+    coll_device = torch.device("cpu") if staged else device
 
     out = {}
     printed = [False]
@@ -243,8 +285,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    stage = Stage(dist, torch, device, use_dist, rank)
+        if staged:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    stage = Stage(dist, torch, coll_device, use_dist, rank)
 
     def barrier():
         if use_dist:
@@ -283,8 +328,18 @@ def main():
             e.record()
             return e
 
+        def reduce_staged(film):
+            # gloo: the film goes through host memory (the render call returned after draining the library's stream)
+            host = film.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                film.copy_(host)
+
         def timed():
-            seconds, stats, _ = run_steps(render_into, films, args.steps, args.warmup, dist, use_dist, torch.cuda.synchronize, record_event, stage)
+            seconds, stats, last = run_steps(render_into, films, args.steps, args.warmup, dist, use_dist, torch.cuda.synchronize, record_event, stage,
+                                             reduce_staged if (staged and use_dist) else None)
+            if args.save_film and rank == 0:
+                np.save(args.save_film, last.cpu().numpy())
             return (seconds, sum(st["rays_closest"] + st["rays_shadow"] for st in stats), sum(st["trace_ms"] for st in stats),
                     sum(st["trace_launches"] for st in stats))
 
@@ -292,7 +347,7 @@ def main():
         my_rays, my_elapsed = rays, elapsed
         if use_dist:
             def gather_times():
-                tt = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=device)
+                tt = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=coll_device)
                 tmax = tt.clone()
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 dist.all_reduce(tt, op=dist.ReduceOp.SUM)
@@ -333,51 +388,57 @@ def main():
                 "l2_resident_8_waves": ctx.probe_gather(2 << 20, rec_bytes, 8) / 1e9,
                 "l1_resident_8_waves": ctx.probe_gather(16 << 10, rec_bytes, 8) / 1e9,
             }
-            # The ceiling the fraction is taken against is the L1-resident one: dependent record fetches cannot go faster
-            # than when every one of them hits L1 at full occupancy. The same-footprint figures are a RANDOM walk over a
-            # table of the tree's size; the kernel's rays are sorted (Morton order of their origins), hit L1 / L2 more often
-            # than a random walk does, and from 3.0 G rays/s on fetch records faster than that walk: reported, not a ceiling.
             peak_rec = ceil["l1_resident_8_waves"]
-            # ---- HBM side: compulsory bytes, and the counter bytes of the committed profile of this command ----
+            # ---- the stamped counter profile of this command (HBM bytes, issue, texture addressers) ----
             tri_bytes = args.tris * 48
             compulsory = 32 * frame_rays + 16 * st_c["rays_closest"] + 4 * st_c["rays_shadow"] + 4 * frame_rays   # rays in, hits out, queue
             compulsory_per_launch = compulsory / max(launches_per_frame, 1) + (table_bytes + tri_bytes)          # + the tree, once
-            rec, why_not = measured_traffic(args, world, spp_total, kernel)
-            traffic = rec["bytes_per_launch"] if rec else None
-            hbm = {
-                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "compulsory_bytes_per_launch": round(compulsory_per_launch),
-                "compulsory_GBps": round(compulsory_per_launch / trace_s_per_launch / 1e9, 1),
-                "counter_bytes_per_launch": traffic,
-                "achieved": round(traffic / trace_s_per_launch / 1e9, 1) if traffic else None,
-                "frac": round(traffic / trace_s_per_launch / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                "source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, commit {rec['commit']}, {rec['profile']}" if rec else why_not),
-            }
-            # the issue side, from the same committed profile: vector wave-instructions per launch against one per two
-            # cycles per SIMD (a wave64 instruction occupies a SIMD-32 for two cycles), 1024 SIMDs at 2.4 GHz
-            valu = None
-            if rec and rec.get("valu_insts_per_launch"):
-                peak_ips = 256 * 4 * 2.4e9 / 2
-                ips = rec["valu_insts_per_launch"] / trace_s_per_launch
-                valu = {"wave_insts_per_launch": round(rec["valu_insts_per_launch"]), "achieved_G_insts_per_s": round(ips / 1e9, 1),
-                        "peak_G_insts_per_s": round(peak_ips / 1e9, 1), "frac": round(ips / peak_ips, 4),
-                        "lane_utilisation": round(rec["valu_lane_utilisation"], 3) if rec.get("valu_lane_utilisation") else None,
-                        "source": f"rocprofv3 --pmc SQ_INSTS_VALU ..., commit {rec['commit']}"}
+            rec, why_not, stale = measured_traffic(args, world, spp_total, kernel)
+            tr = rec["trace"] if rec else None
+            source = (f"{os.path.relpath(TRAFFIC_FILE, ROOT)}: rocprofv3 --pmc passes over this command, commit {rec['commit']}, "
+                      f"kernel sources {rec.get('source_hash')}" + (" (STALE: the kernel sources have changed since)" if stale else "")) if rec else why_not
+            traffic = tr["bytes_per_launch"] if tr else None
+            hbm_frac = traffic / trace_s_per_launch / 1e9 / HBM_PEAK_GBS if traffic else None
+            peak_ips = 256 * 4 * 2.4e9 / 2   # one wave64 vector instruction per two cycles per SIMD, 1024 SIMDs at 2.4 GHz
+            valu_frac = tr["valu_insts_per_launch"] / trace_s_per_launch / peak_ips if tr and tr.get("valu_insts_per_launch") else None
+            ta_frac = tr.get("ta_busy_fraction") if tr else None
+            # Headline (frozen in round 3): the busiest hardware unit of the dominant kernel, from the
+            # stamped counters — the largest of {texture addressers busy, vector issue rate, HBM bytes / peak}. Everything
+            # else in this block is a diagnostic next to it.
+            units = {"TA": ta_frac, "VALU issue": valu_frac, "HBM": hbm_frac}
+            known = {k: v for k, v in units.items() if v is not None}
+            bound = max(known, key=known.get) if known else None
+            if bound == "TA":
+                head = {"achieved": round(tr["ta_busy_cycles_per_launch"]), "peak": round(tr["gpu_cycles_per_launch"]),
+                        "unit": "busy cycles per launch, mean of the 256 texture addressers, against the kernel's GPU cycles"}
+            elif bound == "VALU issue":
+                head = {"achieved": round(tr["valu_insts_per_launch"] / trace_s_per_launch / 1e9, 1), "peak": round(peak_ips / 1e9, 1),
+                        "unit": "G wave-instructions/s"}
+            elif bound == "HBM":
+                head = {"achieved": round(traffic / trace_s_per_launch / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+            else:
+                head = {"achieved": None, "peak": None, "unit": None}
             roofline = {
                 "kernel": kernel,
-                # the record-fetch path (texture addresser / L1: three 16-B lane requests per 48-B record) against the rate of
-                # dependent record fetches from an L1-resident table, measured in this run. The kernel is NOT HBM-bound: the
-                # tree lives in L2 / Infinity Cache ("hbm" below); what it does not spend fetching it spends issuing the
-                # box-filter arithmetic at the lane utilisation "valu" reports ("valu", "ta_busy_fraction": the stamped counters).
-                "bound": "gather", "achieved": round(achieved_rec, 2), "peak": round(peak_rec, 2), "unit": "G records/s",
-                "frac": round(achieved_rec / peak_rec, 4),
-                "peak_is": "pbrt_hip_probe_gather: dependent 48-B record fetches from a 16 KiB (L1-resident) table, 8 waves / SIMD, this run",
-                "ta_busy_fraction": (round(rec["ta_busy_fraction"], 3) if rec and rec.get("ta_busy_fraction") else None),
-                "traffic": traffic,
-                "record_bytes": rec_bytes, "records_per_launch": round(rec_per_launch), "table_bytes": table_bytes,
-                "ceilings_G_records_per_s": {k: round(v, 2) for k, v in ceil.items()},
-                "hbm": hbm,
-                "valu": valu,
+                "bound": bound, **head, "frac": round(known[bound], 4) if bound else None,
+                "definition": "busiest hardware unit of the dominant kernel = max(TA busy, VALU issue, HBM bytes / 8 TB/s), stamped rocprofv3 counters",
+                "traffic": traffic, "stale": stale if rec else None, "source": source,
+                "units": {k: (round(v, 4) if v is not None else None) for k, v in units.items()},
+                "valu_lane_utilisation": round(tr["valu_lane_utilisation"], 3) if tr and tr.get("valu_lane_utilisation") else None,
+                "waves_waiting_fraction": round(tr["wave_cycles_waiting_fraction"], 3) if tr and tr.get("wave_cycles_waiting_fraction") else None,
+                "hbm": {
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "compulsory_bytes_per_launch": round(compulsory_per_launch),
+                    "compulsory_GBps": round(compulsory_per_launch / trace_s_per_launch / 1e9, 1),
+                    "counter_bytes_per_launch": traffic,
+                    "achieved": round(traffic / trace_s_per_launch / 1e9, 1) if traffic else None,
+                    "frac": round(hbm_frac, 4) if hbm_frac is not None else None,
+                },
+                # diagnostic: the kernel's own fetches (48-B records + triangles, counted by k_trace_wide<COUNT>) against dependent
+                # record fetches from an L1-resident table, both measured in this run (pbrt_hip_probe_gather)
+                "gather": {"achieved": round(achieved_rec, 2), "peak": round(peak_rec, 2), "unit": "G records/s",
+                           "frac": round(achieved_rec / peak_rec, 4), "record_bytes": rec_bytes, "records_per_launch": round(rec_per_launch),
+                           "table_bytes": table_bytes, "ceilings_G_records_per_s": {k: round(v, 2) for k, v in ceil.items()}},
                 # SURVEY 8(d)'s figure, kept as a reported quantity: the bytes the REFERENCE's loop touches for these rays
                 "algorithmic": {
                     "bytes_per_launch": round(alg_bytes / max(launches_per_frame, 1)),
@@ -390,11 +451,26 @@ def main():
                 "launches_per_step": launches_per_frame, "avg_launch_ms": round(trace_s_per_launch * 1e3, 4),
                 "trace_fraction_of_step": round(trace_ms * 1e-3 / args.steps / (my_elapsed / args.steps), 3),
             }
+            sh = rec.get("shade") if rec else None
+            if sh and sh.get("avg_launch_ns_under_kernel_trace"):
+                # the second kernel of the frame: k_shade streams the path state (stamped profile; its launch time is the
+                # profile's own, the library times only the traversal launches)
+                gbps = sh["bytes_per_launch"] / sh["avg_launch_ns_under_kernel_trace"]
+                roofline["shade"] = {"kernel": "k_shade", "bound": "HBM", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(gbps / HBM_PEAK_GBS, 4), "traffic": sh["bytes_per_launch"],
+                                     "avg_launch_ms": round(sh["avg_launch_ns_under_kernel_trace"] * 1e-6, 4), "launches_per_step": sh.get("launches_per_step"),
+                                     "valu_lane_utilisation": sh.get("valu_lane_utilisation"), "stale": stale}
             if wc is not None:
                 roofline["wide"] = {"records_per_ray": round(wc["records"] / max(frame_rays, 1), 2),
                                     "leaf_candidates_per_ray": round(wc["leaf_candidates"] / max(frame_rays, 1), 2),
                                     "triangles_per_ray": round(wc["triangles"] / max(frame_rays, 1), 2),
                                     "rays_left_to_binary_kernel": wc["special_rays"], "n_records": n_wide}
+            secondary = None
+            if world == 1 and not args.no_secondary:
+                try:   # reported beside the measurement, never instead of it
+                    secondary = secondary_config5(torch, pbrt_hip, scenes, ctx, device, peak_rec)
+                except Exception as e:  # noqa: BLE001
+                    secondary = {"error": f"{type(e).__name__}: {e}"}
             cpu_baseline = None
             if world == 1 and not args.no_cpu_baseline:
                 # ---- CPU baseline: the oracle (C++ restatement; the Rust reference cannot be built) on a
@@ -431,10 +507,12 @@ def main():
                     "bvh_build_s_host": round(t_bvh, 2),
                     "traversal": f"{kernel}" + (f" ({n_wide} 4-wide records)" if n_wide >= 0 else f" (binary records: {wide_reason})"),
                 },
-                "roofline": roofline, "cpu_baseline": cpu_baseline,
+                "roofline": roofline, "cpu_baseline": cpu_baseline, "secondary": secondary,
             })
+            out["config"]["dist_backend"] = args.dist_backend if use_dist else None
+            out["config"]["runtime_libs"] = loaded_runtime_libs()
 
-        if args.abi_reduce_check and use_dist:
+        if args.abi_reduce_check and use_dist and not staged:
             # Untimed: the same film merge through the C ABI's own RCCL communicator (pbrt_hip_comm_create /
             # pbrt_hip_film_reduce), checked against torch.distributed's reduce. Every rank reports after each stage.
             f = torch.zeros((H, W, 4), dtype=torch.float32, device=device)
@@ -479,6 +557,45 @@ def main():
     if rc:
         sys.stdout.flush()
         os._exit(rc)  # a failed job must not wait in destroy_process_group for ranks that are gone
+
+
+def secondary_config5(torch, pbrt_hip, scenes, ctx, device, peak_rec):
+    """Untimed for `value`: BASELINE config 5's scene (10 000 base triangles x 1000 rigid instances, matte / mirror / glass by
+    instance, env light, PathIntegrator depth 16) at its stated 3840x2160, 8 of the 128 spp (Mrays/s does not depend on spp),
+    through pbrt_hip_render_device — the two-level traversal kernel k_trace_wide<false, 1> (primitive.rs:136-159)."""
+    W5, H5, SPP5, DEPTH5 = 3840, 2160, 8, 16
+    sc5 = scenes.instanced_scene(10_000, 1000)
+    scene5 = pbrt_hip.Scene(ctx, sc5, bvh=pbrt_hip.build_two_level(sc5))
+    cam5 = scenes.instanced_camera(W5, H5)
+    film5 = torch.zeros((H5, W5, 4), dtype=torch.float32, device=device)
+
+    def go():
+        return scene5.render(cam5, W5, H5, SPP5, max_depth=DEPTH5, rr_threshold=1.0, light_strategy=1, seed=0, d_film_ptr=film5.data_ptr())[1]
+    go()
+    runs = [go() for _ in range(3)]
+    st = min(runs, key=lambda r: r["total_ms"])
+    rays = st["rays_closest"] + st["rays_shadow"]
+    n_wide, why = scene5.wide_records()
+    out = {
+        "workload": f"config5 scene: 10000 base triangles x 1000 instances (10 M instanced), matte/mirror/glass by instance, env light, "
+                    f"PathIntegrator max_depth {DEPTH5}, {W5}x{H5}x{SPP5}spp of the 128 (one GPU; best of 3 frames; not part of `value`)",
+        "value": round(rays / st["total_ms"] / 1e3, 1), "unit": "Mrays/s", "ms_per_frame": round(st["total_ms"], 2),
+        "rays_per_frame": int(rays), "trace_only_Mrays_per_s": round(rays / st["trace_ms"] / 1e3, 1),
+        "trace_launches": int(st["trace_launches"]), "trace_fraction_of_frame": round(st["trace_ms"] / st["total_ms"], 3),
+        "kernel": "k_trace_wide<false, 1>" if n_wide >= 0 else f"k_trace<false, 1> (binary records: {why})",
+    }
+    if n_wide >= 0:
+        ctx.set_counting(2)
+        ctx.wide_counters(reset=True)
+        go()
+        wc = ctx.wide_counters(reset=True)
+        ctx.set_counting(0)
+        rec_rate = (wc["records"] + wc["triangles"]) / (st["trace_ms"] * 1e-3) / 1e9
+        out.update({"records_per_ray": round(wc["records"] / rays, 2), "triangles_per_ray": round(wc["triangles"] / rays, 2),
+                    "leaf_candidates_per_ray": round(wc["leaf_candidates"] / rays, 2), "n_records": n_wide,
+                    "gather": {"achieved": round(rec_rate, 2), "peak": round(peak_rec, 2), "unit": "G records/s", "frac": round(rec_rate / peak_rec, 4)}})
+    scene5.close()
+    return out
 
 
 def scene_interior_bytes(scene):

@@ -186,7 +186,11 @@ typedef struct PbrtRenderStats {
     double total_ms;         /* HIP-event time of the whole render (scene resident, film on device) */
 } PbrtRenderStats;
 
-/* ---- context ---- */
+/* ---- context ----
+ * Order of destruction: scenes and communicators (pbrt_hip_comm_destroy takes the context's lock and device) before
+ * their context. A call that gives up on a kernel (the 120 s wavefront deadline of pbrt_hip_render / pbrt_hip_li)
+ * leaves the context LOST: every later call on it fails with PBRT_HIP_ERR_DEVICE, its device buffers are never
+ * reused, and pbrt_hip_context_destroy then releases the host side only. */
 int pbrt_hip_context_create(int device_id, PbrtHipContext** out);
 void pbrt_hip_context_destroy(PbrtHipContext* ctx);
 /* Last error text for this context (or for context creation when ctx == NULL). */
@@ -389,7 +393,7 @@ typedef struct PbrtHipComm PbrtHipComm;
 int pbrt_hip_comm_unique_id(uint8_t id[PBRT_HIP_COMM_ID_BYTES]);
 int pbrt_hip_comm_create(PbrtHipContext* ctx, int32_t world, int32_t rank, const uint8_t id[PBRT_HIP_COMM_ID_BYTES],
                          PbrtHipComm** out);
-void pbrt_hip_comm_destroy(PbrtHipComm* comm);
+void pbrt_hip_comm_destroy(PbrtHipComm* comm); /* before pbrt_hip_context_destroy of the context it was created on */
 int pbrt_hip_film_reduce(PbrtHipComm* comm, float* d_film_xyzw, int64_t n_pixels, int32_t root);
 const char* pbrt_hip_comm_last_error(void);
 

@@ -133,7 +133,7 @@ extern "C" int pbrt_hip_comm_create(PbrtHipContext* ctx, int32_t world, int32_t 
         set_comm_error("pbrt_hip_comm_create: bad argument");
         return PBRT_HIP_ERR_INVALID;
     }
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     Rccl* r = rccl();
     if (!r) {
         set_comm_error(ctx->last_error = g_rccl.error);
@@ -180,7 +180,7 @@ extern "C" int pbrt_hip_film_reduce(PbrtHipComm* comm, float* d_film_xyzw, int64
     }
     Rccl* r = rccl();
     PbrtHipContext* ctx = comm->ctx;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     if (!r) return PBRT_HIP_ERR_DEVICE;
     if (hipSetDevice(ctx->device) != hipSuccess) return PBRT_HIP_ERR_DEVICE;
     if (n_pixels == 0) return PBRT_HIP_OK;

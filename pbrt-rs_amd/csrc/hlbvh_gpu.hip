@@ -594,7 +594,7 @@ extern "C" int pbrt_hip_bvh_build_hlbvh_device(PbrtHipContext* ctx, const float*
                                                PbrtLinearBVHNode** nodes_out, int32_t* n_nodes_out,
                                                int32_t** prim_order_out, double* build_ms) {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     auto invalid = [&](const char* m) {
         ctx->last_error = m;
         return PBRT_HIP_ERR_INVALID;

@@ -64,10 +64,12 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
     // copies a leaf's triangles to wide-order position `first` (and its exact box, where the kernel reads one)
     auto emit_leaf = [&](const PbrtLinearBVHNode& lf, int64_t first) {
         if (opaque) {
-            for (int j = 0; j < lf.n_primitives; ++j) out->order[(size_t)(first + j)] = lf.offset + j + base_of.slot;
-            float* b = &out->leaf_boxes[8 * (size_t)first];
-            std::memcpy(b, lf.bounds_min, 12);
-            std::memcpy(b + 4, lf.bounds_max, 12);
+            for (int j = 0; j < lf.n_primitives; ++j) {  // the leaf's exact box at every one of its positions
+                out->order[(size_t)(first + j)] = lf.offset + j + base_of.slot;
+                float* b = &out->leaf_boxes[8 * (size_t)(first + j)];
+                std::memcpy(b, lf.bounds_min, 12);
+                std::memcpy(b + 4, lf.bounds_max, 12);
+            }
             return;
         }
         wide_emit_leaf(lf, tris, base_of.slot, (size_t)first, out->tris.data(), out->leaf_boxes.data());

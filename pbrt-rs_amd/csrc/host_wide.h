@@ -28,7 +28,7 @@ struct WideBase {
 // Returns nullptr on success, else the reason the scene keeps the binary records only.
 // tris: the 48-B leaf-order triangle records of the tree's primitives (12 floats per slot: 9 vertex floats, prim,
 // material, flags). tris == nullptr: the primitives are opaque (the TransformedPrimitives / triangles of a top-level
-// aggregate): every leaf then keeps its exact box (leaf_boxes at its first position) and out->order[position] = the
+// aggregate): every leaf then keeps its exact box (leaf_boxes, at every position of the leaf) and out->order[position] = the
 // leaf slot of the primitive at that wide-order position; no triangles are copied.
 const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, const float* tris, int32_t n_slots, WideTree* out,
                             const WideBase& base = WideBase());

@@ -72,6 +72,12 @@ extern "C" int pbrt_hip_context_create(int device_id, PbrtHipContext** out) {
 extern "C" void pbrt_hip_context_destroy(PbrtHipContext* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->lost) {
+        // a kernel of an abandoned call may never finish: waiting on the stream or freeing what it writes (hipFree waits
+        // for the device) could block for ever. The device memory of a lost context goes back with the process.
+        delete ctx;
+        return;
+    }
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);
@@ -97,14 +103,14 @@ extern "C" const char* pbrt_hip_last_error(const PbrtHipContext* ctx) {
 
 extern "C" int pbrt_hip_synchronize(PbrtHipContext* ctx) {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PBRT_HIP_OK;
 }
 
 extern "C" int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* total_ms, uint64_t* launches) {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     if (total_ms) *total_ms = ctx->trace_ms;
     if (launches) *launches = ctx->trace_launches;
     if (reset) {
@@ -116,14 +122,14 @@ extern "C" int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* tot
 
 extern "C" int pbrt_hip_set_counting(PbrtHipContext* ctx, int enable) {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     ctx->count_traversal = (enable == 1 || enable == 2) ? enable : 0;
     return PBRT_HIP_OK;
 }
 
 extern "C" int pbrt_hip_get_counters(PbrtHipContext* ctx, int reset, uint64_t counters[4]) {
     if (!ctx || !counters) return PBRT_HIP_ERR_INVALID;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     unsigned long long h[4] = {0, 0, 0, 0};
@@ -140,7 +146,7 @@ extern "C" int pbrt_hip_get_counters(PbrtHipContext* ctx, int reset, uint64_t co
 
 extern "C" int pbrt_hip_get_wide_counters(PbrtHipContext* ctx, int reset, uint64_t counters[4]) {
     if (!ctx || !counters) return PBRT_HIP_ERR_INVALID;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     unsigned long long h[4] = {0, 0, 0, 0};
@@ -331,7 +337,7 @@ extern "C" int pbrt_hip_scene_create_hlbvh(PbrtHipContext* ctx, const float* pos
                                            const PbrtLight* lights, int32_t n_lights, int32_t max_prims_in_node,
                                            PbrtHipScene** out, double* build_ms, double* layout_ms) {
     if (!ctx || !out) return PBRT_HIP_ERR_INVALID;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     *out = nullptr;
     auto fail = [&](const char* msg) {
         ctx->last_error = msg;
@@ -494,7 +500,7 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     // dt != nullptr: the tree, the triangle records and the leaf order are already on the device
     // (pbrt_hip_scene_create_hlbvh); nodes / prim_order are then unused.
     if (!ctx || !out) return PBRT_HIP_ERR_INVALID;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     *out = nullptr;
     if (dt) n_nodes = dt->n_nodes;
     auto fail = [&](const char* msg) {
@@ -822,11 +828,23 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
                     std::memcpy(r + 4, root.bounds_max, 12);
                 }
                 if (wn.empty()) wn.assign(kWideNodeDwords, 0u);
-                std::vector<float> ws((size_t)n_top * 28);
+                // the top-level entries as the wide kernel reads them, in wide order, 20 floats each: the exact box of the leaf
+                // the entry belongs to with two words in the w fields — the binary-layout top slot (hit records name it) and
+                // the object index (an instance) or 0x40000000 | leaf slot (a world-space triangle) — then the three
+                // world-to-object rows
+                std::vector<float> ws((size_t)n_top * 20);
                 for (int32_t pos = 0; pos < n_top; ++pos) {
                     const int32_t slot = top.order[pos];
-                    std::memcpy(&ws[(size_t)pos * 28], &top_slot_records[(size_t)slot * 28], 112);
-                    std::memcpy(&ws[(size_t)pos * 28 + 25], &slot, 4);  // second meta field: the binary-layout top slot (hit records name it)
+                    const float* src = &top_slot_records[(size_t)slot * 28];
+                    float* dst = &ws[(size_t)pos * 20];
+                    int32_t meta[4];
+                    std::memcpy(meta, src + 24, 16);  // (material, id, object | leaf slot, kind)
+                    const int32_t word = meta[3] == 1 ? (0x40000000 | meta[2]) : meta[2];
+                    std::memcpy(dst, &top.leaf_boxes[(size_t)pos * 8], 12);
+                    std::memcpy(dst + 3, &slot, 4);
+                    std::memcpy(dst + 4, &top.leaf_boxes[(size_t)pos * 8 + 4], 12);
+                    std::memcpy(dst + 7, &word, 4);
+                    std::memcpy(dst + 8, src, 48);
                 }
                 s->wide.nodes = (const uint4*)dev_upload(s, wn.data(), wn.size(), &ok);
                 s->wide.tris = (const float4*)dev_upload(s, wt.data(), wt.size(), &ok);
@@ -842,7 +860,7 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
                 std::memcpy(s->wide.obj0_max, ia.objects[0].nodes[0].bounds_max, 12);
                 s->n_wide_records = record_base;
                 s->has_wide = true;
-                spill_entries = std::max(spill_entries, top.stack_need + deepest + 2 - kWideStackLds);
+                spill_entries = std::max(spill_entries, top.stack_need + deepest + 2 - pb::wide_stack_lds(1));
             }
         } else if (!dt && ok && !(std::getenv("PBRT_HIP_WIDE_BUILD") && std::getenv("PBRT_HIP_WIDE_BUILD")[0] == 'h')) {
             // a tree from the host: its flat nodes go up once, the records are laid out on the device from them and from
@@ -985,7 +1003,7 @@ extern "C" int pbrt_hip_scene_wide_records(const PbrtHipScene* s, int32_t* n_rec
 extern "C" int pbrt_hip_debug_wide_export(PbrtHipScene* s, uint32_t* nodes, float* tris, float* boxes, int32_t n_slots) {
     if (!s || !s->has_wide || s->d.bvh.instanced || n_slots != s->d.bvh.n_slots) return PBRT_HIP_ERR_INVALID;
     PbrtHipContext* ctx = s->ctx;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (nodes && s->n_wide_records > 0)
@@ -1050,14 +1068,15 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_I
 template <bool ANY, bool COUNT, int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES)
     k_intersect_batch_wide(WideTrees wt, BatchRayIO<ANY> io, unsigned int* work_counter, unsigned long long* counters) {
-    __shared__ uint2 lds_stack[kWideStackLds * kTraceBlock];
-    __shared__ float lds_world[(INST && PB_WIDE_WORLD_LDS) ? 6 * kTraceBlock : 1];
+    __shared__ uint2 lds_stack[wide_stack_lds(INST) * kTraceBlock];
+    __shared__ float lds_world[INST ? kWideWorldFloats * kTraceBlock : 1];
     trace_wide<BatchRayIO<ANY>, COUNT, INST>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x,
-                                             counters, lds_world + ((INST && PB_WIDE_WORLD_LDS) ? threadIdx.x : 0));
+                                             counters, lds_world + (INST ? threadIdx.x : 0));
 }
 template <bool ANY, int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, INST ? PB_INST_WAVES : PB_TRACE_WAVES)
     k_intersect_batch_special(DevBVH bvh, SpecialListIO<BatchRayIO<ANY>> io, unsigned int* work_counter) {
+    if ((unsigned long long)blockIdx.x * (kTraceBlock / 64) * kChunk >= (unsigned long long)io.n()) return;  // see k_trace_special
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
     trace_persistent<SpecialListIO<BatchRayIO<ANY>>, false, INST, false>(bvh, io, work_counter, lds_stack + threadIdx.x,
                                                                          blockIdx.x * kTraceBlock + threadIdx.x, nullptr);
@@ -1091,7 +1110,7 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
     hipLaunchKernelGGL((k_intersect_batch<ANY, COUNT, INST, SPH>), grid, block, 0, ctx->stream, s->d.bvh, io, ctx->d_work_counter, ctx->d_counters)
 #define PB_LAUNCH_WIDE(COUNT, INST)                                                                                                  \
     hipLaunchKernelGGL((k_intersect_batch_wide<ANY, COUNT, INST>),                                                                   \
-                       dim3(persistent_grid(s, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES, kWideStackLds, (INST && PB_WIDE_WORLD_LDS) ? 6 * 4 * kTraceBlock : 0)), block, 0, ctx->stream, \
+                       dim3(persistent_grid(s, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES, wide_stack_lds(INST), wide_world_lds_bytes(INST))), block, 0, ctx->stream, \
                        wt, io, ctx->d_work_counter, ctx->d_counters)
 #define PB_LAUNCH_SPECIAL(INST) \
     hipLaunchKernelGGL((k_intersect_batch_special<ANY, INST>), grid, block, 0, ctx->stream, s->d.bvh, sio, ctx->d_work_counter + kFollowUpCounter)
@@ -1137,13 +1156,13 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
 
 extern "C" int pbrt_hip_intersect_device(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtHit* d_out) {
     if (!s || n < 0 || (n > 0 && (!d_rays || !d_out))) return PBRT_HIP_ERR_INVALID;
-    PB_LOCK(s->ctx);
+    PB_ENTER(s->ctx);
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     return launch_batch<false>(s, d_rays, n, d_out, nullptr);
 }
 extern "C" int pbrt_hip_intersect_p_device(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, uint8_t* d_out) {
     if (!s || n < 0 || (n > 0 && (!d_rays || !d_out))) return PBRT_HIP_ERR_INVALID;
-    PB_LOCK(s->ctx);
+    PB_ENTER(s->ctx);
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     return launch_batch<true>(s, d_rays, n, nullptr, d_out);
 }
@@ -1153,7 +1172,7 @@ static int intersect_host(PbrtHipScene* s, const PbrtRay* rays, int64_t n, void*
     if (!s || n < 0 || (n > 0 && (!rays || !out))) return PBRT_HIP_ERR_INVALID;
     if (n == 0) return PBRT_HIP_OK;
     PbrtHipContext* ctx = s->ctx;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     PbrtRay* d_rays = nullptr;
     void* d_out = nullptr;

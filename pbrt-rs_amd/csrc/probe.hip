@@ -64,7 +64,7 @@ extern "C" int pbrt_hip_probe_gather(PbrtHipContext* ctx, int64_t table_bytes, i
     if (!ctx || !records_per_second || (record_bytes != 48 && record_bytes != 64) || table_bytes < record_bytes || iters <= 0 ||
         table_bytes > (64ll << 30))
         return PBRT_HIP_ERR_INVALID;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int waves = (waves_per_simd == 4 || waves_per_simd == 5 || waves_per_simd == 6) ? waves_per_simd : 8;
     const uint32_t n_records = (uint32_t)(table_bytes / record_bytes);

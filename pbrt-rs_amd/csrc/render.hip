@@ -27,7 +27,7 @@ using namespace pb;
 extern "C" int pbrt_hip_render_device(PbrtHipScene* s, const PbrtCamera* camera, const PbrtRenderParams* params,
                                       float* d_film, PbrtRenderStats* stats) {
     if (!s || !camera || !params || !d_film) return PBRT_HIP_ERR_INVALID;
-    PB_LOCK(s->ctx);
+    PB_ENTER(s->ctx);
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     return wavefront_render(s, *camera, *params, d_film, stats);
 }
@@ -36,7 +36,7 @@ extern "C" int pbrt_hip_render(PbrtHipScene* s, const PbrtCamera* camera, const 
                                float* film_xyzw, PbrtRenderStats* stats) {
     if (!s || !camera || !params || !film_xyzw) return PBRT_HIP_ERR_INVALID;
     PbrtHipContext* ctx = s->ctx;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (params->width <= 0 || params->height <= 0) return PBRT_HIP_ERR_INVALID;
     size_t bytes = (size_t)params->width * params->height * 4 * sizeof(float);
@@ -69,7 +69,7 @@ extern "C" int pbrt_hip_li_device(PbrtHipScene* s, const PbrtLiParams* lp, const
     PbrtRenderStats zero{};
     if (stats) *stats = zero;
     if (n == 0) return PBRT_HIP_OK;
-    PB_LOCK(s->ctx);
+    PB_ENTER(s->ctx);
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     PbrtRenderParams rp;
     if (li_params_to_render(lp, &rp) != PBRT_HIP_OK) {
@@ -93,7 +93,7 @@ extern "C" int pbrt_hip_li(PbrtHipScene* s, const PbrtLiParams* lp, const PbrtRa
     if (stats) *stats = zero;
     if (n == 0) return PBRT_HIP_OK;
     PbrtHipContext* ctx = s->ctx;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     PbrtRay* d_rays = nullptr;
     uint64_t* d_keys = nullptr;
@@ -119,7 +119,7 @@ extern "C" int pbrt_hip_camera_rays(PbrtHipScene* s, const PbrtCamera* camera, c
                                     PbrtRay* rays, uint64_t* stream_keys, float* p_film, int32_t* pixel_sample, int64_t* n_out) {
     if (!s || !camera || !params || !n_out) return PBRT_HIP_ERR_INVALID;
     PbrtHipContext* ctx = s->ctx;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (params->width <= 0 || params->height <= 0 || params->spp <= 0 || params->x0 > params->x1 || params->y0 > params->y1)
         return PBRT_HIP_ERR_INVALID;
@@ -164,6 +164,7 @@ struct DevBuf {
     PbrtHipContext* ctx;
     explicit DevBuf(PbrtHipContext* c) : ctx(c) {}
     ~DevBuf() {
+        if (ctx->lost) return;  // a kernel of the abandoned call may still be writing these blocks: they stay taken for good
         for (size_t i : taken) ctx->block_cache[i].in_use = false;
         size_t idle = 0;
         for (const auto& b : ctx->block_cache)
@@ -271,7 +272,7 @@ extern "C" int pbrt_hip_scene_set_shading_data(PbrtHipScene* s, const float* pos
                                                const float* tangents, const float* uvs) {
     if (!s) return PBRT_HIP_ERR_INVALID;
     PbrtHipContext* ctx = s->ctx;
-    PB_LOCK(ctx);
+    PB_ENTER(ctx);
     auto fail = [&](const char* msg) {
         ctx->last_error = msg;
         return PBRT_HIP_ERR_INVALID;
@@ -838,7 +839,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
 #define PB_LAUNCH_BINARY(COUNT, INST, SPH) \
     hipLaunchKernelGGL((k_trace<COUNT, INST, SPH>), grid, block, 0, st, s->d.bvh, ps, trace_queue, n_trace, ctx->d_work_counter, ctx->d_counters, segments)
 #define PB_LAUNCH_WIDE(COUNT, INST)                                                                                                        \
-    hipLaunchKernelGGL((k_trace_wide<COUNT, INST>), dim3(persistent_grid(s, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES, kWideStackLds, (INST && PB_WIDE_WORLD_LDS) ? 6 * 4 * kTraceBlock : 0)), \
+    hipLaunchKernelGGL((k_trace_wide<COUNT, INST>), dim3(persistent_grid(s, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES, wide_stack_lds(INST), wide_world_lds_bytes(INST))), \
                        block, 0, st, wt, ps, trace_queue, n_trace, ctx->d_work_counter, segments, ctx->d_counters)
 #define PB_LAUNCH_SPECIAL(INST)                                                                                   \
     hipLaunchKernelGGL(k_trace_special<INST>, grid, block, 0, st, s->d.bvh, ps, trace_queue, n_trace, special_list, \
@@ -916,6 +917,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - spin_start).count();
                         if (waited > kWavefrontDeadlineSeconds) {
                             ctx->last_error = "a wavefront did not finish within the deadline (hung kernel?)";
+                            ctx->lost = true;  // the stream is not drained below: nothing may follow on this context
                             rc = PBRT_HIP_ERR_DEVICE;
                             break;
                         }
@@ -965,9 +967,13 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         }
     }
     RENDER_TRY(hipEventRecord(e_end, st));
-    if (rc == PBRT_HIP_OK || ctx->last_error.find("deadline") == std::string::npos)
-        (void)hipStreamSynchronize(st);  // also after an error: nothing of this call may still run when its buffers go back
-                                         // to the cache (after the deadline the stream is presumed hung: do not wait on it)
+    // Nothing of this call may still run when its buffers go back to the cache: drain the stream, also after an error
+    // (an asynchronous fault of the last kernels surfaces here). After the deadline the stream is presumed hung: it is
+    // not waited on, the context is lost and the buffers are never reused (DevBuf).
+    if (!ctx->lost) {
+        const hipError_t drained = hipStreamSynchronize(st);
+        if (rc == PBRT_HIP_OK && !hip_ok(ctx, drained, "hipStreamSynchronize (end of render)")) rc = PBRT_HIP_ERR_DEVICE;
+    }
     if (rc == PBRT_HIP_OK) {
         float ms = 0.0f;
         RENDER_TRY(hipEventElapsedTime(&ms, e_begin, e_end));
@@ -980,10 +986,10 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
 }
 
 #ifdef PB_LANE_STATS
-extern "C" int pbrt_hip_debug_wide_stats(unsigned long long* out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pb::g_wide_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+extern "C" int pbrt_hip_debug_wide_stats(unsigned long long* out24, int reset) {
+    if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(pb::g_wide_stats), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[32] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(pb::g_wide_stats), z, sizeof(z)) != hipSuccess) return 1;
     }
     return 0;

@@ -20,6 +20,14 @@
 // Calls that reach the device through one context are serialised: the reference's Primitive is Sync + Send and li() is
 // re-entrant (src/core/primitive.rs:179, integrator.rs:412-452), so a drop-in may be entered from several host threads.
 #define PB_LOCK(ctx) std::lock_guard<std::recursive_mutex> pb_lock_((ctx)->mu)
+// ... and refused once the context is lost (a wavefront ran into the deadline: a kernel of that call may still be running
+// on the stream, over buffers the call has abandoned; nothing else may be queued behind it or handed its memory)
+#define PB_ENTER(ctx)                                                                                              \
+    PB_LOCK(ctx);                                                                                                  \
+    if ((ctx)->lost) {                                                                                             \
+        (ctx)->last_error = "context lost: an earlier call ran into the wavefront deadline; destroy the context";  \
+        return PBRT_HIP_ERR_DEVICE;                                                                                \
+    }
 
 struct PbrtHipContext {
     std::recursive_mutex mu;
@@ -28,6 +36,8 @@ struct PbrtHipContext {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 0;
     std::string last_error;
+    // sticky: set when a call gave up on a kernel that did not finish (render.hip); every entry point then fails
+    bool lost = false;
     // traversal-kernel timing (HIP events on `stream`)
     double trace_ms = 0.0;
     uint64_t trace_launches = 0;

@@ -37,8 +37,8 @@ namespace pb {
 #ifndef PB_WIDE_SPECULATE_INST
 #define PB_WIDE_SPECULATE_INST 0  // two-level scenes: measured slower (config 5 geometry 1147 vs 1163 Mrays/s)
 #endif
-#ifndef PB_WIDE_WORLD_LDS
-#define PB_WIDE_WORLD_LDS 1  // two-level scenes: the world ray of a lane inside an instance is kept in LDS (6 KB per block)
+#ifndef PB_WIDE_INST_STACK_LDS
+#define PB_WIDE_INST_STACK_LDS 11  // two-level scenes: one stack entry less in LDS makes room for the world ray (below) at 5 blocks per CU
 #endif
 #ifndef PB_WIDE_INST_GATHER
 #define PB_WIDE_INST_GATHER 1
@@ -47,10 +47,15 @@ namespace pb {
 #define PB_WIDE_REFILL_THRESH 8
 #endif
 constexpr int kWideStackLds = PB_WIDE_STACK_LDS;
+// Two-level scenes: the world ray of a lane inside an instance waits in LDS, [component][lane]: origin, direction and the
+// reciprocal direction (so that leaving an instance costs nine LDS reads and no division). 9 KB per block of 256.
+constexpr int kWideWorldFloats = 9;
+constexpr int wide_stack_lds(int inst) { return inst ? PB_WIDE_INST_STACK_LDS : PB_WIDE_STACK_LDS; }
+constexpr int wide_world_lds_bytes(int inst) { return inst ? kWideWorldFloats * 4 * 256 : 0; }
 
 #ifdef PB_LANE_STATS
 // development instrumentation (tools/lane_stats.py): wave-level iteration counts and lane sums of trace_wide
-__device__ unsigned long long g_wide_stats[16];
+__device__ unsigned long long g_wide_stats[32];
 #define PB_WSTAT(i, v) wstat[i] += (v)
 #define PB_WCLOCK(var) const unsigned long long var = __builtin_readcyclecounter()
 #else
@@ -86,12 +91,16 @@ struct SpecialListIO {
 // floor, a plain triangle is tested in place. An object-space ray the filter's bound does not cover ends the wide
 // traversal of that ray: it goes to the binary kernel like an uncovered world ray. INST == 1: instances of one object
 // aggregate and nothing beside them (its root in the kernel arguments, no per-entry kind / object lookups); 2: general.
-// The world ray is not kept in registers while a lane is inside an instance: it waits in LDS (lds_world, [component][lane];
-// PB_WIDE_WORLD_LDS=0: re-read through io.load, two dependent global loads per exit), and an entry whose object root box the
-// ray misses never replaces the lane's ray in the first place.
+// The world ray is not kept in registers while a lane is inside an instance: it waits in LDS (lds_world, [component][lane],
+// with its reciprocal direction), and an entry whose object root box the ray misses never replaces the lane's ray in the
+// first place. The top-level entries are 80-byte records (wt.top_slots: the exact box of the leaf they belong to, two meta
+// words, the world-to-object rows): whatever a lane's turn in the instance branch needs first arrives in ONE memory round
+// trip (round 3; before, the leaf's box, then the entry's transform, then the object's root came one after the other and
+// the branch cost 2.7 record iterations at 14 lanes).
 template <class IO, bool COUNT = false, int INST = 0>
 PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restrict__ work_counter, uint2* lds_stack,
                        int spill_lane, unsigned long long* counters = nullptr, float* lds_world = nullptr) {
+    constexpr int kLds = wide_stack_lds(INST);  // stack entries per lane in LDS (the rest: wt.spill)
     const uint32_t n = io.n();
     const int lane = threadIdx.x & 63;
     TravRay r;
@@ -111,7 +120,8 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     // base_sp >= 0: the lane is inside an instance whose stack floor is base_sp (-1 outside); the instance that holds the
     // current hit is hit_inst (a top-level slot is visited at most once per ray, so hit_inst == cur_top_slot says "hit
     // inside the instance being left"). No flags: see the lane codes above.
-    int leaf_first = 0, leaf_cnt = 0, leaf_next = 0, cur_top_slot = -1, hit_inst = -1, base_sp = -1;
+    // leaf_state: the top-level leaf being worked through: position of its next entry << 3 | entries left (0 = none)
+    int leaf_state = 0, cur_top_slot = -1, hit_inst = -1, base_sp = -1;
     // What a lane is doing is all in `cur`: a record index (>= 0), a leaf reference (< 0, above the five codes below), or
     // one of the codes. Flags kept as separate booleans cost scalar mask bookkeeping in every iteration of the loops
     // that change them; one integer costs a vector compare where it is asked.
@@ -125,8 +135,9 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     auto is_idle = [&]() -> bool { return ((uint32_t)cur - (uint32_t)kIdle) <= 2u; };
     auto is_leaf_ref = [&]() -> bool { return cur < 0 && cur > kWait; };
 #ifdef PB_LANE_STATS
-    unsigned long long wstat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave-level events (lane 0's copy is kept)
+    unsigned long long wstat[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave-level events (lane 0's copy is kept)
     unsigned int wl_steps = 0, wl_children = 0, wl_cand = 0, wl_pass = 0, wl_tris = 0;  // this lane's own events
+    unsigned int wl_gate = 0, wl_gate_pass = 0, wl_try = 0, wl_entered = 0, wl_exit = 0;  // two-level: top-leaf box tests, entry attempts, exits
 #endif
 
     // the LDS part of the stack through an LDS-typed pointer: with a generic one the compiler merges the two
@@ -146,16 +157,16 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
 #endif
     auto stack_write = [&](int pos, int ref, float entry) {
         uint2 ent = make_uint2((uint32_t)ref, __float_as_uint(entry));
-        if (pos < kWideStackLds)
+        if (pos < kLds)
             lds[pos * kTraceBlock] = ent;
         else
-            wt.spill[(size_t)(pos - kWideStackLds) * wt.spill_stride + spill_lane] = ent;
+            wt.spill[(size_t)(pos - kLds) * wt.spill_stride + spill_lane] = ent;
     };
     auto stack_read = [&](int pos) -> uint2 {
         // the LDS read is unconditional (a conditional one is merged with the spill read into a flat load)
-        unsigned long long raw = *(LdsWord*)&lds[(pos < kWideStackLds ? pos : kWideStackLds - 1) * kTraceBlock];
+        unsigned long long raw = *(LdsWord*)&lds[(pos < kLds ? pos : kLds - 1) * kTraceBlock];
         uint2 ent = make_uint2((uint32_t)raw, (uint32_t)(raw >> 32));
-        if (pos >= kWideStackLds) ent = wt.spill[(size_t)(pos - kWideStackLds) * wt.spill_stride + spill_lane];
+        if (pos >= kLds) ent = wt.spill[(size_t)(pos - kLds) * wt.spill_stride + spill_lane];
         return ent;
     };
     // A finished ray's result stays in the lane's registers (the lane is idle) until the wave next refills, and is
@@ -210,11 +221,10 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         nz = idz < 0.0f;
         negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
     };
-    // TransformedPrimitive::intersect, first half (primitive.rs:136-139). 0 = the ray misses the object's root box,
-    // 1 = entered, 2 = the object-space ray is outside what the filter's bound covers (the ray leaves the wide path)
-    auto enter_instance = [&](int pos, const float4 meta) -> int {
-        const float4* m = wt.top_slots + 7 * (size_t)pos;
-        float4 r0 = m[0], r1 = m[1], r2 = m[2];
+    // TransformedPrimitive::intersect, first half (primitive.rs:136-139), on the entry's loaded record: the top slot it names,
+    // its object word and the three world-to-object rows. 0 = the ray misses the object's root box, 1 = entered, 2 = the
+    // object-space ray is outside what the filter's bound covers (the ray leaves the wide path)
+    auto enter_instance = [&](const int top_slot, const int object, const float4 r0, const float4 r1, const float4 r2) -> int {
         const float x = r.ox, y = r.oy, z = r.oz, wdx = r.dx, wdy = r.dy, wdz = r.dz;  // the lane holds the world ray here
         float ox = r0.x * x + r0.y * y + r0.z * z + r0.w;
         float oy = r1.x * x + r1.y * y + r1.z * z + r1.w;
@@ -242,7 +252,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         float mnx, mny, mnz, mxx, mxy, mxz;
         int root;
         if (INST == 2) {
-            const float4* ob = wt.objects + 2 * (size_t)__float_as_int(meta.z);
+            const float4* ob = wt.objects + 2 * (size_t)object;
             const float4 o0 = ob[0], o1 = ob[1];
             mnx = o0.x, mny = o0.y, mnz = o0.z, mxx = o1.x, mxy = o1.y, mxz = o1.z;
             root = __float_as_int(o0.w);
@@ -265,33 +275,31 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         ny = by;
         nz = bz;
         negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
-        cur_top_slot = __float_as_int(meta.y);
+        cur_top_slot = top_slot;
         base_sp = sp;
         cur = root;
         return 1;
     };
-    // second half (primitive.rs:140-143): r.t_max = ray.t_max on a hit; back to the world ray
+    // second half (primitive.rs:140-143): r.t_max = ray.t_max on a hit; back to the world ray, which waited in LDS with its
+    // reciprocal direction (the same three quotients set_ray_constants computed when the ray was fetched)
     auto exit_instance = [&]() {
         if (hit_inst == cur_top_slot) tmax_world = tmax;
-#if PB_WIDE_WORLD_LDS
-        {
-            // the world ray waits in LDS, [component][lane], while the lane is inside an instance (through the queue it is
-            // two dependent global loads, 1.5 - 2 us during which the whole wave stands still, at every exit)
-            const LdsFloat* w = (const LdsFloat*)lds_world;
-            r.ox = w[0 * kTraceBlock];
-            r.oy = w[1 * kTraceBlock];
-            r.oz = w[2 * kTraceBlock];
-            r.dx = w[3 * kTraceBlock];
-            r.dy = w[4 * kTraceBlock];
-            r.dz = w[5 * kTraceBlock];
-        }
-#else
-        bool any_again;
-        (void)io.load(index, &r, &any_again);
-#endif
+        const LdsFloat* w = (const LdsFloat*)lds_world;
+        r.ox = w[0 * kTraceBlock];
+        r.oy = w[1 * kTraceBlock];
+        r.oz = w[2 * kTraceBlock];
+        r.dx = w[3 * kTraceBlock];
+        r.dy = w[4 * kTraceBlock];
+        r.dz = w[5 * kTraceBlock];
+        idx = w[6 * kTraceBlock];
+        idy = w[7 * kTraceBlock];
+        idz = w[8 * kTraceBlock];
+        nx = idx < 0.0f;
+        ny = idy < 0.0f;
+        nz = idz < 0.0f;
+        negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
         r.tmax = tmax_world;
         tmax = tmax_world;
-        set_ray_constants();
         base_sp = -1;
     };
 
@@ -341,7 +349,6 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 } else {
                     set_ray_constants();
                     if (INST) {
-#if PB_WIDE_WORLD_LDS
                         LdsFloat* w = (LdsFloat*)lds_world;
                         w[0 * kTraceBlock] = r.ox;
                         w[1 * kTraceBlock] = r.oy;
@@ -349,12 +356,14 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                         w[3 * kTraceBlock] = r.dx;
                         w[4 * kTraceBlock] = r.dy;
                         w[5 * kTraceBlock] = r.dz;
-#endif
+                        w[6 * kTraceBlock] = idx;
+                        w[7 * kTraceBlock] = idy;
+                        w[8 * kTraceBlock] = idz;
                         tmax_world = r.tmax;
                         base_sp = -1;
                         cur_top_slot = -2;
                         hit_inst = -1;
-                        leaf_cnt = leaf_next = 0;
+                        leaf_state = 0;
                     }
                     bool covered = wide_ray_covered(r.ox, r.oy, r.oz, idx, idy, idz);
                     special = !covered;
@@ -440,7 +449,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
 #endif
                 // the children the reference visits later go on the stack, last one deepest
                 const bool p3 = h[3] && (h[0] || h[1] || h[2]), p2 = h[2] && (h[0] || h[1]), p1 = h[1] && h[0];
-                if (!__any(sp > kWideStackLds - 3)) {
+                if (!__any(sp > kLds - 3)) {
                     // all three fit the LDS part for every lane of the wave (nearly always): store unconditionally, a
                     // lane that does not push just leaves its stack pointer where it was (the entry above the top of a
                     // stack is never read). No exec-mask bookkeeping: the three predicated pushes below cost about as
@@ -494,30 +503,58 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             const bool others = __any(cur >= 0 || cur == kNeedPop || cur == kWait || (is_leaf_ref() && base_sp >= 0));
             inst_turn = waits && (!others || popc64(__ballot(waits)) >= PB_WIDE_INST_GATHER);
         }
+        PB_WCLOCK(t_inst0);
         if (INST && inst_turn) {
-            bool walk = true;
-            if (base_sp >= 0) {
-                exit_instance();  // the rest of the top-level leaf follows
+            // Either the lane leaves an instance (and takes up what is left of the top-level leaf it was in) or it holds a
+            // fresh top-level leaf. Both need the record of the leaf's next entry; a fresh leaf also needs the leaf's exact
+            // box, which is part of every entry's record: ONE round trip to memory before anything is decided.
+            const bool fresh = base_sp < 0;
+            if (!fresh) {
+#ifdef PB_LANE_STATS
+                wl_exit += 1;
+#endif
+                exit_instance();
             } else {
-                // a candidate top-level leaf: the reference's test on its exact box with the world ray and the current t_max
                 const int v = ~cur;
-                leaf_cnt = (v & 3) + 1;
-                leaf_first = v >> 2;
-                leaf_next = 0;
-                const float4* bp = wt.top_boxes + 2 * (size_t)leaf_first;
-                const float4 b0 = bp[0], b1 = bp[1];
-                float e;
-                walk = slab_test(nx ? b1.x : b0.x, nx ? b0.x : b1.x, ny ? b1.y : b0.y, ny ? b0.y : b1.y, nz ? b1.z : b0.z,
-                                 nz ? b0.z : b1.z, r, idx, idy, idz, tmax, &e);
+                leaf_state = ((v >> 2) << 3) | ((v & 3) + 1);
             }
+            bool walk = (leaf_state & 7) != 0;
+            float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = e0, m0 = e0, m1 = e0, m2 = e0;
+            if (walk) {
+                const float4* ep = wt.top_slots + 5 * (size_t)(leaf_state >> 3);
+                e0 = ep[0];
+                e1 = ep[1];
+                m0 = ep[2];
+                m1 = ep[3];
+                m2 = ep[4];
+            }
+            if (fresh) {
+                // a candidate top-level leaf: the reference's test on its exact box with the world ray and the current t_max
+                float e;
+                walk = slab_test(nx ? e1.x : e0.x, nx ? e0.x : e1.x, ny ? e1.y : e0.y, ny ? e0.y : e1.y, nz ? e1.z : e0.z,
+                                 nz ? e0.z : e1.z, r, idx, idy, idz, tmax, &e);
+                if (!walk) leaf_state = 0;
+#ifdef PB_LANE_STATS
+                wl_gate += 1;
+                wl_gate_pass += walk ? 1 : 0;
+#endif
+            }
+#ifdef PB_LANE_STATS
+            {
+                const unsigned long long act = __ballot(true);
+                if (lane == __builtin_ctzll(act)) {
+                    atomicAdd(&g_wide_stats[21], 1ull);                               // instance sections
+                    atomicAdd(&g_wide_stats[22], (unsigned long long)popc64(act));  // lanes in them
+                }
+            }
+#endif
             bool entered = false, done = false, abandon = false;
-            while (walk && leaf_next < leaf_cnt && !entered && !done && !abandon) {
-                const int pos = leaf_first + leaf_next;
-                leaf_next += 1;
-                const float4 meta = wt.top_slots[7 * (size_t)pos + 6];
-                if (INST == 2 && __float_as_int(meta.w) == 1) {
+            while (walk) {
+                leaf_state += 8 - 1;  // this entry is taken: next position, one entry less
+                const int top_slot = __float_as_int(e0.w), word = __float_as_int(e1.w);
+                if (INST == 2 && (word & 0x40000000)) {
                     // a GeometricPrimitive beside the instances (primitive.rs:65-78): the world ray against its triangle
-                    const int tslot = __float_as_int(meta.z);
+                    const int tslot = word & 0x3fffffff;
                     const float4* tp = wt.slot_tris + 3 * (size_t)tslot;
                     const float4 ta = tp[0], tb = tp[1], tc = tp[2];
                     float b0, b1, b2, t;
@@ -535,11 +572,25 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                             hit_inst = -1;
                         }
                     }
-                    continue;
+                } else {
+                    const int how = enter_instance(top_slot, word, m0, m1, m2);
+#ifdef PB_LANE_STATS
+                    wl_try += 1;
+                    wl_entered += how == 1 ? 1 : 0;
+                    if (lane == __builtin_ctzll(__ballot(true))) atomicAdd(&g_wide_stats[23], 1ull);  // entry-loop trips (wave level)
+#endif
+                    entered = how == 1;
+                    abandon = how == 2;
                 }
-                const int how = enter_instance(pos, meta);
-                entered = how == 1;
-                abandon = how == 2;
+                walk = (leaf_state & 7) != 0 && !entered && !done && !abandon;
+                if (walk) {  // the leaf's next entry (leaves of more than one primitive are rare in SAH trees over instances)
+                    const float4* ep = wt.top_slots + 5 * (size_t)(leaf_state >> 3);
+                    e0 = ep[0];
+                    e1 = ep[1];
+                    m0 = ep[2];
+                    m1 = ep[3];
+                    m2 = ep[4];
+                }
             }
             if (abandon) {
                 // left to the binary kernel, which traces the ray from scratch (rare: one list append per such ray)
@@ -550,20 +601,22 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             } else if (!entered) {
                 cur = kNeedPop;
             }
-        } else if ((SPEC && pend < 0) || (is_leaf_ref() && (!INST || base_sp >= 0))) {
+        }
+        PB_WCLOCK(t_tri0);
+        PB_WSTAT(24, t_tri0 - t_inst0);  // cycles in the instance branch
+        if (!(INST && inst_turn) && ((SPEC && pend < 0) || (is_leaf_ref() && (!INST || base_sp >= 0)))) {
             const bool from_pend = SPEC && pend < 0;  // the postponed leaf first; a leaf in `cur` then waits for the next phase
             const int v = ~(from_pend ? pend : cur);
             const int cnt = (v & 3) + 1;
             const int first = v >> 2;
             if (COUNT) c_cand += 1;
-            float4 ta = make_float4(0.0f, 0.0f, 0.0f, 0.0f), tb = ta, tc = ta;
+            // The leaf's first triangle is fetched whatever the box test will say, and a leaf of several triangles fetches
+            // its exact box in the same round trip (before round 3: the box first, then the triangles, one trip each).
+            if (COUNT) c_tri += 1;
+            const float4* tp0 = wt.tris + 3 * (size_t)first;
+            float4 ta = tp0[0], tb = tp0[1], tc = tp0[2];
             float lox, loy, loz, hix, hiy, hiz;
             if (cnt == 1) {
-                if (COUNT) c_tri += 1;
-                const float4* tp = wt.tris + 3 * (size_t)first;
-                ta = tp[0];
-                tb = tp[1];
-                tc = tp[2];
                 // Triangle::world_bound (the union of the three vertices): exact, so it is the leaf node's box
                 lox = wide_fmin(ta.x, wide_fmin(ta.w, tb.z));
                 hix = wide_fmax(ta.x, wide_fmax(ta.w, tb.z));
@@ -592,10 +645,21 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 wl_tris += cnt;
             }
 #endif
+#ifdef PB_LANE_STATS
+            {
+                const int trips = (__any(pass && cnt >= 1) ? 1 : 0) + (__any(pass && cnt >= 2) ? 1 : 0) + (__any(pass && cnt >= 3) ? 1 : 0) + (__any(pass && cnt >= 4) ? 1 : 0);
+                const int nl = popc64(__ballot(true));
+                if (lane == __builtin_ctzll(__ballot(true))) {
+                    atomicAdd(&g_wide_stats[26], 1ull);                      // triangle sections
+                    atomicAdd(&g_wide_stats[27], (unsigned long long)trips);  // triangle-loop trips (wave level)
+                    atomicAdd(&g_wide_stats[28], (unsigned long long)nl);     // lanes in them
+                }
+            }
+#endif
             if (pass) {
                 const TriRayConst trc = tri_ray_setup(r, idx, idy, idz);
                 for (int i = 0; i < cnt; ++i) {
-                    if (cnt > 1) {
+                    if (i > 0) {
                         if (COUNT) c_tri += 1;
                         const float4* tp = wt.tris + 3 * (size_t)(first + i);
                         ta = tp[0];
@@ -635,22 +699,28 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         }
 #ifdef PB_LANE_STATS
         wstat[15] += __builtin_readcyclecounter() - t_leaf0;
+        wstat[25] += __builtin_readcyclecounter() - t_tri0;  // cycles in the triangle branch
 #endif
     }
     flush_result();
     if (COUNT) count_flush(counters + 4, c_rec, c_cand, c_tri, c_special);
 #ifdef PB_LANE_STATS
     {
-        unsigned long long v[5] = {wl_steps, wl_children, wl_cand, wl_pass, wl_tris};
-        for (int k = 0; k < 5; ++k)
+        unsigned long long v[10] = {wl_steps, wl_children, wl_cand, wl_pass, wl_tris, wl_gate, wl_gate_pass, wl_try, wl_entered, wl_exit};
+        for (int k = 0; k < 10; ++k)
             for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
         wstat[8] = v[1];
         wstat[11] = v[0];
         wstat[12] = v[2];
         wstat[4] = v[3];
         wstat[5] = v[4];
+        wstat[16] = v[5];
+        wstat[17] = v[6];
+        wstat[18] = v[7];
+        wstat[19] = v[8];
+        wstat[20] = v[9];
         if (lane == 0)
-            for (int i = 0; i < 16; ++i) atomicAdd(&g_wide_stats[i], wstat[i]);
+            for (int i = 0; i < 32; ++i) atomicAdd(&g_wide_stats[i], wstat[i]);
     }
 #endif
 }

@@ -223,17 +223,22 @@ template <bool COUNT, int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES)
     k_trace_wide(WideTrees wt, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
                  int segments, unsigned long long* counters) {
-    __shared__ uint2 lds_stack[kWideStackLds * kTraceBlock];
-    __shared__ float lds_world[(INST && PB_WIDE_WORLD_LDS) ? 6 * kTraceBlock : 1];
+    __shared__ uint2 lds_stack[wide_stack_lds(INST) * kTraceBlock];
+    __shared__ float lds_world[INST ? kWideWorldFloats * kTraceBlock : 1];
     WavefrontRayIO io{ps, queue, n, segments};
     trace_wide<WavefrontRayIO, COUNT, INST>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x,
-                                            counters, lds_world + ((INST && PB_WIDE_WORLD_LDS) ? threadIdx.x : 0));
+                                            counters, lds_world + (INST ? threadIdx.x : 0));
 }
 // ... and the rays it left to the binary records (axis-parallel directions and the like; usually none)
 template <int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, INST ? PB_INST_WAVES : PB_TRACE_WAVES)
     k_trace_special(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, const uint32_t* __restrict__ list,
                     const unsigned int* __restrict__ count, unsigned int* work_counter) {
+    // Usually there is nothing to do (44 of 644 M rays in config 3), and the launch must not cost what a traversal launch
+    // costs: a block whose first chunk would start past the end of the list leaves before it touches the shared queue
+    // head (5000 waves x one same-address atomic each were most of the 0.22 ms an empty launch took). The blocks that stay
+    // are enough: a persistent wave keeps grabbing chunks until the list is exhausted.
+    if ((unsigned long long)blockIdx.x * (kTraceBlock / 64) * kChunk >= (unsigned long long)*count) return;
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
     SpecialListIO<WavefrontRayIO> io{WavefrontRayIO{ps, queue, n, 1}, list, count};
     trace_persistent<SpecialListIO<WavefrontRayIO>, false, INST, false>(bvh, io, work_counter, lds_stack + threadIdx.x,

@@ -124,8 +124,10 @@ struct WideTrees {
     unsigned int* __restrict__ special_count;
     // two-level scenes: `nodes` holds the top-level tree's records, then every object aggregate's; the leaves of the
     // top-level tree hold top-level primitives in wide order:
-    const float4* __restrict__ top_slots;  // 7 x float4 per position: DevBVH::instances' record, its second meta field = the binary-layout top slot
-    const float4* __restrict__ top_boxes;  // 2 x float4 per position: the exact box of the top-level leaf that starts there
+    // 5 x float4 per position: (exact box of the entry's leaf: min, binary-layout top slot) (max, object index or
+    // 0x40000000 | leaf slot of a world-space triangle) and the three world-to-object rows
+    const float4* __restrict__ top_slots;
+    const float4* __restrict__ top_boxes;  // 2 x float4 per position: the exact box of the top-level leaf the position belongs to (debug export)
     const float4* __restrict__ objects;    // 2 x float4 per object aggregate: (root box min, wide root reference) (root box max, -)
     const float4* __restrict__ slot_tris;  // DevBVH::tris (the world-space triangles of top-level leaves are read by leaf slot)
     // instances of ONE object aggregate with nothing beside them (config 5's shape, the kernels' INST == 1): that object's

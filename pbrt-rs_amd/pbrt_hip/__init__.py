@@ -305,13 +305,13 @@ def build_general_two_level(scene, max_prims_in_node=4, split_method=SPLIT_SAH):
     return trees, inst, tlas_nodes, tlas_order
 
 
-def build_two_level(scene, max_prims_in_node=4, split_method=SPLIT_SAH):
+def build_two_level(scene, max_prims_in_node=4, split_method=SPLIT_SAH, tlas_max_prims=None):
     """Host BVH builds for an instanced scene: object-level tree over the triangles, top-level tree over
     the instances' world bounds. Returns (blas_nodes, blas_order, instances, tlas_nodes, tlas_order)."""
     blas_nodes, blas_order = bvh_build(scene["positions"], scene["indices"], max_prims_in_node, split_method)
     inst = make_instances(scene)
     lo, hi = instance_bounds(blas_nodes[0]["bmin"], blas_nodes[0]["bmax"], inst)
-    tlas_nodes, tlas_order = bvh_build_boxes(lo, hi, max_prims_in_node, split_method)
+    tlas_nodes, tlas_order = bvh_build_boxes(lo, hi, tlas_max_prims or max_prims_in_node, split_method)
     return blas_nodes, blas_order, inst, tlas_nodes, tlas_order
 
 

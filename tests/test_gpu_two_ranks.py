@@ -1,0 +1,81 @@
+"""The N > 1 job with the HIP kernels in it, in two processes, on the one GPU of the test box.
+
+bench.py --gpus 2 is BASELINE config 4's job: the 16x16 tiles of ONE frame dealt round-robin to the ranks
+(parallel.rs:4-21, integrator.rs:412-477), scene replicated, one film reduce to rank 0 inside the step. RCCL refuses two
+ranks on one device, so the rehearsal uses --dist-backend gloo (films staged through host memory) and --one-gpu; the
+render leg of every rank is pbrt_hip_render_device, exactly as in the measured job. One functional run each, no loops."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import pbrt_hip
+from pbrt_hip import scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, SPP, TRIS, DEPTH = 256, 144, 8, 20000, 5
+ARGS = ["--gpus", "2", "--steps", "1", "--warmup", "1", "--dist-backend", "gloo", "--one-gpu", "--width", str(W), "--height", str(H),
+        "--spp", str(SPP), "--tris", str(TRIS), "--max-depth", str(DEPTH), "--spp-per-pass", str(SPP), "--no-cpu-baseline",
+        "--watchdog-s", "240"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _env():
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env.pop("PBRT_BENCH_FAIL", None)
+    return env
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_reduce_to_the_one_process_frame(hip_ctx, tmp_path):
+    """Launched as the driver launches it (torch.distributed.run, one fresh process per rank): the reduced film is the
+    one-process frame bit for bit, and the rays of the two ranks add up to the frame's."""
+    film_path = str(tmp_path / "film.npy")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + ARGS + ["--save-film", film_path]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["dist_backend"] == "gloo" and "error" not in line
+    assert any("libpbrt_hip" in p for p in line["config"]["runtime_libs"])   # the HIP path is what rendered
+    # the same frame in this process, all tiles on one rank
+    sc = scenes.random_triangles(TRIS, seq=1)
+    g = pbrt_hip.Scene(hip_ctx, sc, bvh=pbrt_hip.bvh_build(sc["positions"], sc["indices"], 4, pbrt_hip.SPLIT_SAH))
+    ref, st = g.render(scenes.random_triangles_camera(W, H), W, H, SPP, max_depth=DEPTH, rr_threshold=1.0, light_strategy=1, seed=0)
+    g.close()
+    film = np.load(film_path)
+    assert film.shape == ref.shape
+    assert film.tobytes() == ref.tobytes()   # non-owned pixels are zero on every rank: the sum is a pure gather
+    assert line["config"]["rays_per_frame"] == st["rays_closest"] + st["rays_shadow"]
+
+
+@pytest.mark.timeout(600)
+def test_a_rank_that_fails_its_render_ends_both_ranks_with_code_4(tmp_path):
+    """PBRT_BENCH_FAIL=render@1: rank 1 fails in the (checked) warm-up render; the agreement collective behind it lets rank 0
+    see that instead of waiting in the film reduce: both leave with exit code 4. Two plain child processes (the launcher's
+    environment set by hand) so that each rank's own exit code is visible."""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = _env()
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PBRT_BENCH_FAIL="render@1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + ARGS, cwd=ROOT, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=540) for p in procs]
+    assert [p.returncode for p in procs] == [4, 4], [o[1][-1500:] for o in outs]

@@ -9,7 +9,7 @@ from pbrt_hip import scenes
 W, H, spp = int(os.environ.get("W", 3840)), int(os.environ.get("H", 2160)), int(os.environ.get("SPP", 4))
 t = time.time()
 sc = scenes.instanced_scene(10_000, 1000)
-bvh = pbrt_hip.build_two_level(sc)
+bvh = pbrt_hip.build_two_level(sc, tlas_max_prims=int(os.environ.get("TLAS_MAX_PRIMS", "4")))
 print(f"scene + host BVHs {time.time()-t:.2f} s; tlas nodes {len(bvh[3])} blas nodes {len(bvh[0])}")
 cam = scenes.instanced_camera(W, H)
 ctx = pbrt_hip.Context(0)

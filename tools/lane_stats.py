@@ -7,16 +7,18 @@ import numpy as np, pbrt_hip
 pbrt_hip.LIB_PATH = sys.argv[1]
 from pbrt_hip import scenes
 W, H, spp = 1920, 1080, int(os.environ.get("SPP", "8"))
+bvh = None
 if os.environ.get("INSTANCED"):
     sc, cam, depth = scenes.instanced_scene(10_000, 1000), scenes.instanced_camera(W, H), 16
+    bvh = pbrt_hip.build_two_level(sc, tlas_max_prims=int(os.environ.get("TLAS_MAX_PRIMS", "4")))
 else:
     sc, cam, depth = scenes.random_triangles(int(os.environ.get("TRIS", "1000000")), seq=1), scenes.random_triangles_camera(W, H), 5
 ctx = pbrt_hip.Context(0)
-g = pbrt_hip.Scene(ctx, sc)
+g = pbrt_hip.Scene(ctx, sc, bvh=bvh)
 g.render(cam, W, H, spp, max_depth=depth, seed=0)
 L = pbrt_hip.lib()
 out = (ctypes.c_uint64 * 8)()
-wout = (ctypes.c_uint64 * 16)()
+wout = (ctypes.c_uint64 * 32)()
 L.pbrt_hip_debug_lane_stats(out, 1)
 L.pbrt_hip_debug_wide_stats(wout, 1)
 film, st = g.render(cam, W, H, spp, max_depth=depth, seed=0)
@@ -36,6 +38,14 @@ if w[0]:
     if cyc:
         print(f"wide refills: {w[9]/1e6:.2f} M ({w[9]/max(w[6],1):.2f} per outer iteration), {w[10]/max(w[9],1):.1f} rays fetched per refill")
         print(f"wave time (s_memtime between sections): refill {100*w[13]/cyc:.1f} %, record loop {100*w[14]/cyc:.1f} %, leaf phase {100*w[15]/cyc:.1f} %")
+    if w[21]:
+        print(f"two-level per ray: top-leaf box tests {w[16]/rays:.2f} (pass {w[17]/max(w[16],1):.2f}), entry attempts {w[18]/rays:.2f}, "
+              f"entered {w[19]/rays:.2f}, exit turns {w[20]/rays:.2f}")
+        print(f"instance sections: {w[21]/1e6:.1f} M at {w[22]/w[21]:.1f} lanes, {w[23]/w[21]:.2f} entry-loop trips per section")
+    if w[26]:
+        cyc = max(w[13] + w[14] + w[15], 1)
+        print(f"triangle sections: {w[26]/1e6:.1f} M at {w[28]/w[26]:.1f} lanes, {w[27]/w[26]:.2f} loop trips per section")
+        print(f"leaf phase split: instance branch {100*w[24]/cyc:.1f} % of wave time, triangle branch {100*w[25]/cyc:.1f} %")
     sys.exit(0)
 print(f"interior: {s[0]/1e6:.1f} M wave iterations, {s[1]/max(s[0],1):.1f} lanes active of 64 ({s[1]/rays:.1f} node steps per ray)")
 print(f"leaves:   {s[2]/1e6:.1f} M wave sections, {s[3]/max(s[2],1):.1f} lanes with a leaf, {s[4]/max(s[2],1):.2f} loop trips per section, "
