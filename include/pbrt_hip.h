@@ -175,6 +175,12 @@ typedef struct PbrtRenderParams {
     int32_t sampler_jitter;
     int32_t sampler_dims;
     float max_sample_luminance; /* Film::max_sample_luminance (src/core/film.rs:24, 253-255); 0 = infinity (no clamp) */
+    /* Order in which the path integrator's shading kernel takes the hits of a wavefront — where the reference dispatches per
+     * hit to the material (src/core/interaction.rs:318-329 -> src/core/material.rs:16-55): 0 = queue order, 1 = by material
+     * inside every block of 256 queue entries (LDS counting sort), 2 = the whole queue sorted by material. The film does not
+     * depend on it. Other integrators ignore it. */
+    int32_t shade_order;
+    int32_t reserved; /* 0 */
 } PbrtRenderParams;
 
 typedef struct PbrtRenderStats {

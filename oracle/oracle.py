@@ -79,6 +79,8 @@ def lib():
         L.orc_sample.argtypes = [ctypes.c_int, vp, ctypes.c_int64, ctypes.c_uint32, vp]
         L.orc_fr_dielectric.restype = ctypes.c_float
         L.orc_fr_dielectric.argtypes = [ctypes.c_float] * 3
+        L.orc_sphere_test.argtypes = [vp, ctypes.c_float, vp, vp]
+        L.orc_sphere_test.restype = None
         L.orc_refract.argtypes = [vp, vp, ctypes.c_float, ctypes.c_uint32, vp]
         L.orc_refract.restype = ctypes.c_int
         L.orc_local_to_world.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, vp]

@@ -583,6 +583,28 @@ void orc_sample(int op, const float* u2, int64_t n, uint32_t quirks, float* out)
         }
     }
 }
+// Sphere::intersect_test (sphere.rs:228-284) of a full sphere placed by a translation: out[0] = hit, out[1..3] = t.v, t.low,
+// t.high of the EFloat root it chose, out[4..10] = the object-space ray it solved for (o, d, t_max)
+void orc_sphere_test(const float* centre, float radius, const float* ray8, float* out11) {
+    auto sp = Sphere::at(Point3f(centre[0], centre[1], centre[2]), radius);
+    Ray r(Point3f(ray8[0], ray8[1], ray8[2]), Vector3f(ray8[3], ray8[4], ray8[5]), ray8[6], 0.0f);
+    Point3f ph;
+    Float phi = 0.0f;
+    Ray ro;
+    EFloat t;
+    const bool hit = sp->intersect_test(r, &ph, &phi, &ro, &t);
+    for (int i = 0; i < 11; ++i) out11[i] = 0.0f;
+    Vector3f oe, de;
+    Ray rx = xform_ray_err(sp->world_to_object, r, &oe, &de);  // the object-space ray, hit or not
+    out11[4] = rx.o.x, out11[5] = rx.o.y, out11[6] = rx.o.z;
+    out11[7] = rx.d.x, out11[8] = rx.d.y, out11[9] = rx.d.z;
+    out11[10] = rx.t_max;
+    if (!hit) return;
+    out11[0] = 1.0f;
+    out11[1] = t.v;
+    out11[2] = t.lower_bound();
+    out11[3] = t.upper_bound();
+}
 float orc_fr_dielectric(float cos_theta_i, float eta_i, float eta_t) { return fr_dielectric(cos_theta_i, eta_i, eta_t); }
 int orc_refract(const float* wi, const float* n, float eta, uint32_t quirks, float* wt) {
     Vector3f t;

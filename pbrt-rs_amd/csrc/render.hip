@@ -563,9 +563,10 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     // rays the wide kernel leaves to the binary one (wide_bvh.h): room for every entry of a trace queue
     const bool use_wide = s->has_wide && ctx->count_traversal != 1;
     uint32_t* special_list = use_wide ? buf.alloc<uint32_t>(N * 3, &ok) : nullptr;
-    // sort-by-material experiment: the shade queue in material order
-    const char* sort_shade_env = std::getenv("PBRT_HIP_SORT_SHADE");
-    const bool sort_shade = sort_shade_env && sort_shade_env[0] == '1' && rp.integrator == PBRT_INTEGRATOR_PATH;
+    // sort-by-material shading (wf_path.h): PbrtRenderParams.shade_order; 2 = the whole shade queue in material order
+    if (rp.shade_order < 0 || rp.shade_order > 2) return invalid("shade_order must be 0 (queue order), 1 (by material inside blocks) or 2 (sorted queue)");
+    const bool sort_shade = rp.shade_order == 2 && rp.integrator == PBRT_INTEGRATOR_PATH;
+    const bool bin_shade = rp.shade_order == 1 && rp.integrator == PBRT_INTEGRATOR_PATH;
     uint32_t *shade_keys[2] = {nullptr, nullptr}, *shade_sorted = nullptr;
     void* shade_tmp = nullptr;
     size_t shade_tmp_bytes = 0;
@@ -890,7 +891,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             }
             else {
                 Queues qin = q[cur];
-                if (sort_shade && wavefront >= 1 && n_shade >= (1u << 16)) {  // the first wavefront is all camera hits in pixel order
+                if (sort_shade && wavefront >= 1 && n_shade >= (1u << 10)) {  // the first wavefront is all camera hits in pixel order
                     hipLaunchKernelGGL(k_shade_sort_keys, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, q[cur].shade, n_shade,
                                        pp.max_depth, shade_keys[0]);
                     size_t tb = shade_tmp_bytes;
@@ -901,7 +902,10 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                     }
                     qin.shade = shade_sorted;
                 }
-                hipLaunchKernelGGL(k_shade, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, qin, q[nxt], pp, tiles, n_shade);
+                if (bin_shade && wavefront >= 1)
+                    hipLaunchKernelGGL(k_shade<true>, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, qin, q[nxt], pp, tiles, n_shade);
+                else
+                    hipLaunchKernelGGL(k_shade<false>, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, qin, q[nxt], pp, tiles, n_shade);
             }
             RENDER_TRY(hipGetLastError());
             RENDER_TRY(hipMemcpyAsync(ctx->h_counts, q[nxt].counts64, sizeof(counts), hipMemcpyDeviceToHost, st));

@@ -40,6 +40,12 @@ namespace pb {
 #ifndef PB_WIDE_INST_STACK_LDS
 #define PB_WIDE_INST_STACK_LDS 11  // two-level scenes: one stack entry less in LDS makes room for the world ray (below) at 5 blocks per CU
 #endif
+#ifndef PB_WIDE_TRI_CONST
+#define PB_WIDE_TRI_CONST 0  // the watertight test's per-ray constants (triangle.rs:84-101) once per ray / instance entry instead of once per leaf: measured, no gain (profiles/r03_two_level_ladder.txt)
+#endif
+#ifndef PB_WIDE_INLINE_EXIT
+#define PB_WIDE_INLINE_EXIT 0  // two-level scenes: a lane whose instance is walked out and whose top-level leaf has no entry left leaves the instance where it pops
+#endif
 #ifndef PB_WIDE_INST_GATHER
 #define PB_WIDE_INST_GATHER 1
 #endif
@@ -108,7 +114,8 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     int hit_slot = -1, sp = 0;
     uint32_t index = 0;
     bool nx = false, ny = false, nz = false, any = false;
-    uint32_t negmask = 0;
+    uint32_t negmask = 0;  // bits 0..2: dir_is_neg; bits 4..5: kz of the watertight test (PB_WIDE_TRI_CONST)
+    float tsx = 0.0f, tsy = 0.0f;  // its shear constants sx, sy (sz is the reciprocal direction component kz)
     r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.tmax = 0.0f;
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
@@ -191,6 +198,29 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             cur = kIdle;
         }
     };
+    // second half (primitive.rs:140-143): r.t_max = ray.t_max on a hit; back to the world ray, which waited in LDS with its
+    // reciprocal direction (the same three quotients set_ray_constants computed when the ray was fetched)
+    auto exit_instance = [&]() {
+        if (hit_inst == cur_top_slot) tmax_world = tmax;
+        const LdsFloat* w = (const LdsFloat*)lds_world;
+        r.ox = w[0 * kTraceBlock];
+        r.oy = w[1 * kTraceBlock];
+        r.oz = w[2 * kTraceBlock];
+        r.dx = w[3 * kTraceBlock];
+        r.dy = w[4 * kTraceBlock];
+        r.dz = w[5 * kTraceBlock];
+        idx = w[6 * kTraceBlock];
+        idy = w[7 * kTraceBlock];
+        idz = w[8 * kTraceBlock];
+        nx = idx < 0.0f;
+        ny = idy < 0.0f;
+        nz = idz < 0.0f;
+        negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+        r.tmax = tmax_world;
+        tmax = tmax_world;
+        base_sp = -1;
+    };
+
     // A lane that ran out of children (need_pop) takes ONE stack entry at the top of the next record iteration, together
     // with the other such lanes: the next entry whose lower bound is still in front of the hit becomes `cur`; an entry
     // behind the hit costs the lane that iteration. Inside an instance the stack ends at the floor laid down on entry:
@@ -199,7 +229,13 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     // or two lanes per iteration, with the exec-mask bookkeeping of a divergent loop in every record step.)
     auto pop_one = [&]() {
         if (INST && sp <= base_sp) {
-            cur = (SPEC && pend < 0) ? kWait : kLeaveInstance;  // the postponed leaf belongs to this instance: test it first
+            if (SPEC && pend < 0) {
+                cur = kWait;  // the postponed leaf belongs to this instance: test it first
+            } else if (PB_WIDE_INLINE_EXIT && (leaf_state & 7) == 0) {
+                exit_instance();  // nothing of the top-level leaf is left: on with the world ray's stack (cur stays kNeedPop)
+            } else {
+                cur = kLeaveInstance;
+            }
         } else if (sp == 0) {
             if (SPEC && pend < 0) {  // nothing left to walk but the postponed leaves: wait for the leaf phase
                 cur = kWait;
@@ -220,6 +256,12 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         ny = idy < 0.0f;
         nz = idz < 0.0f;
         negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+        if (PB_WIDE_TRI_CONST && !INST) {  // (two-level scenes: set on entering an instance, where the triangles are)
+            const TriRayConst c = tri_ray_setup(r, idx, idy, idz);
+            tsx = c.sx;
+            tsy = c.sy;
+            negmask |= (uint32_t)c.kz << 4;
+        }
     };
     // TransformedPrimitive::intersect, first half (primitive.rs:136-139), on the entry's loaded record: the top slot it names,
     // its object word and the three world-to-object rows. 0 = the ray misses the object's root box, 1 = entered, 2 = the
@@ -275,34 +317,17 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         ny = by;
         nz = bz;
         negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+        if (PB_WIDE_TRI_CONST) {
+            const TriRayConst c = tri_ray_setup(r, idx, idy, idz);
+            tsx = c.sx;
+            tsy = c.sy;
+            negmask |= (uint32_t)c.kz << 4;
+        }
         cur_top_slot = top_slot;
         base_sp = sp;
         cur = root;
         return 1;
     };
-    // second half (primitive.rs:140-143): r.t_max = ray.t_max on a hit; back to the world ray, which waited in LDS with its
-    // reciprocal direction (the same three quotients set_ray_constants computed when the ray was fetched)
-    auto exit_instance = [&]() {
-        if (hit_inst == cur_top_slot) tmax_world = tmax;
-        const LdsFloat* w = (const LdsFloat*)lds_world;
-        r.ox = w[0 * kTraceBlock];
-        r.oy = w[1 * kTraceBlock];
-        r.oz = w[2 * kTraceBlock];
-        r.dx = w[3 * kTraceBlock];
-        r.dy = w[4 * kTraceBlock];
-        r.dz = w[5 * kTraceBlock];
-        idx = w[6 * kTraceBlock];
-        idy = w[7 * kTraceBlock];
-        idz = w[8 * kTraceBlock];
-        nx = idx < 0.0f;
-        ny = idy < 0.0f;
-        nz = idz < 0.0f;
-        negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
-        r.tmax = tmax_world;
-        tmax = tmax_world;
-        base_sp = -1;
-    };
-
     for (;;) {
         // ---------------- refill idle lanes (as trace_persistent.h) ----------------
         PB_WCLOCK(t_refill0);
@@ -657,7 +682,15 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             }
 #endif
             if (pass) {
-                const TriRayConst trc = tri_ray_setup(r, idx, idy, idz);
+                TriRayConst trc;
+                if (PB_WIDE_TRI_CONST) {
+                    trc.kz = (int)(negmask >> 4);
+                    trc.sx = tsx;
+                    trc.sy = tsy;
+                    trc.sz = trc.kz == 0 ? idx : (trc.kz == 1 ? idy : idz);
+                } else {
+                    trc = tri_ray_setup(r, idx, idy, idz);
+                }
                 for (int i = 0; i < cnt; ++i) {
                     if (i > 0) {
                         if (COUNT) c_tri += 1;

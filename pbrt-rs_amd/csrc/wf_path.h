@@ -4,14 +4,17 @@
 
 namespace pb {
 
-// Sort-by-material experiment (north_star; the reference dispatches per hit to the material, interaction.rs:318-329):
-// key of a shade-queue entry = what k_shade will branch on: 0 no continuation hit to shade (escaped / dead path, only
-// the pending estimate is resolved), 1 + material type otherwise. PBRT_HIP_SORT_SHADE=1 sorts the queue by it.
-__global__ void k_shade_sort_keys(ShadeConsts sc, PathState ps, const uint32_t* __restrict__ shade_queue, uint32_t n, int max_depth,
-                                  uint32_t* __restrict__ keys) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t p = shade_queue[i];
+// Sort-by-material shading (north_star; the reference dispatches per hit to the material, interaction.rs:318-329 ->
+// material.rs:16-55). Key of a shade-queue entry = what k_shade will branch on: 0 no continuation hit to shade (escaped /
+// dead path, only the pending estimate is resolved), 1 + material type otherwise. PbrtRenderParams.shade_order selects:
+//   0  queue order (one path per lane as the queue has them),
+//   1  material order INSIDE each block of 256 queue entries: the block's entries are counting-sorted by key through LDS
+//      before shading, so a wave shades (mostly) one material while the block still touches the same 256 paths' state —
+//      the reads stay as coalesced as the queue is (round 3),
+//   2  the whole queue radix-sorted by key (round 2's experiment: lane utilisation doubles, the 290 B of path state per
+//      path become scattered gathers and the kernel gets slower).
+// Films are bit-identical in all three: a path's arithmetic does not depend on which lane runs it.
+PB_DEV uint32_t shade_key(const ShadeConsts& sc, const PathState& ps, uint32_t p, int max_depth) {
     int fb = __float_as_int(ps.beta[p].w);
     uint32_t key = 0;
     if ((fb & PF_ALIVE) && (fb >> 8) < max_depth) {
@@ -26,14 +29,52 @@ __global__ void k_shade_sort_keys(ShadeConsts sc, PathState ps, const uint32_t* 
             key = 1u + (uint32_t)sc.materials[mat].type;
         }
     }
-    keys[i] = key;
+    return key;
+}
+__global__ void k_shade_sort_keys(ShadeConsts sc, PathState ps, const uint32_t* __restrict__ shade_queue, uint32_t n, int max_depth,
+                                  uint32_t* __restrict__ keys) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = shade_key(sc, ps, shade_queue[i], max_depth);
 }
 
+constexpr int kShadeKeys = 6;  // 0 nothing to shade, 1 + PBRT_MAT_* (none, matte, mirror, glass), 5 = no queue entry (block tail)
+struct ShadeBins {
+    uint32_t count[4][kShadeKeys];  // per wave of the block, per key
+    uint32_t path[256];
+};
+
+template <bool BIN>
 __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Queues qin, Queues qout, PassParams pp,
                                                  TileList tiles, uint32_t n_in) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool active = i < n_in;
     uint32_t p = active ? qin.shade[i] : 0u;
+    if (BIN) {
+        // counting sort of the block's 256 entries by key: rank inside the wave by ballot + mbcnt, waves and keys through LDS
+        __shared__ ShadeBins bins;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const uint32_t key = active ? shade_key(sc, ps, p, pp.max_depth) : (uint32_t)(kShadeKeys - 1);
+        uint32_t rank = 0;
+#pragma unroll
+        for (int k = 0; k < kShadeKeys; ++k) {
+            const unsigned long long m = __ballot(key == (uint32_t)k);
+            if (key == (uint32_t)k) rank = lane_prefix(m);
+            if (lane == 0) bins.count[wave][k] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        uint32_t before = 0;  // entries of smaller keys in the block, and of this key in the waves before this one
+        for (int k = 0; k < kShadeKeys; ++k)
+            for (int w = 0; w < 4; ++w)
+                before += ((uint32_t)k < key || ((uint32_t)k == key && w < wave)) ? bins.count[w][k] : 0u;
+        bins.path[before + rank] = p;
+        uint32_t n_active = 0;
+        for (int k = 0; k < kShadeKeys - 1; ++k)
+            for (int w = 0; w < 4; ++w) n_active += bins.count[w][k];
+        __syncthreads();
+        p = bins.path[threadIdx.x];
+        active = threadIdx.x < n_active;
+    }
     bool emit_cont = false, emit_mis = false, emit_shadow = false;
 
     uint32_t cell = 0;  // sort cell of the rays this path emits

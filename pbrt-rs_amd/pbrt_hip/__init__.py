@@ -44,7 +44,8 @@ class RenderParams(ctypes.Structure):
                 ("tile_world", ctypes.c_int32), ("spp_per_pass", ctypes.c_int32), ("ao_samples", ctypes.c_int32),
                 ("filter_radius", ctypes.c_float * 2), ("filter_table", ctypes.c_void_p),
                 ("sampler", ctypes.c_int32), ("sampler_x", ctypes.c_int32), ("sampler_y", ctypes.c_int32),
-                ("sampler_jitter", ctypes.c_int32), ("sampler_dims", ctypes.c_int32), ("max_sample_luminance", ctypes.c_float)]
+                ("sampler_jitter", ctypes.c_int32), ("sampler_dims", ctypes.c_int32), ("max_sample_luminance", ctypes.c_float),
+                ("shade_order", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class PbrtObject(ctypes.Structure):
@@ -501,7 +502,8 @@ class Scene:
                                                          ctypes.c_void_p(d_out_ptr)), "pbrt_hip_intersect_p_device")
 
     def _params(self, width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
-                tile_rank, tile_world, spp_per_pass, filter=None, ao_samples=64, sampler=None, max_sample_luminance=0.0):
+                tile_rank, tile_world, spp_per_pass, filter=None, ao_samples=64, sampler=None, max_sample_luminance=0.0,
+                shade_order=0):
         rx, ry, table = (0.5, 0.5, None) if filter is None else filter
         if table is not None:
             table = np.ascontiguousarray(table, dtype=np.float32)
@@ -519,21 +521,22 @@ class Scene:
             raise ValueError(sampler)
         return RenderParams(integrator, max_depth, rr_threshold, light_strategy, spp, width, height, x0, y0, x1, y1,
                             seed, tile_rank, tile_world, spp_per_pass, ao_samples, (ctypes.c_float * 2)(rx, ry),
-                            None if table is None else table.ctypes.data, *smp, float(max_sample_luminance))
+                            None if table is None else table.ctypes.data, *smp, float(max_sample_luminance), int(shade_order), 0)
 
     def render(self, camera, width, height, spp, integrator=INTEGRATOR_PATH, max_depth=5, rr_threshold=1.0,
                light_strategy=1, seed=0, bounds=None, tile_rank=0, tile_world=1, spp_per_pass=0, d_film_ptr=None,
-               filter=None, ao_samples=64, cos_sample=True, sampler=None, max_sample_luminance=0.0):
+               filter=None, ao_samples=64, cos_sample=True, sampler=None, max_sample_luminance=0.0, shade_order=0):
         """Integrator::render. Returns (film[h,w,4] or None when d_film_ptr is given, stats dict).
         integrator: INTEGRATOR_PATH / _DIRECT / _WHITTED / _AO (ao_samples, cos_sample: AOIntegrator::new).
         sampler: None (RandomSampler), ("stratified", nx, ny, jitter, n_dims) or ("zerotwo", n_dims); the samples
         per pixel then become nx * ny / the next power of two of spp.
-        filter = (radius_x, radius_y, table256) from filter_table(), None = 0.5 box."""
+        filter = (radius_x, radius_y, table256) from filter_table(), None = 0.5 box.
+        shade_order: 0 queue order, 1 by material inside blocks, 2 sorted queue (PbrtRenderParams.shade_order)."""
         camera = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
         if integrator == INTEGRATOR_AO:
             light_strategy = int(bool(cos_sample))
         rp = self._params(width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
-                          tile_rank, tile_world, spp_per_pass, filter, ao_samples, sampler, max_sample_luminance)
+                          tile_rank, tile_world, spp_per_pass, filter, ao_samples, sampler, max_sample_luminance, shade_order)
         st = RenderStats()
         if d_film_ptr is None:
             film = np.zeros((height, width, 4), dtype=np.float32)

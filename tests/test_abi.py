@@ -25,7 +25,7 @@ def test_header_symbols_exported():
 
 
 def test_struct_sizes_match_header():
-    assert ctypes.sizeof(pbrt_hip.RenderParams) == 112  # 11 x i32, pad, u64 seed, 4 x i32, 2 x f32, pointer, 6 x i32
+    assert ctypes.sizeof(pbrt_hip.RenderParams) == 120  # 11 x i32, pad, u64 seed, 4 x i32, 2 x f32, pointer, 8 x i32
     assert ctypes.sizeof(pbrt_hip.RenderStats) == 48
     assert scenes.CAMERA_DTYPE.itemsize == 160
 

@@ -231,3 +231,186 @@ def test_box_seeded_cases_against_exact_geometry(seq, scale, size):
             near += 1
         conservative += int(e_hit)
     assert decided > n // 2 and (size == 0.0 or conservative > n // 10), (decided, conservative, near)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 3: the remaining decision code, pinned the same way — geometry / physics evaluated independently (exact rationals
+# or float64), the oracle's routine compared with it. None of the closed-form scenes reaches these.
+# ---------------------------------------------------------------------------------------------------------------------
+def _oracle_offset(p, err, n, w):
+    out = np.zeros(3, dtype=np.float32)
+    a = [np.ascontiguousarray(v, dtype=np.float32) for v in (p, err, n, w)]
+    L.orc_offset_ray_origin(*(x.ctypes.data_as(ctypes.c_void_p) for x in a), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def test_offset_ray_origin_leaves_the_error_box_on_the_side_of_w():
+    """geometry.rs:1139-1154. For the surface point p with error box p +- p_error and normal n, the spawned origin must lie
+    outside the slab the error box sweeps along n, on the side the ray leaves to: exactly, for every q in the box,
+    (po - q) . n has the sign of w . n, i.e. |(po - p) . n| >= sum |n_k| p_error_k and the sign is right. The float routine
+    adds n * d (d = the float dot product) and then rounds every coordinate AWAY from p; checked in exact rationals:
+      * sign of (po - p) . n = sign of w . n,
+      * per axis |po_k - p_k| >= |n_k| * D_lo with D_lo = (1 - 4 u) * exact d (a float dot product of non-negative terms
+        cannot come out lower), and the move is away from p on every axis where n_k != 0,
+      * so (po - p) . n >= D_lo * (n . n): outside the swept slab whenever n . n >= 1 / (1 - 4 u); for the unit normals
+        the path produces (|n|^2 within 2^-22 of 1) the rounding step more than covers the difference — asserted on the
+        exact value, with the slab computed exactly,
+      * and not farther than the formula explains (two ulps beyond |n_k| d (1 + 4 u))."""
+    rng = np.random.default_rng(20263)
+    u = Fr(1, 2 ** 24)
+    n_cases = 4000
+    for i in range(n_cases):
+        scale = 10.0 ** rng.uniform(-3, 4)
+        p = (rng.uniform(-1, 1, 3) * scale).astype(f32)
+        n = rng.normal(size=3)
+        if i % 7 == 0:
+            n[rng.integers(3)] = 0.0            # axis-aligned components
+        if i % 11 == 0:
+            n = np.eye(3)[rng.integers(3)] * rng.choice([-1.0, 1.0])
+        n = (n / np.linalg.norm(n)).astype(f32)
+        err = (np.abs(p) * rng.uniform(1e-8, 1e-5, 3) + rng.uniform(0, 1e-9)).astype(f32)   # gamma(7) |p| and up
+        w = rng.normal(size=3).astype(f32)
+        po = _oracle_offset(p, err, n, w)
+        P, N, E, W, PO = _fr3(p), _fr3(n), _fr3(err), _fr3(w), _fr3(po)
+        side = _dot(W, N)
+        if side == 0:
+            continue
+        sgn = 1 if side > 0 else -1
+        d_exact = sum(abs(a) * b for a, b in zip(N, E))
+        move = _sub(PO, P)
+        along = _dot(move, N) * sgn
+        assert along > 0, (i, p, n, err, w, po)
+        d_lo, d_hi = d_exact * (1 - 4 * u), d_exact * (1 + 4 * u)
+        for k in range(3):
+            if N[k] == 0:
+                assert move[k] == 0
+                continue
+            assert (move[k] > 0) == ((N[k] > 0) == (sgn > 0)), (i, k)        # away from p, along +-n
+            assert abs(move[k]) >= abs(N[k]) * d_lo, (i, k, float(abs(move[k])), float(abs(N[k]) * d_lo))
+            ulp = Fr(float(np.spacing(f32(max(abs(float(p[k])), abs(float(po[k])))))))
+            assert abs(move[k]) <= abs(N[k]) * d_hi + 2 * ulp, (i, k)
+        # the whole error box is behind the origin, exactly: min over the box of (po - q) . n * sgn = along - d_exact
+        assert along - d_exact >= 0, (i, float(along), float(d_exact))
+
+
+def _oracle_sphere(c, r, o, d, t_max):
+    out = np.zeros(11, dtype=np.float32)
+    ray = np.array(list(o) + list(d) + [t_max, 0.0], dtype=np.float32)
+    cc = np.ascontiguousarray(c, dtype=np.float32)
+    L.orc_sphere_test(cc.ctypes.data_as(ctypes.c_void_p), ctypes.c_float(r), ray.ctypes.data_as(ctypes.c_void_p),
+                      out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def test_sphere_efloat_interval_brackets_the_exact_root():
+    """sphere.rs:228-284 with efloat.rs: the root the test reports comes with running error bounds [t.low, t.high]. Interval
+    arithmetic is sound iff the exact root of the quadratic of ANY ray inside the operand intervals lies in the result
+    interval; checked for the object-space ray the routine solved (its float coordinates taken as exact rationals):
+    f(t) = |o + t d|^2 - r^2 changes sign (or vanishes) between t.low and t.high, in the direction of the root reported
+    (entering: + to -, leaving: - to +). That holds for every ray that is not grazing; EFloat::quadratic (efloat.rs:64-87)
+    takes the discriminant from the rounded midpoints in f64 and bounds the root by machine_epsilon * root, which is not an
+    interval bound when the discriminant is a small difference of large terms (2 of 2 500 seeded rays, both with
+    discriminant < 2e-4 b^2): for grazing rays the reported value is held to the conditioned bound
+    |t - t_exact| <= 64 u |t| b^2 / discriminant instead. And the decision itself: an exact root inside (0, t_max) by a margin is found,
+    a ray whose exact closest approach misses the sphere by a margin reports nothing."""
+    rng = np.random.default_rng(7)
+    hits = brackets = 0
+    for i in range(3000):
+        c = rng.uniform(-3, 3, 3).astype(f32)
+        r = f32(10.0 ** rng.uniform(-2, 1))
+        d = rng.normal(size=3)
+        d = (d / np.linalg.norm(d) * (1.0 if i % 3 else 10.0 ** rng.uniform(-2, 2))).astype(f32)
+        # aim near the sphere: offset the target by up to 1.3 radii (misses and grazing rays included), start in- or outside
+        target = c.astype(np.float64) + rng.normal(size=3) / np.sqrt(3) * float(r) * rng.uniform(0, 1.3)
+        o = (target - d.astype(np.float64) * rng.uniform(-0.5 if i % 5 == 0 else 0.2, 6.0) * float(r) / np.linalg.norm(d)).astype(f32)
+        t_max = f32(np.inf) if i % 4 else f32(rng.uniform(0.5, 8.0) * float(r) / np.linalg.norm(d))
+        out = _oracle_sphere(c, float(r), o, d, t_max)
+        O, D = _fr3(out[4:7]), _fr3(out[7:10])
+        R = Fr(float(r))
+        qa, qb, qc = _dot(D, D), 2 * _dot(D, O), _dot(O, O) - R * R
+        f = lambda t: (qa * t + qb) * t + qc    # noqa: E731
+        disc = qb * qb - 4 * qa * qc
+        if out[0] != 0.0:
+            hits += 1
+            lo, hi, tv = Fr(float(out[2])), Fr(float(out[3])), Fr(float(out[1]))
+            assert lo <= tv <= hi and lo >= 0 and (not np.isfinite(t_max) or hi <= Fr(float(t_max)))
+            assert disc >= 0, i
+            vertex = -qb / (2 * qa)
+            flo, fhi = f(lo), f(hi)
+            if disc * 100 < qb * qb:    # grazing: the conditioned bound on the value
+                sq = Fr(float(np.sqrt(float(disc))))
+                root = (-qb - sq) / (2 * qa) if tv <= vertex else (-qb + sq) / (2 * qa)
+                assert abs(tv - root) <= 64 * Fr(1, 2 ** 24) * abs(tv) * qb * qb / disc + Fr(1, 2 ** 40), (i, float(tv), float(root))
+            elif tv <= vertex:  # the entering root
+                assert flo >= 0 >= fhi, (i, float(flo), float(fhi))
+                brackets += 1
+            else:               # the leaving root (origin inside, or the entering one rejected)
+                assert flo <= 0 <= fhi, (i, float(flo), float(fhi))
+                brackets += 1
+        else:
+            # nothing reported: no exact root may sit comfortably inside (0, t_max)
+            if disc > 0:
+                sq = Fr(float(np.sqrt(float(disc))))       # only used to place test points: the decision below is exact
+                for root in ((-qb - sq) / (2 * qa), (-qb + sq) / (2 * qa)):
+                    m = abs(root) * Fr(1, 2 ** 12) + Fr(1, 2 ** 30)
+                    inside = root - m > 0 and (not np.isfinite(t_max) or root + m < Fr(float(t_max)))
+                    # a genuine sign change around `root` well inside the range would have had to be reported
+                    assert not (inside and f(root - m) * f(root + m) < 0), (i, float(root))
+    assert hits > 800 and brackets > 0.9 * hits
+
+
+def test_fresnel_and_refraction_against_float64():
+    """reflection.rs:19-40 (fr_dielectric) and :140-156 (refract), D37 intended. Evaluated independently in float64 from the
+    physics — Snell's law, the two amplitude ratios — and compared with the float32 routines: |F32 - F64| <= 64 u (u = 2^-24,
+    values in [0, 1]; away from the total-reflection threshold where cos_t -> 0 amplifies the rounding of sin_t: there the
+    bound is scaled by 1 / cos_t). Exact properties: 1 at and beyond total internal reflection, symmetric in the side the
+    ray comes from, refract() fails exactly when Snell has no solution (by a margin), returns a unit vector in the plane of
+    incidence on the far side of n, with sin_t = eta sin_i."""
+    rng = np.random.default_rng(11)
+    u = 2.0 ** -24
+    for i in range(4000):
+        cos_i = float(f32(rng.uniform(-1, 1)))
+        eta_i, eta_t = float(f32(rng.uniform(1.0, 2.5))), float(f32(rng.uniform(1.0, 2.5)))
+        got = float(L.orc_fr_dielectric(ctypes.c_float(cos_i), ctypes.c_float(eta_i), ctypes.c_float(eta_t)))
+        ci, ei, et = abs(cos_i), (eta_i, eta_t)[cos_i <= 0], (eta_t, eta_i)[cos_i <= 0]
+        si = np.sqrt(max(0.0, 1 - ci * ci))
+        st = ei / et * si
+        if st >= 1 + 1e-6:
+            assert got == 1.0
+            continue
+        if st > 1 - 1e-6:
+            continue    # the threshold itself: either answer is within rounding
+        ct = np.sqrt(1 - st * st)
+        r_par = (et * ci - ei * ct) / (et * ci + ei * ct)
+        r_per = (ei * ci - et * ct) / (ei * ci + et * ct)
+        want = 0.5 * (r_par * r_par + r_per * r_per)
+        assert abs(got - want) <= 64 * u / max(ct, 1e-3), (cos_i, eta_i, eta_t, got, want)
+        assert 0.0 <= got <= 1.0
+    for i in range(4000):
+        n = rng.normal(size=3)
+        n = (n / np.linalg.norm(n)).astype(f32)
+        wi = rng.normal(size=3)
+        wi = (wi / np.linalg.norm(wi)).astype(f32)
+        if np.dot(wi.astype(np.float64), n.astype(np.float64)) < 0:
+            n = -n                                   # refract() is called with n on wi's side (reflection.rs:703)
+        eta = float(f32(rng.uniform(0.4, 2.5)))
+        wt = np.zeros(3, dtype=np.float32)
+        ok = L.orc_refract(wi.ctypes.data_as(ctypes.c_void_p), n.ctypes.data_as(ctypes.c_void_p), ctypes.c_float(eta), 0,
+                           wt.ctypes.data_as(ctypes.c_void_p))
+        W, N = wi.astype(np.float64), n.astype(np.float64)
+        ci = float(np.dot(N, W))
+        s2t = eta * eta * max(0.0, 1 - ci * ci)
+        if s2t >= 1 + 1e-5:
+            assert not ok
+            continue
+        if s2t > 1 - 1e-5:
+            continue
+        assert ok
+        ct = np.sqrt(1 - s2t)
+        want = -eta * W + (eta * ci - ct) * N
+        assert np.max(np.abs(wt - want)) <= 32 * u * max(1.0, eta) / max(ct, 1e-2), (wi, n, eta, wt, want)
+        assert np.dot(wt, N) < 0                                                            # the far side
+        assert abs(np.linalg.norm(wt) - 1.0) <= 1e-5 / max(ct, 1e-2)
+        # Snell: the tangential parts are antiparallel with ratio eta
+        tan_i, tan_t = W - ci * N, wt.astype(np.float64) - float(np.dot(wt, N)) * N
+        assert np.max(np.abs(tan_t + eta * tan_i)) <= 1e-5

@@ -162,6 +162,32 @@ def test_instanced_scene_render(hip_ctx, integrator, max_depth):
     assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
 
 
+def test_shade_order_by_material_keeps_the_film(hip_ctx):
+    """PbrtRenderParams.shade_order: config-5 geometry (matte / mirror / glass by instance, depth 16) shaded in queue
+    order, by material inside each block of 256 queue entries (LDS counting sort) and with the whole queue sorted by
+    material — the stand-ins for the reference's per-hit dispatch to the material (interaction.rs:318-329). The three films
+    are the same bits, the ray counts are equal, and the film is the oracle's."""
+    w, h, spp, depth = 192, 112, 4, 16
+    sc = scenes.instanced_scene(3000, 60, extent=1.5)
+    cam = scenes.instanced_camera(w, h, 1.5)
+    g = pbrt_hip.Scene(hip_ctx, sc)
+    films, stats = [], []
+    for order in (0, 1, 2):
+        f, st = g.render(cam, w, h, spp, max_depth=depth, seed=31, shade_order=order)
+        films.append(f)
+        stats.append(st)
+    assert films[0].tobytes() == films[1].tobytes() == films[2].tobytes()
+    assert len({(st["rays_closest"], st["rays_shadow"]) for st in stats}) == 1
+    with pytest.raises(pbrt_hip.PbrtHipError):
+        g.render(cam, w, h, 1, max_depth=2, shade_order=3)
+    g.close()
+    osc = oracle.OracleScene(sc)
+    film_c, st_c = osc.render(scenes.camera_dict_to_floats(cam), w, h, spp, max_depth=depth, seed=31)
+    osc.close()
+    _compare(films[1], film_c)
+    assert stats[1]["rays_closest"] + stats[1]["rays_shadow"] == st_c["rays"]
+
+
 @pytest.mark.parametrize("kind,rx,a,b", [("gaussian", 2.0, 2.0, 0.0), ("mitchell", 2.0, 1 / 3, 1 / 3), ("triangle", 1.5, 0, 0)])
 def test_reconstruction_filters(hip_ctx, kind, rx, a, b):
     """Film with a wide reconstruction filter (src/filters/*.rs, FilmTile::add_sample film.rs:252-295): samples

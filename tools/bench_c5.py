@@ -7,6 +7,7 @@ import pbrt_hip
 if os.environ.get("PBRT_LIB"): pbrt_hip.LIB_PATH = os.environ["PBRT_LIB"]
 from pbrt_hip import scenes
 W, H, spp = int(os.environ.get("W", 3840)), int(os.environ.get("H", 2160)), int(os.environ.get("SPP", 4))
+ORDER = int(os.environ.get("SHADE_ORDER", "0"))   # PbrtRenderParams.shade_order
 t = time.time()
 sc = scenes.instanced_scene(10_000, 1000)
 bvh = pbrt_hip.build_two_level(sc, tlas_max_prims=int(os.environ.get("TLAS_MAX_PRIMS", "4")))
@@ -16,18 +17,18 @@ ctx = pbrt_hip.Context(0)
 scene = pbrt_hip.Scene(ctx, sc, bvh=bvh)
 print("wide records:", scene.wide_records())
 for it in range(2):
-    film, st = scene.render(cam, W, H, spp, max_depth=16, seed=0)
+    film, st = scene.render(cam, W, H, spp, max_depth=16, seed=0, shade_order=ORDER)
 rays = st["rays_closest"] + st["rays_shadow"]
 print(f"{W}x{H}x{spp}: total {st['total_ms']:.1f} ms trace {st['trace_ms']:.1f} ms ({st['trace_launches']} launches) "
       f"rays {rays/1e6:.1f}M -> {rays/st['total_ms']/1e3:.0f} Mrays/s")
 if os.environ.get("NO_COUNT"): sys.exit(0)
 if scene.wide_records()[0] > 0:
     ctx.set_counting(2); ctx.wide_counters(reset=True)
-    scene.render(cam, W, H, spp, max_depth=16, seed=0)
+    scene.render(cam, W, H, spp, max_depth=16, seed=0, shade_order=ORDER)
     wc = ctx.wide_counters(reset=True)
     print("wide per ray: " + " ".join(f"{k} {v/rays:.2f}" for k, v in wc.items()))
 ctx.set_counting(True); ctx.counters(reset=True)
-film, st2 = scene.render(cam, W, H, spp, max_depth=16, seed=0)
+film, st2 = scene.render(cam, W, H, spp, max_depth=16, seed=0, shade_order=ORDER)
 c = ctx.counters(reset=True); ctx.set_counting(False)
 rays = c["rays"]
 alg = 32*rays + 32*c["node_tests"] + 48*c["prim_tests"] + 112*c.get("inst_tests",0) + 16*st2["rays_closest"] + 4*st2["rays_shadow"]

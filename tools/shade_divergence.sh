@@ -1,15 +1,16 @@
 #!/bin/bash
-# what does k_shade's per-lane branch on mat.type cost on config 5, and what does sorting the shade
-# queue by material buy? Config 5 geometry at 1920x1080 x 16 spp, depth 16 (tools/bench_c5.py), shade queue as is and
-# sorted (PBRT_HIP_SORT_SHADE=1): frame time, per-kernel times (rocprofv3 --kernel-trace --stats), VALU lane utilisation
-# of k_shade (SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU x 64), own --pmc pass). Films must be bit-identical.
+# What does k_shade's per-lane branch on mat.type cost on config 5, and what does shading in material order buy?
+# Config 5 geometry at 1920x1080 x 16 spp, depth 16 (tools/bench_c5.py) with PbrtRenderParams.shade_order = 0 (queue
+# order), 1 (by material inside each block, LDS counting sort) and 2 (whole queue radix-sorted): frame time, per-kernel
+# times (rocprofv3 --kernel-trace --stats), VALU lane utilisation and waiting of k_shade (own --pmc pass).
+# Films must be bit-identical (also a -m gpu test: test_shade_order_by_material_keeps_the_film).
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 export W=1920 H=1080 SPP=16
 OUT=gpurun_out/shade_div; rm -rf $OUT; mkdir -p $OUT
-for MODE in 0 1; do
-  export PBRT_HIP_SORT_SHADE=$MODE
-  echo "===== PBRT_HIP_SORT_SHADE=$MODE"
+for MODE in 0 1 2; do
+  export SHADE_ORDER=$MODE
+  echo "===== shade_order=$MODE"
   timeout -k 10 300 python3 tools/bench_c5.py 2>&1 | grep -v amdgpu.ids | tee $OUT/run$MODE.txt || exit 1
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats$MODE -o s -- python3 tools/bench_c5.py > $OUT/stats$MODE.log 2>&1 || exit 1
   python3 - $OUT/stats$MODE <<'PY'
@@ -32,8 +33,9 @@ import numpy as np, pbrt_hip
 from pbrt_hip import scenes
 sc = scenes.instanced_scene(10_000, 1000); cam = scenes.instanced_camera(640, 360)
 ctx = pbrt_hip.Context(0); g = pbrt_hip.Scene(ctx, sc)
-os.environ["PBRT_HIP_SORT_SHADE"] = "0"; a, _ = g.render(cam, 640, 360, 8, max_depth=16, seed=1)
-os.environ["PBRT_HIP_SORT_SHADE"] = "1"; b, _ = g.render(cam, 640, 360, 8, max_depth=16, seed=1)
-print("films bit-identical with and without the shade sort:", a.tobytes() == b.tobytes())
+a, _ = g.render(cam, 640, 360, 8, max_depth=16, seed=1, shade_order=0)
+b, _ = g.render(cam, 640, 360, 8, max_depth=16, seed=1, shade_order=1)
+c, _ = g.render(cam, 640, 360, 8, max_depth=16, seed=1, shade_order=2)
+print("films bit-identical in queue order / by material inside blocks / sorted queue:", a.tobytes() == b.tobytes() == c.tobytes())
 PY
 find $OUT -name "*.csv" -size +1M -delete
