@@ -17,6 +17,9 @@
 #include "trace.h"
 #include "wavefront.h"
 
+#ifndef PB_SHADE_SPLIT
+#define PB_SHADE_SPLIT 0
+#endif
 static constexpr double kWavefrontDeadlineSeconds = 120.0;  // no wavefront of a render takes this long
 
 using namespace pb;
@@ -902,10 +905,15 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                     }
                     qin.shade = shade_sorted;
                 }
+#if PB_SHADE_SPLIT  // development: one bounce as two launches (wf_path.h, PART)
+                hipLaunchKernelGGL((k_shade<false, 1>), dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, qin, q[nxt], pp, tiles, n_shade);
+                hipLaunchKernelGGL((k_shade<false, 2>), dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, qin, q[nxt], pp, tiles, n_shade);
+#else
                 if (bin_shade && wavefront >= 1)
                     hipLaunchKernelGGL(k_shade<true>, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, qin, q[nxt], pp, tiles, n_shade);
                 else
                     hipLaunchKernelGGL(k_shade<false>, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, qin, q[nxt], pp, tiles, n_shade);
+#endif
             }
             RENDER_TRY(hipGetLastError());
             RENDER_TRY(hipMemcpyAsync(ctx->h_counts, q[nxt].counts64, sizeof(counts), hipMemcpyDeviceToHost, st));

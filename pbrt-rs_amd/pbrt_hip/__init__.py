@@ -17,7 +17,7 @@ from . import scenes
 from .scenes import (CAMERA_DTYPE, HIT_DTYPE, INSTANCE_DTYPE, LIGHT_DTYPE, MATERIAL_DTYPE, NODE_DTYPE, RAY_DTYPE)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpbrt_hip.so")
+LIB_PATH = os.environ.get("PBRT_HIP_LIB") or os.path.join(_HERE, "libpbrt_hip.so")   # PBRT_HIP_LIB: a variant build (development A/Bs)
 
 SPLIT_SAH, SPLIT_HLBVH, SPLIT_MIDDLE, SPLIT_EQUAL_COUNTS = 0, 1, 2, 3
 INTEGRATOR_PATH, INTEGRATOR_DIRECT, INTEGRATOR_WHITTED, INTEGRATOR_AO = 0, 1, 2, 3

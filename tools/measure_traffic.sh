@@ -1,12 +1,14 @@
 #!/bin/bash
-# Writes profiles/r02_traffic.json (fabric-side bytes per launch of the dominant traversal kernel, for bench.py's
-# roofline.traffic) and profiles/r02_bench_kernel_stats.csv from rocprofv3 runs of the default bench.py command.
-# Three separate runs (--kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE), as gpurun requires.
+# Writes profiles/r03_traffic.json — the stamped counter profile behind bench.py's roofline block: per launch of the dominant
+# traversal kernel and of k_shade, fabric-side bytes (FETCH_SIZE + WRITE_SIZE), vector instructions and lane utilisation,
+# texture-addresser busy cycles — and profiles/r03_bench_kernel_stats.csv, from rocprofv3 runs of the default bench.py
+# command. Separate runs (--kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE; SQ counters; TA), as gpurun requires.
+# Stamped with the commit and with bench.py's hash of the kernel sources: bench.py flags the figures stale when they differ.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 OUT=gpurun_out/traffic
 rm -rf $OUT; mkdir -p $OUT profiles
-CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
 grep '^{' $OUT/stats.log | tail -1 > $OUT/bench_line_under_rocprof.json
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -41,41 +43,53 @@ def pick(d):
     ks = [k for k in d if re.search(r"k_trace_wide<false(, 0)?>|k_trace_wide<\(bool\)0", k)] or [k for k in d if re.search(r"k_trace<false, (false|0), false>", k)]
     return ks[0]
 kf, kw = pick(fetch), pick(write)
-fb, wb = fetch[kf] * 1024 / nf[kf], write[kw] * 1024 / nw[kw]
+ks = [k for k in fetch if "k_shade<" in k or re.search(r"k_shade\(", k)][0]   # the path integrator's shading kernel
 stats = glob.glob(f"{out}/stats/**/*kernel_stats.csv", recursive=True)
-avg_ns = None
+avg = {}
 if stats:
     for row in csv.DictReader(open(stats[0], newline="")):
-        if row["Name"] == kf: avg_ns = float(row["AverageNs"]); calls = int(row["Calls"])
-    os.system(f"cp {stats[0]} profiles/r02_bench_kernel_stats.csv")
+        avg[row["Name"]] = (float(row["AverageNs"]), int(row["Calls"]))
+    os.system(f"cp {stats[0]} profiles/r03_bench_kernel_stats.csv")
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("PB_COMMIT", "unknown")
-sq = {}
-for c in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"):
-    t, n = per_kernel_in("SQ", c)
-    if kf in t: sq[c] = t[kf] / n[kf]
-ta = {}
-for c in ("TA_TA_BUSY_sum", "GRBM_GUI_ACTIVE"):
-    t, n = per_kernel_in("TA", c)
-    if kf in t: ta[c] = t[kf] / n[kf]
+import sys
+sys.path.insert(0, ".")
+import bench
+def kernel_block(k):
+    sq, ta = {}, {}
+    for c in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"):
+        t, n = per_kernel_in("SQ", c)
+        if k in t: sq[c] = t[k] / n[k]
+    for c in ("TA_TA_BUSY_sum", "GRBM_GUI_ACTIVE"):
+        t, n = per_kernel_in("TA", c)
+        if k in t: ta[c] = t[k] / n[k]
+    fb, wb = fetch[k] * 1024 / nf[k], write[k] * 1024 / nw[k]
+    return {
+        "kernel_name": k, "launches_profiled": nf[k],
+        "avg_launch_ns_under_kernel_trace": avg.get(k, (None, 0))[0], "launches_in_stats_run": avg.get(k, (None, 0))[1],
+        "bytes_per_launch": round(fb + wb), "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
+        "ta_busy_cycles_per_launch": (ta["TA_TA_BUSY_sum"] / 256) if ta.get("TA_TA_BUSY_sum") else None,
+        "gpu_cycles_per_launch": (ta["GRBM_GUI_ACTIVE"] / 8) if ta.get("GRBM_GUI_ACTIVE") else None,
+        "ta_busy_fraction": (ta["TA_TA_BUSY_sum"] / 256 / (ta["GRBM_GUI_ACTIVE"] / 8)) if ta.get("GRBM_GUI_ACTIVE") else None,
+        "valu_insts_per_launch": sq.get("SQ_INSTS_VALU"), "salu_insts_per_launch": sq.get("SQ_INSTS_SALU"),
+        "valu_lane_utilisation": (sq["SQ_THREAD_CYCLES_VALU"] / (sq["SQ_INSTS_VALU"] * 64)) if sq.get("SQ_INSTS_VALU") else None,
+        "wave_cycles_waiting_fraction": (sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAVE_CYCLES") else None,
+    }
+trace, shade = kernel_block(kf), kernel_block(ks)
+shade["launches_per_step"] = 6
 rec = {
-    "ta_busy_fraction": (ta["TA_TA_BUSY_sum"] / 256 / (ta["GRBM_GUI_ACTIVE"] / 8)) if ta.get("GRBM_GUI_ACTIVE") else None,
-    "valu_insts_per_launch": sq.get("SQ_INSTS_VALU"), "salu_insts_per_launch": sq.get("SQ_INSTS_SALU"),
-    "valu_lane_utilisation": (sq["SQ_THREAD_CYCLES_VALU"] / (sq["SQ_INSTS_VALU"] * 64)) if sq.get("SQ_INSTS_VALU") else None,
-    "wave_cycles_waiting_fraction": (sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAVE_CYCLES") else None,
-    "gpu_cycles_per_launch": (sq["GRBM_GUI_ACTIVE"] / 8) if sq.get("GRBM_GUI_ACTIVE") else None,
-    "bytes_per_launch": round(fb + wb), "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
-    "kernel_name": kf, "launches_profiled": nf[kf], "avg_launch_ns_under_kernel_trace": avg_ns,
+    "trace": trace, "shade": shade,
     "config": {"n_gpus": 1, "tris": 1000000, "width": 1920, "height": 1080, "spp": 64, "max_depth": 5,
                "kernel": "k_trace_wide" if "wide" in kf else "k_trace"},
-    "commit": os.environ.get("PB_COMMIT", commit),
-    "profile": "profiles/r02_bench_kernel_stats.csv + rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on "
-               "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`; FETCH_SIZE = TCC_EA0_RDREQ x 64 B (Infinity-Cache hits "
+    "commit": os.environ.get("PB_COMMIT", commit), "source_hash": bench.kernel_source_hash(),
+    "profile": "profiles/r03_bench_kernel_stats.csv + rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU "
+               "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE; TA_TA_BUSY_sum GRBM_GUI_ACTIVE — one run each) on "
+               "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary`; FETCH_SIZE = TCC_EA0_RDREQ x 64 B (Infinity-Cache hits "
                "included), used without the x2 of wide coalesced streams: calibrated on this gather pattern in "
                "profiles/r01_fetch_size_calibration.txt (0.986)",
 }
-json.dump(rec, open("profiles/r02_traffic.json", "w"), indent=1)
-json.dump(rec, open(f"{out}/r02_traffic.json", "w"), indent=1)
+json.dump(rec, open("profiles/r03_traffic.json", "w"), indent=1)
+json.dump(rec, open(f"{out}/r03_traffic.json", "w"), indent=1)
 print(json.dumps(rec, indent=1))
 PY
-cp profiles/r02_bench_kernel_stats.csv $OUT/ 2>/dev/null
+cp profiles/r03_bench_kernel_stats.csv $OUT/ 2>/dev/null
 find $OUT -name "*.csv" -size +2M -delete

@@ -10,8 +10,8 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             k = row.get("Kernel_Name", "")
             m = re.search(r"(k_\w+|trampoline_kernel)", k)
             name = m.group(1) if m else k[:40]
-            if "k_trace" in k or "k_intersect" in k:
-                t = re.search(r"(k_trace\w*|k_intersect\w*)(<[^>]*>)?", k)
+            if "k_trace" in k or "k_intersect" in k or "k_shade" in k:
+                t = re.search(r"(k_trace\w*|k_intersect\w*|k_shade\w*)(<[^>]*>)?", k)
                 name = t.group(0) if t else name
             c = row["Counter_Name"]
             tot[name][c] += float(row["Counter_Value"])
