@@ -6,6 +6,7 @@
 // quantised box contains the float box it stands for in exact arithmetic, so the traversal kernel's filter can only
 // pass more, never less (wide_bvh.h).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -133,23 +134,29 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
     if (tri_cursor != n_slots) return "leaves do not cover the triangle list";
     out->nodes.assign(recs.size() * kWideNodeDwords, 0u);
     // ---- (3) the records ----
+    std::atomic<long long> n_coarse{0};
     if (const char* why = parallel_chunks(recs.size(), 1 << 13, [&](size_t w0, size_t w1) -> const char* {
+            long long coarse_here = 0;
             for (size_t w = w0; w < w1; ++w) {
                 const int32_t i = recs[w].node;
                 int32_t slot_node[4];
                 int axis_c[2], tri_off[4];
                 wide_slots_of(nodes, i, slot_node, axis_c);
                 uint32_t rec[kWideNodeDwords] = {0};
+                int coarse = 0;
                 if (int code = wide_make_record(nodes, i, slot_node, axis_c, (uint32_t)((int64_t)recs[w].first_child + base_of.record),
-                                                (uint32_t)(recs[w].first_tri + base_of.tri), rec, tri_off))
+                                                (uint32_t)(recs[w].first_tri + base_of.tri), rec, tri_off, &coarse))
                     return wide_error_text(code);
+                coarse_here += coarse;
                 for (int s = 0; s < 4; ++s)
                     if (slot_node[s] >= 0 && nodes[slot_node[s]].n_primitives > 0) emit_leaf(nodes[slot_node[s]], recs[w].first_tri + tri_off[s]);
                 std::memcpy(&out->nodes[w * kWideNodeDwords], rec, sizeof(rec));
             }
+            n_coarse += coarse_here;
             return nullptr;
         }))
         return why;
+    if (n_coarse.load() * 8 > (long long)recs.size()) return wide_error_text(kWideErrCoarse);
     out->root_ref = base_of.record;
     out->n_records = (int)recs.size();
     {

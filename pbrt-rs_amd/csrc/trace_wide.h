@@ -40,12 +40,6 @@ namespace pb {
 #ifndef PB_WIDE_INST_STACK_LDS
 #define PB_WIDE_INST_STACK_LDS 11  // two-level scenes: one stack entry less in LDS makes room for the world ray (below) at 5 blocks per CU
 #endif
-#ifndef PB_WIDE_TRI_CONST
-#define PB_WIDE_TRI_CONST 0  // the watertight test's per-ray constants (triangle.rs:84-101) once per ray / instance entry instead of once per leaf: measured, no gain (profiles/r03_two_level_ladder.txt)
-#endif
-#ifndef PB_WIDE_INLINE_EXIT
-#define PB_WIDE_INLINE_EXIT 0  // two-level scenes: a lane whose instance is walked out and whose top-level leaf has no entry left leaves the instance where it pops
-#endif
 #ifndef PB_WIDE_INST_GATHER
 #define PB_WIDE_INST_GATHER 1
 #endif
@@ -114,8 +108,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     int hit_slot = -1, sp = 0;
     uint32_t index = 0;
     bool nx = false, ny = false, nz = false, any = false;
-    uint32_t negmask = 0;  // bits 0..2: dir_is_neg; bits 4..5: kz of the watertight test (PB_WIDE_TRI_CONST)
-    float tsx = 0.0f, tsy = 0.0f;  // its shear constants sx, sy (sz is the reciprocal direction component kz)
+    uint32_t negmask = 0;
     r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.tmax = 0.0f;
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
@@ -229,13 +222,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     // or two lanes per iteration, with the exec-mask bookkeeping of a divergent loop in every record step.)
     auto pop_one = [&]() {
         if (INST && sp <= base_sp) {
-            if (SPEC && pend < 0) {
-                cur = kWait;  // the postponed leaf belongs to this instance: test it first
-            } else if (PB_WIDE_INLINE_EXIT && (leaf_state & 7) == 0) {
-                exit_instance();  // nothing of the top-level leaf is left: on with the world ray's stack (cur stays kNeedPop)
-            } else {
-                cur = kLeaveInstance;
-            }
+            cur = (SPEC && pend < 0) ? kWait : kLeaveInstance;  // the postponed leaf belongs to this instance: test it first
         } else if (sp == 0) {
             if (SPEC && pend < 0) {  // nothing left to walk but the postponed leaves: wait for the leaf phase
                 cur = kWait;
@@ -256,12 +243,6 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         ny = idy < 0.0f;
         nz = idz < 0.0f;
         negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
-        if (PB_WIDE_TRI_CONST && !INST) {  // (two-level scenes: set on entering an instance, where the triangles are)
-            const TriRayConst c = tri_ray_setup(r, idx, idy, idz);
-            tsx = c.sx;
-            tsy = c.sy;
-            negmask |= (uint32_t)c.kz << 4;
-        }
     };
     // TransformedPrimitive::intersect, first half (primitive.rs:136-139), on the entry's loaded record: the top slot it names,
     // its object word and the three world-to-object rows. 0 = the ray misses the object's root box, 1 = entered, 2 = the
@@ -317,12 +298,6 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         ny = by;
         nz = bz;
         negmask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
-        if (PB_WIDE_TRI_CONST) {
-            const TriRayConst c = tri_ray_setup(r, idx, idy, idz);
-            tsx = c.sx;
-            tsy = c.sy;
-            negmask |= (uint32_t)c.kz << 4;
-        }
         cur_top_slot = top_slot;
         base_sp = sp;
         cur = root;
@@ -682,15 +657,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             }
 #endif
             if (pass) {
-                TriRayConst trc;
-                if (PB_WIDE_TRI_CONST) {
-                    trc.kz = (int)(negmask >> 4);
-                    trc.sx = tsx;
-                    trc.sy = tsy;
-                    trc.sz = trc.kz == 0 ? idx : (trc.kz == 1 ? idy : idz);
-                } else {
-                    trc = tri_ray_setup(r, idx, idy, idz);
-                }
+                const TriRayConst trc = tri_ray_setup(r, idx, idy, idz);
                 for (int i = 0; i < cnt; ++i) {
                     if (i > 0) {
                         if (COUNT) c_tri += 1;

@@ -23,7 +23,13 @@ enum WideBuildError {
     kWideErrChildOutside,
     kWideErrExponent,
     kWideErrQuantisation,
+    kWideErrCoarse,
 };
+// A record is COARSE when keeping m[0..2] in the low mantissa bytes of base.xyz (a displacement of up to 256 ulp of the
+// coordinate) forces cells more than 8 times larger than the node's largest extent needs: far from the origin the 8-bit planes
+// then stop filtering — hits stay exact, steps per ray do not. A tree with more than one coarse record in eight keeps the
+// binary records.
+constexpr int kWideCoarseShift = 3;
 inline const char* wide_error_text(int code) {
     switch (code) {
         case kWideOk: return nullptr;
@@ -33,6 +39,7 @@ inline const char* wide_error_text(int code) {
         case kWideErrLooseLeaf: return "single-triangle leaf box is not the triangle's bounds";
         case kWideErrChildOutside: return "child box not inside its parent's";
         case kWideErrExponent: return "node extent beyond the exponent range";
+        case kWideErrCoarse: return "scene too far from the origin for the 8-bit planes (one record in eight would not filter)";
         default: return "quantisation out of range";
     }
 }
@@ -123,7 +130,8 @@ PB_HD void wide_slots_of(const PbrtLinearBVHNode* nodes, int32_t i, int32_t slot
 // wide-order position of its first leaf child's first triangle. tri_off_of_slot[s]: offset of slot s's triangles inside
 // the record's run (leaf slots only). Returns a WideBuildError.
 PB_HD int wide_make_record(const PbrtLinearBVHNode* nodes, int32_t i, const int32_t slot_node[4], const int axis_c[2],
-                           uint32_t first_child, uint32_t first_tri, uint32_t rec[kWideNodeDwords], int tri_off_of_slot[4]) {
+                           uint32_t first_child, uint32_t first_tri, uint32_t rec[kWideNodeDwords], int tri_off_of_slot[4],
+                           int* coarse = nullptr) {
     const PbrtLinearBVHNode& nd = nodes[i];
     // children first: the bytes m[] are part of base.xyz
     uint32_t m[4] = {0xff, 0xff, 0xff, 0xff};
@@ -155,6 +163,13 @@ PB_HD int wide_make_record(const PbrtLinearBVHNode* nodes, int32_t i, const int3
         }
         if (ek > kExpMax) return kWideErrExponent;
         e[k] = ek;
+    }
+    if (coarse) {  // against the node's LARGEST extent: a thick cell on a flat node's thin axis costs nothing
+        double ext = 0.0;
+        for (int k = 0; k < 3; ++k) ext = fmax(ext, (double)nd.bounds_max[k] - (double)nd.bounds_min[k]);
+        const int need = wb_cell_exponent(ext);
+        for (int k = 0; k < 3; ++k)
+            if (e[k] > need + kWideCoarseShift) *coarse = 1;
     }
     uint32_t q[6] = {0, 0, 0, 0, 0, 0};
     for (int s = 0; s < 4; ++s) {

@@ -54,7 +54,7 @@ constexpr float kWideOriginLimit = 16777216.0f;           // 2^24
 // near_q <= near_exact  and  far_q >= far_exact * (1 + 2 gamma_3): the roundings of A, of the two fmas and of the
 // exact formula's own two (three) add up to < 14 u (|A| + 256 |S|) per plane; k |A| covers the |A| part and the
 // kWideSlack cells the builder leaves between the quantised and the float plane (2^-8 |S|) cover the |S| part
-// ("wide records").
+// (DESIGN.md section 4.1).
 struct WideSetup {
     float Sx, Sy, Sz;
     float Anx, Afx, Any, Afy, Anz, Afz;

@@ -67,8 +67,10 @@ __global__ void __launch_bounds__(kWB) k_wide_emit(const PbrtLinearBVHNode* __re
     const uint32_t child_off = (uint32_t)off, first_tri = tri_base + (uint32_t)(off >> 32);
     uint32_t rec[kWideNodeDwords];
     for (int k = 0; k < kWideNodeDwords; ++k) rec[k] = 0u;
-    int code = wide_make_record(nodes, i, slot_node, axis_c, next_base + child_off, first_tri, rec, tri_off);
+    int coarse = 0;
+    int code = wide_make_record(nodes, i, slot_node, axis_c, next_base + child_off, first_tri, rec, tri_off, &coarse);
     if (code) atomicMax(error, code);
+    if (coarse) atomicAdd(error + 1, 1);  // records whose planes do not filter (wide_build.h): counted, judged by the host
     uint32_t* dst = out_nodes + (size_t)(level_base + (uint32_t)j) * kWideNodeDwords;
     for (int k = 0; k < kWideNodeDwords; ++k) dst[k] = rec[k];
     int n_interior = 0;
@@ -101,7 +103,9 @@ __global__ void __launch_bounds__(kWB) k_wide_stack_need(const uint32_t* __restr
 
 }  // namespace
 
-// d_nodes: n_nodes LinearBVHNodes, d_tris: n_slots 48-B leaf-order triangle records, both on the device. On success the
+// d_nodes: n_nodes LinearBVHNodes that have ALREADY passed convert_tree's validation of offsets and counts (k_wide_count /
+// k_wide_emit follow child offsets before k_wide_check's verdict is read back), d_tris: n_slots 48-B leaf-order triangle
+// records, both on the device. On success the
 // three output arrays are hipMalloc'ed (the caller owns them) and *reason is nullptr; when the tree does not qualify
 // (*reason says why) or a HIP call fails (returns false, ctx->last_error set) nothing is left allocated.
 bool build_wide_tree_device(PbrtHipContext* ctx, const PbrtLinearBVHNode* d_nodes, int32_t n_nodes, const float* d_tris,
@@ -140,10 +144,19 @@ bool build_wide_tree_device(PbrtHipContext* ctx, const PbrtLinearBVHNode* d_node
         if (e == hipSuccess && temporary) tmp.push_back(*p);
         return e;
     };
-#define WB_TRY(call, what)                         \
-    do {                                           \
-        hipError_t e_ = (call);                    \
-        if (e_ != hipSuccess) return fail(e_, what); \
+    // Out of device memory for the (optional) records is not a failure of the scene: it keeps the binary records, and
+    // pbrt_hip_scene_wide_records says why. Anything else that goes wrong on the device is.
+#define WB_TRY(call, what)                                         \
+    do {                                                           \
+        hipError_t e_ = (call);                                    \
+        if (e_ == hipErrorOutOfMemory) {                           \
+            (void)hipGetLastError();                               \
+            (void)hipStreamSynchronize(st);                        \
+            release(true);                                         \
+            *reason = "out of device memory for the wide records"; \
+            return true;                                           \
+        }                                                          \
+        if (e_ != hipSuccess) return fail(e_, what);               \
     } while (0)
     int* d_error = nullptr;
     WB_TRY(alloc((void**)&d_error, 2 * sizeof(int), true), "wide build: alloc");
@@ -230,11 +243,13 @@ bool build_wide_tree_device(PbrtHipContext* ctx, const PbrtLinearBVHNode* d_node
     for (size_t l = levels.size(); l-- > 0;)
         hipLaunchKernelGGL(k_wide_stack_need, dim3(wb_blocks(levels[l].second)), dim3(kWB), 0, st, (const uint32_t*)p_nodes, levels[l].first,
                            levels[l].second, d_need);
-    int h_err = 0, h_need = 0;
+    int h_err2[2] = {0, 0}, h_need = 0;
     WB_TRY(hipGetLastError(), "wide build: launch");
-    WB_TRY(hipMemcpyAsync(&h_err, d_error, sizeof(int), hipMemcpyDeviceToHost, st), "wide build: result");
+    WB_TRY(hipMemcpyAsync(h_err2, d_error, 2 * sizeof(int), hipMemcpyDeviceToHost, st), "wide build: result");
     WB_TRY(hipMemcpyAsync(&h_need, d_need, sizeof(int), hipMemcpyDeviceToHost, st), "wide build: result");
     WB_TRY(hipStreamSynchronize(st), "wide build: result");
+    int h_err = h_err2[0];
+    if (!h_err && (long long)h_err2[1] * 8 > (long long)n_records) h_err = kWideErrCoarse;
     if (h_err || tri_base != (uint32_t)n_slots) {
         release(true);
         *reason = h_err ? wide_error_text(h_err) : "leaves do not cover the triangle list";

@@ -83,6 +83,44 @@ def test_wide_records_are_what_runs(hip_ctx, which):
     osc.close()
 
 
+@pytest.mark.parametrize("device_build", [False, True])
+def test_scene_far_from_the_origin_keeps_the_binary_records(hip_ctx, device_build):
+    """at coordinates around 6e4 the byte-in-base displacement (256 ulp = a whole unit) would leave the 8-bit
+    planes of small nodes filtering nothing; both builders (the device one over a host tree and over a device-built tree)
+    count such records and decline the tree. The scene still traces exactly, over the binary records; moved by 60 only, it
+    keeps its wide records and steps about as many of them per ray as the scene at the origin."""
+    base = scenes.random_triangles(30_000, seq=8, size=0.03)
+    steps = {}
+    for off in (0.0, 60.0, 60000.0):
+        sc = dict(base, positions=(base["positions"] + np.float32(off)).astype(np.float32))
+        gsc = pbrt_hip.Scene(hip_ctx, sc, device_build=device_build)
+        osc = oracle.OracleScene(sc, split_method=pbrt_hip.SPLIT_HLBVH) if device_build else oracle.OracleScene(sc)
+        n_rec, why = gsc.wide_records()
+        root = osc.nodes()[0]
+        rays = _rays_into(root["bmin"], root["bmax"], 20_000, 5)
+        hip_ctx.set_counting(2)
+        hip_ctx.wide_counters(reset=True)
+        got = gsc.intersect(rays)
+        wc = hip_ctx.wide_counters(reset=True)
+        hip_ctx.set_counting(0)
+        cpu, _ = osc.intersect(rays)
+        for f in ("prim_id", "t", "b0", "b1", "b2"):
+            assert np.array_equal(got[f], cpu[f]), (off, f)
+        if off > 1000.0 and n_rec < 0:
+            assert "too far from the origin" in why, (n_rec, why)
+            assert wc["records"] == 0
+        elif off > 1000.0:
+            # (the device-built HLBVH tree: leaves of four triangles, larger nodes, fewer than one coarse record in eight —
+            # it keeps its records, and they must still filter)
+            assert device_build and wc["records"] / len(rays) <= 3.0 * steps[0.0], (wc, steps)
+        else:
+            assert n_rec > 0, why
+            steps[off] = wc["records"] / len(rays)
+        gsc.close()
+        osc.close()
+    assert steps[60.0] <= 1.15 * steps[0.0], steps
+
+
 def test_rays_outside_the_filters_range_take_the_binary_records(hip_ctx):
     """Axis-parallel directions (infinite reciprocals), denormal-small components, far origins: the wide kernel lists them,
     a follow-up launch of the binary kernel traces them; the count is exactly the number wide_ray_covered rejects."""

@@ -30,7 +30,7 @@ OUT = os.path.join(HERE, "native", "_build", "libwide_check.so")
 @pytest.fixture(scope="module")
 def chk():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    deps = [SRC] + [os.path.join(HERE, "..", "pbrt-rs_amd", "csrc", f) for f in ("host_wide.cpp", "host_wide.h", "wide_bvh.h")]
+    deps = [SRC] + [os.path.join(HERE, "..", "pbrt-rs_amd", "csrc", f) for f in ("host_wide.cpp", "host_wide.h", "wide_bvh.h", "wide_build.h")]
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-o", OUT, SRC])
     L = ctypes.CDLL(OUT)
@@ -101,6 +101,21 @@ def test_builder_declines_what_the_argument_does_not_cover(chk):
     loose["bmin"][leaf1] -= np.float32(0.5)   # a single-triangle leaf whose box is not the triangle's bounds
     rc, _, why = _structure(chk, loose, tris)
     assert rc == -100 and ("not the triangle" in why or "not inside" in why)
+
+
+@pytest.mark.parametrize("offset,declined", [(0.0, False), (60.0, False), (60000.0, True)])
+def test_builder_declines_scenes_the_planes_would_not_filter(chk, offset, declined):
+    """The descriptor bytes ride in the low mantissa bytes of base.xyz, which moves the base down by up to 256 ulp of the
+    COORDINATE: around 6e4 that is a whole unit, the cells of a node 0.05 across come out at 1 / 255 and its 8-bit planes
+    filter nothing. Hits would stay exact; steps per ray would not. Such a tree keeps the binary records."""
+    sc = scenes.random_triangles(30_000, seq=6, size=0.03)
+    sc = dict(sc, positions=(sc["positions"] + np.float32(offset)).astype(np.float32))
+    nodes, tris = _tree(sc, 4)
+    rc, _, why = _structure(chk, nodes, tris)
+    if declined:
+        assert rc == -100 and "too far from the origin" in why, (rc, why)
+    else:
+        assert rc == 0, (rc, why)
 
 
 def test_slab_restatement_is_the_oracles(chk):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3: the whole GPU suite, the stamped counter profile (tools/measure_traffic.sh), then the bench line as the driver
-# runs it (one process, then one rank under torch.distributed.run with RCCL). usage: tools/gpu_r3_bench.sh tag
+# runs it (one process, then one rank under torch.distributed.run with RCCL). usage: tools/gpu_bench_check.sh tag
 set -o pipefail
 tag=${1:-run}
 mkdir -p gpurun_out
