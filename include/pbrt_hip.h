@@ -199,6 +199,9 @@ typedef struct PbrtRenderStats {
  * reused, and pbrt_hip_context_destroy then releases the host side only. */
 int pbrt_hip_context_create(int device_id, PbrtHipContext** out);
 void pbrt_hip_context_destroy(PbrtHipContext* ctx);
+/* How long pbrt_hip_render / pbrt_hip_li wait for one wavefront before they give the context up for lost (default 120 s; a
+ * profiler or a debug build may need more, a service less). seconds > 0. */
+int pbrt_hip_context_set_deadline(PbrtHipContext* ctx, double seconds);
 /* Last error text for this context (or for context creation when ctx == NULL). */
 const char* pbrt_hip_last_error(const PbrtHipContext* ctx);
 

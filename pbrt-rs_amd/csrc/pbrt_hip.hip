@@ -97,6 +97,13 @@ extern "C" void pbrt_hip_context_destroy(PbrtHipContext* ctx) {
     delete ctx;
 }
 
+extern "C" int pbrt_hip_context_set_deadline(PbrtHipContext* ctx, double seconds) {
+    if (!ctx || !(seconds > 0.0)) return PBRT_HIP_ERR_INVALID;
+    PB_LOCK(ctx);
+    ctx->wavefront_deadline_s = seconds;
+    return PBRT_HIP_OK;
+}
+
 extern "C" const char* pbrt_hip_last_error(const PbrtHipContext* ctx) {
     return ctx ? ctx->last_error.c_str() : g_create_error.c_str();
 }
@@ -1017,8 +1024,10 @@ extern "C" void pbrt_hip_scene_destroy(PbrtHipScene* s) {
     if (!s) return;
     PB_LOCK(s->ctx);
     (void)hipSetDevice(s->ctx->device);
-    (void)hipStreamSynchronize(s->ctx->stream);
-    for (void* p : s->allocs) (void)hipFree(p);
+    if (!s->ctx->lost) {  // a lost context: an abandoned kernel may still read the scene, and waiting for it may never end
+        (void)hipStreamSynchronize(s->ctx->stream);
+        for (void* p : s->allocs) (void)hipFree(p);
+    }
     delete s;
 }
 

@@ -20,7 +20,6 @@
 #ifndef PB_SHADE_SPLIT
 #define PB_SHADE_SPLIT 0
 #endif
-static constexpr double kWavefrontDeadlineSeconds = 120.0;  // no wavefront of a render takes this long
 
 using namespace pb;
 
@@ -927,7 +926,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                 while ((qe = hipEventQuery(ctx->ev_sync)) == hipErrorNotReady) {
                     if ((++polls & 0xfffu) == 0) {
                         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - spin_start).count();
-                        if (waited > kWavefrontDeadlineSeconds) {
+                        if (waited > ctx->wavefront_deadline_s) {
                             ctx->last_error = "a wavefront did not finish within the deadline (hung kernel?)";
                             ctx->lost = true;  // the stream is not drained below: nothing may follow on this context
                             rc = PBRT_HIP_ERR_DEVICE;

@@ -38,6 +38,7 @@ struct PbrtHipContext {
     std::string last_error;
     // sticky: set when a call gave up on a kernel that did not finish (render.hip); every entry point then fails
     bool lost = false;
+    double wavefront_deadline_s = 120.0;  // no wavefront of a render takes this long (pbrt_hip_context_set_deadline)
     // traversal-kernel timing (HIP events on `stream`)
     double trace_ms = 0.0;
     uint64_t trace_launches = 0;

@@ -621,3 +621,33 @@ def test_general_two_level_scene_with_area_light(hip_ctx, integrator, kw):
     assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
     rgb = oracle.film_to_rgb(film_c)
     assert rgb.mean() > 0.05 and rgb.max() > 5.0       # the emitter itself is in view
+
+
+def test_a_wavefront_past_its_deadline_loses_the_context_and_nothing_is_reused():
+    """a render that gives up on a kernel must not hand that kernel's buffers to the next call. With the
+    deadline set below what one wavefront of this render takes, the call fails with PBRT_HIP_ERR_DEVICE ("deadline"), the
+    context is LOST: every later entry point on it fails at once and says so, scene and context destruction return (nothing
+    waits on the abandoned stream), and a fresh context on the same device renders the same frame as ever."""
+    w, h, spp = 640, 360, 16
+    sc = scenes.random_triangles(200_000, seq=12)
+    cam = scenes.random_triangles_camera(w, h)
+    ctx = pbrt_hip.Context(0)
+    g = pbrt_hip.Scene(ctx, sc)
+    ref, st_ref = g.render(cam, w, h, spp, max_depth=5, seed=3)        # healthy context, default deadline
+    with pytest.raises(pbrt_hip.PbrtHipError):
+        ctx.set_deadline(0.0)
+    ctx.set_deadline(1e-7)
+    with pytest.raises(pbrt_hip.PbrtHipError, match="deadline"):
+        g.render(cam, w, h, spp, max_depth=5, seed=3)
+    for call in (lambda: g.render(cam, w, h, 1, max_depth=1), lambda: g.intersect(np.zeros(1, dtype=pbrt_hip.RAY_DTYPE)),
+                 ctx.synchronize, lambda: pbrt_hip.Scene(ctx, scenes.cornell_box())):
+        with pytest.raises(pbrt_hip.PbrtHipError, match="context lost"):
+            call()
+    g.close()
+    ctx.close()
+    ctx2 = pbrt_hip.Context(0)
+    g2 = pbrt_hip.Scene(ctx2, sc)
+    again, st2 = g2.render(cam, w, h, spp, max_depth=5, seed=3)
+    assert again.tobytes() == ref.tobytes() and st2["rays_closest"] == st_ref["rays_closest"]
+    g2.close()
+    ctx2.close()
