@@ -500,8 +500,9 @@ def main():
                     "workload": f"{config_name}: {args.tris} random triangles + constant env light, PathIntegrator "
                                 f"max_depth {args.max_depth}, {W}x{H}x{spp_total}spp ({split}), "
                                 f"SAH BVH <=4 prims/leaf, seed 0",
-                    "parallelism": f"tiles16x16 round-robin over {world} GPU(s); RCCL film reduce inside the step" if world > 1
-                                   else "1 GPU",
+                    "parallelism": (f"tiles16x16 round-robin over {world} rank(s); "
+                                    + ("film reduce staged through host memory (gloo), all ranks on GPU 0: a rehearsal, not a scaling number"
+                                       if staged else "RCCL film reduce") + " inside the step") if world > 1 else "1 GPU",
                     "sec_per_frame": round(elapsed / args.steps, 4),
                     "rays_per_frame": int(rays / args.steps),
                     "bvh_build_s_host": round(t_bvh, 2),
