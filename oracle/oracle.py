@@ -79,6 +79,8 @@ def lib():
         L.orc_sample.argtypes = [ctypes.c_int, vp, ctypes.c_int64, ctypes.c_uint32, vp]
         L.orc_fr_dielectric.restype = ctypes.c_float
         L.orc_fr_dielectric.argtypes = [ctypes.c_float] * 3
+        L.orc_node_visits.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int, vp]
+        L.orc_node_visits.restype = None
         L.orc_sphere_test.argtypes = [vp, ctypes.c_float, vp, vp]
         L.orc_sphere_test.restype = None
         L.orc_refract.argtypes = [vp, vp, ctypes.c_float, ctypes.c_uint32, vp]

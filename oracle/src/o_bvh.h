@@ -33,6 +33,7 @@ namespace oracle {
 
 struct TraversalCounters {
     uint64_t rays = 0, node_tests = 0, prim_tests = 0, inst_tests = 0;
+    uint64_t* node_entered = nullptr;  // optional: per node of the (single-level) tree, how many rays passed its box test
     void add(const TraversalCounters& o) {
         rays += o.rays;
         node_tests += o.node_tests;
@@ -478,6 +479,7 @@ struct BVHAccel : Primitive {
             const LinearBVHNode& node = nodes[current];
             if (ctr) ctr->node_tests++;
             if (bounds_intersect_p(node.bounds, ray, inv_dir, dir_is_neg, quirks)) {
+                if (ctr && ctr->node_entered) ctr->node_entered[current]++;
                 if (node.n_primitives > 0) {
                     for (int i = 0; i < node.n_primitives; ++i) {
                         if (ctr) ((leaves_are_instances && primitives[node.primitive_or_second_child_offset + i]->is_instance()) ? ctr->inst_tests : ctr->prim_tests)++;
@@ -514,6 +516,7 @@ struct BVHAccel : Primitive {
             const LinearBVHNode& node = nodes[current];
             if (ctr) ctr->node_tests++;
             if (bounds_intersect_p(node.bounds, ray, inv_dir, dir_is_neg, quirks)) {
+                if (ctr && ctr->node_entered) ctr->node_entered[current]++;
                 if (node.n_primitives > 0) {
                     for (int i = 0; i < node.n_primitives; ++i) {
                         if (ctr) ((leaves_are_instances && primitives[node.primitive_or_second_child_offset + i]->is_instance()) ? ctr->inst_tests : ctr->prim_tests)++;

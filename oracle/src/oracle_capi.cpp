@@ -330,6 +330,22 @@ void orc_intersect(void* h, const float* rays, int64_t n, void* out_hits, uint64
         counters[3] = s.inst_tests;
     }
 }
+// Instrumentation for the layout study of the wide records (tools/wide_fill_study.py): for a single-level scene, how many of
+// these rays pass the box test of every node of BVHAccel::intersect's walk (any == 0) or intersect_p's (any != 0).
+void orc_node_visits(void* h, const float* rays, int64_t n, int any, uint64_t* entered_per_node) {
+    const Scene& sc = ((OracleScene*)h)->scene;
+    TraversalCounters tc;
+    tc.node_entered = entered_per_node;
+    for (int64_t i = 0; i < n; ++i) {
+        const float* r = rays + 8 * i;
+        Ray ray(Point3f(r[0], r[1], r[2]), Vector3f(r[3], r[4], r[5]), r[6], r[7]);
+        SurfaceInteraction si;
+        if (any)
+            (void)sc.intersect_p(ray, &tc);
+        else
+            (void)sc.intersect(ray, &si, &tc);
+    }
+}
 void orc_intersect_p(void* h, const float* rays, int64_t n, uint8_t* out, uint64_t* counters, int n_threads) {
     const Scene& sc = ((OracleScene*)h)->scene;
     std::vector<TraversalCounters> tc(std::max(1, n_threads));
