@@ -322,14 +322,27 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
                 int near_c = neg ? c1 : c0, far_c = neg ? c0 : c1;
                 bool near_h = neg ? h1 : h0, far_h = neg ? h0 : h1;
                 float far_e = neg ? e0 : e1;
+                // The reference tests the far child when it POPS it, with the t_max of that moment — and t_max can move UP by
+                // an ulp: the range test of triangle.rs:127-130 compares t_scaled with t_max * det, the quotient t = t_scaled /
+                // det is rounded again and may come out one ulp above the t_max it was accepted under (two hits within an ulp
+                // of each other: rays through a shared vertex). A far child behind the hit NOW may be in front of it THEN, so
+                // whether it is kept cannot depend on t_max here: it is kept whenever the ray meets its slabs at all, and its
+                // entry distance is compared with the t_max current at the pop, which is exactly the reference's test
+                // (found by tests/test_gpu_wide.py's adversarial meshes at 3000 examples, round 3).
+                float unused;
+                const bool k0 = slab_test(s.nx ? q0.w : q0.x, s.nx ? q0.x : q0.w, s.ny ? q1.x : q0.y, s.ny ? q0.y : q1.x,
+                                          s.nz ? q1.y : q0.z, s.nz ? q0.z : q1.y, s.r, s.idx, s.idy, s.idz, kInf, &unused);
+                const bool k1 = slab_test(s.nx ? q2.y : q1.z, s.nx ? q1.z : q2.y, s.ny ? q2.z : q1.w, s.ny ? q1.w : q2.z,
+                                          s.nz ? q2.w : q2.x, s.nz ? q2.x : q2.w, s.r, s.idx, s.idy, s.idz, kInf, &unused);
+                const bool far_keep = neg ? k0 : k1;  // (the same arithmetic as h0 / h1: only the last comparison differs)
                 if (COUNT) {
                     n_node += 1;               // the near child is tested as soon as it is visited
                     if (!near_h) n_node += 1;  // near missed: the far child is popped and tested next
-                    if (!far_h) far_e = kInf;
+                    if (!far_keep) far_e = kInf;
                 }
                 if (near_h) {
                     s.cur = near_c;
-                    if (far_h || COUNT) stack_push(bvh, lds_stack, spill_lane, s.sp, far_c, far_e);
+                    if (far_keep || COUNT) stack_push(bvh, lds_stack, spill_lane, s.sp, far_c, far_e);
                 } else if (far_h) {
                     s.cur = far_c;
                 } else if (!advance()) {

@@ -563,6 +563,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                         if (any) {
                             done = true;
                         } else if (!(__float_as_int(tc.w) & kTriDegenerate)) {
+                            if (t > tmax) abandon = true;  // t_max would move UP: see `raised` in the triangle branch
                             tmax = t;
                             tmax_world = t;
                             hb0 = b0;
@@ -638,6 +639,13 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             bool pass = slab_test(nx ? hix : lox, nx ? lox : hix, ny ? hiy : loy, ny ? loy : hiy, nz ? hiz : loz, nz ? loz : hiz, r,
                                   idx, idy, idz, tmax, &entry);
             bool done = false;
+            // Everything this kernel is (wide_bvh.h) rests on ray.t_max only ever SHRINKING. It nearly does: the range test of
+            // triangle.rs:127-130 compares t_scaled with t_max * det, the quotient t = t_scaled / det is rounded once more and
+            // can come out an ulp ABOVE the t_max it was accepted under (two hits within an ulp of each other: a ray through a
+            // vertex several triangles share). The reference then carries on with the larger t_max, and a node it pruned
+            // before may count again, or one it would have pruned may not. A ray to which that happens leaves this kernel: the
+            // binary kernel, whose every box test is the reference's at the reference's moment, traces it from scratch.
+            bool raised = false;
 #ifdef PB_LANE_STATS
             wl_cand += 1;
             if (pass) {
@@ -676,6 +684,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                             break;
                         }
                         if (!(__float_as_int(tc.z) & kTriDegenerate)) {
+                            if (t > tmax) raised = true;
                             tmax = t;  // primitive.rs:70
                             hb0 = b0;
                             hb1 = b1;
@@ -688,7 +697,12 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                     }
                 }
             }
-            if (done)
+            if (raised) {
+                wt.special_list[atomicAdd(wt.special_count, 1u)] = index;  // (one list append per such ray: they are rare)
+                if (COUNT) c_special += 1;
+                cur = kIdle;
+                if (SPEC) pend = pend2 = 0;
+            } else if (done)
                 finish(true);
             else if (from_pend) {
                 pend = pend2;

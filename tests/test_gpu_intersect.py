@@ -480,3 +480,63 @@ def test_handles_shared_between_host_threads(hip_ctx):
             assert np.array_equal(got, want_film)
     ga.close()
     gb.close()
+
+
+def _aimed_rays(verts, idx, seed=7):
+    """Rays aimed exactly at every vertex, edge midpoint and centroid of the mesh from origins at the target's own scale, a
+    fifth of them with one direction component zeroed (as tests/test_gpu_wide.py's adversarial meshes)."""
+    tri = verts[idx]
+    targets = np.concatenate([tri.reshape(-1, 3), (tri[:, 0] + tri[:, 1]) * np.float32(0.5), tri.mean(axis=1)])
+    n = 3 * len(targets)
+    rays = scenes.random_rays(n, seed, origin_extent=2.0)
+    tgt = targets[np.arange(n) % len(targets)]
+    scale = np.maximum(np.abs(tgt).max(axis=1, keepdims=True), 1.0).astype(np.float32)
+    rays["o"] = (tgt + rays["o"] * scale).astype(np.float32)
+    rays["d"] = (tgt - rays["o"]).astype(np.float32)
+    k = np.arange(n)
+    par = k % 5 == 0
+    rays["d"][par, k[par] % 3] = 0.0
+    rays["d"][np.all(rays["d"] == 0, axis=1)] = (0.0, 0.0, 1.0)
+    return np.ascontiguousarray(rays)
+
+
+def _scene_of(verts, idx):
+    return dict(positions=verts, indices=idx, tri_material=np.zeros(len(idx), dtype=np.int32),
+                materials=scenes._materials([(1, (0.5, 0.5, 0.5), (0, 0, 0), 1.0)]),
+                tri_light=np.full(len(idx), -1, dtype=np.int32), lights=scenes._lights([]))
+
+
+@pytest.mark.parametrize("case", ["hypothesis counter-example", "the three triangles alone", "fan mesh"])
+def test_t_max_that_moves_up_by_an_ulp(hip_ctx, case):
+    """ray.t_max does not only shrink. Triangle::intersect_test accepts a hit when t_scaled <= t_max * det
+    (triangle.rs:127-130) and then sets t = t_scaled / det, rounded once more: with two hits within an ulp of each other
+    (a ray through a vertex three triangles share) the second t can come out ABOVE the t_max it was accepted under, and
+    BVHAccel::intersect carries on with the larger value — a node popped later is tested against it (bvh.rs:841-842).
+    Round 3's hypothesis run (3000 examples) found the mesh below: the binary kernel had dropped a far child at its parent
+    because it lay behind the hit THEN. Fixed in both kernels: the binary one keeps a far child whenever the ray meets its
+    slabs and decides at the pop, as the reference does; a ray whose t_max moves up leaves the wide kernel for the binary one."""
+    verts = np.array([[0, 0, 1], [0, 0, -1e3], [0, 1, 1e3], [-1e3, 0.375, 0]], dtype=np.float32)
+    if case == "hypothesis counter-example":
+        idx = np.array([[0, 0, 0]] * 28 + [[0, 1, 3], [0, 2, 3], [1, 2, 3]], dtype=np.int32)
+    elif case == "the three triangles alone":
+        idx = np.array([[0, 1, 3], [0, 2, 3], [1, 2, 3]], dtype=np.int32)
+    else:
+        # closed fans around shared vertices at coordinates of a thousand units: many triangles meet in every vertex
+        g = np.array([[x, y, 0.0] for y in range(7) for x in range(7)], dtype=np.float32)
+        g[:, 2] = (np.sin(g[:, 0] * 1.3) + np.cos(g[:, 1] * 0.7)).astype(np.float32)
+        verts = (g * np.float32(333.0) + np.float32(-1000.0)).astype(np.float32)
+        quad = [(y * 7 + x, y * 7 + x + 1, (y + 1) * 7 + x + 1, (y + 1) * 7 + x) for y in range(6) for x in range(6)]
+        idx = np.array([t for a, b, c, d in quad for t in ((a, b, c), (a, c, d))], dtype=np.int32)
+    sc = _scene_of(verts, idx)
+    rays = _aimed_rays(verts, idx)
+    for max_prims, split in ((1, 0), (4, 0), (2, 2)):
+        osc = oracle.OracleScene(sc, max_prims, split)
+        gsc = pbrt_hip.Scene(hip_ctx, sc, max_prims_in_node=max_prims, split_method=split)
+        cpu, _ = osc.intersect(rays)
+        gpu = gsc.intersect(rays)
+        for f in ("prim_id", "t", "b0", "b1", "b2"):
+            bad = np.flatnonzero(gpu[f] != cpu[f])
+            assert len(bad) == 0, (case, max_prims, split, f, bad[:5], gpu[bad[:3]], cpu[bad[:3]], gsc.wide_records())
+        assert np.array_equal(gsc.intersect_p(rays), osc.intersect_p(rays)[0])
+        gsc.close()
+        osc.close()

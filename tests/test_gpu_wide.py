@@ -275,7 +275,7 @@ def test_adversarial_meshes_and_rays_through_vertices_and_edges(hip_ctx):
     from hypothesis import given, settings, strategies as st
     from test_property_host import meshes
 
-    @settings(max_examples=int(os.environ.get("PB_HYP_EXAMPLES", "50")), deadline=None)
+    @settings(max_examples=int(os.environ.get("PB_HYP_EXAMPLES", "400")), deadline=None)
     @given(mesh=meshes(), max_prims=st.sampled_from([1, 2, 4]), split=st.sampled_from([0, 1, 2, 3]))
     def check(mesh, max_prims, split):
         verts, idx = mesh
