@@ -3,6 +3,8 @@
 Bar: bit-exact (hit, prim_id, t, b0, b1, b2) — the kernels evaluate the same IEEE operations in
 the same order as the oracle (src/accelerators/bvh.rs:828-932, src/shapes/triangle.rs:74-158).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -332,7 +334,7 @@ def test_gpu_hlbvh_adversarial_meshes(hip_ctx):
     from hypothesis import given, settings, strategies as st
     from test_property_host import meshes
 
-    @settings(max_examples=60, deadline=None)
+    @settings(max_examples=int(os.environ.get("PB_HYP_EXAMPLES", "150")), deadline=None)
     @given(mesh=meshes(), max_prims=st.sampled_from([1, 2, 4, 255]))
     def check(mesh, max_prims):
         verts, idx = mesh

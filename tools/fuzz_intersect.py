@@ -1,0 +1,132 @@
+"""Fuzz campaign for Scene::intersect / intersect_p: random meshes WITH shared vertices and edges (height fields, fans, duplicated
+triangles) at several coordinate scales, rays aimed exactly at vertices, edge midpoints and centroids (where equal-t ties and
+one-ulp differences live) plus random rays; the wide kernel (default), the binary kernel (instrumented instantiation) and the
+oracle must agree bit for bit on (prim, t, b0, b1, b2) and on occlusion.
+usage: python tools/fuzz_intersect.py [n_cases] [first_seed]   (GPU box; exits 1 if any case mismatches)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pbrt-rs_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import oracle, pbrt_hip
+from pbrt_hip import scenes
+
+
+def make_mesh(rng):
+    scale = float(rng.choice([1e-3, 1.0, 1.0, 37.0, 1000.0]))
+    parts_p, parts_i, base = [], [], 0
+    for _ in range(int(rng.integers(1, 4))):
+        kind = rng.choice(["grid", "fan", "cloud", "dup"])
+        if kind == "grid":
+            n = int(rng.integers(2, 12))
+            xs = np.linspace(-1, 1, n)
+            amp = float(rng.choice([0.0, 0.05, 0.5]))
+            p = np.array([[x, amp * np.sin(3 * x + 2 * z), z] for z in xs for x in xs])
+            q = [(z * n + x, z * n + x + 1, (z + 1) * n + x + 1, (z + 1) * n + x) for z in range(n - 1) for x in range(n - 1)]
+            i = np.array([t for a, b, c, d in q for t in ((a, b, c), (a, c, d))])
+        elif kind == "fan":
+            k = int(rng.integers(3, 40))
+            ang = np.linspace(0, 2 * np.pi, k, endpoint=False)
+            p = np.concatenate([[[0.0, float(rng.uniform(-0.5, 0.5)), 0.0]], np.stack([np.cos(ang), rng.uniform(-0.2, 0.2, k), np.sin(ang)], 1)])
+            i = np.array([(0, 1 + j, 1 + (j + 1) % k) for j in range(k)])
+        elif kind == "cloud":
+            n = int(rng.integers(1, 300))
+            c = scenes.random_triangles(n, seq=int(rng.integers(1, 10000)), extent=1.0, size=float(rng.choice([0.02, 0.2])))
+            p, i = c["positions"].astype(np.float64), c["indices"]
+        else:   # the same triangle several times under different primitive numbers, and a degenerate one
+            p = rng.uniform(-1, 1, (3, 3))
+            i = np.array([(0, 1, 2)] * int(rng.integers(2, 6)) + [(0, 0, 1)])
+        off = rng.uniform(-1, 1, 3) * float(rng.choice([0.0, 0.5]))
+        parts_p.append((p + off) * scale)
+        parts_i.append(np.asarray(i) + base)
+        base += len(p)
+    return np.concatenate(parts_p).astype(np.float32), np.concatenate(parts_i).astype(np.int32), scale
+
+
+def aimed_rays(rng, verts, idx, scale, n_random):
+    tri = verts[idx]
+    targets = np.concatenate([tri.reshape(-1, 3), (tri[:, 0] + tri[:, 1]) * np.float32(0.5), (tri[:, 1] + tri[:, 2]) * np.float32(0.5), tri.mean(axis=1)])
+    if len(targets) > 600:
+        targets = targets[rng.choice(len(targets), 600, replace=False)]
+    reps = 3
+    tgt = np.repeat(targets, reps, axis=0)
+    o = tgt + rng.normal(size=tgt.shape) * scale * rng.choice([0.5, 3.0, 30.0], (len(tgt), 1))
+    rays = np.zeros(len(tgt) + n_random, dtype=pbrt_hip.RAY_DTYPE)
+    rays["o"][:len(tgt)] = o.astype(np.float32)
+    rays["d"][:len(tgt)] = (tgt - rays["o"][:len(tgt)]).astype(np.float32)
+    k = np.arange(len(tgt))
+    par = k % 7 == 0
+    rays["d"][:len(tgt)][par, k[par] % 3] = 0.0                        # axis-parallel among them
+    rr = scenes.random_rays(n_random, int(rng.integers(1, 1 << 20)), origin_extent=2.0)
+    rays["o"][len(tgt):] = rr["o"] * np.float32(scale)
+    rays["d"][len(tgt):] = rr["d"]
+    rays["t_max"] = np.inf
+    some = rng.random(len(rays)) < 0.2
+    rays["t_max"][some] = (rng.uniform(0.2, 1.5, some.sum())).astype(np.float32)  # finite t_max: around the aimed hits' t = 1
+    rays["d"][np.all(rays["d"] == 0, axis=1)] = (0.0, 0.0, 1.0)
+    return np.ascontiguousarray(rays)
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    ctx = pbrt_hip.Context(0)
+    bad, n_wide, t0 = 0, 0, time.time()
+    for seed in range(first, first + n_cases):
+        rng = np.random.default_rng(seed)
+        verts, idx, scale = make_mesh(rng)
+        sc = dict(positions=verts, indices=idx, tri_material=np.zeros(len(idx), dtype=np.int32),
+                  materials=scenes._materials([(1, (0.5, 0.5, 0.5), (0, 0, 0), 1.0)]),
+                  tri_light=np.full(len(idx), -1, dtype=np.int32), lights=scenes._lights([]))
+        n_inst = 0
+        if rng.random() < 0.3:
+            # TransformedPrimitive instances of the mesh (primitive.rs:105-159), overlapping; rays aimed at instanced vertices
+            n_inst = int(rng.integers(1, 25))
+            inst = np.zeros((n_inst, 2, 4, 4), dtype=np.float32)
+            wv = []
+            for k in range(n_inst):
+                m = scenes._random_rigid(rng.uniform(0, 1, 3))
+                m[:3, 3] = rng.uniform(-1.5, 1.5, 3) * scale
+                inst[k, 0], inst[k, 1] = m.astype(np.float32), np.linalg.inv(m).astype(np.float32)
+                wv.append((verts.astype(np.float64) @ m[:3, :3].T + m[:3, 3]).astype(np.float32))
+            inst[:, :, 3, :] = (0, 0, 0, 1)
+            sc.update(instances=inst, instance_material=np.zeros(n_inst, dtype=np.int32))
+            pick = rng.choice(n_inst, min(n_inst, 4), replace=False)
+            rays = np.concatenate([aimed_rays(rng, wv[k], idx, scale, 60) for k in pick])
+        else:
+            rays = aimed_rays(rng, verts, idx, scale, 200)
+        max_prims, split = int(rng.choice([1, 2, 4])), int(rng.choice([0, 0, 1, 2, 3]))
+        desc = f"seed {seed}: {len(idx)} triangles, {n_inst} instances, scale {scale}, max_prims {max_prims}, split {split}, {len(rays)} rays"
+        try:
+            osc = oracle.OracleScene(sc, max_prims, split)
+            gsc = pbrt_hip.Scene(ctx, sc, max_prims_in_node=max_prims, split_method=split)
+            n_rec, why = gsc.wide_records()
+            n_wide += n_rec > 0
+            cpu, _ = osc.intersect(rays)
+            occ = osc.intersect_p(rays)[0]
+            got = {"default": (gsc.intersect(rays), gsc.intersect_p(rays))}
+            ctx.set_counting(1)
+            got["binary"] = (gsc.intersect(rays), gsc.intersect_p(rays))
+            ctx.set_counting(0)
+            gsc.close(); osc.close()
+            for name, (h, p) in got.items():
+                m = np.zeros(len(rays), dtype=bool)
+                for f in ("prim_id", "t", "b0", "b1", "b2") + (("instance_id",) if n_inst and "instance_id" in h.dtype.names and "instance_id" in cpu.dtype.names else ()):
+                    m |= h[f] != cpu[f]
+                m |= p != occ
+                if m.any():
+                    bad += 1
+                    i = int(np.flatnonzero(m)[0])
+                    print(f"MISMATCH ({name} kernel, wide records {n_rec} {why!r}) {desc}: {int(m.sum())} rays, first {i}: o {rays['o'][i]} d {rays['d'][i]} "
+                          f"tmax {rays['t_max'][i]}\n   oracle {cpu[i]} occluded {occ[i]}\n   gpu    {h[i]} occluded {p[i]}", flush=True)
+                    break
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print(f"ERROR {desc}\n   {type(e).__name__}: {e}", flush=True)
+        if (seed - first + 1) % 200 == 0:
+            print(f"... {seed - first + 1} cases ({n_wide} with wide records), {bad} bad, {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz_intersect: {n_cases} cases from seed {first} ({n_wide} with wide records): {bad} mismatching", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

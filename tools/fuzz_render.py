@@ -1,0 +1,130 @@
+"""Fuzz campaign: random small scenes through Integrator::render on the GPU and in the oracle, same seed; every film must agree
+to the parity tests' tolerance and every ray count exactly. What the fixed scenes of tests/test_gpu_render.py cannot reach:
+random mixes of geometry scale, shared-vertex meshes, materials, light kinds, integrators, samplers, depths, crop windows.
+usage: python tools/fuzz_render.py [n_cases] [first_seed]   (GPU box; prints one line per failing case, exits 1 if any)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pbrt-rs_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import oracle, pbrt_hip
+from pbrt_hip import scenes
+
+TOL_PIXEL, TOL_RMSE = 1e-5, 1e-6   # tests/test_gpu_render.py
+
+
+def grid_mesh(rng, n, scale):
+    """A height-field of (n-1)^2 * 2 triangles with shared vertices (ties on edges and vertices are possible)."""
+    xs = np.linspace(-1, 1, n)
+    g = np.array([[x, rng.uniform(-0.15, 0.15), z] for z in xs for x in xs], dtype=np.float64)
+    quads = [(z * n + x, z * n + x + 1, (z + 1) * n + x + 1, (z + 1) * n + x) for z in range(n - 1) for x in range(n - 1)]
+    idx = np.array([t for a, b, c, d in quads for t in ((a, c, b), (a, d, c))], dtype=np.int32)
+    return (g * scale).astype(np.float32), idx
+
+
+def make_case(seed):
+    rng = np.random.default_rng(seed)
+    scale = float(rng.choice([0.01, 1.0, 1.0, 1.0, 300.0]))
+    kind = rng.choice(["cloud", "grid", "cloud+grid", "cornell"])
+    pos, idx = [], []
+    if kind == "cornell":
+        sc = scenes.cornell_box()
+        cam_eye = None
+    else:
+        if "cloud" in kind:
+            n = int(rng.integers(1, 400))
+            c = scenes.random_triangles(n, seq=int(rng.integers(1, 1000)), extent=1.0, size=float(rng.choice([0.02, 0.1, 0.4])))
+            pos.append(c["positions"] * np.float32(scale)); idx.append(c["indices"])
+        if "grid" in kind:
+            gp, gi = grid_mesh(rng, int(rng.integers(2, 9)), scale)
+            gi = gi + (len(pos[0]) if pos else 0)
+            pos.append(gp); idx.append(gi)
+        positions, indices = np.concatenate(pos).astype(np.float32), np.concatenate(idx).astype(np.int32)
+        n_t = len(indices)
+        mats = scenes._materials([(scenes.MAT_MATTE, tuple(rng.uniform(0.2, 0.8, 3)), (0, 0, 0), 1.0),
+                                  (scenes.MAT_MIRROR, (0.9, 0.9, 0.9), (0, 0, 0), 1.0),
+                                  (scenes.MAT_GLASS, (1.0, 1.0, 1.0), (0.95, 0.95, 0.95), float(rng.choice([1.33, 1.5, 2.0]))),
+                                  (scenes.MAT_NONE, (0, 0, 0), (0, 0, 0), 1.0)])
+        pm = rng.choice([[1, 0, 0, 0], [0.6, 0.2, 0.2, 0.0], [0.5, 0.2, 0.2, 0.1]])
+        tri_material = rng.choice(4, n_t, p=np.array(pm, dtype=np.float64)).astype(np.int32)
+        tri_light = np.full(n_t, -1, dtype=np.int32)
+        lights = []
+        if rng.random() < 0.75:
+            lights.append((scenes.LIGHT_INFINITE, tuple(rng.uniform(0.2, 1.0, 3)), -1, 0, 1))
+        for _ in range(int(rng.integers(0, 4))):                     # area lights on random triangles
+            t = int(rng.integers(0, n_t))
+            if tri_light[t] < 0:
+                tri_light[t] = len(lights)
+                tri_material[t] = 0
+                lights.append((scenes.LIGHT_DIFFUSE_AREA, tuple(rng.uniform(2, 20, 3)), t, int(rng.integers(0, 2)), int(rng.integers(1, 3))))
+        if rng.random() < 0.3:
+            lights.append(scenes.point_light(tuple(rng.uniform(-1.5, 1.5, 3) * scale), tuple(rng.uniform(1, 5, 3) * scale * scale)))
+        if rng.random() < 0.2:
+            lights.append(scenes.distant_light(tuple(rng.normal(size=3)), tuple(rng.uniform(0.5, 2, 3))))
+        if rng.random() < 0.2:
+            lights.append(scenes.spot_light(tuple(rng.uniform(1, 2, 3) * scale), (0.0, 0.0, 0.0), tuple(rng.uniform(2, 8, 3) * scale * scale)))
+        if not lights:
+            lights.append((scenes.LIGHT_INFINITE, (1.0, 1.0, 1.0), -1, 0, 1))
+        sc = dict(positions=positions, indices=indices, tri_material=tri_material, materials=mats, tri_light=tri_light,
+                  lights=scenes._lights(lights))
+        cam_eye = tuple(np.array([rng.uniform(-1, 1), rng.uniform(0.3, 1.5), rng.uniform(2.0, 3.5)]) * scale)
+    w, h = int(rng.choice([24, 33, 48])), int(rng.choice([16, 24, 31]))
+    cam = scenes.cornell_camera(w, h) if cam_eye is None else scenes.perspective_camera(cam_eye, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), float(rng.uniform(25, 60)), w, h,
+                                                                                        lens_radius=float(rng.choice([0.0, 0.0, 0.05 * scale])), focal_distance=3.0 * scale)
+    integ = int(rng.choice([0, 0, 0, 1, 2, 3]))
+    kw = dict(integrator=integ, max_depth=int(rng.integers(1, 9)), seed=int(rng.integers(0, 1 << 30)))
+    if integ == 0:
+        kw.update(rr_threshold=float(rng.choice([1.0, 0.3])), light_strategy=int(rng.integers(0, 3)))
+    elif integ == 1:
+        kw.update(light_strategy=int(rng.integers(0, 2)))
+    elif integ == 3:
+        kw.update(ao_samples=int(rng.integers(1, 9)), cos_sample=bool(rng.integers(0, 2)))
+    smp = rng.choice(["random", "random", "stratified", "zerotwo", "halton"])
+    spp = int(rng.choice([1, 2, 4]))
+    if smp == "stratified":
+        kw["sampler"] = ("stratified", 2, spp, bool(rng.integers(0, 2)), int(rng.integers(0, 5)))
+    elif smp == "zerotwo":
+        kw["sampler"] = ("zerotwo", int(rng.integers(0, 5)))
+    elif smp == "halton":
+        kw["sampler"] = ("halton",)
+    if rng.random() < 0.3:
+        x0, y0 = int(rng.integers(0, w // 2)), int(rng.integers(0, h // 2))
+        kw["bounds"] = (x0, y0, int(rng.integers(x0 + 1, w + 1)), int(rng.integers(y0 + 1, h + 1)))
+    return sc, cam, w, h, spp, kw, f"{kind} scale {scale} tris {len(sc['indices'])} lights {len(sc['lights'])} {w}x{h}x{spp} {kw}"
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    ctx = pbrt_hip.Context(0)
+    bad, t0 = 0, time.time()
+    for seed in range(first, first + n_cases):
+        sc, cam, w, h, spp, kw, desc = make_case(seed)
+        try:
+            osc = oracle.OracleScene(sc)
+            gsc = pbrt_hip.Scene(ctx, sc)
+            okw = dict(kw)
+            film_c, st_c = osc.render(scenes.camera_dict_to_floats(cam), w, h, spp, n_threads=4, **okw)
+            film_g, st_g = gsc.render(cam, w, h, spp, **kw)
+            gsc.close(); osc.close()
+            rays_g = st_g["rays_closest"] + st_g["rays_shadow"]
+            rgb_g, rgb_c = pbrt_hip.film_to_rgb(film_g), oracle.film_to_rgb(film_c)
+            err = np.abs(rgb_g - rgb_c)
+            ok = (np.array_equal(film_g[..., 3], film_c[..., 3]) and np.all(np.isfinite(rgb_g) == np.isfinite(rgb_c))
+                  and np.all(err[np.isfinite(err)] <= TOL_PIXEL * np.maximum(1.0, np.abs(rgb_c[np.isfinite(err)])))
+                  and rays_g == st_c["rays"])
+            if not ok:
+                bad += 1
+                fin = np.isfinite(err)
+                print(f"MISMATCH seed {seed}: {desc}\n   rays gpu {rays_g} cpu {st_c['rays']}; max err {err[fin].max() if fin.any() else None}; "
+                      f"pixels off {(err > TOL_PIXEL * np.maximum(1.0, np.abs(rgb_c))).any(axis=-1).sum()} of {w * h}", flush=True)
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print(f"ERROR seed {seed}: {desc}\n   {type(e).__name__}: {e}", flush=True)
+        if (seed - first + 1) % 50 == 0:
+            print(f"... {seed - first + 1} cases, {bad} bad, {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz_render: {n_cases} cases from seed {first}: {bad} mismatching", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
