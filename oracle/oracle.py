@@ -43,7 +43,7 @@ def lib():
                                                     vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                     ctypes.c_uint32]
         L.orc_scene_create_instanced.restype = vp
-        L.orc_scene_create_instanced.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, ctypes.c_int, vp,
+        L.orc_scene_create_instanced.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, ctypes.c_int, vp,
                                                  ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_uint32]
         L.orc_scene_create_two_level.restype = vp
@@ -208,11 +208,12 @@ class OracleScene:
             positions=_f32(scene["positions"]), indices=np.ascontiguousarray(scene["indices"], dtype=np.int32),
             instances=_f32(scene["instances"]).reshape(-1, 32),
             instance_material=np.ascontiguousarray(scene["instance_material"], dtype=np.int32),
+            tri_material=np.ascontiguousarray(scene.get("tri_material", np.zeros(len(scene["indices"]), dtype=np.int32)), dtype=np.int32),
             materials=_materials_flat(scene["materials"]), lights=_lights_flat(scene["lights"]))
         k = self._keep
         self.n_tris = k["indices"].shape[0]
         self.n_instances = k["instances"].shape[0]
-        self.h = L.orc_scene_create_instanced(_p(k["positions"]), k["positions"].shape[0], _p(k["indices"]), self.n_tris,
+        self.h = L.orc_scene_create_instanced(_p(k["positions"]), k["positions"].shape[0], _p(k["indices"]), self.n_tris, _p(k["tri_material"]),
                                               _p(k["instances"]), _p(k["instance_material"]), self.n_instances,
                                               _p(k["materials"]), len(k["materials"]), _p(k["lights"]),
                                               len(k["lights"]), max_prims_in_node, split_method, quirks)

@@ -138,7 +138,8 @@ void* orc_scene_create_with_spheres(const float* positions, int n_verts, const i
 // Instanced scene (config 5): one base mesh in object space inside a BVHAccel (BLAS), n_inst
 // TransformedPrimitives of it (primitive.rs:105-177) inside a top-level BVHAccel.
 // instances: n_inst x 32 floats {to_world[16], to_object[16]} row-major; inst_material[i] = material of instance i.
-void* orc_scene_create_instanced(const float* positions, int n_verts, const int32_t* indices, int n_tris,
+// tri_material: material of every base triangle (nullptr = material 0), used where an instance carries no override (-1)
+void* orc_scene_create_instanced(const float* positions, int n_verts, const int32_t* indices, int n_tris, const int32_t* tri_material,
                                  const float* instances, const int32_t* inst_material, int n_inst,
                                  const float* materials, int n_mat, const float* lights, int n_light,
                                  int max_prims_in_node, int split_method, uint32_t quirks) {
@@ -169,8 +170,11 @@ void* orc_scene_create_instanced(const float* positions, int n_verts, const int3
     std::vector<std::shared_ptr<Primitive>> prims(n_tris);
     sc.prim_material.assign(n_tris, 0);
     sc.prim_light.assign(n_tris, -1);
-    for (int i = 0; i < n_tris; ++i)
-        prims[i] = std::make_shared<GeometricPrimitive>(std::make_shared<Triangle>(mesh, i, false, quirks), 0, -1, i);
+    for (int i = 0; i < n_tris; ++i) {
+        const int mat = tri_material ? tri_material[i] : 0;
+        sc.prim_material[i] = mat;
+        prims[i] = std::make_shared<GeometricPrimitive>(std::make_shared<Triangle>(mesh, i, false, quirks), mat, -1, i);
+    }
     os->blas = std::make_shared<BVHAccel>(prims, max_prims_in_node, (SplitMethod)split_method, quirks);
     os->blas->counts_rays = false;
     std::vector<std::shared_ptr<Primitive>> insts(n_inst);

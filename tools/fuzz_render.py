@@ -64,8 +64,31 @@ def make_case(seed):
             lights.append(scenes.spot_light(tuple(rng.uniform(1, 2, 3) * scale), (0.0, 0.0, 0.0), tuple(rng.uniform(2, 8, 3) * scale * scale)))
         if not lights:
             lights.append((scenes.LIGHT_INFINITE, (1.0, 1.0, 1.0), -1, 0, 1))
+        extra = {}
+        r_extra = rng.random()
+        if r_extra < 0.2:
+            # full spheres placed by a translation beside the triangles (sphere.rs), some of them area lights: primitive n_t + i
+            sph = []
+            for k in range(int(rng.integers(1, 4))):
+                light = -1
+                if rng.random() < 0.4:
+                    light = len(lights)
+                    lights.append((scenes.LIGHT_DIFFUSE_AREA, tuple(rng.uniform(2, 12, 3)), n_t + k, 0, int(rng.integers(1, 3))))
+                sph.append([*(rng.uniform(-0.8, 0.8, 3) * scale), float(rng.uniform(0.1, 0.5)) * scale, 0 if light >= 0 else int(rng.integers(0, 3)), light, 0, 0])
+            extra["spheres"] = np.array(sph, dtype=np.float32)
+        elif r_extra < 0.35 and not any(tri_light >= 0):
+            # TransformedPrimitive instances of the mesh, material by instance (primitive.rs:105-159; instances carry no area lights)
+            n_inst = int(rng.integers(1, 12))
+            inst = np.zeros((n_inst, 2, 4, 4), dtype=np.float32)
+            for k in range(n_inst):
+                m = scenes._random_rigid(rng.uniform(0, 1, 3))
+                m[:3, 3] = rng.uniform(-1.2, 1.2, 3) * scale
+                inst[k, 0], inst[k, 1] = m.astype(np.float32), np.linalg.inv(m).astype(np.float32)
+            inst[:, :, 3, :] = (0, 0, 0, 1)
+            extra["instances"] = inst
+            extra["instance_material"] = rng.integers(-1, 3, n_inst).astype(np.int32)
         sc = dict(positions=positions, indices=indices, tri_material=tri_material, materials=mats, tri_light=tri_light,
-                  lights=scenes._lights(lights))
+                  lights=scenes._lights(lights), **extra)
         cam_eye = tuple(np.array([rng.uniform(-1, 1), rng.uniform(0.3, 1.5), rng.uniform(2.0, 3.5)]) * scale)
     w, h = int(rng.choice([24, 33, 48])), int(rng.choice([16, 24, 31]))
     cam = scenes.cornell_camera(w, h) if cam_eye is None else scenes.perspective_camera(cam_eye, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), float(rng.uniform(25, 60)), w, h,
@@ -86,10 +109,12 @@ def make_case(seed):
         kw["sampler"] = ("zerotwo", int(rng.integers(0, 5)))
     elif smp == "halton":
         kw["sampler"] = ("halton",)
+    gpu_only = dict(shade_order=int(rng.integers(0, 3)), spp_per_pass=int(rng.integers(0, 3)))   # must not change the film
     if rng.random() < 0.3:
         x0, y0 = int(rng.integers(0, w // 2)), int(rng.integers(0, h // 2))
         kw["bounds"] = (x0, y0, int(rng.integers(x0 + 1, w + 1)), int(rng.integers(y0 + 1, h + 1)))
-    return sc, cam, w, h, spp, kw, f"{kind} scale {scale} tris {len(sc['indices'])} lights {len(sc['lights'])} {w}x{h}x{spp} {kw}"
+    what = kind + (" +spheres" if "spheres" in sc else "") + (" instanced" if "instances" in sc else "")
+    return sc, cam, w, h, spp, kw, gpu_only, f"{what} scale {scale} tris {len(sc['indices'])} lights {len(sc['lights'])} {w}x{h}x{spp} {kw} {gpu_only}"
 
 
 def main():
@@ -98,13 +123,13 @@ def main():
     ctx = pbrt_hip.Context(0)
     bad, t0 = 0, time.time()
     for seed in range(first, first + n_cases):
-        sc, cam, w, h, spp, kw, desc = make_case(seed)
+        sc, cam, w, h, spp, kw, gpu_only, desc = make_case(seed)
         try:
             osc = oracle.OracleScene(sc)
             gsc = pbrt_hip.Scene(ctx, sc)
             okw = dict(kw)
             film_c, st_c = osc.render(scenes.camera_dict_to_floats(cam), w, h, spp, n_threads=4, **okw)
-            film_g, st_g = gsc.render(cam, w, h, spp, **kw)
+            film_g, st_g = gsc.render(cam, w, h, spp, **kw, **gpu_only)
             gsc.close(); osc.close()
             rays_g = st_g["rays_closest"] + st_g["rays_shadow"]
             rgb_g, rgb_c = pbrt_hip.film_to_rgb(film_g), oracle.film_to_rgb(film_c)
