@@ -66,39 +66,77 @@ def aimed_rays(rng, verts, idx, scale, n_random):
     return np.ascontiguousarray(rays)
 
 
+def make_case(seed):
+    rng = np.random.default_rng(seed)
+    verts, idx, scale = make_mesh(rng)
+    sc = dict(positions=verts, indices=idx, tri_material=np.zeros(len(idx), dtype=np.int32),
+              materials=scenes._materials([(1, (0.5, 0.5, 0.5), (0, 0, 0), 1.0)]),
+              tri_light=np.full(len(idx), -1, dtype=np.int32), lights=scenes._lights([]))
+    n_inst = 0
+    kw = {}
+    r_kind = rng.random()
+    if r_kind < 0.15:
+        # the general two-level scene (primitive.rs:105-159): several object aggregates, instances of them, world-space
+        # triangles beside the instances in the top-level leaves
+        objs, n_obj = [], int(rng.integers(1, 4))
+        for _ in range(n_obj):
+            ov, oi, _s = make_mesh(rng)
+            objs.append(dict(positions=(ov / np.float32(_s) * np.float32(scale)).astype(np.float32), indices=oi, tri_material=np.zeros(len(oi), dtype=np.int32)))
+        n_inst = int(rng.integers(1, 20))
+        inst = np.zeros((n_inst, 2, 4, 4), dtype=np.float32)
+        io = rng.integers(0, n_obj, n_inst).astype(np.int32)
+        tgt_sets = []
+        for k in range(n_inst):
+            m = scenes._random_rigid(rng.uniform(0, 1, 3))
+            m[:3, 3] = rng.uniform(-1.5, 1.5, 3) * scale
+            inst[k, 0], inst[k, 1] = m.astype(np.float32), np.linalg.inv(m).astype(np.float32)
+            tgt_sets.append(((objs[io[k]]["positions"].astype(np.float64) @ m[:3, :3].T + m[:3, 3]).astype(np.float32), objs[io[k]]["indices"]))
+        inst[:, :, 3, :] = (0, 0, 0, 1)
+        wv, wi, _s = make_mesh(rng)
+        wv = (wv / np.float32(_s) * np.float32(scale)).astype(np.float32)
+        sc = dict(objects=objs, instances=inst, instance_object=io, instance_material=np.full(n_inst, -1, dtype=np.int32),
+                  world=dict(positions=wv, indices=wi, tri_material=np.zeros(len(wi), dtype=np.int32), tri_light=np.full(len(wi), -1, dtype=np.int32)),
+                  materials=sc["materials"], lights=scenes._lights([]))
+        tgt_sets.append((wv, wi))
+        pick = rng.choice(len(tgt_sets), min(len(tgt_sets), 4), replace=False)
+        rays = np.concatenate([aimed_rays(rng, tgt_sets[k][0], tgt_sets[k][1], scale, 60) for k in pick])
+        idx = np.concatenate([o["indices"] for o in objs] + [wi])
+    elif r_kind < 0.45:
+        # TransformedPrimitive instances of the mesh (primitive.rs:105-159), overlapping; rays aimed at instanced vertices
+        n_inst = int(rng.integers(1, 25))
+        inst = np.zeros((n_inst, 2, 4, 4), dtype=np.float32)
+        wv = []
+        for k in range(n_inst):
+            m = scenes._random_rigid(rng.uniform(0, 1, 3))
+            m[:3, 3] = rng.uniform(-1.5, 1.5, 3) * scale
+            inst[k, 0], inst[k, 1] = m.astype(np.float32), np.linalg.inv(m).astype(np.float32)
+            wv.append((verts.astype(np.float64) @ m[:3, :3].T + m[:3, 3]).astype(np.float32))
+        inst[:, :, 3, :] = (0, 0, 0, 1)
+        sc.update(instances=inst, instance_material=np.zeros(n_inst, dtype=np.int32))
+        pick = rng.choice(n_inst, min(n_inst, 4), replace=False)
+        rays = np.concatenate([aimed_rays(rng, wv[k], idx, scale, 60) for k in pick])
+    else:
+        rays = aimed_rays(rng, verts, idx, scale, 200)
+        if rng.random() < 0.2:
+            kw = dict(device_build=True)     # the tree built on the device (HLBVH, bvh.rs:475-811) against the oracle's HLBVH
+    max_prims, split = int(rng.choice([1, 2, 4])), int(rng.choice([0, 0, 1, 2, 3]))
+    if kw:
+        split = pbrt_hip.SPLIT_HLBVH
+    desc = (f"seed {seed}: {len(idx)} triangles, {n_inst} instances{' of ' + str(len(sc['objects'])) + ' objects + world triangles' if 'objects' in sc else ''}"
+            f"{' (device-built tree)' if kw else ''}, scale {scale}, max_prims {max_prims}, split {split}, {len(rays)} rays")
+    return sc, rays, max_prims, split, kw, n_inst, desc
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     ctx = pbrt_hip.Context(0)
     bad, n_wide, t0 = 0, 0, time.time()
     for seed in range(first, first + n_cases):
-        rng = np.random.default_rng(seed)
-        verts, idx, scale = make_mesh(rng)
-        sc = dict(positions=verts, indices=idx, tri_material=np.zeros(len(idx), dtype=np.int32),
-                  materials=scenes._materials([(1, (0.5, 0.5, 0.5), (0, 0, 0), 1.0)]),
-                  tri_light=np.full(len(idx), -1, dtype=np.int32), lights=scenes._lights([]))
-        n_inst = 0
-        if rng.random() < 0.3:
-            # TransformedPrimitive instances of the mesh (primitive.rs:105-159), overlapping; rays aimed at instanced vertices
-            n_inst = int(rng.integers(1, 25))
-            inst = np.zeros((n_inst, 2, 4, 4), dtype=np.float32)
-            wv = []
-            for k in range(n_inst):
-                m = scenes._random_rigid(rng.uniform(0, 1, 3))
-                m[:3, 3] = rng.uniform(-1.5, 1.5, 3) * scale
-                inst[k, 0], inst[k, 1] = m.astype(np.float32), np.linalg.inv(m).astype(np.float32)
-                wv.append((verts.astype(np.float64) @ m[:3, :3].T + m[:3, 3]).astype(np.float32))
-            inst[:, :, 3, :] = (0, 0, 0, 1)
-            sc.update(instances=inst, instance_material=np.zeros(n_inst, dtype=np.int32))
-            pick = rng.choice(n_inst, min(n_inst, 4), replace=False)
-            rays = np.concatenate([aimed_rays(rng, wv[k], idx, scale, 60) for k in pick])
-        else:
-            rays = aimed_rays(rng, verts, idx, scale, 200)
-        max_prims, split = int(rng.choice([1, 2, 4])), int(rng.choice([0, 0, 1, 2, 3]))
-        desc = f"seed {seed}: {len(idx)} triangles, {n_inst} instances, scale {scale}, max_prims {max_prims}, split {split}, {len(rays)} rays"
+        sc, rays, max_prims, split, kw, n_inst, desc = make_case(seed)
         try:
             osc = oracle.OracleScene(sc, max_prims, split)
-            gsc = pbrt_hip.Scene(ctx, sc, max_prims_in_node=max_prims, split_method=split)
+            gsc = pbrt_hip.Scene(ctx, sc, max_prims_in_node=max_prims, split_method=split, **kw)
             n_rec, why = gsc.wide_records()
             n_wide += n_rec > 0
             cpu, _ = osc.intersect(rays)

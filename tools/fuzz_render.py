@@ -89,10 +89,24 @@ def make_case(seed):
             extra["instance_material"] = rng.integers(-1, 3, n_inst).astype(np.int32)
         sc = dict(positions=positions, indices=indices, tri_material=tri_material, materials=mats, tri_light=tri_light,
                   lights=scenes._lights(lights), **extra)
+        if not extra and rng.random() < 0.25:
+            # TriangleMesh n / s / uv (triangle.rs:17-26, 252-312): shading frames from per-vertex data
+            sc = scenes.with_vertex_shading(sc, seq=int(rng.integers(1, 1000)), normals=bool(rng.integers(0, 2)), uvs=bool(rng.integers(0, 2)) or True,
+                                            tangents=bool(rng.integers(0, 2)))
         cam_eye = tuple(np.array([rng.uniform(-1, 1), rng.uniform(0.3, 1.5), rng.uniform(2.0, 3.5)]) * scale)
     w, h = int(rng.choice([24, 33, 48])), int(rng.choice([16, 24, 31]))
-    cam = scenes.cornell_camera(w, h) if cam_eye is None else scenes.perspective_camera(cam_eye, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), float(rng.uniform(25, 60)), w, h,
-                                                                                        lens_radius=float(rng.choice([0.0, 0.0, 0.05 * scale])), focal_distance=3.0 * scale)
+    if cam_eye is None:
+        cam = scenes.cornell_camera(w, h)
+    else:
+        ck = rng.choice(["perspective", "perspective", "perspective", "orthographic", "environment"])
+        if ck == "orthographic":     # cameras/orthographic.rs:82-104
+            cam = scenes.orthographic_camera(cam_eye, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 1.3 * scale, w, h,
+                                             lens_radius=float(rng.choice([0.0, 0.05 * scale])), focal_distance=3.0 * scale)
+        elif ck == "environment":    # cameras/environment.rs:37-56
+            cam = scenes.environment_camera(tuple(np.array(cam_eye) * 0.2), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+        else:
+            cam = scenes.perspective_camera(cam_eye, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), float(rng.uniform(25, 60)), w, h,
+                                            lens_radius=float(rng.choice([0.0, 0.0, 0.05 * scale])), focal_distance=3.0 * scale)
     integ = int(rng.choice([0, 0, 0, 1, 2, 3]))
     kw = dict(integrator=integ, max_depth=int(rng.integers(1, 9)), seed=int(rng.integers(0, 1 << 30)))
     if integ == 0:
@@ -110,11 +124,21 @@ def make_case(seed):
     elif smp == "halton":
         kw["sampler"] = ("halton",)
     gpu_only = dict(shade_order=int(rng.integers(0, 3)), spp_per_pass=int(rng.integers(0, 3)))   # must not change the film
-    if rng.random() < 0.3:
+    plain = "spheres" not in sc and "instances" not in sc and "normals" not in sc and "uvs" not in sc and "tangents" not in sc
+    opts = dict(device_build=bool(plain and rng.random() < 0.2),     # the tree built on the device (HLBVH) against the oracle's HLBVH
+                tile_split=int(rng.choice([1, 1, 2, 3])))              # the frame as the sum of the ranks' tile shares
+    r_f = rng.random()
+    if r_f < 0.3:
         x0, y0 = int(rng.integers(0, w // 2)), int(rng.integers(0, h // 2))
         kw["bounds"] = (x0, y0, int(rng.integers(x0 + 1, w + 1)), int(rng.integers(y0 + 1, h + 1)))
+    elif r_f < 0.42:
+        # a wider reconstruction filter (src/filters/*.rs, FilmTile::add_sample film.rs:252-295): float atomics on the GPU, tile
+        # merges in the oracle — only the order of the additions differs (tests/test_gpu_render.py::test_reconstruction_filters)
+        fk = [("gaussian", 2.0, 2.0, 0.0), ("mitchell", 2.0, 1 / 3, 1 / 3), ("triangle", 1.5, 0.0, 0.0), ("lanczos", 3.0, 3.0, 0.0)][int(rng.integers(0, 4))]
+        kw["filter"] = pbrt_hip.filter_table(fk[0], fk[1], fk[1], fk[2], fk[3])
     what = kind + (" +spheres" if "spheres" in sc else "") + (" instanced" if "instances" in sc else "")
-    return sc, cam, w, h, spp, kw, gpu_only, f"{what} scale {scale} tris {len(sc['indices'])} lights {len(sc['lights'])} {w}x{h}x{spp} {kw} {gpu_only}"
+    what += (" +vertex data" if ("normals" in sc or "uvs" in sc or "tangents" in sc) else "")
+    return sc, cam, w, h, spp, kw, gpu_only, opts, f"{what} scale {scale} tris {len(sc['indices'])} lights {len(sc['lights'])} {w}x{h}x{spp} {kw} {gpu_only} {opts}"
 
 
 def main():
@@ -123,20 +147,37 @@ def main():
     ctx = pbrt_hip.Context(0)
     bad, t0 = 0, time.time()
     for seed in range(first, first + n_cases):
-        sc, cam, w, h, spp, kw, gpu_only, desc = make_case(seed)
+        sc, cam, w, h, spp, kw, gpu_only, opts, desc = make_case(seed)
         try:
-            osc = oracle.OracleScene(sc)
-            gsc = pbrt_hip.Scene(ctx, sc)
+            if opts["device_build"]:
+                osc = oracle.OracleScene(sc, split_method=pbrt_hip.SPLIT_HLBVH)
+                gsc = pbrt_hip.Scene(ctx, sc, device_build=True)
+            else:
+                osc = oracle.OracleScene(sc, normals=sc.get("normals"), uvs=sc.get("uvs"), tangents=sc.get("tangents"))
+                gsc = pbrt_hip.Scene(ctx, sc)
             okw = dict(kw)
             film_c, st_c = osc.render(scenes.camera_dict_to_floats(cam), w, h, spp, n_threads=4, **okw)
-            film_g, st_g = gsc.render(cam, w, h, spp, **kw, **gpu_only)
+            if opts["tile_split"] == 1:
+                film_g, st_g = gsc.render(cam, w, h, spp, **kw, **gpu_only)
+            else:   # integrator.rs:412-477 over ranks: the films of the tile shares add up to the frame, their rays to its rays
+                film_g, st_g = None, dict(rays_closest=0, rays_shadow=0)
+                for rank in range(opts["tile_split"]):
+                    f, st = gsc.render(cam, w, h, spp, tile_rank=rank, tile_world=opts["tile_split"], **kw, **gpu_only)
+                    film_g = f if film_g is None else film_g + f
+                    st_g["rays_closest"] += st["rays_closest"]
+                    st_g["rays_shadow"] += st["rays_shadow"]
             gsc.close(); osc.close()
             rays_g = st_g["rays_closest"] + st_g["rays_shadow"]
             rgb_g, rgb_c = pbrt_hip.film_to_rgb(film_g), oracle.film_to_rgb(film_c)
             err = np.abs(rgb_g - rgb_c)
-            ok = (np.array_equal(film_g[..., 3], film_c[..., 3]) and np.all(np.isfinite(rgb_g) == np.isfinite(rgb_c))
-                  and np.all(err[np.isfinite(err)] <= TOL_PIXEL * np.maximum(1.0, np.abs(rgb_c[np.isfinite(err)])))
-                  and rays_g == st_c["rays"])
+            if "filter" in kw:
+                fin = np.isfinite(film_c) & np.isfinite(film_g)
+                ok = (np.all(np.isfinite(film_c) == np.isfinite(film_g)) and np.allclose(film_g[fin], film_c[fin], rtol=5e-5, atol=5e-5 * max(1.0, float(np.abs(film_c[fin]).max(initial=0.0))))
+                      and rays_g == st_c["rays"])
+            else:
+                ok = (np.array_equal(film_g[..., 3], film_c[..., 3]) and np.all(np.isfinite(rgb_g) == np.isfinite(rgb_c))
+                      and np.all(err[np.isfinite(err)] <= TOL_PIXEL * np.maximum(1.0, np.abs(rgb_c[np.isfinite(err)])))
+                      and rays_g == st_c["rays"])
             if not ok:
                 bad += 1
                 fin = np.isfinite(err)
