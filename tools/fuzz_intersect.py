@@ -145,6 +145,19 @@ def main():
             ctx.set_counting(1)
             got["binary"] = (gsc.intersect(rays), gsc.intersect_p(rays))
             ctx.set_counting(0)
+            if n_rec >= 0 and "instances" not in sc and "objects" not in sc and seed % 3 == 0:
+                # the device builder of the wide records (wide_gpu.hip) against the host builder (host_wide.cpp): same bytes
+                os.environ["PBRT_HIP_WIDE_BUILD"] = "host"
+                try:
+                    hsc = pbrt_hip.Scene(ctx, sc, max_prims_in_node=max_prims, split_method=split, **kw)
+                finally:
+                    del os.environ["PBRT_HIP_WIDE_BUILD"]
+                n_t = len(sc["indices"])
+                same = hsc.wide_records() == (n_rec, why) and all(a.tobytes() == b.tobytes() for a, b in zip(gsc.debug_wide_export(n_t), hsc.debug_wide_export(n_t)))
+                hsc.close()
+                if not same:
+                    bad += 1
+                    print(f"BUILDERS DIFFER {desc}: device {(n_rec, why)} host {hsc.wide_records() if False else '?'}", flush=True)
             gsc.close(); osc.close()
             for name, (h, p) in got.items():
                 m = np.zeros(len(rays), dtype=bool)

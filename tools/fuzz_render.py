@@ -166,6 +166,25 @@ def main():
                     film_g = f if film_g is None else film_g + f
                     st_g["rays_closest"] += st["rays_closest"]
                     st_g["rays_shadow"] += st["rays_shadow"]
+            li_bad = None
+            if "sampler" not in kw and seed % 4 == 0:
+                # Integrator::li in batch form (integrator.rs:29-42): arbitrary rays and stream keys against the oracle's li
+                lrng = np.random.default_rng(seed ^ 0x5bd1e995)
+                n_li = int(lrng.integers(1, 700))
+                cen = sc["positions"].mean(axis=0)
+                ext = float(np.abs(sc["positions"] - cen).max()) + 1e-6
+                lr = scenes.random_rays(n_li, int(lrng.integers(1, 1 << 20)), origin_extent=1.0)
+                lr["o"] = (lr["o"] * np.float32(ext * 1.2) + cen).astype(np.float32)
+                keys = lrng.integers(0, 1 << 62, n_li).astype(np.uint64)
+                lkw = {k: v for k, v in kw.items() if k in ("integrator", "max_depth", "rr_threshold", "light_strategy", "ao_samples", "cos_sample")}
+                skip = int(lrng.choice([0, 5]))
+                lc, lst_c = osc.li(lr, keys, draws_before_li=skip, **lkw)
+                lg, lst_g = gsc.li(lr, keys, draws_before_li=skip, **{k: v for k, v in lkw.items() if k != "cos_sample"},
+                                   **({"light_strategy": int(bool(lkw.get("cos_sample", True)))} if lkw.get("integrator") == 3 else {}))
+                fin = np.isfinite(lc) & np.isfinite(lg)
+                if (lst_g["rays_closest"] + lst_g["rays_shadow"] != lst_c["rays"] or np.any(np.isfinite(lc) != np.isfinite(lg))
+                        or np.any(np.abs(lg[fin] - lc[fin]) > 1e-5 * np.maximum(1.0, np.abs(lc[fin])))):
+                    li_bad = f"li: rays gpu {lst_g['rays_closest'] + lst_g['rays_shadow']} cpu {lst_c['rays']}, max err {np.abs(lg[fin] - lc[fin]).max() if fin.any() else None}"
             gsc.close(); osc.close()
             rays_g = st_g["rays_closest"] + st_g["rays_shadow"]
             rgb_g, rgb_c = pbrt_hip.film_to_rgb(film_g), oracle.film_to_rgb(film_c)
@@ -178,6 +197,9 @@ def main():
                 ok = (np.array_equal(film_g[..., 3], film_c[..., 3]) and np.all(np.isfinite(rgb_g) == np.isfinite(rgb_c))
                       and np.all(err[np.isfinite(err)] <= TOL_PIXEL * np.maximum(1.0, np.abs(rgb_c[np.isfinite(err)])))
                       and rays_g == st_c["rays"])
+            if li_bad:
+                bad += 1
+                print(f"MISMATCH seed {seed}: {desc}\n   {li_bad}", flush=True)
             if not ok:
                 bad += 1
                 fin = np.isfinite(err)
