@@ -11,13 +11,16 @@ import oracle, pbrt_hip
 from pbrt_hip import scenes
 
 
+BIG = bool(os.environ.get("FUZZ_BIG"))   # FUZZ_BIG=1: meshes of 10^4 - 10^5 triangles (deep trees, stack spills), 10^5 rays per case
+
+
 def make_mesh(rng):
     scale = float(rng.choice([1e-3, 1.0, 1.0, 37.0, 1000.0]))
     parts_p, parts_i, base = [], [], 0
     for _ in range(int(rng.integers(1, 4))):
         kind = rng.choice(["grid", "fan", "cloud", "dup"])
         if kind == "grid":
-            n = int(rng.integers(2, 12))
+            n = int(rng.integers(40, 160)) if BIG else int(rng.integers(2, 12))
             xs = np.linspace(-1, 1, n)
             amp = float(rng.choice([0.0, 0.05, 0.5]))
             p = np.array([[x, amp * np.sin(3 * x + 2 * z), z] for z in xs for x in xs])
@@ -29,8 +32,8 @@ def make_mesh(rng):
             p = np.concatenate([[[0.0, float(rng.uniform(-0.5, 0.5)), 0.0]], np.stack([np.cos(ang), rng.uniform(-0.2, 0.2, k), np.sin(ang)], 1)])
             i = np.array([(0, 1 + j, 1 + (j + 1) % k) for j in range(k)])
         elif kind == "cloud":
-            n = int(rng.integers(1, 300))
-            c = scenes.random_triangles(n, seq=int(rng.integers(1, 10000)), extent=1.0, size=float(rng.choice([0.02, 0.2])))
+            n = int(rng.integers(10_000, 150_000)) if BIG else int(rng.integers(1, 300))
+            c = scenes.random_triangles(n, seq=int(rng.integers(1, 10000)), extent=1.0, size=float(rng.choice([0.01, 0.05]) if BIG else rng.choice([0.02, 0.2])))
             p, i = c["positions"].astype(np.float64), c["indices"]
         else:   # the same triangle several times under different primitive numbers, and a degenerate one
             p = rng.uniform(-1, 1, (3, 3))
@@ -45,8 +48,9 @@ def make_mesh(rng):
 def aimed_rays(rng, verts, idx, scale, n_random):
     tri = verts[idx]
     targets = np.concatenate([tri.reshape(-1, 3), (tri[:, 0] + tri[:, 1]) * np.float32(0.5), (tri[:, 1] + tri[:, 2]) * np.float32(0.5), tri.mean(axis=1)])
-    if len(targets) > 600:
-        targets = targets[rng.choice(len(targets), 600, replace=False)]
+    cap = 15_000 if BIG else 600
+    if len(targets) > cap:
+        targets = targets[rng.choice(len(targets), cap, replace=False)]
     reps = 3
     tgt = np.repeat(targets, reps, axis=0)
     o = tgt + rng.normal(size=tgt.shape) * scale * rng.choice([0.5, 3.0, 30.0], (len(tgt), 1))
@@ -116,7 +120,7 @@ def make_case(seed):
         pick = rng.choice(n_inst, min(n_inst, 4), replace=False)
         rays = np.concatenate([aimed_rays(rng, wv[k], idx, scale, 60) for k in pick])
     else:
-        rays = aimed_rays(rng, verts, idx, scale, 200)
+        rays = aimed_rays(rng, verts, idx, scale, 50_000 if BIG else 200)
         if rng.random() < 0.2:
             kw = dict(device_build=True)     # the tree built on the device (HLBVH, bvh.rs:475-811) against the oracle's HLBVH
     max_prims, split = int(rng.choice([1, 2, 4])), int(rng.choice([0, 0, 1, 2, 3]))
