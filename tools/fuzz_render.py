@@ -50,7 +50,7 @@ def make_case(seed):
         lights = []
         if rng.random() < 0.75:
             lights.append((scenes.LIGHT_INFINITE, tuple(rng.uniform(0.2, 1.0, 3)), -1, 0, 1))
-        for _ in range(int(rng.integers(0, 4))):                     # area lights on random triangles
+        for _ in range(int(rng.integers(0, 4)) if rng.random() < 0.8 else int(rng.integers(4, 14))):   # area lights on random triangles
             t = int(rng.integers(0, n_t))
             if tri_light[t] < 0:
                 tri_light[t] = len(lights)
@@ -89,7 +89,36 @@ def make_case(seed):
             extra["instance_material"] = rng.integers(-1, 3, n_inst).astype(np.int32)
         sc = dict(positions=positions, indices=indices, tri_material=tri_material, materials=mats, tri_light=tri_light,
                   lights=scenes._lights(lights), **extra)
-        if not extra and rng.random() < 0.25:
+        if not extra and rng.random() < 0.12:
+            # the general two-level scene: this mesh cut into 1-3 object aggregates, instances of them, and world-space triangles
+            # (a floor and, sometimes, an emitting quad) beside the instances in the top-level leaves (primitive.rs:105-159)
+            n_obj = int(rng.integers(1, 4))
+            cuts = np.sort(rng.choice(np.arange(1, max(n_t, 2)), size=min(n_obj - 1, max(n_t - 1, 0)), replace=False)) if n_t > 1 else np.array([], dtype=np.int64)
+            parts = np.split(np.arange(n_t), cuts)
+            objs = [dict(positions=positions, indices=indices[p_], tri_material=tri_material[p_]) for p_ in parts if len(p_)]
+            n_inst = int(rng.integers(1, 10))
+            inst = np.zeros((n_inst, 2, 4, 4), dtype=np.float32)
+            for k in range(n_inst):
+                m = scenes._random_rigid(rng.uniform(0, 1, 3))
+                m[:3, 3] = rng.uniform(-1.0, 1.0, 3) * scale
+                inst[k, 0], inst[k, 1] = m.astype(np.float32), np.linalg.inv(m).astype(np.float32)
+            inst[:, :, 3, :] = (0, 0, 0, 1)
+            e = 1.8 * scale
+            wp = np.array([[-e, -1.3 * scale, -e], [e, -1.3 * scale, -e], [e, -1.3 * scale, e], [-e, -1.3 * scale, e],
+                           [-0.5 * scale, 1.5 * scale, -0.5 * scale], [0.5 * scale, 1.5 * scale, -0.5 * scale], [0.5 * scale, 1.5 * scale, 0.5 * scale], [-0.5 * scale, 1.5 * scale, 0.5 * scale]], dtype=np.float32)
+            wi = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7]], dtype=np.int32)
+            wl = np.array([-1, -1, -1, -1], dtype=np.int32)
+            lts = [l for l in lights if not (isinstance(l, tuple) and l[0] == scenes.LIGHT_DIFFUSE_AREA)]   # instanced triangles carry no area lights
+            if rng.random() < 0.6:
+                wl[2], wl[3] = len(lts), len(lts) + 1
+                lts += [(scenes.LIGHT_DIFFUSE_AREA, (12.0, 11.0, 9.0), 2, 0, 1), (scenes.LIGHT_DIFFUSE_AREA, (12.0, 11.0, 9.0), 3, 0, 1)]
+            if not lts:
+                lts.append((scenes.LIGHT_INFINITE, (1.0, 1.0, 1.0), -1, 0, 1))
+            sc = dict(objects=objs, instances=inst, instance_object=rng.integers(0, len(objs), n_inst).astype(np.int32),
+                      instance_material=rng.integers(-1, 3, n_inst).astype(np.int32),
+                      world=dict(positions=wp, indices=wi, tri_material=np.zeros(4, dtype=np.int32), tri_light=wl),
+                      materials=mats, lights=scenes._lights(lts), positions=positions, indices=indices)
+        elif not extra and rng.random() < 0.25:
             # TriangleMesh n / s / uv (triangle.rs:17-26, 252-312): shading frames from per-vertex data
             sc = scenes.with_vertex_shading(sc, seq=int(rng.integers(1, 1000)), normals=bool(rng.integers(0, 2)), uvs=bool(rng.integers(0, 2)) or True,
                                             tangents=bool(rng.integers(0, 2)))
@@ -108,7 +137,9 @@ def make_case(seed):
             cam = scenes.perspective_camera(cam_eye, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), float(rng.uniform(25, 60)), w, h,
                                             lens_radius=float(rng.choice([0.0, 0.0, 0.05 * scale])), focal_distance=3.0 * scale)
     integ = int(rng.choice([0, 0, 0, 1, 2, 3]))
-    kw = dict(integrator=integ, max_depth=int(rng.integers(1, 9)), seed=int(rng.integers(0, 1 << 30)))
+    kw = dict(integrator=integ, max_depth=int(rng.integers(1, 9)) if rng.random() < 0.85 else int(rng.integers(9, 20)), seed=int(rng.integers(0, 1 << 30)))
+    if rng.random() < 0.15:
+        kw["max_sample_luminance"] = float(rng.choice([0.5, 2.0, 10.0]))   # Film::max_sample_luminance (film.rs:253-255)
     if integ == 0:
         kw.update(rr_threshold=float(rng.choice([1.0, 0.3])), light_strategy=int(rng.integers(0, 3)))
     elif integ == 1:
@@ -124,7 +155,7 @@ def make_case(seed):
     elif smp == "halton":
         kw["sampler"] = ("halton",)
     gpu_only = dict(shade_order=int(rng.integers(0, 3)), spp_per_pass=int(rng.integers(0, 3)))   # must not change the film
-    plain = "spheres" not in sc and "instances" not in sc and "normals" not in sc and "uvs" not in sc and "tangents" not in sc
+    plain = "spheres" not in sc and "instances" not in sc and "objects" not in sc and "normals" not in sc and "uvs" not in sc and "tangents" not in sc
     opts = dict(device_build=bool(plain and rng.random() < 0.2),     # the tree built on the device (HLBVH) against the oracle's HLBVH
                 tile_split=int(rng.choice([1, 1, 2, 3])))              # the frame as the sum of the ranks' tile shares
     r_f = rng.random()
@@ -136,7 +167,7 @@ def make_case(seed):
         # merges in the oracle — only the order of the additions differs (tests/test_gpu_render.py::test_reconstruction_filters)
         fk = [("gaussian", 2.0, 2.0, 0.0), ("mitchell", 2.0, 1 / 3, 1 / 3), ("triangle", 1.5, 0.0, 0.0), ("lanczos", 3.0, 3.0, 0.0)][int(rng.integers(0, 4))]
         kw["filter"] = pbrt_hip.filter_table(fk[0], fk[1], fk[1], fk[2], fk[3])
-    what = kind + (" +spheres" if "spheres" in sc else "") + (" instanced" if "instances" in sc else "")
+    what = kind + (" +spheres" if "spheres" in sc else "") + (" two-level" if "objects" in sc else " instanced" if "instances" in sc else "")
     what += (" +vertex data" if ("normals" in sc or "uvs" in sc or "tangents" in sc) else "")
     return sc, cam, w, h, spp, kw, gpu_only, opts, f"{what} scale {scale} tris {len(sc['indices'])} lights {len(sc['lights'])} {w}x{h}x{spp} {kw} {gpu_only} {opts}"
 
