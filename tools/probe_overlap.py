@@ -4,6 +4,7 @@ import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pbrt-rs_amd"))
 import pbrt_hip
+if os.environ.get("PBRT_LIB"): pbrt_hip.LIB_PATH = os.environ["PBRT_LIB"]
 from pbrt_hip import scenes
 W, H = 1920, 1080
 sc = scenes.random_triangles(1_000_000, seq=1)
