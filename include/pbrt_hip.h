@@ -169,7 +169,9 @@ typedef struct PbrtRenderParams {
      * (src/samplers/stratified.rs:22-40: sampler_x * sampler_y samples per pixel replace `spp`, sampler_jitter,
      * sampler_dims = n_sampled_dimensions) or PBRT_SAMPLER_ZEROTWO (src/samplers/zerotwosequence.rs:17-23:
      * `spp` is rounded up to a power of two, sampler_dims) or PBRT_SAMPLER_HALTON (src/samplers/halton.rs:63-98 over
-     * the film's sample bounds, sample_at_pixel_center = false). All zero = the random sampler. */
+     * the film's sample bounds, sample_at_pixel_center = false; a render whose sample arrays reach past the 1000 tabulated
+     * dimensions, where the reference panics on PRIME_SUMS (halton.rs:100-108), is refused with PBRT_HIP_INVALID).
+     * All zero = the random sampler. */
     int32_t sampler;
     int32_t sampler_x, sampler_y;
     int32_t sampler_jitter;

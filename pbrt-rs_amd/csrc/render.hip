@@ -645,7 +645,9 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         smp.n_arrays = (int)arrays.size();
         smp.array_end_dim = 5 + 2 * smp.n_arrays;  // sampler.rs:344-345
         if (rp.sampler == PBRT_SAMPLER_HALTON) {
-            if (smp.array_end_dim > 990) return invalid("Halton sampler: too many sample arrays for 1000 dimensions");
+            // start_pixel fills the arrays' dimensions 5..array_end_dim (sampler.rs:355-368); the first one past the
+            // prime table indexes PRIME_SUMS out of range (halton.rs:100-108) and the reference panics there
+            if (smp.array_end_dim > 1000) return invalid("Halton sampler: too many sample arrays for 1000 dimensions");
             elems = 0;
         }
         smp.n_elems = (int)elems;

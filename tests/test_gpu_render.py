@@ -373,6 +373,27 @@ def test_halton_wide_filter_and_deep_paths(hip_ctx):
     assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
 
 
+def test_halton_sample_arrays_up_to_the_last_tabulated_dimension(hip_ctx):
+    """uniform_sample_all_lights requests 2 * max_depth * n_lights 2-D arrays (directlighting.rs:64-75); start_pixel
+    fills dimensions 5 .. 5 + 2 * n_arrays (sampler.rs:344-368). 31 lights x depth 8 end at dimension 997 and render;
+    83 lights x depth 3 reach dimension 1000, where the reference panics on PRIME_SUMS (halton.rs:100-108): refused."""
+    w, h = 24, 16
+    rng = np.random.default_rng(7)
+    box = scenes.cornell_box()
+    pts = [scenes.point_light(tuple(rng.uniform(100.0, 450.0, 3)), (4e3, 4e3, 4e3)) for _ in range(83)]
+    sc = scenes.with_lights(box, pts[:31], keep_existing=False)
+    film_g, st_g, film_c, st_c = _render_both(hip_ctx, sc, scenes.cornell_camera(w, h), w, h, 2, integrator=1, max_depth=8,
+                                              light_strategy=0, seed=5, sampler=("halton",))
+    _compare(film_g, film_c)
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    g = pbrt_hip.Scene(hip_ctx, scenes.with_lights(box, pts, keep_existing=False))
+    with pytest.raises(pbrt_hip.PbrtHipError, match="too many sample arrays"):
+        g.render(scenes.cornell_camera(w, h), w, h, 2, integrator=1, max_depth=3, light_strategy=0, seed=5, sampler=("halton",))
+    film, _ = g.render(scenes.cornell_camera(w, h), w, h, 2, integrator=1, max_depth=3, light_strategy=1, seed=5, sampler=("halton",))
+    assert np.isfinite(film).all()          # one light per vertex needs no arrays: the same scene renders
+    g.close()
+
+
 @pytest.mark.parametrize("normals,uvs,tangents", [(True, False, False), (False, True, False), (True, True, False),
                                                   (False, False, True), (True, True, True)])
 @pytest.mark.parametrize("integrator,kw", [(0, dict(max_depth=5, light_strategy=1)), (1, dict(max_depth=3, light_strategy=0)),

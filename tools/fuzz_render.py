@@ -176,7 +176,7 @@ def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     ctx = pbrt_hip.Context(0)
-    bad, t0 = 0, time.time()
+    bad, refused, t0 = 0, 0, time.time()
     for seed in range(first, first + n_cases):
         sc, cam, w, h, spp, kw, gpu_only, opts, desc = make_case(seed)
         try:
@@ -236,12 +236,22 @@ def main():
                 fin = np.isfinite(err)
                 print(f"MISMATCH seed {seed}: {desc}\n   rays gpu {rays_g} cpu {st_c['rays']}; max err {err[fin].max() if fin.any() else None}; "
                       f"pixels off {(err > TOL_PIXEL * np.maximum(1.0, np.abs(rgb_c))).any(axis=-1).sum()} of {w * h}", flush=True)
+        except pbrt_hip.PbrtHipError as e:
+            # the one refusal the generator can reach: Halton sample arrays past the 1000 tabulated dimensions, where the
+            # reference panics in start_pixel (halton.rs:100-108 via sampler.rs:355-368) — expected exactly then
+            n_arrays = 2 * kw.get("max_depth", 5) * len(sc["lights"]) if (kw.get("integrator") == 1 and kw.get("light_strategy") == 0) else 0
+            if "too many sample arrays" in str(e) and kw.get("sampler", ("",))[0] == "halton" and 5 + 2 * n_arrays > 1000:
+                refused += 1
+            else:
+                bad += 1
+                print(f"ERROR seed {seed}: {desc}\n   {type(e).__name__}: {e}", flush=True)
         except Exception as e:  # noqa: BLE001
             bad += 1
             print(f"ERROR seed {seed}: {desc}\n   {type(e).__name__}: {e}", flush=True)
         if (seed - first + 1) % 50 == 0:
             print(f"... {seed - first + 1} cases, {bad} bad, {time.time() - t0:.0f} s", flush=True)
-    print(f"fuzz_render: {n_cases} cases from seed {first}: {bad} mismatching", flush=True)
+    print(f"fuzz_render: {n_cases} cases from seed {first}: {bad} mismatching"
+          + (f" ({refused} refused where the reference panics: Halton arrays past 1000 dimensions)" if refused else ""), flush=True)
     sys.exit(1 if bad else 0)
 
 
