@@ -333,6 +333,16 @@ int pbrt_hip_synchronize(PbrtHipContext* ctx);
  * since the last call with reset != 0, and their count. */
 int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* total_ms, uint64_t* launches);
 
+/* Which traversal kernel the context's intersect / render calls launch (src/accelerators/bvh.rs:828-932 in every case: same
+ * visiting order, same tests, same hits):
+ *   PBRT_TRAVERSAL_AUTO      the 4-wide quantised records where the scene has them, else the binary records with a stack;
+ *   PBRT_TRAVERSAL_STACK     the binary child-pair records with the per-lane stack (the reference's own form);
+ *   PBRT_TRAVERSAL_STACKLESS the binary records with parent links and a 64-bit trail instead of a stack — single-level
+ *                            triangle scenes only: calls on other scenes fail with PBRT_HIP_ERR_INVALID.
+ * AUTO is the fast one (DESIGN.md section 4.8 has all three on BASELINE config 3). */
+enum { PBRT_TRAVERSAL_AUTO = 0, PBRT_TRAVERSAL_STACK = 1, PBRT_TRAVERSAL_STACKLESS = 2 };
+int pbrt_hip_context_set_traversal(PbrtHipContext* ctx, int traversal);
+
 /* Instrumentation for the roofline accounting: when enabled, traversal launches
  * run an instrumented variant that counts the box tests (src/accelerators/bvh.rs:841-842) and
  * triangle tests (src/shapes/triangle.rs:74) the reference's loops perform for the same rays.

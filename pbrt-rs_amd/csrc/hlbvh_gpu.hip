@@ -558,7 +558,19 @@ __global__ void __launch_bounds__(kBlock) k_convert(const PbrtLinearBVHNode* __r
     r[2] = make_float4(c1.bounds_min[2], c1.bounds_max[0], c1.bounds_max[1], c1.bounds_max[2]);
     r[3] = make_float4(__int_as_float(child_ref(nodes, interior_index, i + 1, count_bits)),
                        __int_as_float(child_ref(nodes, interior_index, nd.offset, count_bits)), __int_as_float((int)nd.axis),
-                       __int_as_float(0));
+                       __int_as_float(-1));  // parent link: k_parent_links
+}
+// the record an interior node is a child of, into the fourth field of its last float4 (trace_stackless.h); the root keeps -1.
+// After k_convert: the two kernels write different words of a child's record, but k_convert writes the whole float4.
+__global__ void __launch_bounds__(kBlock) k_parent_links(const PbrtLinearBVHNode* __restrict__ nodes, int n_nodes,
+                                                         const int* __restrict__ interior_index, float4* __restrict__ inodes) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_nodes) return;
+    PbrtLinearBVHNode nd = nodes[i];
+    if (nd.n_primitives > 0) return;
+    const int me = interior_index[i];
+    if (nodes[i + 1].n_primitives == 0) ((int*)(inodes + 4 * (size_t)interior_index[i + 1] + 3))[3] = me;
+    if (nodes[nd.offset].n_primitives == 0) ((int*)(inodes + 4 * (size_t)interior_index[nd.offset] + 3))[3] = me;
 }
 __global__ void __launch_bounds__(kBlock) k_tri_records(const float* __restrict__ pos, const int* __restrict__ idx,
                                                         const int* __restrict__ order, const int* __restrict__ tri_material,
@@ -746,6 +758,8 @@ int hlbvh_build_scene_tree(PbrtHipContext* ctx, const float* positions, int32_t 
         return PBRT_HIP_ERR_INVALID;
     }
     hipLaunchKernelGGL(k_convert, dim3(blocks_for(n_nodes)), dim3(kBlock), 0, st, d_nodes, n_nodes, d_interior_index, count_bits,
+                       (float4*)p_inodes);
+    hipLaunchKernelGGL(k_parent_links, dim3(blocks_for(n_nodes)), dim3(kBlock), 0, st, d_nodes, n_nodes, d_interior_index,
                        (float4*)p_inodes);
     hipLaunchKernelGGL(k_tri_records, dim3(blocks_for(n)), dim3(kBlock), 0, st, d_pos, d_idx, d_order, d_mat, d_tl, n,
                        (float4*)p_tris, d_prim_slot);

@@ -18,6 +18,7 @@
 #include "trace.h"
 #include "trace_persistent.h"
 #include "trace_wide.h"
+#include "trace_stackless.h"
 
 using namespace pb;
 
@@ -131,6 +132,17 @@ extern "C" int pbrt_hip_set_counting(PbrtHipContext* ctx, int enable) {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(ctx);
     ctx->count_traversal = (enable == 1 || enable == 2) ? enable : 0;
+    return PBRT_HIP_OK;
+}
+
+extern "C" int pbrt_hip_context_set_traversal(PbrtHipContext* ctx, int traversal) {
+    if (!ctx) return PBRT_HIP_ERR_INVALID;
+    PB_ENTER(ctx);
+    if (traversal < PBRT_TRAVERSAL_AUTO || traversal > PBRT_TRAVERSAL_STACKLESS) {
+        ctx->last_error = "traversal must be PBRT_TRAVERSAL_AUTO, _STACK or _STACKLESS";
+        return PBRT_HIP_ERR_INVALID;
+    }
+    ctx->traversal = traversal;
     return PBRT_HIP_OK;
 }
 
@@ -272,6 +284,11 @@ static const char* convert_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes,
         return base + interior_index[node];
     };
     out->inodes.assign((size_t)n_interior * 16, 0.0f);
+    std::vector<int32_t> parent_record(n_nodes, -1);  // of interior nodes: the record holding them as a child (trace_stackless.h)
+    for (int32_t i = 0; i < n_nodes; ++i) {
+        if (interior_index[i] < 0) continue;
+        parent_record[i + 1] = parent_record[nodes[i].offset] = base + interior_index[i];
+    }
     for (int32_t i = 0; i < n_nodes; ++i) {
         if (interior_index[i] < 0) continue;
         const PbrtLinearBVHNode& c0 = nodes[i + 1];
@@ -281,7 +298,7 @@ static const char* convert_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes,
         r[3] = c0.bounds_max[0]; r[4] = c0.bounds_max[1]; r[5] = c0.bounds_max[2];
         r[6] = c1.bounds_min[0]; r[7] = c1.bounds_min[1]; r[8] = c1.bounds_min[2];
         r[9] = c1.bounds_max[0]; r[10] = c1.bounds_max[1]; r[11] = c1.bounds_max[2];
-        int32_t refs[4] = {child_ref(i + 1), child_ref(nodes[i].offset), (int32_t)nodes[i].axis, 0};
+        int32_t refs[4] = {child_ref(i + 1), child_ref(nodes[i].offset), (int32_t)nodes[i].axis, parent_record[i]};
         std::memcpy(r + 12, refs, 16);
     }
     out->n_interior = n_interior;
@@ -1073,6 +1090,13 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_I
                                                         blockIdx.x * kTraceBlock + threadIdx.x, counters);
 }
 
+// the binary records without a stack (trace_stackless.h)
+template <bool ANY>
+__global__ void __launch_bounds__(kTraceBlock, PB_STACKLESS_WAVES)
+    k_intersect_batch_stackless(DevBVH bvh, BatchRayIO<ANY> io, unsigned int* work_counter) {
+    trace_stackless<BatchRayIO<ANY>>(bvh, io, work_counter);
+}
+
 // the same batch over the 4-wide records (trace_wide.h), and the follow-up over the rays that kernel left out
 template <bool ANY, bool COUNT, int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES)
@@ -1099,7 +1123,9 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
         ctx->last_error = "batch too large for one launch (split it below 2^32 rays)";
         return PBRT_HIP_ERR_INVALID;
     }
-    const bool wide = s->has_wide && ctx->count_traversal != 1;
+    const bool wide = s->has_wide && ctx->count_traversal != 1 && ctx->traversal == PBRT_TRAVERSAL_AUTO;
+    const bool stackless = ctx->traversal == PBRT_TRAVERSAL_STACKLESS;
+    if (stackless && !stackless_applies(s)) return PBRT_HIP_ERR_INVALID;
     if (wide && ctx->special_capacity < (size_t)n) {  // room for the queue positions of the rays the wide kernel leaves out
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_special_list) (void)hipFree(ctx->d_special_list);
@@ -1123,7 +1149,9 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
                        wt, io, ctx->d_work_counter, ctx->d_counters)
 #define PB_LAUNCH_SPECIAL(INST) \
     hipLaunchKernelGGL((k_intersect_batch_special<ANY, INST>), grid, block, 0, ctx->stream, s->d.bvh, sio, ctx->d_work_counter + kFollowUpCounter)
-        if (wide) {
+        if (stackless) {
+            hipLaunchKernelGGL((k_intersect_batch_stackless<ANY>), dim3(stackless_grid(s)), block, 0, ctx->stream, s->d.bvh, io, ctx->d_work_counter);
+        } else if (wide) {
             WideTrees wt = s->wide;
             wt.special_list = ctx->d_special_list;
             wt.special_count = ctx->d_work_counter + kSpecialCount;

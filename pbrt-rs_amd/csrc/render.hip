@@ -563,7 +563,9 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         sort_tmp = buf.alloc<char>(sort_tmp_bytes, &ok);
     }
     // rays the wide kernel leaves to the binary one (wide_bvh.h): room for every entry of a trace queue
-    const bool use_wide = s->has_wide && ctx->count_traversal != 1;
+    const bool use_wide = s->has_wide && ctx->count_traversal != 1 && ctx->traversal == PBRT_TRAVERSAL_AUTO;
+    const bool stackless = ctx->traversal == PBRT_TRAVERSAL_STACKLESS;
+    if (stackless && !stackless_applies(s)) return PBRT_HIP_ERR_INVALID;
     uint32_t* special_list = use_wide ? buf.alloc<uint32_t>(N * 3, &ok) : nullptr;
     // sort-by-material shading (wf_path.h): PbrtRenderParams.shade_order; 2 = the whole shade queue in material order
     if (rp.shade_order < 0 || rp.shade_order > 2) return invalid("shade_order must be 0 (queue order), 1 (by material inside blocks) or 2 (sorted queue)");
@@ -849,7 +851,10 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
 #define PB_LAUNCH_SPECIAL(INST)                                                                                   \
     hipLaunchKernelGGL(k_trace_special<INST>, grid, block, 0, st, s->d.bvh, ps, trace_queue, n_trace, special_list, \
                        ctx->d_work_counter + kSpecialCount, ctx->d_work_counter + kFollowUpCounter)
-                    if (use_wide) {
+                    if (stackless) {
+                        hipLaunchKernelGGL(k_trace_stackless, dim3(stackless_grid(s)), block, 0, st, s->d.bvh, ps, trace_queue, n_trace,
+                                           ctx->d_work_counter, segments);
+                    } else if (use_wide) {
                         WideTrees wt = s->wide;
                         wt.special_list = special_list;
                         wt.special_count = ctx->d_work_counter + kSpecialCount;

@@ -47,6 +47,7 @@ struct PbrtHipContext {
     // 0 = off; 1 = the binary kernels count the reference's box / triangle tests; 2 = the wide kernels count their own
     // record / leaf / triangle fetches (pbrt_hip_set_counting)
     int count_traversal = 0;
+    int traversal = 0;  // PBRT_TRAVERSAL_*: pbrt_hip_context_set_traversal
     unsigned long long* d_counters = nullptr;  // [0..3] mode 1: node, prim, rays, instance tests; [4..7] mode 2
     uint64_t counted_rays = 0;
     // ray-queue heads of the persistent traversal kernels: [0, kQueueSegments) the launch's segments,
@@ -240,6 +241,19 @@ __host__ __device__ inline bool triangle_rejected_by_intersect(const float* a, c
 inline int persistent_grid(const PbrtHipScene* s, int waves = PB_TRACE_WAVES, int stack_lds = kStackLds, int other_lds_bytes = 0) {
     int per_cu = std::min(waves, (160 * 1024) / (stack_lds * kTraceBlock * (int)sizeof(uint2) + other_lds_bytes));
     return std::min(s->ctx->n_cus * per_cu, s->spill_lanes / kTraceBlock);
+}
+
+// the stackless walk (trace_stackless.h) keeps no LDS: its grid is set by the registers alone
+#ifndef PB_STACKLESS_WAVES
+#define PB_STACKLESS_WAVES 5  // 80 registers: 6 waves spill 11 of them (config 3 trace-only: 5 -> 1137, 6 -> 1110, 8 -> 963 Mrays/s)
+#endif
+inline int stackless_grid(const PbrtHipScene* s) { return s->ctx->n_cus * PB_STACKLESS_WAVES; }
+// PBRT_TRAVERSAL_STACKLESS covers single-level triangle scenes; sets last_error otherwise
+inline bool stackless_applies(const PbrtHipScene* s) {
+    if (!s->d.bvh.instanced && !s->d.bvh.has_spheres && s->ctx->count_traversal == 0) return true;
+    s->ctx->last_error = s->ctx->count_traversal ? "PBRT_TRAVERSAL_STACKLESS has no counting variant (pbrt_hip_set_counting)"
+                                                 : "PBRT_TRAVERSAL_STACKLESS: single-level triangle scenes only";
+    return false;
 }
 
 }  // namespace pb

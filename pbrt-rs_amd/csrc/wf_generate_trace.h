@@ -218,6 +218,13 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_I
                                                   blockIdx.x * kTraceBlock + threadIdx.x, counters);
 }
 
+// the binary records without a stack (trace_stackless.h; PBRT_TRAVERSAL_STACKLESS)
+__global__ void __launch_bounds__(kTraceBlock, PB_STACKLESS_WAVES)
+    k_trace_stackless(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter, int segments) {
+    WavefrontRayIO io{ps, queue, n, segments};
+    trace_stackless<WavefrontRayIO>(bvh, io, work_counter);
+}
+
 // the same wavefront over the 4-wide records (trace_wide.h) ...
 template <bool COUNT, int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WAVES : PB_WIDE_WAVES)

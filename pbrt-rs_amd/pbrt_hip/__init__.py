@@ -22,13 +22,14 @@ LIB_PATH = os.environ.get("PBRT_HIP_LIB") or os.path.join(_HERE, "libpbrt_hip.so
 SPLIT_SAH, SPLIT_HLBVH, SPLIT_MIDDLE, SPLIT_EQUAL_COUNTS = 0, 1, 2, 3
 INTEGRATOR_PATH, INTEGRATOR_DIRECT, INTEGRATOR_WHITTED, INTEGRATOR_AO = 0, 1, 2, 3
 SAMPLER_RANDOM, SAMPLER_STRATIFIED, SAMPLER_ZEROTWO, SAMPLER_HALTON = 0, 1, 2, 3
+TRAVERSAL_AUTO, TRAVERSAL_STACK, TRAVERSAL_STACKLESS = 0, 1, 2   # pbrt_hip_context_set_traversal
 
 EXPORTS = [
     "pbrt_hip_context_create", "pbrt_hip_context_destroy", "pbrt_hip_last_error", "pbrt_hip_bvh_build",
     "pbrt_hip_free", "pbrt_hip_bvh_build_boxes", "pbrt_hip_instance_bounds", "pbrt_hip_scene_create",
     "pbrt_hip_scene_create_instanced", "pbrt_hip_scene_create_with_spheres", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
     "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
-    "pbrt_hip_context_set_deadline",
+    "pbrt_hip_context_set_deadline", "pbrt_hip_context_set_traversal",
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
     "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png", "pbrt_hip_write_exr",
     "pbrt_hip_comm_unique_id", "pbrt_hip_comm_create", "pbrt_hip_comm_destroy", "pbrt_hip_film_reduce",
@@ -124,6 +125,7 @@ def lib():
         L.pbrt_hip_trace_timing.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_uint64)]
         L.pbrt_hip_set_counting.argtypes = [vp, ctypes.c_int]
+        L.pbrt_hip_context_set_traversal.argtypes = [vp, ctypes.c_int]
         L.pbrt_hip_get_counters.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64 * 4)]
         L.pbrt_hip_get_wide_counters.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64 * 4)]
         L.pbrt_hip_probe_gather.argtypes = [vp, i64, i32, i32, i32, ctypes.POINTER(ctypes.c_double)]
@@ -175,6 +177,11 @@ class Context:
         ms, n = ctypes.c_double(), ctypes.c_uint64()
         self.check(lib().pbrt_hip_trace_timing(self.h, int(reset), ctypes.byref(ms), ctypes.byref(n)), "trace_timing")
         return ms.value, n.value
+
+    def set_traversal(self, traversal):
+        """TRAVERSAL_AUTO (4-wide records where the scene has them), TRAVERSAL_STACK (binary records, per-lane stack) or
+        TRAVERSAL_STACKLESS (binary records, parent links + bit trail; single-level triangle scenes only)."""
+        self.check(lib().pbrt_hip_context_set_traversal(self.h, int(traversal)), "context_set_traversal")
 
     def set_counting(self, enable):
         """Instrumented traversal. True / 1: box / triangle test counts of the reference's loops (binary kernels);

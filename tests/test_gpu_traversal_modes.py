@@ -1,0 +1,176 @@
+"""pbrt_hip_context_set_traversal: the three traversal kernels compute BVHAccel::intersect / intersect_p
+(src/accelerators/bvh.rs:828-932) bit for bit — the 4-wide records (default), the binary records with a stack, and the
+binary records walked without one (parent links + a 64-bit trail, csrc/trace_stackless.h: the kernel BASELINE.json's
+north_star names). Every mode against the oracle, and against each other on the film."""
+import contextlib
+
+import numpy as np
+import pytest
+
+import oracle
+import pbrt_hip
+from pbrt_hip import scenes
+
+pytestmark = pytest.mark.gpu
+
+MODES = [pbrt_hip.TRAVERSAL_AUTO, pbrt_hip.TRAVERSAL_STACK, pbrt_hip.TRAVERSAL_STACKLESS]
+
+
+@contextlib.contextmanager
+def traversal(ctx, mode):
+    ctx.set_traversal(mode)
+    try:
+        yield
+    finally:
+        ctx.set_traversal(pbrt_hip.TRAVERSAL_AUTO)      # the context is shared by the session
+
+
+def _bits_equal(gpu, cpu, what):
+    for f in ("prim_id", "t", "b0", "b1", "b2"):
+        a, b = gpu[f], cpu[f]
+        if a.dtype.kind == "f":
+            a, b = a.view(np.uint32), b.view(np.uint32)
+        bad = np.flatnonzero(a != b)
+        assert len(bad) == 0, (what, f, bad[:5], gpu[bad[:3]], cpu[bad[:3]])
+
+
+def _aimed_rays(verts, idx, seed=7):
+    """Rays through every vertex, edge midpoint and centroid, a fifth of them with one direction component zeroed
+    (tests/test_gpu_intersect.py::test_t_max_that_moves_up_by_an_ulp)."""
+    tri = verts[idx]
+    targets = np.concatenate([tri.reshape(-1, 3), (tri[:, 0] + tri[:, 1]) * np.float32(0.5), tri.mean(axis=1)])
+    n = 3 * len(targets)
+    rays = scenes.random_rays(n, seed, origin_extent=2.0)
+    tgt = targets[np.arange(n) % len(targets)]
+    scale = np.maximum(np.abs(tgt).max(axis=1, keepdims=True), 1.0).astype(np.float32)
+    rays["o"] = (tgt + rays["o"] * scale).astype(np.float32)
+    rays["d"] = (tgt - rays["o"]).astype(np.float32)
+    k = np.arange(n)
+    par = k % 5 == 0
+    rays["d"][par, k[par] % 3] = 0.0
+    rays["d"][np.all(rays["d"] == 0, axis=1)] = (0.0, 0.0, 1.0)
+    return np.ascontiguousarray(rays)
+
+
+def _plain(verts, idx):
+    return dict(positions=verts, indices=idx, tri_material=np.zeros(len(idx), dtype=np.int32),
+                materials=scenes._materials([(1, (0.5, 0.5, 0.5), (0, 0, 0), 1.0)]),
+                tri_light=np.full(len(idx), -1, dtype=np.int32), lights=scenes._lights([]))
+
+
+def _fan_mesh():
+    g = np.array([[x, y, 0.0] for y in range(7) for x in range(7)], dtype=np.float32)
+    g[:, 2] = (np.sin(g[:, 0] * 1.3) + np.cos(g[:, 1] * 0.7)).astype(np.float32)
+    verts = (g * np.float32(333.0) + np.float32(-1000.0)).astype(np.float32)
+    quad = [(y * 7 + x, y * 7 + x + 1, (y + 1) * 7 + x + 1, (y + 1) * 7 + x) for y in range(6) for x in range(6)]
+    return verts, np.array([t for a, b, c, d in quad for t in ((a, b, c), (a, c, d))], dtype=np.int32)
+
+
+def _chain(n):
+    """SPLIT_MIDDLE peels one triangle off per level: a tree n levels deep (test_too_deep_tree_is_refused)."""
+    x = (3.0 ** np.arange(n)).astype(np.float32)
+    pos = np.zeros((3 * n, 3), dtype=np.float32)
+    pos[0::3, 0], pos[1::3, 0], pos[2::3, 0] = x, x, x
+    pos[1::3, 1], pos[2::3, 2] = 1e-3, 1e-3
+    return pos, np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+
+
+CASES = {
+    "cornell": lambda: (scenes.cornell_box(), 4, pbrt_hip.SPLIT_SAH, None),
+    "rand20k": lambda: (scenes.random_triangles(20_000, seq=3, size=0.05), 4, pbrt_hip.SPLIT_SAH, None),
+    "rand20k leaves of one": lambda: (scenes.random_triangles(20_000, seq=4, size=0.05), 1, pbrt_hip.SPLIT_EQUAL_COUNTS, None),
+    "mixed hlbvh": lambda: (scenes.mixed_materials_scene(), 4, pbrt_hip.SPLIT_HLBVH, None),
+    "one triangle": lambda: (_plain(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32),
+                                    np.array([[0, 1, 2]], dtype=np.int32)), 4, pbrt_hip.SPLIT_SAH, None),
+    "fan mesh (t_max moves up)": lambda: (_plain(*_fan_mesh()), 1, pbrt_hip.SPLIT_SAH, _aimed_rays(*_fan_mesh())),
+    "chain 64 levels deep": lambda: (_plain(*_chain(64)), 1, pbrt_hip.SPLIT_MIDDLE, None),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_every_traversal_is_the_reference_walk(hip_ctx, name):
+    sc, max_prims, split, rays = CASES[name]()
+    osc = oracle.OracleScene(sc, max_prims, split)
+    gsc = pbrt_hip.Scene(hip_ctx, sc, max_prims_in_node=max_prims, split_method=split)
+    if rays is None:
+        n = 60_000
+        rays = scenes.random_rays(n, 11, origin_extent=600.0 if name == "cornell" else 1.5)
+        if name == "cornell":
+            rays["o"] = np.abs(rays["o"]) * np.float32(0.9)
+        if name.startswith("chain"):
+            # along the chain (every level's box is entered), from both ends, and across it
+            rays["o"][:, 0] = np.where(np.arange(n) % 2 == 0, -1.0, 4e30).astype(np.float32)
+            rays["o"][:, 1:] *= np.float32(1e-3)
+            rays["d"] = np.where((np.arange(n) % 2 == 0)[:, None], [1.0, 0.0, 0.0], [-1.0, 0.0, 0.0]).astype(np.float32)
+            rays["d"][:, 1:] += (rays["o"][:, 1:] * np.float32(-1e-3)).astype(np.float32)
+        rays["t_max"][::4] = np.float32(300.0 if name == "cornell" else 0.75)
+        if name.startswith("chain"):
+            rays["t_max"][:] = np.inf
+    cpu, _ = osc.intersect(rays)
+    cpu_p, _ = osc.intersect_p(rays)
+    assert (cpu["prim_id"] >= 0).any()
+    for mode in MODES:
+        with traversal(hip_ctx, mode):
+            _bits_equal(gsc.intersect(rays), cpu, (name, mode))
+            assert np.array_equal(gsc.intersect_p(rays), cpu_p), (name, mode)
+    gsc.close()
+    osc.close()
+
+
+def test_stackless_on_a_device_built_tree(hip_ctx):
+    """The parent links of a tree built and laid out on the GPU (hlbvh_gpu.hip k_parent_links)."""
+    sc = scenes.random_triangles(50_000, seq=8, size=0.03)
+    osc = oracle.OracleScene(sc, split_method=pbrt_hip.SPLIT_HLBVH)
+    gsc = pbrt_hip.Scene(hip_ctx, sc, device_build=True)
+    rays = scenes.random_rays(80_000, 5, origin_extent=1.5)
+    cpu, _ = osc.intersect(rays)
+    for mode in MODES:
+        with traversal(hip_ctx, mode):
+            _bits_equal(gsc.intersect(rays), cpu, mode)
+    gsc.close()
+    osc.close()
+
+
+@pytest.mark.parametrize("integrator,kw", [(pbrt_hip.INTEGRATOR_PATH, dict(max_depth=6, light_strategy=1)),
+                                           (pbrt_hip.INTEGRATOR_DIRECT, dict(max_depth=3, light_strategy=0)),
+                                           (pbrt_hip.INTEGRATOR_AO, dict(ao_samples=4, cos_sample=True))])
+def test_the_film_does_not_depend_on_the_traversal(hip_ctx, integrator, kw):
+    """The wavefront renderer under each kernel: the same bits on the film, the same ray counts."""
+    w, h = 96, 64
+    sc, cam = scenes.mixed_materials_scene(), scenes.random_triangles_camera(w, h)
+    g = pbrt_hip.Scene(hip_ctx, sc)
+    out = []
+    for mode in MODES:
+        with traversal(hip_ctx, mode):
+            out.append(g.render(cam, w, h, 4, integrator=integrator, seed=17, **kw))
+    g.close()
+    assert out[0][0].tobytes() == out[1][0].tobytes() == out[2][0].tobytes()
+    assert len({(st["rays_closest"], st["rays_shadow"]) for _, st in out}) == 1
+    assert out[0][1]["rays_closest"] > w * h
+
+
+def test_stackless_refuses_what_it_does_not_cover(hip_ctx):
+    with pytest.raises(pbrt_hip.PbrtHipError, match="PBRT_TRAVERSAL"):
+        hip_ctx.set_traversal(3)
+    rays = scenes.random_rays(100, 1)
+    inst = pbrt_hip.Scene(hip_ctx, scenes.instanced_scene(200, 5, extent=1.5))
+    sph = pbrt_hip.Scene(hip_ctx, dict(scenes.cornell_box(), spheres=np.array([[250, 250, 250, 60, 0, -1, 0, 0]], dtype=np.float32)))
+    plain = pbrt_hip.Scene(hip_ctx, scenes.cornell_box())
+    with traversal(hip_ctx, pbrt_hip.TRAVERSAL_STACKLESS):
+        for g in (inst, sph):
+            with pytest.raises(pbrt_hip.PbrtHipError, match="single-level triangle scenes only"):
+                g.intersect(rays)
+            with pytest.raises(pbrt_hip.PbrtHipError, match="single-level triangle scenes only"):
+                g.intersect_p(rays)
+        with pytest.raises(pbrt_hip.PbrtHipError, match="single-level triangle scenes only"):
+            inst.render(scenes.instanced_camera(16, 16, 1.5), 16, 16, 1, max_depth=2)
+        hip_ctx.set_counting(1)
+        try:
+            with pytest.raises(pbrt_hip.PbrtHipError, match="no counting variant"):
+                plain.intersect(rays)
+        finally:
+            hip_ctx.set_counting(0)
+        assert len(plain.intersect(rays)) == 100
+    for g in (inst, sph, plain):
+        assert len(g.intersect(rays)) == 100          # back on TRAVERSAL_AUTO
+        g.close()

@@ -158,6 +158,13 @@ def main():
             ctx.set_counting(1)
             got["binary"] = (gsc.intersect(rays), gsc.intersect_p(rays))
             ctx.set_counting(0)
+            if "instances" not in sc and "objects" not in sc and "spheres" not in sc:
+                # the binary records walked without a stack (trace_stackless.h), on host- and device-built trees alike
+                ctx.set_traversal(pbrt_hip.TRAVERSAL_STACKLESS)
+                try:
+                    got["stackless"] = (gsc.intersect(rays), gsc.intersect_p(rays))
+                finally:
+                    ctx.set_traversal(pbrt_hip.TRAVERSAL_AUTO)
             if n_rec >= 0 and "instances" not in sc and "objects" not in sc and seed % 3 == 0:
                 # the device builder of the wide records (wide_gpu.hip) against the host builder (host_wide.cpp): same bytes
                 os.environ["PBRT_HIP_WIDE_BUILD"] = "host"

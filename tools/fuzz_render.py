@@ -157,7 +157,10 @@ def make_case(seed):
     gpu_only = dict(shade_order=int(rng.integers(0, 3)), spp_per_pass=int(rng.integers(0, 3)))   # must not change the film
     plain = "spheres" not in sc and "instances" not in sc and "objects" not in sc and "normals" not in sc and "uvs" not in sc and "tangents" not in sc
     opts = dict(device_build=bool(plain and rng.random() < 0.2),     # the tree built on the device (HLBVH) against the oracle's HLBVH
-                tile_split=int(rng.choice([1, 1, 2, 3])))              # the frame as the sum of the ranks' tile shares
+                tile_split=int(rng.choice([1, 1, 2, 3])),              # the frame as the sum of the ranks' tile shares
+                # pbrt_hip_context_set_traversal: wide records / binary + stack / binary stackless (single-level triangle scenes)
+                # (its own generator: the draws of the cases above stay what they were in profiles/r03_fuzz.txt)
+                traversal=int(np.random.default_rng(seed ^ 0x7ac3).choice([0, 0, 1, 2] if ("spheres" not in sc and "instances" not in sc and "objects" not in sc) else [0, 0, 1])))
     r_f = rng.random()
     if r_f < 0.3:
         x0, y0 = int(rng.integers(0, w // 2)), int(rng.integers(0, h // 2))
@@ -179,6 +182,7 @@ def main():
     bad, refused, t0 = 0, 0, time.time()
     for seed in range(first, first + n_cases):
         sc, cam, w, h, spp, kw, gpu_only, opts, desc = make_case(seed)
+        ctx.set_traversal(pbrt_hip.TRAVERSAL_AUTO)
         try:
             if opts["device_build"]:
                 osc = oracle.OracleScene(sc, split_method=pbrt_hip.SPLIT_HLBVH)
@@ -188,6 +192,7 @@ def main():
                 gsc = pbrt_hip.Scene(ctx, sc)
             okw = dict(kw)
             film_c, st_c = osc.render(scenes.camera_dict_to_floats(cam), w, h, spp, n_threads=4, **okw)
+            ctx.set_traversal(opts["traversal"])
             if opts["tile_split"] == 1:
                 film_g, st_g = gsc.render(cam, w, h, spp, **kw, **gpu_only)
             else:   # integrator.rs:412-477 over ranks: the films of the tile shares add up to the frame, their rays to its rays

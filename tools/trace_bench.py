@@ -12,6 +12,9 @@ cam = scenes.random_triangles_camera(W, H)
 ctx = pbrt_hip.Context(0)
 scene = pbrt_hip.Scene(ctx, sc)
 print("wide records:", scene.wide_records())
+mode = int(os.environ.get("TRAVERSAL", "0"))     # pbrt_hip.TRAVERSAL_*: 0 wide records, 1 binary + stack, 2 binary stackless
+ctx.set_traversal(mode)
+print("traversal:", {0: "auto (4-wide records)", 1: "binary records, stack", 2: "binary records, stackless"}[mode])
 for it in range(3):
     film, st = scene.render(cam, W, H, spp, max_depth=5, seed=0)
 rays = st["rays_closest"] + st["rays_shadow"]
