@@ -339,7 +339,7 @@ int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* total_ms, uint
  *   PBRT_TRAVERSAL_STACK     the binary child-pair records with the per-lane stack (the reference's own form);
  *   PBRT_TRAVERSAL_STACKLESS the binary records with parent links and a 64-bit trail instead of a stack — single-level
  *                            triangle scenes only: calls on other scenes fail with PBRT_HIP_ERR_INVALID.
- * AUTO is the fast one (DESIGN.md section 4.8 has all three on BASELINE config 3). */
+ * AUTO is the fast one (DESIGN.md section 4.6 has all three on BASELINE config 3). */
 enum { PBRT_TRAVERSAL_AUTO = 0, PBRT_TRAVERSAL_STACK = 1, PBRT_TRAVERSAL_STACKLESS = 2 };
 int pbrt_hip_context_set_traversal(PbrtHipContext* ctx, int traversal);
 

@@ -2,7 +2,7 @@
 //
 // BASELINE.json's north_star names "a stackless BVH traversal kernel"; this is that kernel, selected with
 // pbrt_hip_context_set_traversal(ctx, PBRT_TRAVERSAL_STACKLESS), parity-tested like the others and measured beside them
-// (DESIGN.md section 4.8). It is not the default: see the numbers there.
+// (DESIGN.md section 4.6). It is not the default: see the numbers there.
 //
 // What has to be preserved is the reference's ORDER (src/accelerators/bvh.rs:828-932): depth first, the child on the
 // ray's side of the split axis first (bvh.rs:857-865), the other child pushed untested and tested with the ray.t_max of
@@ -118,7 +118,17 @@ PB_DEV void trace_stackless(const DevBVH& bvh, const IO& io, unsigned int* __res
             }
             if (interior) {
                 const float4* nd = bvh.inodes + 4 * (size_t)s.cur;
-                float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+                // a lane climbing through a node whose far child is not pending needs the parent link only: one 16-B
+                // request instead of four (the kernel sits on the texture addressers). The condition is in registers, so
+                // the loads that are issued still go out together.
+                const bool pending = (trail & 1ull) != 0;
+                const float4 q3 = nd[3];
+                float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q1 = q0, q2 = q0;
+                if (!up || pending) {
+                    q0 = nd[0];
+                    q1 = nd[1];
+                    q2 = nd[2];
+                }
                 float e0, e1, unused;
                 bool h0 = slab_test(s.nx ? q0.w : q0.x, s.nx ? q0.x : q0.w, s.ny ? q1.x : q0.y, s.ny ? q0.y : q1.x,
                                     s.nz ? q1.y : q0.z, s.nz ? q0.z : q1.y, s.r, s.idx, s.idy, s.idz, s.tmax, &e0);
@@ -136,7 +146,6 @@ PB_DEV void trace_stackless(const DevBVH& bvh, const IO& io, unsigned int* __res
                 const bool far_keep = neg ? k0 : k1;
                 // down: near child first, the far one left as a bit; up: the far child if its bit is set and its box
                 // passes NOW (bvh.rs:841-842 at the pop), else one level higher
-                const bool pending = (trail & 1ull) != 0;
                 const bool go_near = !up && near_h;
                 const bool go_far = up ? (pending && far_h) : (!near_h && far_h);
                 if (go_near) {
