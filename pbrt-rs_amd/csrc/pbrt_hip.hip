@@ -1062,6 +1062,7 @@ struct BatchRayIO {
     uint8_t* __restrict__ out_flags;
     PB_DEV uint32_t n() const { return count; }
     PB_DEV int segments() const { return 1; }
+    PB_DEV uint32_t token(uint32_t i) const { return i; }  // a batch ray's token is its position
     PB_DEV bool load(uint32_t i, TravRay* r, bool* any) const {
         const float4* rp = reinterpret_cast<const float4*>(rays + i);
         float4 a = rp[0], b = rp[1];

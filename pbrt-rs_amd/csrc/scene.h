@@ -53,7 +53,7 @@ struct PbrtHipContext {
     // ray-queue heads of the persistent traversal kernels: [0, kQueueSegments) the launch's segments,
     // [kFollowUpCounter] the follow-up launch over the rays the wide kernel left out, [kSpecialCount] their number
     unsigned int* d_work_counter = nullptr;
-    uint32_t* d_special_list = nullptr;  // batch calls: queue positions of those rays (grown on demand)
+    uint32_t* d_special_list = nullptr;  // batch calls: tokens (IO::token) of those rays (grown on demand)
     size_t special_capacity = 0;
     // the render loop reads the queue lengths back once per wavefront: pinned landing buffer + an event the host
     // spins on (a blocking stream sync costs a scheduler wake-up per wavefront, milliseconds on a busy host)

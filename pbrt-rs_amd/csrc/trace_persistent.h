@@ -55,7 +55,7 @@ struct LaneState {
     float b0, b1, b2;
     int hit_slot;
     int cur, sp;
-    uint32_t index;  // queue position of this lane's ray
+    uint32_t index;  // token of this lane's ray (IO::token: the queue entry / batch position load and store name it by)
     bool nx, ny, nz, any, has_work;
 };
 // two-level state (INST)
@@ -96,7 +96,8 @@ PB_DEV bool root_box_test(const LaneState& s, const float* mn, const float* mx) 
                      s.nz ? mx[2] : mn[2], s.nz ? mn[2] : mx[2], s.r, s.idx, s.idy, s.idz, s.tmax, &e);
 }
 
-// IO policy: n(), segments(), load(i, &ray, &any) -> bool real ray, store(i, any, found, t, b0, b1, b2, slot, instance)
+// IO policy: n(), segments(), token(i) of queue position i, load(token, &ray, &any) -> bool real ray,
+// store(token, any, found, t, b0, b1, b2, slot, instance)
 // INST: 0 = one level; 1 = instances of ONE object aggregate and nothing beside them (config 5's shape: the object's root
 // rides in the kernel arguments); 2 = the general top level (several objects, world-space triangles beside the instances).
 // A template value rather than a run-time flag: with the general code compiled in, the 96-register build of the
@@ -257,8 +258,8 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
             uint32_t my = chunk_next + prefix;
             chunk_next += ((uint32_t)n_idle < avail) ? (uint32_t)n_idle : avail;
             if (take) {
-                s.index = my;
-                bool real = io.load(my, &s.r, &s.any);
+                s.index = io.token(my);
+                bool real = io.load(s.index, &s.r, &s.any);
                 s.tmax = s.r.tmax;
                 s.hit_slot = -1;
                 s.b0 = s.b1 = s.b2 = 0.0f;

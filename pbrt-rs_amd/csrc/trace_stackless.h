@@ -83,8 +83,8 @@ PB_DEV void trace_stackless(const DevBVH& bvh, const IO& io, unsigned int* __res
             uint32_t my = chunk_next + prefix;
             chunk_next += ((uint32_t)n_idle < avail) ? (uint32_t)n_idle : avail;
             if (take) {
-                s.index = my;
-                bool real = io.load(my, &s.r, &s.any);
+                s.index = io.token(my);
+                bool real = io.load(s.index, &s.r, &s.any);
                 s.tmax = s.r.tmax;
                 s.hit_slot = -1;
                 s.b0 = s.b1 = s.b2 = 0.0f;

@@ -68,8 +68,9 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
     return __builtin_popcount((uint32_t)m) + __builtin_popcount((uint32_t)(m >> 32));
 }
 
-// The rays trace_wide left to the binary kernel, as an IO policy of trace_persistent: ray i of this launch is ray
-// list[i] of the original queue; their number is read from device memory (the wide launch counted them).
+// The rays trace_wide left to the binary kernel, as an IO policy of trace_persistent: ray i of this launch is the ray
+// whose token (the IO's own: queue entry / batch position) is list[i]; their number is read from device memory (the wide
+// launch counted them).
 template <class Inner>
 struct SpecialListIO {
     Inner inner;
@@ -77,9 +78,10 @@ struct SpecialListIO {
     const unsigned int* __restrict__ count;
     PB_DEV uint32_t n() const { return *count; }
     PB_DEV int segments() const { return 1; }
-    PB_DEV bool load(uint32_t i, TravRay* r, bool* any) const { return inner.load(list[i], r, any); }
-    PB_DEV void store(uint32_t i, bool any, bool found, float t, float b0, float b1, float b2, int slot, int inst) const {
-        inner.store(list[i], any, found, t, b0, b1, b2, slot, inst);
+    PB_DEV uint32_t token(uint32_t i) const { return list[i]; }
+    PB_DEV bool load(uint32_t tok, TravRay* r, bool* any) const { return inner.load(tok, r, any); }
+    PB_DEV void store(uint32_t tok, bool any, bool found, float t, float b0, float b1, float b2, int slot, int inst) const {
+        inner.store(tok, any, found, t, b0, b1, b2, slot, inst);
     }
 };
 
@@ -106,7 +108,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     TravRay r;
     float idx = 0.0f, idy = 0.0f, idz = 0.0f, tmax = 0.0f, hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
     int hit_slot = -1, sp = 0;
-    uint32_t index = 0;
+    uint32_t index = 0;  // the ray's token (IO::token): what load, store and the special list name it by
     bool nx = false, ny = false, nz = false, any = false;
     uint32_t negmask = 0;
     r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.tmax = 0.0f;
@@ -337,8 +339,8 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             chunk_next += ((uint32_t)n_idle < avail) ? (uint32_t)n_idle : avail;
             bool special = false;
             if (take) {
-                index = my;
-                bool real = io.load(my, &r, &any);
+                index = io.token(my);
+                bool real = io.load(index, &r, &any);
                 tmax = r.tmax;
                 hit_slot = -1;
                 hb0 = hb1 = hb2 = 0.0f;

@@ -165,8 +165,11 @@ struct WavefrontRayIO {
     int n_segments;
     PB_DEV uint32_t n() const { return count; }
     PB_DEV int segments() const { return n_segments; }
-    PB_DEV bool load(uint32_t i, TravRay* r, bool* any) const {
-        uint32_t e = queue[i];
+    // The traversal kernels keep a ray's TOKEN from load to store — here the queue entry itself (path << 2 | ray slot), not
+    // its position: the store then needs no second look at the queue (one dependent load less in the refill path every
+    // idle lane of the wave waits in).
+    PB_DEV uint32_t token(uint32_t i) const { return queue[i]; }
+    PB_DEV bool load(uint32_t e, TravRay* r, bool* any) const {
         uint32_t p = e >> 2, slot = e & 3u;
         size_t ri = ray_index(ps, p, slot);
         float4 a = ps.ray[ri], b = ps.ray[ri + 1];
@@ -175,8 +178,7 @@ struct WavefrontRayIO {
         // t_max < 0 marks the placeholder ray of a path outside pixel_bounds (k_generate): not a ray of the frame
         return !(b.z < 0.0f);
     }
-    PB_DEV void store(uint32_t i, bool any, bool found, float t, float b0, float b1, float b2, int slot, int inst) const {
-        uint32_t e = queue[i];
+    PB_DEV void store(uint32_t e, bool any, bool found, float t, float b0, float b1, float b2, int slot, int inst) const {
         uint32_t p = e >> 2, rs = e & 3u;
         size_t ri = hit_index(ps, p, rs);
         if (any) {

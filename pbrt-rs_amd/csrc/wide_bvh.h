@@ -120,7 +120,7 @@ struct WideTrees {
     int root_ref;
     uint2* __restrict__ spill;  // [entry][global lane]
     int spill_stride;
-    uint32_t* __restrict__ special_list;  // queue positions of the rays left to the binary kernel
+    uint32_t* __restrict__ special_list;  // tokens (IO::token) of the rays left to the binary kernel
     unsigned int* __restrict__ special_count;
     // two-level scenes: `nodes` holds the top-level tree's records, then every object aggregate's; the leaves of the
     // top-level tree hold top-level primitives in wide order:
