@@ -516,6 +516,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     bool ok = true;
     PathState ps;
     ps.n_paths = N;
+    ps.two_level = s->d.bvh.instanced ? 1 : 0;
     ps.ray = buf.alloc<float4>(N * 6, &ok);
     ps.hit = buf.alloc<float4>(N * 6, &ok);
     ps.rng = buf.alloc<uint64_t>(N, &ok);

@@ -104,9 +104,9 @@ __global__ void __launch_bounds__(256, PB_DIRECT_WAVES) k_shade_direct(ShadeCons
         auto load_surface = [&]() {
             float4 r0 = ps.ray[rbase], r1 = ps.ray[rbase + 1];
             rd = V3{r0.w, r1.x, r1.y};
-            float4 h0 = ps.hit[hbase], h1 = ps.hit[hbase + 1];
-            int hslot = __float_as_int(h1.x);
-            sf = surface_from_hit(sc.bvh, hslot, __float_as_int(h1.y), h0.y, h0.z, h0.w, rd);
+            float4 h0 = ps.hit[hbase];
+            int hslot = __float_as_int(h0.x);
+            sf = surface_from_hit(sc.bvh, hslot, hit_instance(ps, hbase), h0.y, h0.z, h0.w, rd);
             mat = sc.materials[sf.material];
             fr = make_frame(sf);
             kd = V3{mat.kd[0], mat.kd[1], mat.kd[2]};
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256, PB_DIRECT_WAVES) k_shade_direct(ShadeCons
             if (!have_vertex) {
                 // ---- arrive at the hit of the continuation ray: directlighting.rs:86-106 ----
                 flags &= ~PF_ALIVE;
-                int hslot = __float_as_int(ps.hit[hbase + 1].x);
+                int hslot = __float_as_int(ps.hit[hbase].x);
                 if (hslot < 0) {
                     float4 r0 = ps.ray[rbase];
                     (void)r0;
@@ -275,9 +275,8 @@ __global__ void __launch_bounds__(256, PB_DIRECT_WAVES) k_shade_direct(ShadeCons
                         size_t fi = ((size_t)p * pp.max_depth + sp) * 3;
                         float4 h0 = ps.hit[hbase];
                         ds.frames[fi] = make_float4(rd.x, rd.y, rd.z, h0.y);
-                        float4 h1 = ps.hit[hbase + 1];
-                        ds.frames[fi + 1] = make_float4(h0.z, h0.w, h1.x, __int_as_float(depth));
-                        ds.frames[fi + 2] = make_float4(T.x, T.y, T.z, h1.y);
+                        ds.frames[fi + 1] = make_float4(h0.z, h0.w, h0.x, __int_as_float(depth));
+                        ds.frames[fi + 2] = make_float4(T.x, T.y, T.z, __int_as_float(hit_instance(ps, hbase)));
                         sp += 1;
                     }
                     T = mulv(T, f * (ad / pdf));
@@ -302,8 +301,8 @@ __global__ void __launch_bounds__(256, PB_DIRECT_WAVES) k_shade_direct(ShadeCons
             float4 r0 = ps.ray[rbase];
             ps.ray[rbase] = make_float4(r0.x, r0.y, r0.z, f0.x);
             ps.ray[rbase + 1] = make_float4(f0.y, f0.z, kInf, 0.0f);
-            ps.hit[hbase] = make_float4(0.0f, f0.w, f1.x, f1.y);
-            ps.hit[hbase + 1] = make_float4(f1.z, f2.w, 0.0f, 0.0f);
+            ps.hit[hbase] = make_float4(f1.z, f0.w, f1.x, f1.y);
+            if (ps.two_level) ps.hit[hbase + 1] = make_float4(f2.w, 0.0f, 0.0f, 0.0f);
             depth = __float_as_int(f1.w);
             T = V3{f2.x, f2.y, f2.z};
             stage = total + 1;  // transmit branch

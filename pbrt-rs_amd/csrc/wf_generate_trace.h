@@ -158,6 +158,8 @@ __global__ void k_camera_rays_out(PathState ps, PassParams pp, TileList tiles, P
 }
 
 // ---- trace: every pending ray of the wavefront (trace_persistent.h) ----
+// TWO_LEVEL: the scene has instances — hit records carry the instance slot in a second float4 (wf_state.h)
+template <bool TWO_LEVEL>
 struct WavefrontRayIO {
     PathState ps;
     const uint32_t* __restrict__ queue;
@@ -184,8 +186,9 @@ struct WavefrontRayIO {
         if (any) {
             ps.hit[ri] = make_float4(found ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
         } else {
-            ps.hit[ri] = make_float4(t, b0, b1, b2);
-            ps.hit[ri + 1] = make_float4(__int_as_float(found ? slot : -1), __int_as_float(inst), 0.0f, 0.0f);
+            (void)t;
+            ps.hit[ri] = make_float4(__int_as_float(found ? slot : -1), b0, b1, b2);
+            if (TWO_LEVEL) ps.hit[ri + 1] = make_float4(__int_as_float(inst), 0.0f, 0.0f, 0.0f);
         }
     }
 };
@@ -215,16 +218,16 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_I
     k_trace(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
             unsigned long long* counters, int segments) {
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
-    WavefrontRayIO io{ps, queue, n, segments};
-    trace_persistent<WavefrontRayIO, COUNT, INST, SPH>(bvh, io, work_counter, lds_stack + threadIdx.x,
+    WavefrontRayIO<INST != 0> io{ps, queue, n, segments};
+    trace_persistent<WavefrontRayIO<INST != 0>, COUNT, INST, SPH>(bvh, io, work_counter, lds_stack + threadIdx.x,
                                                   blockIdx.x * kTraceBlock + threadIdx.x, counters);
 }
 
 // the binary records without a stack (trace_stackless.h; PBRT_TRAVERSAL_STACKLESS)
 __global__ void __launch_bounds__(kTraceBlock, PB_STACKLESS_WAVES)
     k_trace_stackless(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter, int segments) {
-    WavefrontRayIO io{ps, queue, n, segments};
-    trace_stackless<WavefrontRayIO>(bvh, io, work_counter);
+    WavefrontRayIO<false> io{ps, queue, n, segments};
+    trace_stackless<WavefrontRayIO<false>>(bvh, io, work_counter);
 }
 
 // the same wavefront over the 4-wide records (trace_wide.h) ...
@@ -234,8 +237,8 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WA
                  int segments, unsigned long long* counters) {
     __shared__ uint2 lds_stack[wide_stack_lds(INST) * kTraceBlock];
     __shared__ float lds_world[INST ? kWideWorldFloats * kTraceBlock : 1];
-    WavefrontRayIO io{ps, queue, n, segments};
-    trace_wide<WavefrontRayIO, COUNT, INST>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x,
+    WavefrontRayIO<INST != 0> io{ps, queue, n, segments};
+    trace_wide<WavefrontRayIO<INST != 0>, COUNT, INST>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x,
                                             counters, lds_world + (INST ? threadIdx.x : 0));
 }
 // ... and the rays it left to the binary records (axis-parallel directions and the like; usually none)
@@ -249,8 +252,8 @@ __global__ void __launch_bounds__(kTraceBlock, INST ? PB_INST_WAVES : PB_TRACE_W
     // are enough: a persistent wave keeps grabbing chunks until the list is exhausted.
     if ((unsigned long long)blockIdx.x * (kTraceBlock / 64) * kChunk >= (unsigned long long)*count) return;
     __shared__ uint2 lds_stack[kStackLds * kTraceBlock];
-    SpecialListIO<WavefrontRayIO> io{WavefrontRayIO{ps, queue, n, 1}, list, count};
-    trace_persistent<SpecialListIO<WavefrontRayIO>, false, INST, false>(bvh, io, work_counter, lds_stack + threadIdx.x,
+    SpecialListIO<WavefrontRayIO<INST != 0>> io{WavefrontRayIO<INST != 0>{ps, queue, n, 1}, list, count};
+    trace_persistent<SpecialListIO<WavefrontRayIO<INST != 0>>, false, INST, false>(bvh, io, work_counter, lds_stack + threadIdx.x,
                                                                         blockIdx.x * kTraceBlock + threadIdx.x, nullptr);
 }
 

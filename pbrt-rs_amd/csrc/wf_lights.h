@@ -382,7 +382,7 @@ PB_DEV V3 estimate_direct_resolve(const ShadeConsts& sc, const PathState& ps, ui
         if (!occluded) ld = ld + V3{na.x, na.y, na.z};
     }
     if (flags & PF_NEE_MIS) {
-        int hslot = __float_as_int(ps.hit[hit_index(ps, p, RS_MIS) + 1].x);
+        int hslot = __float_as_int(ps.hit[hit_index(ps, p, RS_MIS)].x);
         float4 r0 = ps.ray[ray_index(ps, p, RS_MIS)], r1 = ps.ray[ray_index(ps, p, RS_MIS) + 1];
         V3 wi = V3{r0.w, r1.x, r1.y};
         DevLight lt = sc.lights[light_id];

@@ -18,8 +18,8 @@ PB_DEV uint32_t shade_key(const ShadeConsts& sc, const PathState& ps, uint32_t p
     int fb = __float_as_int(ps.beta[p].w);
     uint32_t key = 0;
     if ((fb & PF_ALIVE) && (fb >> 8) < max_depth) {
-        float4 h1 = ps.hit[hit_index(ps, p, RS_CONT) + 1];
-        int slot = __float_as_int(h1.x), inst = __float_as_int(h1.y);
+        const size_t hb = hit_index(ps, p, RS_CONT);
+        int slot = __float_as_int(ps.hit[hb].x), inst = hit_instance(ps, hb);
         if (slot >= 0) {
             int mat = __float_as_int(sc.bvh.tris[3 * (size_t)slot + 2].z);
             if (sc.bvh.instanced && inst >= 0) {
@@ -117,12 +117,11 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
             float4 r0 = ps.ray[rbase], r1 = ps.ray[rbase + 1];
             V3 rd = V3{r0.w, r1.x, r1.y};
             float4 h0 = ps.hit[hbase];
-            float4 h1 = ps.hit[hbase + 1];
-            int hslot = __float_as_int(h1.x);
+            int hslot = __float_as_int(h0.x);
             bool found = hslot >= 0;
             Surf sf;
             if (found) {
-                sf = surface_from_hit(sc.bvh, hslot, __float_as_int(h1.y), h0.y, h0.z, h0.w, rd);
+                sf = surface_from_hit(sc.bvh, hslot, hit_instance(ps, hbase), h0.y, h0.z, h0.w, rd);
                 if (qout.keys) cell = ray_sort_cell(sf.p.x, sf.p.y, sf.p.z, qout.key_lo, qout.key_inv);
             }
             // path.rs:80-88

@@ -22,7 +22,11 @@ enum RaySlot : int { RS_CONT = 0, RS_MIS = 1, RS_SHADOW = 2 };
 
 struct PathState {
     float4* ray;     // [ray_index(p, slot) + k]: (o.xyz, d.x) (d.yz, t_max, -)
-    float4* hit;     // [ray_index(p, slot) + k]: (t, b0, b1, b2) (slot, -, -, -); shadow slot: .x = occluded
+    // [hit_index(p, slot)]: (leaf slot of the hit or -1 as int bits, b0, b1, b2) — t is not kept: nothing downstream reads it
+    // (the hit point comes from the barycentrics, triangle.rs:160-178) and ONE 16-B store per closest-hit ray is one memory
+    // instruction less on the traversal kernel's refill path; [.. + 1]: (instance slot, -, -, -), written and read in two-level
+    // scenes only; shadow slot: .x = occluded
+    float4* hit;
     size_t n_paths;  // paths of a pass (the stride between the three slots' arrays)
     uint64_t* rng;   // PCG32 state (inc is recomputed from the sample index)
     float4* L;       // L.rgb, eta_scale
@@ -33,7 +37,10 @@ struct PathState {
     int* nee_light;  // light index of the pending estimate
     float2* pfilm;   // CameraSample::p_film
     int* samp;       // sampler counters: current_1d_dimension (Halton: dimension) | current_2d_dimension << 10 | array_2d_offset << 16
+    int two_level;   // the scene has instances: hit records carry the instance slot in their second float4
 };
+// the instance slot of a hit record (-1: none)
+PB_DEV int hit_instance(const PathState& ps, size_t hit_base) { return ps.two_level ? __float_as_int(ps.hit[hit_base + 1].x) : -1; }
 
 // Rays and hit records are kept slot-major, [slot][path][2 x float4]: the lanes of a wave that write (k_generate,
 // k_shade) or read (the unsorted wavefronts of k_trace) the same slot of consecutive paths touch consecutive 32-B
