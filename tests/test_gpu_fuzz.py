@@ -1,5 +1,5 @@
 """A slice of the fuzz campaigns of tools/fuzz_intersect.py and tools/fuzz_render.py in the suite (the full campaigns:
-profiles/r03_fuzz.txt — 217 500 / 576 500 cases). Random shared-vertex meshes with rays aimed at their vertices and edges, wide,
+profiles/r03_fuzz.txt — 225 500 / 626 500 cases). Random shared-vertex meshes with rays aimed at their vertices and edges, wide,
 binary and stackless kernels against the oracle bit for bit; random small scenes through every integrator / sampler / light kind, films against
 the oracle. Seeds are fixed, so a failure names its case."""
 import os
