@@ -198,9 +198,17 @@ typedef struct PbrtRenderStats {
  * Order of destruction: scenes and communicators (pbrt_hip_comm_destroy takes the context's lock and device) before
  * their context. A call that gives up on a kernel (the 120 s wavefront deadline of pbrt_hip_render / pbrt_hip_li)
  * leaves the context LOST: every later call on it fails with PBRT_HIP_ERR_DEVICE, its device buffers are never
- * reused, and pbrt_hip_context_destroy then releases the host side only. */
+ * reused, and pbrt_hip_context_destroy then releases the host side only. What a lost context held on the device — its
+ * block cache (tens of GB after a large frame), the buffers of the abandoned call, its scenes (pbrt_hip_scene_destroy and
+ * pbrt_hip_comm_destroy after the loss release their host side only, in either order with the context) — goes back
+ * with the PROCESS, not before: a long-lived host should ask pbrt_hip_context_is_lost after a PBRT_HIP_ERR_DEVICE and,
+ * if so, finish in a fresh child process or exit non-zero. The caller's own device buffers of the abandoned *_device
+ * call (d_film, d_rgb, d_rays, d_stream_keys) may still be written or read by the kernel that never finished: they must
+ * not be freed (hipFree waits for the device) or reused either. */
 int pbrt_hip_context_create(int device_id, PbrtHipContext** out);
 void pbrt_hip_context_destroy(PbrtHipContext* ctx);
+/* 1 when a call on this context ran into the wavefront deadline (see above), else 0; -1 for NULL. Takes no lock. */
+int pbrt_hip_context_is_lost(const PbrtHipContext* ctx);
 /* How long pbrt_hip_render / pbrt_hip_li wait for one wavefront before they give the context up for lost (default 120 s; a
  * profiler or a debug build may need more, a service less). seconds > 0. */
 int pbrt_hip_context_set_deadline(PbrtHipContext* ctx, double seconds);

@@ -18,6 +18,7 @@
 #include "trace.h"
 #include "trace_persistent.h"
 #include "trace_wide.h"
+#include "trace_wide_any.h"
 #include "trace_stackless.h"
 
 using namespace pb;
@@ -97,6 +98,8 @@ extern "C" void pbrt_hip_context_destroy(PbrtHipContext* ctx) {
     if (ctx->d_halton_perms) (void)hipFree(ctx->d_halton_perms);
     delete ctx;
 }
+
+extern "C" int pbrt_hip_context_is_lost(const PbrtHipContext* ctx) { return ctx ? (ctx->lost ? 1 : 0) : -1; }
 
 extern "C" int pbrt_hip_context_set_deadline(PbrtHipContext* ctx, double seconds) {
     if (!ctx || !(seconds > 0.0)) return PBRT_HIP_ERR_INVALID;
@@ -1063,6 +1066,7 @@ struct BatchRayIO {
     PB_DEV uint32_t n() const { return count; }
     PB_DEV int segments() const { return 1; }
     PB_DEV uint32_t token(uint32_t i) const { return i; }  // a batch ray's token is its position
+    PB_DEV bool strict(uint32_t) const { return false; }   // pbrt_hip_intersect_p is Primitive::intersect_p
     PB_DEV bool load(uint32_t i, TravRay* r, bool* any) const {
         const float4* rp = reinterpret_cast<const float4*>(rays + i);
         float4 a = rp[0], b = rp[1];
@@ -1106,6 +1110,13 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WA
     __shared__ float lds_world[INST ? kWideWorldFloats * kTraceBlock : 1];
     trace_wide<BatchRayIO<ANY>, COUNT, INST>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x,
                                              counters, lds_world + (INST ? threadIdx.x : 0));
+}
+// Primitive::intersect_p over the 4-wide records of a one-level scene: the order-free walk (trace_wide_any.h)
+template <bool COUNT>
+__global__ void __launch_bounds__(kTraceBlock, COUNT ? PB_WIDE_INST_WAVES : PB_ANY_WAVES)
+    k_intersect_batch_wide_any(WideTrees wt, BatchRayIO<true> io, unsigned int* work_counter, unsigned long long* counters) {
+    __shared__ uint32_t lds_stack[kAnyStackLds * kTraceBlock];
+    trace_wide_any<BatchRayIO<true>, COUNT>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x, counters);
 }
 template <bool ANY, int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, INST ? PB_INST_WAVES : PB_TRACE_WAVES)
@@ -1163,6 +1174,15 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
             } else if (inst == 1) {
                 if (count_wide) PB_LAUNCH_WIDE(true, 1); else PB_LAUNCH_WIDE(false, 1);
                 PB_LAUNCH_SPECIAL(1);
+            } else if (ANY) {
+                if constexpr (ANY) {
+                    const dim3 any_grid(persistent_grid(s, count_wide ? PB_WIDE_INST_WAVES : PB_ANY_WAVES, (kAnyStackLds + 1) / 2));
+                    if (count_wide)
+                        hipLaunchKernelGGL(k_intersect_batch_wide_any<true>, any_grid, block, 0, ctx->stream, wt, io, ctx->d_work_counter, ctx->d_counters);
+                    else
+                        hipLaunchKernelGGL(k_intersect_batch_wide_any<false>, any_grid, block, 0, ctx->stream, wt, io, ctx->d_work_counter, ctx->d_counters);
+                }
+                PB_LAUNCH_SPECIAL(0);
             } else {
                 if (count_wide) PB_LAUNCH_WIDE(true, 0); else PB_LAUNCH_WIDE(false, 0);
                 PB_LAUNCH_SPECIAL(0);

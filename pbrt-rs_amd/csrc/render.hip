@@ -17,11 +17,15 @@
 #include "trace.h"
 #include "wavefront.h"
 
-#ifndef PB_SHADE_SPLIT
-#define PB_SHADE_SPLIT 0
-#endif
-
 using namespace pb;
+
+// measurement switches of the boolean-ray path (profiles/r04_wide_kernel_ladder.txt); the product is built with both on
+#ifndef PB_MIS_BOOL
+#define PB_MIS_BOOL 1   // MIS rays towards non-area lights are queued as RS_MIS_BOOL (wf_state.h)
+#endif
+#ifndef PB_ANY_SPLIT
+#define PB_ANY_SPLIT 1  // the boolean rays at the end of a sorted queue go to trace_wide_any
+#endif
 
 // ------------------------------------------------------------------------------------
 // render: see wavefront.h
@@ -47,7 +51,8 @@ extern "C" int pbrt_hip_render(PbrtHipScene* s, const PbrtCamera* camera, const 
     int rc = wavefront_render(s, *camera, *params, d_film, stats);
     if (rc == PBRT_HIP_OK && !hip_ok(ctx, hipMemcpy(film_xyzw, d_film, bytes, hipMemcpyDeviceToHost), "film D2H"))
         rc = PBRT_HIP_ERR_DEVICE;
-    (void)hipFree(d_film);
+    // after a deadline (ctx->lost) an abandoned kernel may still write the film and hipFree waits for the device: it stays
+    if (!ctx->lost) (void)hipFree(d_film);
     return rc;
 }
 
@@ -111,9 +116,11 @@ extern "C" int pbrt_hip_li(PbrtHipScene* s, const PbrtLiParams* lp, const PbrtRa
     if (rc == PBRT_HIP_OK) rc = pbrt_hip_li_device(s, lp, d_rays, d_keys, n, d_rgb, stats);
     if (rc == PBRT_HIP_OK && !hip_ok(ctx, hipMemcpy(rgb, d_rgb, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost), "D2H"))
         rc = PBRT_HIP_ERR_DEVICE;
-    (void)hipFree(d_rays);
-    (void)hipFree(d_keys);
-    (void)hipFree(d_rgb);
+    if (!ctx->lost) {  // as pbrt_hip_render: what an abandoned kernel may still touch is never freed
+        (void)hipFree(d_rays);
+        (void)hipFree(d_keys);
+        (void)hipFree(d_rgb);
+    }
     return rc;
 }
 
@@ -148,10 +155,12 @@ extern "C" int pbrt_hip_camera_rays(PbrtHipScene* s, const PbrtCamera* camera, c
                               !hip_ok(ctx, hipMemcpy(p_film, b.out_pfilm, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost), "D2H") ||
                               !hip_ok(ctx, hipMemcpy(pixel_sample, b.out_pixel_sample, (size_t)n * 3 * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H")))
         rc = PBRT_HIP_ERR_DEVICE;
-    (void)hipFree(b.out_rays);
-    (void)hipFree(b.out_keys);
-    (void)hipFree(b.out_pfilm);
-    (void)hipFree(b.out_pixel_sample);
+    if (!ctx->lost) {
+        (void)hipFree(b.out_rays);
+        (void)hipFree(b.out_keys);
+        (void)hipFree(b.out_pfilm);
+        (void)hipFree(b.out_pixel_sample);
+    }
     return rc;
 }
 
@@ -717,6 +726,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     sc.total_light_samples = prefix.back();
     sc.spatial = nullptr;
     sc.n_voxel[0] = sc.n_voxel[1] = sc.n_voxel[2] = 1;
+    sc.mis_bool = (PB_MIS_BOOL && ctx->count_traversal != 1) ? 1 : 0;  // wf_state.h: RS_MIS_BOOL
     if (rp.integrator == PBRT_INTEGRATOR_PATH && rp.light_strategy == 2 && s->d.n_lights > 1) {
         // create_light_sample_distribution("spatial") -> SpatialLightDistribution::new(scene, 64) (lightdistrib.rs:85-107, 228)
         if (!s->d_spatial) {
@@ -815,11 +825,13 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         local.rays_closest += (uint64_t)valid_pixels * pp.n_samples;
         bool first = true;
         int wavefront = 0;  // 0 = camera rays, 1 = first bounce + its shadow rays, ...
+        uint32_t n_boolean = 0;  // shadow + RS_MIS_BOOL entries of the queue about to be traced (the sort puts them last)
         while (rc == PBRT_HIP_OK && counts[1] > 0) {
             uint32_t n_trace = (uint32_t)counts[0], n_shade = (uint32_t)counts[1];
             if (n_trace > 0) {
                 RENDER_TRY(hipMemsetAsync(ctx->d_work_counter, 0, kWorkCounters * sizeof(unsigned int), st));
                 const uint32_t* trace_queue = q[cur].trace;
+                bool sorted = false;
                 if (sort_rays && wavefront >= sort_from && n_trace >= (1u << 20)) {
                     // from the second bounce on the rays of a wavefront start all over the scene (the first bounce still
                     // follows the pixel order of its camera rays): trace them in Morton order of their origins
@@ -836,6 +848,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                         rc = PBRT_HIP_ERR_DEVICE;
                     }
                     trace_queue = sort_vals;
+                    sorted = true;
                 }
                 RENDER_TRY(hipEventRecord(e_t0, st));
                 {
@@ -859,7 +872,25 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                         WideTrees wt = s->wide;
                         wt.special_list = special_list;
                         wt.special_count = ctx->d_work_counter + kSpecialCount;
-                        if (inst == 2) {
+                        // a sorted queue ends with its boolean rays (sort key's top bit): they go to the order-free kernel
+                        const uint32_t n_any = (PB_ANY_SPLIT && sorted && inst == 0 && n_boolean <= n_trace) ? n_boolean : 0u;
+                        if (n_any >= (1u << 16)) {
+                            const uint32_t n_front = n_trace - n_any;
+                            const uint32_t* any_queue = trace_queue + n_front;
+                            const dim3 any_grid(persistent_grid(s, count_wide ? PB_WIDE_INST_WAVES : PB_ANY_WAVES, (kAnyStackLds + 1) / 2));
+                            n_trace = n_front;
+                            if (n_front > 0) {
+                                if (count_wide) PB_LAUNCH_WIDE(true, 0); else PB_LAUNCH_WIDE(false, 0);
+                            }
+                            if (count_wide)
+                                hipLaunchKernelGGL(k_trace_wide_any<true>, any_grid, block, 0, st, wt, ps, any_queue, n_any,
+                                                   ctx->d_work_counter + kAnyCounter, ctx->d_counters);
+                            else
+                                hipLaunchKernelGGL(k_trace_wide_any<false>, any_grid, block, 0, st, wt, ps, any_queue, n_any,
+                                                   ctx->d_work_counter + kAnyCounter, ctx->d_counters);
+                            n_trace = n_front + n_any;
+                            PB_LAUNCH_SPECIAL(0);
+                        } else if (inst == 2) {
                             if (count_wide) PB_LAUNCH_WIDE(true, 2); else PB_LAUNCH_WIDE(false, 2);
                             PB_LAUNCH_SPECIAL(2);
                         } else if (inst == 1) {
@@ -912,15 +943,10 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                     }
                     qin.shade = shade_sorted;
                 }
-#if PB_SHADE_SPLIT  // development: one bounce as two launches (wf_path.h, PART)
-                hipLaunchKernelGGL((k_shade<false, 1>), dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, qin, q[nxt], pp, tiles, n_shade);
-                hipLaunchKernelGGL((k_shade<false, 2>), dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, qin, q[nxt], pp, tiles, n_shade);
-#else
                 if (bin_shade && wavefront >= 1)
                     hipLaunchKernelGGL(k_shade<true>, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, qin, q[nxt], pp, tiles, n_shade);
                 else
                     hipLaunchKernelGGL(k_shade<false>, dim3((n_shade + 255) / 256), dim3(256), 0, st, sc, ps, qin, q[nxt], pp, tiles, n_shade);
-#endif
             }
             RENDER_TRY(hipGetLastError());
             RENDER_TRY(hipMemcpyAsync(ctx->h_counts, q[nxt].counts64, sizeof(counts), hipMemcpyDeviceToHost, st));
@@ -962,6 +988,8 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                 local.rays_closest += n_rays - n_shadow;
                 local.rays_shadow += n_shadow;
                 counts[0] = n_rays;
+                n_boolean = (uint32_t)(n_shadow + (counts[1] >> 32));
+                counts[1] &= 0xffffffffull;
             }
             (void)first;
             first = false;

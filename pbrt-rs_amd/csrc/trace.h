@@ -108,6 +108,16 @@ PB_DEV bool slab_test(float bx0, float bx1, float by0, float by1, float bz0, flo
     *entry = t_min;
     return ((fail_xy | fail_z) == 0) & (t_min < tmax_ray) & (t_max > 0.0f);
 }
+// The same test, and beside it what it would say with ray.t_max = +inf (`keep`: the ray meets the box's slabs at all) — the
+// part of the decision that does not depend on t_max, which can move (trace_persistent.h): one evaluation, two answers.
+PB_DEV bool slab_test_keep(float bx0, float bx1, float by0, float by1, float bz0, float bz1, const TravRay& r, float idx,
+                           float idy, float idz, float tmax_ray, float* entry, bool* keep) {
+    float e;
+    const bool any_t = slab_test(bx0, bx1, by0, by1, bz0, bz1, r, idx, idy, idz, kInf, &e);
+    *entry = e;
+    *keep = any_t;
+    return any_t & (e < tmax_ray);
+}
 
 // Per-ray constants of the watertight test (triangle.rs:84-101)
 struct TriRayConst {

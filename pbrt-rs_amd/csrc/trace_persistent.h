@@ -97,6 +97,8 @@ PB_DEV bool root_box_test(const LaneState& s, const float* mn, const float* mx) 
 }
 
 // IO policy: n(), segments(), token(i) of queue position i, load(token, &ray, &any) -> bool real ray,
+// strict(token): an any-hit ray that asks for the boolean of Primitive::intersect instead of intersect_p's — a hit on a
+// triangle that Triangle::intersect rejects (kTriDegenerate, triangle.rs:197-216) does not count (wf_state.h: RS_MIS_BOOL),
 // store(token, any, found, t, b0, b1, b2, slot, instance)
 // INST: 0 = one level; 1 = instances of ONE object aggregate and nothing beside them (config 5's shape: the object's root
 // rides in the kernel arguments); 2 = the general top level (several objects, world-space triangles beside the instances).
@@ -314,10 +316,11 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
                 const float4* nd = bvh.inodes + 4 * (size_t)s.cur;
                 float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
                 float e0, e1;
-                bool h0 = slab_test(s.nx ? q0.w : q0.x, s.nx ? q0.x : q0.w, s.ny ? q1.x : q0.y, s.ny ? q0.y : q1.x,
-                                    s.nz ? q1.y : q0.z, s.nz ? q0.z : q1.y, s.r, s.idx, s.idy, s.idz, s.tmax, &e0);
-                bool h1 = slab_test(s.nx ? q2.y : q1.z, s.nx ? q1.z : q2.y, s.ny ? q2.z : q1.w, s.ny ? q1.w : q2.z,
-                                    s.nz ? q2.w : q2.x, s.nz ? q2.x : q2.w, s.r, s.idx, s.idy, s.idz, s.tmax, &e1);
+                bool k0, k1;  // the t_max-independent part of the two tests (see far_keep)
+                bool h0 = slab_test_keep(s.nx ? q0.w : q0.x, s.nx ? q0.x : q0.w, s.ny ? q1.x : q0.y, s.ny ? q0.y : q1.x,
+                                         s.nz ? q1.y : q0.z, s.nz ? q0.z : q1.y, s.r, s.idx, s.idy, s.idz, s.tmax, &e0, &k0);
+                bool h1 = slab_test_keep(s.nx ? q2.y : q1.z, s.nx ? q1.z : q2.y, s.ny ? q2.z : q1.w, s.ny ? q1.w : q2.z,
+                                         s.nz ? q2.w : q2.x, s.nz ? q2.x : q2.w, s.r, s.idx, s.idy, s.idz, s.tmax, &e1, &k1);
                 int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y), axis = __float_as_int(q3.z);
                 bool neg = axis == 0 ? s.nx : (axis == 1 ? s.ny : s.nz);  // bvh.rs:857-865
                 int near_c = neg ? c1 : c0, far_c = neg ? c0 : c1;
@@ -330,12 +333,7 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
                 // whether it is kept cannot depend on t_max here: it is kept whenever the ray meets its slabs at all, and its
                 // entry distance is compared with the t_max current at the pop, which is exactly the reference's test
                 // (found by tests/test_gpu_wide.py's adversarial meshes at 3000 examples, round 3).
-                float unused;
-                const bool k0 = slab_test(s.nx ? q0.w : q0.x, s.nx ? q0.x : q0.w, s.ny ? q1.x : q0.y, s.ny ? q0.y : q1.x,
-                                          s.nz ? q1.y : q0.z, s.nz ? q0.z : q1.y, s.r, s.idx, s.idy, s.idz, kInf, &unused);
-                const bool k1 = slab_test(s.nx ? q2.y : q1.z, s.nx ? q1.z : q2.y, s.ny ? q2.z : q1.w, s.ny ? q1.w : q2.z,
-                                          s.nz ? q2.w : q2.x, s.nz ? q2.x : q2.w, s.r, s.idx, s.idy, s.idz, kInf, &unused);
-                const bool far_keep = neg ? k0 : k1;  // (the same arithmetic as h0 / h1: only the last comparison differs)
+                const bool far_keep = neg ? k0 : k1;
                 if (COUNT) {
                     n_node += 1;               // the near child is tested as soon as it is visited
                     if (!near_h) n_node += 1;  // near missed: the far child is popped and tested next
@@ -399,7 +397,7 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
                         const TriRayConst c = tri_ray_setup(s.r);
                         if (triangle_test(p0, p1, p2, s.r, c, s.tmax, &b0, &b1, &b2, &t)) {
                             if (s.any) {
-                                done = true;
+                                done = !(io.strict(s.index) && (flags & kTriDegenerate));
                             } else if (!(flags & kTriDegenerate)) {
                                 s.tmax = t;
                                 w.tmax_world = t;
@@ -444,6 +442,7 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
                     }
                     if (hit) {
                         if (s.any) {
+                            if (io.strict(s.index) && (flags & kTriDegenerate)) continue;  // (see IO::strict)
                             done = true;
                             break;
                         }

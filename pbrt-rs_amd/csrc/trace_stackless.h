@@ -129,15 +129,19 @@ PB_DEV void trace_stackless(const DevBVH& bvh, const IO& io, unsigned int* __res
                     q1 = nd[1];
                     q2 = nd[2];
                 }
-                float e0, e1, unused;
-                bool h0 = slab_test(s.nx ? q0.w : q0.x, s.nx ? q0.x : q0.w, s.ny ? q1.x : q0.y, s.ny ? q0.y : q1.x,
-                                    s.nz ? q1.y : q0.z, s.nz ? q0.z : q1.y, s.r, s.idx, s.idy, s.idz, s.tmax, &e0);
-                bool h1 = slab_test(s.nx ? q2.y : q1.z, s.nx ? q1.z : q2.y, s.ny ? q2.z : q1.w, s.ny ? q1.w : q2.z,
-                                    s.nz ? q2.w : q2.x, s.nz ? q2.x : q2.w, s.r, s.idx, s.idy, s.idz, s.tmax, &e1);
-                const bool k0 = slab_test(s.nx ? q0.w : q0.x, s.nx ? q0.x : q0.w, s.ny ? q1.x : q0.y, s.ny ? q0.y : q1.x,
-                                          s.nz ? q1.y : q0.z, s.nz ? q0.z : q1.y, s.r, s.idx, s.idy, s.idz, kInf, &unused);
-                const bool k1 = slab_test(s.nx ? q2.y : q1.z, s.nx ? q1.z : q2.y, s.ny ? q2.z : q1.w, s.ny ? q1.w : q2.z,
-                                          s.nz ? q2.w : q2.x, s.nz ? q2.x : q2.w, s.r, s.idx, s.idy, s.idz, kInf, &unused);
+                // (a lane that only climbs holds zeros in q0..q2: its box results are forced to false below rather than left
+                // to whatever 0-sized boxes give for that ray — nothing reads them on that path, go_near / go_far are masked)
+                const bool boxes = !up || pending;
+                float e0, e1;
+                bool k0, k1;
+                bool h0 = slab_test_keep(s.nx ? q0.w : q0.x, s.nx ? q0.x : q0.w, s.ny ? q1.x : q0.y, s.ny ? q0.y : q1.x,
+                                         s.nz ? q1.y : q0.z, s.nz ? q0.z : q1.y, s.r, s.idx, s.idy, s.idz, s.tmax, &e0, &k0);
+                bool h1 = slab_test_keep(s.nx ? q2.y : q1.z, s.nx ? q1.z : q2.y, s.ny ? q2.z : q1.w, s.ny ? q1.w : q2.z,
+                                         s.nz ? q2.w : q2.x, s.nz ? q2.x : q2.w, s.r, s.idx, s.idy, s.idz, s.tmax, &e1, &k1);
+                h0 = h0 && boxes;
+                h1 = h1 && boxes;
+                k0 = k0 && boxes;
+                k1 = k1 && boxes;
                 const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y), axis = __float_as_int(q3.z);
                 const int parent = __float_as_int(q3.w);
                 const bool neg = axis == 0 ? s.nx : (axis == 1 ? s.ny : s.nz);  // bvh.rs:857-865
@@ -181,6 +185,7 @@ PB_DEV void trace_stackless(const DevBVH& bvh, const IO& io, unsigned int* __res
                 float b0, b1, b2, t;
                 if (triangle_test(p0, p1, p2, s.r, s.trc, s.tmax, &b0, &b1, &b2, &t)) {
                     if (s.any) {
+                        if (io.strict(s.index) && (flags & kTriDegenerate)) continue;
                         done = true;
                         break;
                     }

@@ -32,10 +32,7 @@ namespace pb {
 #define PB_WIDE_INST_INTERIOR_THRESH 24  // two-level scenes: more kinds of work wait behind the record loop (config 5: 24 +5 %, 40 -8 %)
 #endif
 #ifndef PB_WIDE_SPECULATE
-#define PB_WIDE_SPECULATE 1  // one-level scenes: a lane keeps walking records with ONE candidate leaf postponed (see `pend`)
-#endif
-#ifndef PB_WIDE_SPECULATE_INST
-#define PB_WIDE_SPECULATE_INST 0  // two-level scenes: measured slower (config 5 geometry 1147 vs 1163 Mrays/s)
+#define PB_WIDE_SPECULATE 1  // one-level scenes: a lane keeps walking records with ONE candidate leaf postponed (see `pend`); two-level scenes never (measured slower, profiles/r03_two_level_ladder.txt)
 #endif
 #ifndef PB_WIDE_INST_STACK_LDS
 #define PB_WIDE_INST_STACK_LDS 11  // two-level scenes: one stack entry less in LDS makes room for the world ray (below) at 5 blocks per CU
@@ -79,6 +76,7 @@ struct SpecialListIO {
     PB_DEV uint32_t n() const { return *count; }
     PB_DEV int segments() const { return 1; }
     PB_DEV uint32_t token(uint32_t i) const { return list[i]; }
+    PB_DEV bool strict(uint32_t tok) const { return inner.strict(tok); }
     PB_DEV bool load(uint32_t tok, TravRay* r, bool* any) const { return inner.load(tok, r, any); }
     PB_DEV void store(uint32_t tok, bool any, bool found, float t, float b0, float b1, float b2, int slot, int inst) const {
         inner.store(tok, any, found, t, b0, b1, b2, slot, inst);
@@ -180,12 +178,11 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
     // confirmed with the t_max current when its turn comes. Turns are kept: the postponed leaf is tested before any leaf
     // found after it; a lane that finds a second one waits, as every lane did before. More lanes step records, and the
     // leaf phase finds more lanes with a leaf to test.
-    constexpr bool SPEC = PB_WIDE_SPECULATE && (INST == 0 || PB_WIDE_SPECULATE_INST);  // two levels: triangle leaves inside an instance
-    constexpr bool SPEC2 = SPEC && PB_WIDE_SPECULATE >= 2;  // two postponed leaves (pend first, then pend2)
-    int pend = 0, pend2 = 0;
+    constexpr bool SPEC = PB_WIDE_SPECULATE && INST == 0;
+    int pend = 0;
     auto finish = [&](bool found) {
         cur = found ? kDoneHit : kDoneMiss;
-        if (SPEC) pend = pend2 = 0;
+        if (SPEC) pend = 0;
     };
     auto flush_result = [&]() {
         if (cur == kDoneHit || cur == kDoneMiss) {
@@ -345,7 +342,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 hit_slot = -1;
                 hb0 = hb1 = hb2 = 0.0f;
                 sp = 0;
-                if (SPEC) pend = pend2 = 0;
+                if (SPEC) pend = 0;
                 if (!real) {
                     finish(false);  // placeholder of a path outside pixel_bounds: not a ray of the frame
                 } else {
@@ -392,11 +389,8 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
         PB_WCLOCK(t_rec0);
         PB_WSTAT(13, t_rec0 - t_refill0);
         for (;;) {
-            if (SPEC && (SPEC2 ? pend2 : pend) >= 0 && is_leaf_ref() && (!INST || base_sp >= 0)) {  // postpone the leaf, walk on
-                if (SPEC2 && pend < 0)
-                    pend2 = cur;
-                else
-                    pend = cur;
+            if (SPEC && pend >= 0 && is_leaf_ref()) {  // postpone the leaf, walk on
+                pend = cur;
                 cur = kNeedPop;
             }
             if (cur == kNeedPop) pop_one();
@@ -563,7 +557,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                     const TriRayConst c = tri_ray_setup(r, idx, idy, idz);
                     if (triangle_test(V3{ta.x, ta.y, ta.z}, V3{ta.w, tb.x, tb.y}, V3{tb.z, tb.w, tc.x}, r, c, tmax, &b0, &b1, &b2, &t)) {
                         if (any) {
-                            done = true;
+                            done = !(io.strict(index) && (__float_as_int(tc.w) & kTriDegenerate));
                         } else if (!(__float_as_int(tc.w) & kTriDegenerate)) {
                             if (t > tmax) abandon = true;  // t_max would move UP: see `raised` in the triangle branch
                             tmax = t;
@@ -681,6 +675,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                                              &b2, &t);
                     if (hit) {
                         if (any) {
+                            if (io.strict(index) && (__float_as_int(tc.z) & kTriDegenerate)) continue;  // (IO::strict, trace_persistent.h)
                             done = true;
                             hit_slot = __float_as_int(tc.y);
                             break;
@@ -703,13 +698,12 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 wt.special_list[atomicAdd(wt.special_count, 1u)] = index;  // (one list append per such ray: they are rare)
                 if (COUNT) c_special += 1;
                 cur = kIdle;
-                if (SPEC) pend = pend2 = 0;
+                if (SPEC) pend = 0;
             } else if (done)
                 finish(true);
             else if (from_pend) {
-                pend = pend2;
-                pend2 = 0;
-                if (cur == kWait && pend >= 0) cur = kNeedPop;  // (the pop finds the stack empty and finishes the ray)
+                pend = 0;
+                if (cur == kWait) cur = kNeedPop;  // (the pop finds the stack empty and finishes the ray)
             } else
                 cur = kNeedPop;
         }

@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256, PB_DIRECT_WAVES) k_shade_direct(ShadeCons
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool active = i < n_in;
     uint32_t p = active ? qin.shade[i] : 0u;
-    bool emit_cont = false, emit_mis = false, emit_shadow = false;
+    bool emit_cont = false, emit_mis = false, emit_shadow = false, mis_bool = false;
     if (active && !(__float_as_int(ps.beta[p].w) & PF_VALID)) active = false;  // placeholder path outside pixel_bounds
 
     if (active) {
@@ -239,9 +239,10 @@ __global__ void __launch_bounds__(256, PB_DIRECT_WAVES) k_shade_direct(ShadeCons
                 int nee_flags = estimate_direct_emit(sc, ps, p, sf, fr, matte, kd, light_num, ul0, ul1, us0, us1, pick_pdf, T);
                 stage += 1;
                 if (nee_flags) {
-                    flags |= nee_flags;
+                    flags |= nee_flags & 0xff;
                     emit_shadow = (nee_flags & PF_NEE_SHADOW) != 0;
                     emit_mis = (nee_flags & PF_NEE_MIS) != 0;
+                    mis_bool = (nee_flags & NEE_MIS_BOOL) != 0;
                     break;  // trace, then come back to this vertex
                 }
                 close_light_if_done(stage);  // the sample contributed nothing
@@ -317,7 +318,7 @@ __global__ void __launch_bounds__(256, PB_DIRECT_WAVES) k_shade_direct(ShadeCons
     }
 
     __shared__ BlockAppend sh;
-    block_append(sh, qout, p, emit_cont, emit_mis, emit_shadow, emit_cont || emit_mis || emit_shadow);
+    block_append(sh, qout, p, emit_cont, emit_mis, emit_shadow, emit_cont || emit_mis || emit_shadow, 0, mis_bool);
 }
 
 }  // namespace pb

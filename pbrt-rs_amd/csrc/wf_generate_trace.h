@@ -171,17 +171,22 @@ struct WavefrontRayIO {
     // its position: the store then needs no second look at the queue (one dependent load less in the refill path every
     // idle lane of the wave waits in).
     PB_DEV uint32_t token(uint32_t i) const { return queue[i]; }
+    PB_DEV bool strict(uint32_t e) const { return (e & 3u) == RS_MIS_BOOL; }
     PB_DEV bool load(uint32_t e, TravRay* r, bool* any) const {
         uint32_t p = e >> 2, slot = e & 3u;
-        size_t ri = ray_index(ps, p, slot);
+        size_t ri = ray_index(ps, p, slot == RS_MIS_BOOL ? (uint32_t)RS_MIS : slot);
         float4 a = ps.ray[ri], b = ps.ray[ri + 1];
         *r = TravRay{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
-        *any = slot == RS_SHADOW;
+        *any = slot >= RS_SHADOW;  // RS_SHADOW, RS_MIS_BOOL: only the boolean is wanted
         // t_max < 0 marks the placeholder ray of a path outside pixel_bounds (k_generate): not a ray of the frame
         return !(b.z < 0.0f);
     }
     PB_DEV void store(uint32_t e, bool any, bool found, float t, float b0, float b1, float b2, int slot, int inst) const {
         uint32_t p = e >> 2, rs = e & 3u;
+        if (rs == RS_MIS_BOOL) {  // `found` where the MIS ray's hit record would say it: a leaf slot >= 0 or -1
+            ps.hit[hit_index(ps, p, RS_MIS)] = make_float4(__int_as_float(found ? 0 : -1), 0.0f, 0.0f, 0.0f);
+            return;
+        }
         size_t ri = hit_index(ps, p, rs);
         if (any) {
             ps.hit[ri] = make_float4(found ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
@@ -203,14 +208,15 @@ __global__ void k_ray_sort_keys(PathState ps, const uint32_t* __restrict__ queue
     if (i >= n) return;
     uint32_t e = queue[i];
     uint32_t p = e >> 2, slot = e & 3u;
-    float4 a = ps.ray[ray_index(ps, p, slot)];
+    const uint32_t rslot = slot == RS_MIS_BOOL ? (uint32_t)RS_MIS : slot;
+    float4 a = ps.ray[ray_index(ps, p, rslot)];
     const float l[3] = {lo.x, lo.y, lo.z}, iv[3] = {inv_extent.x, inv_extent.y, inv_extent.z};
     uint32_t code = ray_sort_cell(a.x, a.y, a.z, l, iv);
 #if PB_SORT_OCTANT
-    float4 d = ps.ray[ray_index(ps, p, slot) + 1];  // (d.y, d.z, t_max, -); d.x rides in a.w
+    float4 d = ps.ray[ray_index(ps, p, rslot) + 1];  // (d.y, d.z, t_max, -); d.x rides in a.w
     code = (code << 3) | (a.w < 0.0f ? 1u : 0u) | (d.x < 0.0f ? 2u : 0u) | (d.y < 0.0f ? 4u : 0u);
 #endif
-    keys[i] = code | ((slot == RS_SHADOW ? 1u : 0u) << (kSortKeyBits - 1));
+    keys[i] = code | ((slot >= RS_SHADOW ? 1u : 0u) << (kSortKeyBits - 1));
 }
 
 template <bool COUNT, int INST, bool SPH = false>
@@ -241,7 +247,16 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WA
     trace_wide<WavefrontRayIO<INST != 0>, COUNT, INST>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x,
                                             counters, lds_world + (INST ? threadIdx.x : 0));
 }
-// ... and the rays it left to the binary records (axis-parallel directions and the like; usually none)
+// ... the boolean rays at the end of a sorted queue (shadow rays, RS_MIS_BOOL) in no particular order (trace_wide_any.h) ...
+template <bool COUNT>
+__global__ void __launch_bounds__(kTraceBlock, COUNT ? PB_WIDE_INST_WAVES : PB_ANY_WAVES)
+    k_trace_wide_any(WideTrees wt, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
+                     unsigned long long* counters) {
+    __shared__ uint32_t lds_stack[kAnyStackLds * kTraceBlock];
+    WavefrontRayIO<false> io{ps, queue, n, 1};
+    trace_wide_any<WavefrontRayIO<false>, COUNT>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x, counters);
+}
+// ... and the rays they left to the binary records (axis-parallel directions and the like; usually none)
 template <int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, INST ? PB_INST_WAVES : PB_TRACE_WAVES)
     k_trace_special(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, const uint32_t* __restrict__ list,

@@ -360,6 +360,8 @@ PB_DEV int estimate_direct_emit(const ShadeConsts& sc, const PathState& ps, uint
             store_ray(ps, p, RS_MIS, o2, wi2, kInf);
             ps.nee_f[p] = make_float4(f2.x, f2.y, f2.z, weight);
             nee_flags |= PF_NEE_MIS;
+            // only an area light looks at WHAT the ray hit (integrator.rs:247-256); for the others `found` is enough
+            if (sc.mis_bool && lt.type != PBRT_LIGHT_DIFFUSE_AREA) nee_flags |= NEE_MIS_BOOL;
         }
     }
     if (nee_flags) {
@@ -388,8 +390,9 @@ PB_DEV V3 estimate_direct_resolve(const ShadeConsts& sc, const PathState& ps, ui
         DevLight lt = sc.lights[light_id];
         V3 li = V3{0.0f, 0.0f, 0.0f};
         if (hslot >= 0) {
-            // D26 (intended): Le only when the hit primitive's area light is this light
-            int hl = (__float_as_int(sc.bvh.tris[3 * (size_t)hslot + 2].w) & kPrimLightMask) - 1;
+            // D26 (intended): Le only when the hit primitive's area light is this light (an RS_MIS_BOOL ray left 0 for
+            // "found" here, not a leaf slot: it is never queued for an area light)
+            int hl = lt.type == PBRT_LIGHT_DIFFUSE_AREA ? (__float_as_int(sc.bvh.tris[3 * (size_t)hslot + 2].w) & kPrimLightMask) - 1 : -2;
             if (hl == light_id) {
                 float4 hb = ps.hit[hit_index(ps, p, RS_MIS)];
                 V3 n = tri_interaction_normal(sc.bvh, hslot, hb.y, hb.z, hb.w);

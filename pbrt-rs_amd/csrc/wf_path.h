@@ -44,14 +44,7 @@ struct ShadeBins {
     uint32_t path[256];
 };
 
-// PART (development, PB_SHADE_SPLIT): 0 = the whole bounce in one launch; 1 / 2 = the same bounce split at the boundary
-// between light sampling and BSDF sampling into two launches over the same queue — k_shade<.., 1> resolves the pending
-// estimate, adds emission, builds the surface and samples the light (marks the path PF_BSDF_PENDING), k_shade<.., 2>
-// rebuilds the surface from the hit record and samples the BSDF, plays roulette and spawns the continuation ray.
-// Measured in round 3 (profiles/r03_shade_split.txt): the first half keeps the register count (the two halves of
-// estimate_direct carry it), the second re-reads ray, hit, triangle and material; not adopted.
-constexpr int PF_BSDF_PENDING = 32;
-template <bool BIN, int PART = 0>
+template <bool BIN>
 __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Queues qin, Queues qout, PassParams pp,
                                                  TileList tiles, uint32_t n_in) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,8 +75,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
         p = bins.path[threadIdx.x];
         active = threadIdx.x < n_active;
     }
-    bool emit_cont = false, emit_mis = false, emit_shadow = false;
-    bool pending_out = false, nee_after = false;  // split bounce (PART 1 / 2)
+    bool emit_cont = false, emit_mis = false, emit_shadow = false, mis_bool = false;
 
     uint32_t cell = 0;  // sort cell of the rays this path emits
     if (active) {
@@ -96,13 +88,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
         size_t rbase = ray_index(ps, p, RS_CONT), hbase = hit_index(ps, p, RS_CONT);
 
         // ---- (1) resolve the pending direct-lighting estimate (integrator.rs:136-266) ----
-        const bool second = PART == 2;  // second launch of a split bounce: only what the first one left pending
-        const bool pending = second && (flags & PF_BSDF_PENDING);
-        if (second) {
-            nee_after = (flags & (PF_NEE_SHADOW | PF_NEE_MIS)) != 0;
-            flags &= ~PF_BSDF_PENDING;
-        }
-        if (!second && (flags & (PF_NEE_SHADOW | PF_NEE_MIS))) {
+        if (flags & (PF_NEE_SHADOW | PF_NEE_MIS)) {
             float pick_pdf;
             V3 beta_v;
             V3 ld = estimate_direct_resolve(sc, ps, p, flags, &pick_pdf, &beta_v);
@@ -112,7 +98,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
         }
 
         // ---- (2) the continuation hit ----
-        if (second ? pending : (flags & PF_ALIVE) != 0) {
+        if (flags & PF_ALIVE) {
             flags &= ~PF_ALIVE;
             float4 r0 = ps.ray[rbase], r1 = ps.ray[rbase + 1];
             V3 rd = V3{r0.w, r1.x, r1.y};
@@ -125,7 +111,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
                 if (qout.keys) cell = ray_sort_cell(sf.p.x, sf.p.y, sf.p.z, qout.key_lo, qout.key_inv);
             }
             // path.rs:80-88
-            if (!second && (bounces == 0 || (flags & PF_SPECULAR_BOUNCE))) {
+            if (bounces == 0 || (flags & PF_SPECULAR_BOUNCE)) {
                 if (found) {
                     L = L + mulv(beta, surface_le(sc, sf, -rd));
                 } else {
@@ -138,7 +124,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
             if (found && bounces < pp.max_depth) {  // path.rs:90
                 DevMaterial mat = sc.materials[sf.material];
                 Samp sm = path_sampler(ps, pp, tiles, p);
-                if (mat.type == PBRT_MAT_NONE && !second) {
+                if (mat.type == PBRT_MAT_NONE) {
                     // path.rs:95-98: no BSDF -> continue through the surface, bounces unchanged
                     V3 o = offset_ray_origin(sf.p, sf.p_error, sf.n, rd);
                     store_ray(ps, p, RS_CONT, o, rd, kInf);
@@ -155,7 +141,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
                     bool nonspecular = (mat.type == PBRT_MAT_MATTE) && has_lobe;
 
                     // ---- uniform_sample_one_light (integrator.rs:92-134) ----
-                    if (!second && nonspecular && sc.n_lights > 0) {
+                    if (nonspecular && sc.n_lights > 0) {
                         float u_pick = samp_1d(pp, sm);
                         DevDistribution1D distrib = light_distribution_lookup(sc, sf.p);  // path.rs:115
                         int light_num = find_interval_cdf(distrib.cdf, distrib.n + 1, u_pick);
@@ -167,23 +153,20 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
                             samp_2d(pp, sm, &us0, &us1);
                             int nee_flags = estimate_direct_emit(sc, ps, p, sf, fr, true, kd, light_num, ul0, ul1, us0, us1,
                                                                  pick_pdf, beta);
-                            flags |= nee_flags;
+                            flags |= nee_flags & 0xff;
                             emit_shadow = (nee_flags & PF_NEE_SHADOW) != 0;
                             emit_mis = (nee_flags & PF_NEE_MIS) != 0;
+                            mis_bool = (nee_flags & NEE_MIS_BOOL) != 0;
                         }
                     }
 
-                    if (PART == 1) {  // the rest of this vertex belongs to the second launch
-                        flags |= PF_BSDF_PENDING;
-                        pending_out = true;
-                    }
                     // ---- BSDF sampling for the next vertex (path.rs:123-152) ----
                     float u0 = 0.0f, u1 = 0.0f;
-                    if (PART != 1) samp_2d(pp, sm, &u0, &u1);
+                    samp_2d(pp, sm, &u0, &u1);
                     V3 wi = V3{0.0f, 0.0f, 0.0f}, f = V3{0.0f, 0.0f, 0.0f};
                     float pdf = 0.0f;
                     bool sampled_specular = false, sampled_transmission = false;
-                    if (has_lobe && PART != 1) {
+                    if (has_lobe) {
                         if (mat.type == PBRT_MAT_MATTE) {
                             bool ok;
                             f = matte_sample_f(fr, kd, wo, u0, u1, &wi, &pdf, &ok);
@@ -227,18 +210,14 @@ __global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Que
                 samp_store(ps, p, sm);
             }
         }
-        if (PART != 2 || pending) {
-            ps.L[p] = make_float4(L.x, L.y, L.z, eta_scale);
-            ps.beta[p] = make_float4(beta.x, beta.y, beta.z, __int_as_float((bounces << 8) | flags));
-        }
+        ps.L[p] = make_float4(L.x, L.y, L.z, eta_scale);
+        ps.beta[p] = make_float4(beta.x, beta.y, beta.z, __int_as_float((bounces << 8) | flags));
     }
 
     // ---- queue appends (block-aggregated) ----
-    // a split bounce: the first launch queues the shadow / MIS rays (and what it finished itself), the second the continuation
-    // ray, and the path's place in the next shade queue for the paths it was left
     __shared__ BlockAppend sh;
-    const bool again = PART == 2 ? (emit_cont || nee_after) : ((emit_cont || emit_mis || emit_shadow) && !pending_out);
-    block_append(sh, qout, p, emit_cont, emit_mis, emit_shadow, again, cell);
+    const bool again = emit_cont || emit_mis || emit_shadow;
+    block_append(sh, qout, p, emit_cont, emit_mis, emit_shadow, again, cell, mis_bool);
 }
 
 }  // namespace pb

@@ -6,6 +6,7 @@
 #include "trace.h"
 #include "trace_persistent.h"
 #include "trace_wide.h"
+#include "trace_wide_any.h"
 #include "trace_stackless.h"
 
 namespace pb {
@@ -19,6 +20,17 @@ enum PathFlags : int {
     PF_VALID = 16,      // the path belongs to a pixel inside pixel_bounds
 };
 enum RaySlot : int { RS_CONT = 0, RS_MIS = 1, RS_SHADOW = 2 };
+// A trace-queue entry is path << 2 | what: the three ray slots, and RS_MIS_BOOL = the path's MIS ray (slot RS_MIS) of which
+// only `found` is wanted. estimate_direct (integrator.rs:232-262) calls scene.intersect for the BSDF-sampled direction and
+// then looks at the hit only if the light is an area light (`light_isect.primitive.get_area_light() == light`); for an
+// infinite light everything that follows depends on `found_surface_interaction` alone. BVHAccel::intersect finds its first
+// hit under the ray's original t_max, walking exactly as intersect_p walks, so `found` = "some leaf whose box passes holds a
+// triangle that Triangle::intersect accepts" — a boolean that does not depend on the visiting order and needs no closest
+// hit: such a ray is traced as an any-hit ray that skips the triangles Triangle::intersect rejects (IO::strict), ends at its
+// first hit, and sorts with the shadow rays.
+constexpr uint32_t RS_MIS_BOOL = 3;
+// estimate_direct_emit's return value carries this beside the PF_NEE_* bits (it is not a path flag)
+constexpr int NEE_MIS_BOOL = 0x100;
 
 struct PathState {
     float4* ray;     // [ray_index(p, slot) + k]: (o.xyz, d.x) (d.yz, t_max, -)
@@ -102,7 +114,7 @@ struct Queues {
     uint32_t* trace;   // entries: path*4 + slot
     uint32_t* shade;   // entries: path
     // counts64[0]: low 32 bits = trace-queue length, high 32 bits = shadow rays among them;
-    // counts64[1]: shade-queue length
+    // counts64[1]: low 32 bits = shade-queue length, high 32 bits = RS_MIS_BOOL entries of the trace queue
     unsigned long long* counts64;
     // sort key of every trace-queue entry (ray_sort_key), written with the entry when the next wavefront will be
     // traced in Morton order; null otherwise
@@ -146,6 +158,7 @@ PB_DEV uint64_t sample_sequence(const PassParams& pp, int x, int y, int s) {
 struct BlockAppend {
     uint32_t wave_rays[16];   // per-wave totals (blocks of up to 1024 threads)
     uint32_t wave_shadow[16];
+    uint32_t wave_bool[16];
     uint32_t wave_paths[16];
     uint32_t base_rays, base_paths;
 };
@@ -153,44 +166,47 @@ PB_DEV uint32_t lane_prefix(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 // Every thread of the block must call this. n_cont/n_mis/n_shadow in {0,1}; again = path stays in the shade queue.
-// cell = ray_sort_cell of the point the path's rays leave from (used only when q.keys is set).
+// cell = ray_sort_cell of the point the path's rays leave from (used only when q.keys is set). mis_bool: the MIS ray is
+// queued as RS_MIS_BOOL.
 PB_DEV void block_append(BlockAppend& sh, const Queues& q, uint32_t p, bool cont, bool mis, bool shadow, bool again,
-                         uint32_t cell = 0) {
+                         uint32_t cell = 0, bool mis_bool = false) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63) >> 6;
     unsigned long long mc = __ballot(cont), mm = __ballot(mis), ms = __ballot(shadow), ma = __ballot(again);
     uint32_t wc = (uint32_t)__popcll(mc), wm = (uint32_t)__popcll(mm), ws = (uint32_t)__popcll(ms);
     if (lane == 0) {
         sh.wave_rays[wave] = wc + wm + ws;
         sh.wave_shadow[wave] = ws;
+        sh.wave_bool[wave] = (uint32_t)__popcll(__ballot(mis && mis_bool));
         sh.wave_paths[wave] = (uint32_t)__popcll(ma);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t tr = 0, tsd = 0, tp = 0;
+        uint32_t tr = 0, tsd = 0, tp = 0, tb = 0;
         for (int w = 0; w < n_waves; ++w) {
             uint32_t r = sh.wave_rays[w], pth = sh.wave_paths[w];
             sh.wave_rays[w] = tr;   // exclusive prefix
             sh.wave_paths[w] = tp;
             tr += r;
             tsd += sh.wave_shadow[w];
+            tb += sh.wave_bool[w];
             tp += pth;
         }
         unsigned long long old = 0;
         if (tr) old = atomicAdd(&q.counts64[0], (unsigned long long)tr | ((unsigned long long)tsd << 32));
         sh.base_rays = (uint32_t)old;
-        sh.base_paths = tp ? (uint32_t)atomicAdd(&q.counts64[1], (unsigned long long)tp) : 0u;
+        sh.base_paths = (tp | tb) ? (uint32_t)atomicAdd(&q.counts64[1], (unsigned long long)tp | ((unsigned long long)tb << 32)) : 0u;
     }
     __syncthreads();
     uint32_t rbase = sh.base_rays + sh.wave_rays[wave];
     // within the wave: all continuation rays, then MIS rays, then shadow rays
     uint32_t ic = rbase + lane_prefix(mc), im = rbase + wc + lane_prefix(mm), is = rbase + wc + wm + lane_prefix(ms);
     if (cont) q.trace[ic] = p * 4u + RS_CONT;
-    if (mis) q.trace[im] = p * 4u + RS_MIS;
+    if (mis) q.trace[im] = p * 4u + (mis_bool ? RS_MIS_BOOL : (uint32_t)RS_MIS);
     if (shadow) q.trace[is] = p * 4u + RS_SHADOW;
     if (q.keys) {  // the three rays leave from the same surface point: one cell, the any-hit flag on top
         if (PB_SORT_OCTANT) cell <<= 3;
         if (cont) q.keys[ic] = cell;
-        if (mis) q.keys[im] = cell;
+        if (mis) q.keys[im] = mis_bool ? (cell | (1u << (kSortKeyBits - 1))) : cell;
         if (shadow) q.keys[is] = cell | (1u << (kSortKeyBits - 1));
     }
     if (again) q.shade[sh.base_paths + sh.wave_paths[wave] + lane_prefix(ma)] = p;

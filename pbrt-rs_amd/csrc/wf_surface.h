@@ -324,6 +324,9 @@ struct ShadeConsts {
     // spatial[v * (2 n + 2)] = func[n], cdf[n + 1], func_int; null = the fixed `distrib`
     const float* spatial;
     int n_voxel[3];
+    // MIS rays towards lights that are not area lights are queued as RS_MIS_BOOL (wf_state.h); off while the reference's
+    // loops are being counted (pbrt_hip_set_counting(1): the reference walks those rays to their closest hit)
+    int mis_bool;
 };
 
 // SpatialLightDistribution::lookup (lightdistrib.rs:171-182): the voxel of p, then its distribution

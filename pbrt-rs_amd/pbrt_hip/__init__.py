@@ -29,7 +29,7 @@ EXPORTS = [
     "pbrt_hip_free", "pbrt_hip_bvh_build_boxes", "pbrt_hip_instance_bounds", "pbrt_hip_scene_create",
     "pbrt_hip_scene_create_instanced", "pbrt_hip_scene_create_with_spheres", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
     "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
-    "pbrt_hip_context_set_deadline", "pbrt_hip_context_set_traversal",
+    "pbrt_hip_context_set_deadline", "pbrt_hip_context_set_traversal", "pbrt_hip_context_is_lost",
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
     "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png", "pbrt_hip_write_exr",
     "pbrt_hip_comm_unique_id", "pbrt_hip_comm_create", "pbrt_hip_comm_destroy", "pbrt_hip_film_reduce",
@@ -122,6 +122,7 @@ def lib():
         L.pbrt_hip_comm_last_error.restype = ctypes.c_char_p
         L.pbrt_hip_synchronize.argtypes = [vp]
         L.pbrt_hip_context_set_deadline.argtypes = [vp, ctypes.c_double]
+        L.pbrt_hip_context_is_lost.argtypes = [vp]
         L.pbrt_hip_trace_timing.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_uint64)]
         L.pbrt_hip_set_counting.argtypes = [vp, ctypes.c_int]
@@ -172,6 +173,10 @@ class Context:
     def set_deadline(self, seconds):
         """Seconds pbrt_hip_render / pbrt_hip_li wait for one wavefront before the context is given up for lost."""
         self.check(lib().pbrt_hip_context_set_deadline(self.h, float(seconds)), "set_deadline")
+
+    def is_lost(self):
+        """True once a call on this context ran into the wavefront deadline: its device memory only goes back with the process."""
+        return lib().pbrt_hip_context_is_lost(self.h) == 1
 
     def trace_timing(self, reset=False):
         ms, n = ctypes.c_double(), ctypes.c_uint64()

@@ -658,8 +658,10 @@ def test_a_wavefront_past_its_deadline_loses_the_context_and_nothing_is_reused()
     with pytest.raises(pbrt_hip.PbrtHipError):
         ctx.set_deadline(0.0)
     ctx.set_deadline(1e-7)
+    assert not ctx.is_lost()
     with pytest.raises(pbrt_hip.PbrtHipError, match="deadline"):
-        g.render(cam, w, h, spp, max_depth=5, seed=3)
+        g.render(cam, w, h, spp, max_depth=5, seed=3)      # host film: its device copy is left alone, not hipFree'd
+    assert ctx.is_lost()
     for call in (lambda: g.render(cam, w, h, 1, max_depth=1), lambda: g.intersect(np.zeros(1, dtype=pbrt_hip.RAY_DTYPE)),
                  ctx.synchronize, lambda: pbrt_hip.Scene(ctx, scenes.cornell_box())):
         with pytest.raises(pbrt_hip.PbrtHipError, match="context lost"):
