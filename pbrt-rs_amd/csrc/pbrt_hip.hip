@@ -18,7 +18,6 @@
 #include "trace.h"
 #include "trace_persistent.h"
 #include "trace_wide.h"
-#include "trace_wide_any.h"
 #include "trace_stackless.h"
 
 using namespace pb;
@@ -1111,13 +1110,6 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WA
     trace_wide<BatchRayIO<ANY>, COUNT, INST>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x,
                                              counters, lds_world + (INST ? threadIdx.x : 0));
 }
-// Primitive::intersect_p over the 4-wide records of a one-level scene: the order-free walk (trace_wide_any.h)
-template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock, COUNT ? PB_WIDE_INST_WAVES : PB_ANY_WAVES)
-    k_intersect_batch_wide_any(WideTrees wt, BatchRayIO<true> io, unsigned int* work_counter, unsigned long long* counters) {
-    __shared__ uint32_t lds_stack[kAnyStackLds * kTraceBlock];
-    trace_wide_any<BatchRayIO<true>, COUNT>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x, counters);
-}
 template <bool ANY, int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, INST ? PB_INST_WAVES : PB_TRACE_WAVES)
     k_intersect_batch_special(DevBVH bvh, SpecialListIO<BatchRayIO<ANY>> io, unsigned int* work_counter) {
@@ -1174,15 +1166,6 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
             } else if (inst == 1) {
                 if (count_wide) PB_LAUNCH_WIDE(true, 1); else PB_LAUNCH_WIDE(false, 1);
                 PB_LAUNCH_SPECIAL(1);
-            } else if (ANY) {
-                if constexpr (ANY) {
-                    const dim3 any_grid(persistent_grid(s, count_wide ? PB_WIDE_INST_WAVES : PB_ANY_WAVES, (kAnyStackLds + 1) / 2));
-                    if (count_wide)
-                        hipLaunchKernelGGL(k_intersect_batch_wide_any<true>, any_grid, block, 0, ctx->stream, wt, io, ctx->d_work_counter, ctx->d_counters);
-                    else
-                        hipLaunchKernelGGL(k_intersect_batch_wide_any<false>, any_grid, block, 0, ctx->stream, wt, io, ctx->d_work_counter, ctx->d_counters);
-                }
-                PB_LAUNCH_SPECIAL(0);
             } else {
                 if (count_wide) PB_LAUNCH_WIDE(true, 0); else PB_LAUNCH_WIDE(false, 0);
                 PB_LAUNCH_SPECIAL(0);

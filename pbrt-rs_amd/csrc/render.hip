@@ -19,14 +19,6 @@
 
 using namespace pb;
 
-// measurement switches of the boolean-ray path (profiles/r04_wide_kernel_ladder.txt); the product is built with both on
-#ifndef PB_MIS_BOOL
-#define PB_MIS_BOOL 1   // MIS rays towards non-area lights are queued as RS_MIS_BOOL (wf_state.h)
-#endif
-#ifndef PB_ANY_SPLIT
-#define PB_ANY_SPLIT 1  // the boolean rays at the end of a sorted queue go to trace_wide_any
-#endif
-
 // ------------------------------------------------------------------------------------
 // render: see wavefront.h
 // ------------------------------------------------------------------------------------
@@ -726,7 +718,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     sc.total_light_samples = prefix.back();
     sc.spatial = nullptr;
     sc.n_voxel[0] = sc.n_voxel[1] = sc.n_voxel[2] = 1;
-    sc.mis_bool = (PB_MIS_BOOL && ctx->count_traversal != 1) ? 1 : 0;  // wf_state.h: RS_MIS_BOOL
+    sc.mis_bool = ctx->count_traversal != 1 ? 1 : 0;  // wf_state.h: RS_MIS_BOOL
     if (rp.integrator == PBRT_INTEGRATOR_PATH && rp.light_strategy == 2 && s->d.n_lights > 1) {
         // create_light_sample_distribution("spatial") -> SpatialLightDistribution::new(scene, 64) (lightdistrib.rs:85-107, 228)
         if (!s->d_spatial) {
@@ -825,13 +817,11 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         local.rays_closest += (uint64_t)valid_pixels * pp.n_samples;
         bool first = true;
         int wavefront = 0;  // 0 = camera rays, 1 = first bounce + its shadow rays, ...
-        uint32_t n_boolean = 0;  // shadow + RS_MIS_BOOL entries of the queue about to be traced (the sort puts them last)
         while (rc == PBRT_HIP_OK && counts[1] > 0) {
             uint32_t n_trace = (uint32_t)counts[0], n_shade = (uint32_t)counts[1];
             if (n_trace > 0) {
                 RENDER_TRY(hipMemsetAsync(ctx->d_work_counter, 0, kWorkCounters * sizeof(unsigned int), st));
                 const uint32_t* trace_queue = q[cur].trace;
-                bool sorted = false;
                 if (sort_rays && wavefront >= sort_from && n_trace >= (1u << 20)) {
                     // from the second bounce on the rays of a wavefront start all over the scene (the first bounce still
                     // follows the pixel order of its camera rays): trace them in Morton order of their origins
@@ -848,7 +838,6 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                         rc = PBRT_HIP_ERR_DEVICE;
                     }
                     trace_queue = sort_vals;
-                    sorted = true;
                 }
                 RENDER_TRY(hipEventRecord(e_t0, st));
                 {
@@ -872,25 +861,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                         WideTrees wt = s->wide;
                         wt.special_list = special_list;
                         wt.special_count = ctx->d_work_counter + kSpecialCount;
-                        // a sorted queue ends with its boolean rays (sort key's top bit): they go to the order-free kernel
-                        const uint32_t n_any = (PB_ANY_SPLIT && sorted && inst == 0 && n_boolean <= n_trace) ? n_boolean : 0u;
-                        if (n_any >= (1u << 16)) {
-                            const uint32_t n_front = n_trace - n_any;
-                            const uint32_t* any_queue = trace_queue + n_front;
-                            const dim3 any_grid(persistent_grid(s, count_wide ? PB_WIDE_INST_WAVES : PB_ANY_WAVES, (kAnyStackLds + 1) / 2));
-                            n_trace = n_front;
-                            if (n_front > 0) {
-                                if (count_wide) PB_LAUNCH_WIDE(true, 0); else PB_LAUNCH_WIDE(false, 0);
-                            }
-                            if (count_wide)
-                                hipLaunchKernelGGL(k_trace_wide_any<true>, any_grid, block, 0, st, wt, ps, any_queue, n_any,
-                                                   ctx->d_work_counter + kAnyCounter, ctx->d_counters);
-                            else
-                                hipLaunchKernelGGL(k_trace_wide_any<false>, any_grid, block, 0, st, wt, ps, any_queue, n_any,
-                                                   ctx->d_work_counter + kAnyCounter, ctx->d_counters);
-                            n_trace = n_front + n_any;
-                            PB_LAUNCH_SPECIAL(0);
-                        } else if (inst == 2) {
+                        if (inst == 2) {
                             if (count_wide) PB_LAUNCH_WIDE(true, 2); else PB_LAUNCH_WIDE(false, 2);
                             PB_LAUNCH_SPECIAL(2);
                         } else if (inst == 1) {
@@ -988,8 +959,6 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                 local.rays_closest += n_rays - n_shadow;
                 local.rays_shadow += n_shadow;
                 counts[0] = n_rays;
-                n_boolean = (uint32_t)(n_shadow + (counts[1] >> 32));
-                counts[1] &= 0xffffffffull;
             }
             (void)first;
             first = false;

@@ -51,8 +51,7 @@ struct PbrtHipContext {
     unsigned long long* d_counters = nullptr;  // [0..3] mode 1: node, prim, rays, instance tests; [4..7] mode 2
     uint64_t counted_rays = 0;
     // ray-queue heads of the persistent traversal kernels: [0, kQueueSegments) the launch's segments,
-    // [kFollowUpCounter] the follow-up launch over the rays the wide kernel left out, [kSpecialCount] their number,
-    // [kAnyCounter] the launch of trace_wide_any over the boolean rays at the end of a sorted queue
+    // [kFollowUpCounter] the follow-up launch over the rays the wide kernel left out, [kSpecialCount] their number
     unsigned int* d_work_counter = nullptr;
     uint32_t* d_special_list = nullptr;  // batch calls: tokens (IO::token) of those rays (grown on demand)
     size_t special_capacity = 0;
@@ -75,7 +74,7 @@ struct PbrtHipContext {
 
 namespace pb {
 
-constexpr int kWorkCounters = 16, kFollowUpCounter = 8, kAnyCounter = 10, kSpecialCount = 12;
+constexpr int kWorkCounters = 16, kFollowUpCounter = 8, kSpecialCount = 12;
 
 // device-side light / material tables
 struct DevLight {

@@ -247,16 +247,7 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WA
     trace_wide<WavefrontRayIO<INST != 0>, COUNT, INST>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x,
                                             counters, lds_world + (INST ? threadIdx.x : 0));
 }
-// ... the boolean rays at the end of a sorted queue (shadow rays, RS_MIS_BOOL) in no particular order (trace_wide_any.h) ...
-template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock, COUNT ? PB_WIDE_INST_WAVES : PB_ANY_WAVES)
-    k_trace_wide_any(WideTrees wt, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, unsigned int* work_counter,
-                     unsigned long long* counters) {
-    __shared__ uint32_t lds_stack[kAnyStackLds * kTraceBlock];
-    WavefrontRayIO<false> io{ps, queue, n, 1};
-    trace_wide_any<WavefrontRayIO<false>, COUNT>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x, counters);
-}
-// ... and the rays they left to the binary records (axis-parallel directions and the like; usually none)
+// ... and the rays it left to the binary records (axis-parallel directions and the like; usually none)
 template <int INST = 0>
 __global__ void __launch_bounds__(kTraceBlock, INST ? PB_INST_WAVES : PB_TRACE_WAVES)
     k_trace_special(DevBVH bvh, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, const uint32_t* __restrict__ list,

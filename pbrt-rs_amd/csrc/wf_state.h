@@ -6,7 +6,6 @@
 #include "trace.h"
 #include "trace_persistent.h"
 #include "trace_wide.h"
-#include "trace_wide_any.h"
 #include "trace_stackless.h"
 
 namespace pb {
@@ -27,7 +26,7 @@ enum RaySlot : int { RS_CONT = 0, RS_MIS = 1, RS_SHADOW = 2 };
 // hit under the ray's original t_max, walking exactly as intersect_p walks, so `found` = "some leaf whose box passes holds a
 // triangle that Triangle::intersect accepts" — a boolean that does not depend on the visiting order and needs no closest
 // hit: such a ray is traced as an any-hit ray that skips the triangles Triangle::intersect rejects (IO::strict), ends at its
-// first hit, and sorts with the shadow rays.
+// first hit, and sorts with the shadow rays (+2.3 % of a config-3 frame, +4.3 % of config 5's: profiles/r04_wide_kernel_ladder.txt).
 constexpr uint32_t RS_MIS_BOOL = 3;
 // estimate_direct_emit's return value carries this beside the PF_NEE_* bits (it is not a path flag)
 constexpr int NEE_MIS_BOOL = 0x100;
@@ -114,7 +113,7 @@ struct Queues {
     uint32_t* trace;   // entries: path*4 + slot
     uint32_t* shade;   // entries: path
     // counts64[0]: low 32 bits = trace-queue length, high 32 bits = shadow rays among them;
-    // counts64[1]: low 32 bits = shade-queue length, high 32 bits = RS_MIS_BOOL entries of the trace queue
+    // counts64[1]: shade-queue length
     unsigned long long* counts64;
     // sort key of every trace-queue entry (ray_sort_key), written with the entry when the next wavefront will be
     // traced in Morton order; null otherwise
@@ -158,7 +157,6 @@ PB_DEV uint64_t sample_sequence(const PassParams& pp, int x, int y, int s) {
 struct BlockAppend {
     uint32_t wave_rays[16];   // per-wave totals (blocks of up to 1024 threads)
     uint32_t wave_shadow[16];
-    uint32_t wave_bool[16];
     uint32_t wave_paths[16];
     uint32_t base_rays, base_paths;
 };
@@ -176,25 +174,23 @@ PB_DEV void block_append(BlockAppend& sh, const Queues& q, uint32_t p, bool cont
     if (lane == 0) {
         sh.wave_rays[wave] = wc + wm + ws;
         sh.wave_shadow[wave] = ws;
-        sh.wave_bool[wave] = (uint32_t)__popcll(__ballot(mis && mis_bool));
         sh.wave_paths[wave] = (uint32_t)__popcll(ma);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t tr = 0, tsd = 0, tp = 0, tb = 0;
+        uint32_t tr = 0, tsd = 0, tp = 0;
         for (int w = 0; w < n_waves; ++w) {
             uint32_t r = sh.wave_rays[w], pth = sh.wave_paths[w];
             sh.wave_rays[w] = tr;   // exclusive prefix
             sh.wave_paths[w] = tp;
             tr += r;
             tsd += sh.wave_shadow[w];
-            tb += sh.wave_bool[w];
             tp += pth;
         }
         unsigned long long old = 0;
         if (tr) old = atomicAdd(&q.counts64[0], (unsigned long long)tr | ((unsigned long long)tsd << 32));
         sh.base_rays = (uint32_t)old;
-        sh.base_paths = (tp | tb) ? (uint32_t)atomicAdd(&q.counts64[1], (unsigned long long)tp | ((unsigned long long)tb << 32)) : 0u;
+        sh.base_paths = tp ? (uint32_t)atomicAdd(&q.counts64[1], (unsigned long long)tp) : 0u;
     }
     __syncthreads();
     uint32_t rbase = sh.base_rays + sh.wave_rays[wave];
