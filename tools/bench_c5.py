@@ -16,6 +16,7 @@ cam = scenes.instanced_camera(W, H)
 ctx = pbrt_hip.Context(0)
 scene = pbrt_hip.Scene(ctx, sc, bvh=bvh)
 print("wide records:", scene.wide_records())
+ctx.set_traversal(int(os.environ.get("TRAVERSAL", "0")))   # 3 = PBRT_TRAVERSAL_ROUNDS
 for it in range(2):
     film, st = scene.render(cam, W, H, spp, max_depth=16, seed=0, shade_order=ORDER)
 rays = st["rays_closest"] + st["rays_shadow"]
