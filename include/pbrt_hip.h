@@ -346,13 +346,9 @@ int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* total_ms, uint
  *   PBRT_TRAVERSAL_AUTO      the 4-wide quantised records where the scene has them, else the binary records with a stack;
  *   PBRT_TRAVERSAL_STACK     the binary child-pair records with the per-lane stack (the reference's own form);
  *   PBRT_TRAVERSAL_STACKLESS the binary records with parent links and a 64-bit trail instead of a stack — single-level
- *                            triangle scenes only: calls on other scenes fail with PBRT_HIP_ERR_INVALID;
- *   PBRT_TRAVERSAL_ROUNDS    pbrt_hip_render / pbrt_hip_li on a pbrt_hip_scene_create_instanced scene: TransformedPrimitive::
- *                            intersect (src/core/primitive.rs:136-159) unnested — the top-level walk and the walks inside the
- *                            instances run in launches of their own, a ray's instances still one after the other with the
- *                            t_max the last one left (csrc/trace_rounds.h); everything else as AUTO.
- * AUTO is the fast one (DESIGN.md section 4.6 has the first three on BASELINE config 3, section 4.3 the fourth on config 5). */
-enum { PBRT_TRAVERSAL_AUTO = 0, PBRT_TRAVERSAL_STACK = 1, PBRT_TRAVERSAL_STACKLESS = 2, PBRT_TRAVERSAL_ROUNDS = 3 };
+ *                            triangle scenes only: calls on other scenes fail with PBRT_HIP_ERR_INVALID.
+ * AUTO is the fast one (DESIGN.md section 4.6 has all three on BASELINE config 3). */
+enum { PBRT_TRAVERSAL_AUTO = 0, PBRT_TRAVERSAL_STACK = 1, PBRT_TRAVERSAL_STACKLESS = 2 };
 int pbrt_hip_context_set_traversal(PbrtHipContext* ctx, int traversal);
 
 /* Instrumentation for the roofline accounting: when enabled, traversal launches

@@ -140,8 +140,8 @@ extern "C" int pbrt_hip_set_counting(PbrtHipContext* ctx, int enable) {
 extern "C" int pbrt_hip_context_set_traversal(PbrtHipContext* ctx, int traversal) {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(ctx);
-    if (traversal < PBRT_TRAVERSAL_AUTO || traversal > PBRT_TRAVERSAL_ROUNDS) {
-        ctx->last_error = "traversal must be PBRT_TRAVERSAL_AUTO, _STACK, _STACKLESS or _ROUNDS";
+    if (traversal < PBRT_TRAVERSAL_AUTO || traversal > PBRT_TRAVERSAL_STACKLESS) {
+        ctx->last_error = "traversal must be PBRT_TRAVERSAL_AUTO, _STACK or _STACKLESS";
         return PBRT_HIP_ERR_INVALID;
     }
     ctx->traversal = traversal;
@@ -1065,7 +1065,6 @@ struct BatchRayIO {
     PB_DEV uint32_t n() const { return count; }
     PB_DEV int segments() const { return 1; }
     PB_DEV uint32_t token(uint32_t i) const { return i; }  // a batch ray's token is its position
-    PB_DEV static constexpr uint32_t chunk() { return kChunk; }
     PB_DEV bool strict(uint32_t) const { return false; }   // pbrt_hip_intersect_p is Primitive::intersect_p
     PB_DEV bool load(uint32_t i, TravRay* r, bool* any) const {
         const float4* rp = reinterpret_cast<const float4*>(rays + i);
@@ -1128,7 +1127,7 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
         ctx->last_error = "batch too large for one launch (split it below 2^32 rays)";
         return PBRT_HIP_ERR_INVALID;
     }
-    const bool wide = s->has_wide && ctx->count_traversal != 1 && (ctx->traversal == PBRT_TRAVERSAL_AUTO || ctx->traversal == PBRT_TRAVERSAL_ROUNDS);
+    const bool wide = s->has_wide && ctx->count_traversal != 1 && ctx->traversal == PBRT_TRAVERSAL_AUTO;
     const bool stackless = ctx->traversal == PBRT_TRAVERSAL_STACKLESS;
     if (stackless && !stackless_applies(s)) return PBRT_HIP_ERR_INVALID;
     if (wide && ctx->special_capacity < (size_t)n) {  // room for the queue positions of the rays the wide kernel leaves out

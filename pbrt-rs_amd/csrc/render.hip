@@ -565,42 +565,10 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         sort_tmp = buf.alloc<char>(sort_tmp_bytes, &ok);
     }
     // rays the wide kernel leaves to the binary one (wide_bvh.h): room for every entry of a trace queue
-    const bool use_wide = s->has_wide && ctx->count_traversal != 1 &&
-                          (ctx->traversal == PBRT_TRAVERSAL_AUTO || ctx->traversal == PBRT_TRAVERSAL_ROUNDS);
+    const bool use_wide = s->has_wide && ctx->count_traversal != 1 && ctx->traversal == PBRT_TRAVERSAL_AUTO;
     const bool stackless = ctx->traversal == PBRT_TRAVERSAL_STACKLESS;
     if (stackless && !stackless_applies(s)) return PBRT_HIP_ERR_INVALID;
     uint32_t* special_list = use_wide ? buf.alloc<uint32_t>(N * 3, &ok) : nullptr;
-    // instanced scenes in rounds (trace_rounds.h): two entry buffers of `cap` entries (a wavefront longer than that is traced
-    // in slices), the list of entries whose object walk left the wide path, work-queue heads and entry counts
-    const bool use_rounds = use_wide && ctx->traversal == PBRT_TRAVERSAL_ROUNDS && ctx->count_traversal == 0 && s->d.bvh.instanced &&
-                            !s->d.bvh.general_top;
-    RoundEntries rounds[2] = {};
-    uint32_t* rounds_abandoned = nullptr;
-    // [0, 64) work-queue heads, [64] / [65] the two buffers' slot counts, [66] abandoned entries, [67] / [68] the buffers' entries
-    unsigned int* rounds_counters = nullptr;
-    constexpr int kRoundsHeads = 64, kRoundsCounters = kRoundsHeads + 8;
-    uint32_t rounds_slice = 0;  // rays per slice of a wavefront
-    if (use_rounds) {
-        rounds_slice = (uint32_t)std::min<size_t>(N * 3, (size_t)1 << 25);
-        // every resident wave may leave one slot block unfinished (holes)
-        const uint32_t cap = rounds_slice + (uint32_t)(ctx->n_cus * 32 + 64) * kRoundsSlotBlock;
-        rounds_counters = buf.alloc<unsigned int>(kRoundsCounters, &ok);
-        rounds_abandoned = buf.alloc<uint32_t>(cap, &ok);
-        for (int k = 0; k < 2; ++k) {
-            rounds[k].A0 = buf.alloc<float4>(cap, &ok);
-            rounds[k].A1 = buf.alloc<float4>(cap, &ok);
-            rounds[k].A2 = buf.alloc<float4>(cap, &ok);
-            rounds[k].A3 = buf.alloc<float4>(cap, &ok);
-            rounds[k].A4 = buf.alloc<float4>(cap, &ok);
-            rounds[k].A5 = buf.alloc<uint4>(cap, &ok);
-            rounds[k].S = buf.alloc<uint2>((size_t)cap * kRoundsStackSave, &ok);
-            rounds[k].R0 = buf.alloc<float4>(cap, &ok);
-            rounds[k].R1 = buf.alloc<float>(cap, &ok);
-            rounds[k].count = rounds_counters + kRoundsHeads + k;
-            rounds[k].real = rounds_counters + kRoundsHeads + 3 + k;
-            rounds[k].cap = cap;
-        }
-    }
     // sort-by-material shading (wf_path.h): PbrtRenderParams.shade_order; 2 = the whole shade queue in material order
     if (rp.shade_order < 0 || rp.shade_order > 2) return invalid("shade_order must be 0 (queue order), 1 (by material inside blocks) or 2 (sorted queue)");
     const bool sort_shade = rp.shade_order == 2 && rp.integrator == PBRT_INTEGRATOR_PATH;
@@ -789,25 +757,6 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
 #define RENDER_TRY(call)                                  \
     if (rc == PBRT_HIP_OK && !hip_ok(ctx, (call), #call)) rc = PBRT_HIP_ERR_DEVICE;
 
-    // Wait for ctx->ev_sync: spin on the event (a blocking sync costs a scheduler wake-up per wavefront), but not for ever — a
-    // kernel that never finishes must surface as an error of this call, with the context's lock released
-    auto wait_for_event = [&]() -> int {
-        hipError_t qe;
-        const auto spin_start = std::chrono::steady_clock::now();
-        uint32_t polls = 0;
-        while ((qe = hipEventQuery(ctx->ev_sync)) == hipErrorNotReady) {
-            if ((++polls & 0xfffu) == 0) {
-                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - spin_start).count();
-                if (waited > ctx->wavefront_deadline_s) {
-                    ctx->last_error = "a wavefront did not finish within the deadline (hung kernel?)";
-                    ctx->lost = true;  // the stream is not drained below: nothing may follow on this context
-                    return PBRT_HIP_ERR_DEVICE;
-                }
-                if (waited > 0.05) std::this_thread::yield();  // long wavefronts: stop burning a core
-            }
-        }
-        return hip_ok(ctx, qe, "hipEventQuery") ? PBRT_HIP_OK : PBRT_HIP_ERR_DEVICE;
-    };
     RENDER_TRY(hipEventRecord(e_begin, st));
     bool tables_ready = !tabulated || rp.sampler == PBRT_SAMPLER_HALTON;
     for (int s0 = 0; s0 < rp.spp && rc == PBRT_HIP_OK; s0 += spp_pass) {
@@ -908,49 +857,6 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                     if (stackless) {
                         hipLaunchKernelGGL(k_trace_stackless, dim3(stackless_grid(s)), block, 0, st, s->d.bvh, ps, trace_queue, n_trace,
                                            ctx->d_work_counter, segments);
-                    } else if (use_rounds) {
-                        // TransformedPrimitive::intersect unnested (trace_rounds.h). Per slice of the queue: the top-level walk
-                        // over the rays, then rounds of {object walks over the entries, top-level walk resumed} until a round
-                        // leaves no entry; the number of entries is read back every second round.
-                        WideTrees wt = s->wide;
-                        wt.special_list = special_list;
-                        wt.special_count = ctx->d_work_counter + kSpecialCount;
-                        WideTrees wo = s->wide;  // the object aggregate as a one-level tree; its drop-outs are ENTRIES
-                        wo.root_ref = s->wide.obj0_root;
-                        wo.special_list = rounds_abandoned;
-                        wo.special_count = rounds_counters + kRoundsHeads + 2;
-                        const dim3 top_grid(persistent_grid(s, PB_ROUNDS_TOP_WAVES, kRoundsStackLds, 6 * 4 * kTraceBlock));
-                        const dim3 obj_grid(persistent_grid(s, PB_WIDE_WAVES, wide_stack_lds(0)));
-                        for (uint32_t off = 0; off < n_trace && rc == PBRT_HIP_OK; off += rounds_slice) {
-                            const uint32_t m = std::min(rounds_slice, n_trace - off);
-                            RENDER_TRY(hipMemsetAsync(rounds_counters, 0, kRoundsCounters * sizeof(unsigned int), st));
-                            int head = 0, b = 0;
-                            hipLaunchKernelGGL(k_rounds_top<false>, top_grid, block, 0, st, wt, ps, trace_queue + off, m, rounds[1], rounds[0],
-                                               rounds_counters + head++);
-                            for (int round = 0; rc == PBRT_HIP_OK; ++round) {
-                                if (head + 2 > kRoundsHeads) {
-                                    RENDER_TRY(hipMemsetAsync(rounds_counters, 0, kRoundsHeads * sizeof(unsigned int), st));
-                                    head = 0;
-                                }
-                                hipLaunchKernelGGL(k_rounds_object, obj_grid, block, 0, st, wo, rounds[b], rounds_counters + head++);
-                                hipLaunchKernelGGL(k_rounds_mark_abandoned, dim3(64), dim3(256), 0, st, rounds[b], rounds_abandoned,
-                                                   rounds_counters + kRoundsHeads + 2);
-                                RENDER_TRY(hipMemsetAsync(rounds_counters + kRoundsHeads + 2, 0, sizeof(unsigned int), st));
-                                RENDER_TRY(hipMemsetAsync(rounds[b ^ 1].count, 0, sizeof(unsigned int), st));
-                                RENDER_TRY(hipMemsetAsync(rounds[b ^ 1].real, 0, sizeof(unsigned int), st));
-                                hipLaunchKernelGGL(k_rounds_top<true>, top_grid, block, 0, st, wt, ps, trace_queue + off, m, rounds[b], rounds[b ^ 1],
-                                                   rounds_counters + head++);
-                                RENDER_TRY(hipGetLastError());
-                                b ^= 1;
-                                if (round & 1) {
-                                    RENDER_TRY(hipMemcpyAsync(ctx->h_counts, rounds[b].real, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-                                    RENDER_TRY(hipEventRecord(ctx->ev_sync, st));
-                                    if (rc == PBRT_HIP_OK) rc = wait_for_event();
-                                    if (rc != PBRT_HIP_OK || *(volatile unsigned int*)ctx->h_counts == 0u) break;
-                                }
-                            }
-                        }
-                        if (rc == PBRT_HIP_OK) PB_LAUNCH_SPECIAL(1);
                     } else if (use_wide) {
                         WideTrees wt = s->wide;
                         wt.special_list = special_list;
@@ -1016,7 +922,26 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             RENDER_TRY(hipGetLastError());
             RENDER_TRY(hipMemcpyAsync(ctx->h_counts, q[nxt].counts64, sizeof(counts), hipMemcpyDeviceToHost, st));
             RENDER_TRY(hipEventRecord(ctx->ev_sync, st));
-            if (rc == PBRT_HIP_OK) rc = wait_for_event();
+            if (rc == PBRT_HIP_OK) {
+                // spin on the event (a blocking sync costs a scheduler wake-up per wavefront), but not for ever: a kernel
+                // that never finishes must surface as an error of this call, with the context's lock released
+                hipError_t qe;
+                const auto spin_start = std::chrono::steady_clock::now();
+                uint32_t polls = 0;
+                while ((qe = hipEventQuery(ctx->ev_sync)) == hipErrorNotReady) {
+                    if ((++polls & 0xfffu) == 0) {
+                        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - spin_start).count();
+                        if (waited > ctx->wavefront_deadline_s) {
+                            ctx->last_error = "a wavefront did not finish within the deadline (hung kernel?)";
+                            ctx->lost = true;  // the stream is not drained below: nothing may follow on this context
+                            rc = PBRT_HIP_ERR_DEVICE;
+                            break;
+                        }
+                        if (waited > 0.05) std::this_thread::yield();  // long wavefronts: stop burning a core
+                    }
+                }
+                if (rc == PBRT_HIP_OK) RENDER_TRY(qe);
+            }
             counts[0] = ctx->h_counts[0];
             counts[1] = ctx->h_counts[1];
             if (n_trace > 0 && rc == PBRT_HIP_OK) {

@@ -96,7 +96,7 @@ PB_DEV bool root_box_test(const LaneState& s, const float* mn, const float* mx) 
                      s.nz ? mx[2] : mn[2], s.nz ? mn[2] : mx[2], s.r, s.idx, s.idy, s.idz, s.tmax, &e);
 }
 
-// IO policy: n(), segments(), chunk() = rays per wave-level queue grab, token(i) of queue position i, load(token, &ray, &any) -> bool real ray,
+// IO policy: n(), segments(), token(i) of queue position i, load(token, &ray, &any) -> bool real ray,
 // strict(token): an any-hit ray that asks for the boolean of Primitive::intersect instead of intersect_p's — a hit on a
 // triangle that Triangle::intersect rejects (kTriDegenerate, triangle.rs:197-216) does not count (wf_state.h: RS_MIS_BOOL),
 // store(token, any, found, t, b0, b1, b2, slot, instance)
@@ -241,11 +241,11 @@ PB_DEV void trace_persistent(const DevBVH& bvh, const IO& io, unsigned int* __re
                     uint32_t seg_begin = (uint32_t)(((unsigned long long)n * (unsigned)seg) / (unsigned)n_seg);
                     uint32_t seg_end = (uint32_t)(((unsigned long long)n * (unsigned)(seg + 1)) / (unsigned)n_seg);
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(work_counter + seg, (unsigned int)IO::chunk());
+                    if (lane == 0) base = atomicAdd(work_counter + seg, (unsigned int)kChunk);
                     base = (uint32_t)__builtin_amdgcn_readfirstlane(base) + seg_begin;
                     if (base < seg_end && base >= seg_begin) {
                         chunk_next = base;
-                        chunk_end = (base + IO::chunk()) < seg_end ? (base + IO::chunk()) : seg_end;
+                        chunk_end = (base + kChunk) < seg_end ? (base + kChunk) : seg_end;
                         break;
                     }
                     seg = (seg + 1 == n_seg) ? 0 : seg + 1;

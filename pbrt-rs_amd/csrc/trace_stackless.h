@@ -64,11 +64,11 @@ PB_DEV void trace_stackless(const DevBVH& bvh, const IO& io, unsigned int* __res
                     uint32_t seg_begin = (uint32_t)(((unsigned long long)n * (unsigned)seg) / (unsigned)n_seg);
                     uint32_t seg_end = (uint32_t)(((unsigned long long)n * (unsigned)(seg + 1)) / (unsigned)n_seg);
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(work_counter + seg, (unsigned int)IO::chunk());
+                    if (lane == 0) base = atomicAdd(work_counter + seg, (unsigned int)kChunk);
                     base = (uint32_t)__builtin_amdgcn_readfirstlane(base) + seg_begin;
                     if (base < seg_end && base >= seg_begin) {
                         chunk_next = base;
-                        chunk_end = (base + IO::chunk()) < seg_end ? (base + IO::chunk()) : seg_end;
+                        chunk_end = (base + kChunk) < seg_end ? (base + kChunk) : seg_end;
                         break;
                     }
                     seg = (seg + 1 == n_seg) ? 0 : seg + 1;

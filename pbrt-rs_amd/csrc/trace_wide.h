@@ -76,7 +76,6 @@ struct SpecialListIO {
     PB_DEV uint32_t n() const { return *count; }
     PB_DEV int segments() const { return 1; }
     PB_DEV uint32_t token(uint32_t i) const { return list[i]; }
-    PB_DEV static constexpr uint32_t chunk() { return kChunk; }
     PB_DEV bool strict(uint32_t tok) const { return inner.strict(tok); }
     PB_DEV bool load(uint32_t tok, TravRay* r, bool* any) const { return inner.load(tok, r, any); }
     PB_DEV void store(uint32_t tok, bool any, bool found, float t, float b0, float b1, float b2, int slot, int inst) const {
@@ -315,11 +314,11 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                     uint32_t seg_begin = (uint32_t)(((unsigned long long)n * (unsigned)seg) / (unsigned)n_seg);
                     uint32_t seg_end = (uint32_t)(((unsigned long long)n * (unsigned)(seg + 1)) / (unsigned)n_seg);
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(work_counter + seg, (unsigned int)IO::chunk());
+                    if (lane == 0) base = atomicAdd(work_counter + seg, (unsigned int)kChunk);
                     base = (uint32_t)__builtin_amdgcn_readfirstlane(base) + seg_begin;
                     if (base < seg_end && base >= seg_begin) {
                         chunk_next = base;
-                        chunk_end = (base + IO::chunk()) < seg_end ? (base + IO::chunk()) : seg_end;
+                        chunk_end = (base + kChunk) < seg_end ? (base + kChunk) : seg_end;
                         break;
                     }
                     seg = (seg + 1 == n_seg) ? 0 : seg + 1;

@@ -171,7 +171,6 @@ struct WavefrontRayIO {
     // its position: the store then needs no second look at the queue (one dependent load less in the refill path every
     // idle lane of the wave waits in).
     PB_DEV uint32_t token(uint32_t i) const { return queue[i]; }
-    PB_DEV static constexpr uint32_t chunk() { return kChunk; }
     PB_DEV bool strict(uint32_t e) const { return (e & 3u) == RS_MIS_BOOL; }
     PB_DEV bool load(uint32_t e, TravRay* r, bool* any) const {
         uint32_t p = e >> 2, slot = e & 3u;
@@ -247,26 +246,6 @@ __global__ void __launch_bounds__(kTraceBlock, (COUNT || INST) ? PB_WIDE_INST_WA
     WavefrontRayIO<INST != 0> io{ps, queue, n, segments};
     trace_wide<WavefrontRayIO<INST != 0>, COUNT, INST>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x,
                                             counters, lds_world + (INST ? threadIdx.x : 0));
-}
-// ... instanced scenes in rounds (trace_rounds.h): the top-level walk over the wavefront's rays (RESUME false) or over the
-// entries of the round before, and the object walks over a round's entries. A block whose first chunks would start past the
-// end of its input leaves at once (see k_trace_special): late rounds hold few entries.
-template <bool RESUME>
-__global__ void __launch_bounds__(kTraceBlock, PB_ROUNDS_TOP_WAVES)
-    k_rounds_top(WideTrees wt, PathState ps, const uint32_t* __restrict__ queue, uint32_t n, RoundEntries in, RoundEntries out,
-                 unsigned int* work_counter) {
-    if ((unsigned long long)blockIdx.x * (kTraceBlock / 64) * kRoundsChunk >= (unsigned long long)(RESUME ? *in.count : n)) return;
-    __shared__ uint2 lds_stack[kRoundsStackLds * kTraceBlock];
-    __shared__ float lds_world[6 * kTraceBlock];
-    WavefrontRayIO<true> io{ps, queue, n, 1};
-    trace_rounds_top<WavefrontRayIO<true>, RESUME>(wt, io, in, out, work_counter, lds_stack + threadIdx.x,
-                                                    blockIdx.x * kTraceBlock + threadIdx.x, lds_world + threadIdx.x);
-}
-__global__ void __launch_bounds__(kTraceBlock, PB_WIDE_WAVES) k_rounds_object(WideTrees wt, RoundEntries en, unsigned int* work_counter) {
-    if ((unsigned long long)blockIdx.x * (kTraceBlock / 64) * kRoundsChunk >= (unsigned long long)*en.count) return;
-    __shared__ uint2 lds_stack[wide_stack_lds(0) * kTraceBlock];
-    RoundObjectIO io{en};
-    trace_wide<RoundObjectIO, false, 0>(wt, io, work_counter, lds_stack + threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x);
 }
 // ... and the rays it left to the binary records (axis-parallel directions and the like; usually none)
 template <int INST = 0>

@@ -6,7 +6,6 @@
 #include "trace.h"
 #include "trace_persistent.h"
 #include "trace_wide.h"
-#include "trace_rounds.h"
 #include "trace_stackless.h"
 
 namespace pb {

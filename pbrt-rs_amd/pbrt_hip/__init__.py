@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("PBRT_HIP_LIB") or os.path.join(_HERE, "libpbrt_hip.so
 SPLIT_SAH, SPLIT_HLBVH, SPLIT_MIDDLE, SPLIT_EQUAL_COUNTS = 0, 1, 2, 3
 INTEGRATOR_PATH, INTEGRATOR_DIRECT, INTEGRATOR_WHITTED, INTEGRATOR_AO = 0, 1, 2, 3
 SAMPLER_RANDOM, SAMPLER_STRATIFIED, SAMPLER_ZEROTWO, SAMPLER_HALTON = 0, 1, 2, 3
-TRAVERSAL_AUTO, TRAVERSAL_STACK, TRAVERSAL_STACKLESS, TRAVERSAL_ROUNDS = 0, 1, 2, 3   # pbrt_hip_context_set_traversal
+TRAVERSAL_AUTO, TRAVERSAL_STACK, TRAVERSAL_STACKLESS = 0, 1, 2   # pbrt_hip_context_set_traversal
 
 EXPORTS = [
     "pbrt_hip_context_create", "pbrt_hip_context_destroy", "pbrt_hip_last_error", "pbrt_hip_bvh_build",
@@ -185,8 +185,7 @@ class Context:
 
     def set_traversal(self, traversal):
         """TRAVERSAL_AUTO (4-wide records where the scene has them), TRAVERSAL_STACK (binary records, per-lane stack) or
-        TRAVERSAL_STACKLESS (binary records, parent links + bit trail; single-level triangle scenes only), TRAVERSAL_ROUNDS
-        (instanced scenes: top-level walk and object walks in launches of their own; otherwise as AUTO)."""
+        TRAVERSAL_STACKLESS (binary records, parent links + bit trail; single-level triangle scenes only)."""
         self.check(lib().pbrt_hip_context_set_traversal(self.h, int(traversal)), "context_set_traversal")
 
     def set_counting(self, enable):

@@ -10,14 +10,14 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             k = row.get("Kernel_Name", "")
             m = re.search(r"(k_\w+|trampoline_kernel)", k)
             name = m.group(1) if m else k[:40]
-            if "k_trace" in k or "k_intersect" in k or "k_shade" in k or "k_rounds" in k:
-                t = re.search(r"(k_trace\w*|k_intersect\w*|k_shade\w*|k_rounds\w*)(<[^>]*>)?", k)
+            if "k_trace" in k or "k_intersect" in k or "k_shade" in k:
+                t = re.search(r"(k_trace\w*|k_intersect\w*|k_shade\w*)(<[^>]*>)?", k)
                 name = t.group(0) if t else name
             c = row["Counter_Name"]
             tot[name][c] += float(row["Counter_Value"])
             calls[name][c] += 1
 for name in sorted(tot, key=lambda n: -tot[n].get("SQ_WAVE_CYCLES", tot[n].get("GRBM_GUI_ACTIVE", 0))):
-    if not any(s in name for s in ("k_trace", "k_shade", "k_intersect", "k_rounds")):
+    if not any(s in name for s in ("k_trace", "k_shade", "k_intersect")):
         continue
     c = tot[name]
     n = max(calls[name].values())
