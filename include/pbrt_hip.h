@@ -182,7 +182,8 @@ typedef struct PbrtRenderParams {
      * inside every block of 256 queue entries (LDS counting sort), 2 = the whole queue sorted by material. The film does not
      * depend on it. Other integrators ignore it. */
     int32_t shade_order;
-    int32_t reserved; /* 0 */
+    int32_t ray_order; /* 0: the path integrator's ray queues are put into Morton order of the ray origins from the second bounce on
+                        * (cache order: the rays of a wave walk the same part of the tree); 1: queue order. Same film either way. */
 } PbrtRenderParams;
 
 typedef struct PbrtRenderStats {
@@ -322,9 +323,16 @@ void pbrt_hip_scene_destroy(PbrtHipScene* scene);
  * Bounds3f::intersect_p (src/core/geometry.rs:709-751) on the exact leaf box, so results are the reference's bit for
  * bit. Two-level scenes carry them for the top-level tree and for every object aggregate. n_records = number of wide
  * records (all trees of the scene), 0 when the tree is a single leaf, -1 when the scene has none; *reason then says why
- * (spheres, a leaf with more than 4 primitives, coordinates beyond 2^20, PBRT_HIP_WIDE=0 ...). The string lives as long
+ * (spheres, a leaf with more than 4 primitives, coordinates beyond 2^20, PBRT_WIDE_BUILD_NONE ...). The string lives as long
  * as the scene. */
 int pbrt_hip_scene_wide_records(const PbrtHipScene* scene, int32_t* n_records, const char** reason);
+/* Where the scenes created on this context from now on get those records:
+ *   PBRT_WIDE_BUILD_DEVICE  laid out on the device from the flat tree (csrc/wide_gpu.hip; two-level scenes: on the host) — the default;
+ *   PBRT_WIDE_BUILD_HOST    by the host builder (csrc/host_wide.cpp): the same bytes, tens of ms per million triangles slower
+ *                           (kept for the test of exactly that);
+ *   PBRT_WIDE_BUILD_NONE    not at all: the scene is traced over the binary records. */
+enum { PBRT_WIDE_BUILD_DEVICE = 0, PBRT_WIDE_BUILD_HOST = 1, PBRT_WIDE_BUILD_NONE = 2 };
+int pbrt_hip_context_set_wide_build(PbrtHipContext* ctx, int where);
 
 /* ---- batch Primitive::intersect / intersect_p (src/core/primitive.rs:17-30 via
  * Scene::intersect / intersect_p, src/core/scene.rs:40-46) ----

@@ -784,16 +784,12 @@ int hlbvh_build_scene_tree(PbrtHipContext* ctx, const float* positions, int32_t 
     }
     {
         // The wide records are laid over the flat tree while it is still on the device (wide_gpu.hip: a few ms per 10 M
-        // triangles). PBRT_HIP_WIDE_BUILD=host brings the flat tree and the triangle records back instead and lets the host
-        // builder do it (host_wide.cpp; 80 B per triangle over PCIe + tens of ms per million triangles): same bytes, kept
-        // for the test of exactly that. PBRT_HIP_WIDE_DEVICE_TREES=0: binary records only.
-        const char* w1 = std::getenv("PBRT_HIP_WIDE");
-        const char* w2 = std::getenv("PBRT_HIP_WIDE_DEVICE_TREES");
-        const char* w3 = std::getenv("PBRT_HIP_WIDE_BUILD");
-        const bool want_wide = !(w1 && w1[0] == '0') && !(w2 && w2[0] == '0');
-        if (!want_wide) {
-            out->wide_reason = (w1 && w1[0] == '0') ? "disabled by PBRT_HIP_WIDE=0" : "tree built on the device (PBRT_HIP_WIDE_DEVICE_TREES=0)";
-        } else if (!(w3 && w3[0] == 'h')) {
+        // triangles). PBRT_WIDE_BUILD_HOST (pbrt_hip_context_set_wide_build) brings the flat tree and the triangle records back
+        // instead and lets the host builder do it (host_wide.cpp; 80 B per triangle over PCIe + tens of ms per million
+        // triangles): same bytes, kept for the test of exactly that. PBRT_WIDE_BUILD_NONE: binary records only.
+        if (ctx->wide_build == PBRT_WIDE_BUILD_NONE) {
+            out->wide_reason = "disabled by PBRT_WIDE_BUILD_NONE";
+        } else if (ctx->wide_build != PBRT_WIDE_BUILD_HOST) {
             if (!pb::build_wide_tree_device(ctx, d_nodes, n_nodes, (const float*)p_tris, n, root, &out->wide, &out->wide_reason)) {
                 release();
                 return PBRT_HIP_ERR_DEVICE;

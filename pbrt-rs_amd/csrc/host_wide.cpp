@@ -87,10 +87,8 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
     // ---- (2) structure ----
     // A record's index is fixed when its parent is laid out (the parent's interior children take the next free indices,
     // contiguously); the ORDER in which records are laid out decides which records and triangles end up near each other:
-    // first-in-first-out = breadth-first (levels contiguous), last-in-first-out = depth-first (subtrees nearly contiguous).
-    // (Measured: no difference for the traversal, profiles/r02_scene_rates.txt.)
-    const char* order_env = std::getenv("PBRT_HIP_WIDE_ORDER");
-    const bool depth_first = order_env && order_env[0] == 'd';
+    // first-in-first-out = breadth-first (levels contiguous), which is also what the device builder emits (depth-first order
+    // measured no different for the traversal, profiles/r02_scene_rates.txt).
     struct Rec {
         int32_t node;         // the binary node this record stands for
         int32_t first_child;  // record index of its first interior child
@@ -103,32 +101,22 @@ const char* build_wide_tree(const PbrtLinearBVHNode* nodes, int32_t n_nodes, con
     size_t work_head = 0;
     int64_t tri_cursor = 0;
     while (work_head < work.size()) {
-        size_t w;
-        if (depth_first) {
-            w = work.back();
-            work.pop_back();
-        } else {
-            w = work[work_head++];
-        }
+        const size_t w = work[work_head++];
         int32_t slot_node[4];
         int axis_c[2];
         wide_slots_of(nodes, recs[w].node, slot_node, axis_c);
         recs[w].first_child = (int32_t)recs.size();
         recs[w].first_tri = tri_cursor;
-        int n_interior = 0;
         for (int s = 0; s < 4; ++s) {
             if (slot_node[s] < 0) continue;
             const PbrtLinearBVHNode& ch = nodes[slot_node[s]];
             if (ch.n_primitives > 0) {
                 tri_cursor += ch.n_primitives;
             } else {
-                ++n_interior;
                 recs.push_back(Rec{slot_node[s], 0, 0});
                 work.push_back(recs.size() - 1);
             }
         }
-        if (depth_first && n_interior > 1)  // walk the first interior child first, as BVHAccel's flattening does
-            std::reverse(work.end() - n_interior, work.end());
         if (recs.size() >= (1u << 31)) return "too many records";
     }
     if (tri_cursor != n_slots) return "leaves do not cover the triangle list";

@@ -137,6 +137,17 @@ extern "C" int pbrt_hip_set_counting(PbrtHipContext* ctx, int enable) {
     return PBRT_HIP_OK;
 }
 
+extern "C" int pbrt_hip_context_set_wide_build(PbrtHipContext* ctx, int where) {
+    if (!ctx) return PBRT_HIP_ERR_INVALID;
+    PB_ENTER(ctx);
+    if (where < PBRT_WIDE_BUILD_DEVICE || where > PBRT_WIDE_BUILD_NONE) {
+        ctx->last_error = "wide build must be PBRT_WIDE_BUILD_DEVICE, _HOST or _NONE";
+        return PBRT_HIP_ERR_INVALID;
+    }
+    ctx->wide_build = where;
+    return PBRT_HIP_OK;
+}
+
 extern "C" int pbrt_hip_context_set_traversal(PbrtHipContext* ctx, int traversal) {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(ctx);
@@ -795,12 +806,11 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
         s->n_instances = ia.n_instances;
     }
     // ---- 4-wide quantised records over the same tree (wide_bvh.h): single-level triangle scenes whose tree came
-    // from the host; PBRT_HIP_WIDE=0 keeps the scene on the binary records ----
+    // from the host; PBRT_WIDE_BUILD_NONE keeps the scene on the binary records ----
     int spill_entries = kStackSpill;
     {
-        const char* wide_env = std::getenv("PBRT_HIP_WIDE");
-        if (wide_env && wide_env[0] == '0') {
-            s->wide_reason = "disabled by PBRT_HIP_WIDE=0";
+        if (ctx->wide_build == PBRT_WIDE_BUILD_NONE) {
+            s->wide_reason = "disabled by PBRT_WIDE_BUILD_NONE";
         } else if (sa.n > 0) {
             s->wide_reason = "scene with spheres";
         } else if (dt && dt->wide.n_records >= 0) {
@@ -888,10 +898,10 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
                 s->has_wide = true;
                 spill_entries = std::max(spill_entries, top.stack_need + deepest + 2 - pb::wide_stack_lds(1));
             }
-        } else if (!dt && ok && !(std::getenv("PBRT_HIP_WIDE_BUILD") && std::getenv("PBRT_HIP_WIDE_BUILD")[0] == 'h')) {
+        } else if (!dt && ok && ctx->wide_build != PBRT_WIDE_BUILD_HOST) {
             // a tree from the host: its flat nodes go up once, the records are laid out on the device from them and from
             // the triangle records already there (wide_gpu.hip; the host builder produces the same bytes, tens of ms per
-            // million triangles slower: PBRT_HIP_WIDE_BUILD=host)
+            // million triangles slower: PBRT_WIDE_BUILD_HOST)
             bool up = true;
             PbrtLinearBVHNode* d_flat = dev_upload(s, nodes, (size_t)n_nodes, &up);
             pb::WideDeviceTree wd;

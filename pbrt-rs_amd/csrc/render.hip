@@ -541,18 +541,12 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         }
     }
     // ray-queue sort (spatial order for the bounce rays): keys in / out, sorted entries, rocPRIM scratch
-    const char* sort_env = std::getenv("PBRT_HIP_SORT_RAYS");
     // only the path integrator's later bounces are incoherent; the stage machine of the other integrators keeps
-    // shooting from the camera rays' hit points, which are already in pixel order (AO: -6 % with the sort)
-    const bool sort_rays = !(sort_env && sort_env[0] == '0') && rp.integrator == PBRT_INTEGRATOR_PATH;
-    const char* seg_env = std::getenv("PBRT_HIP_SEGMENTS_ALL");  // development knob: one queue segment per XCD for every wavefront
-    const bool seg_all = seg_env && seg_env[0] == '1';
-    const char* sort_from_env = std::getenv("PBRT_HIP_SORT_FROM");  // first sorted wavefront (development knob)
-    const int sort_from = sort_from_env ? std::atoi(sort_from_env) : 2;
-    // the keys are written by k_shade together with the queue entries; PBRT_HIP_SORT_FUSED=0 (and the builds with
-    // direction-octant bits) compute them in a pass of their own
-    const char* fused_env = std::getenv("PBRT_HIP_SORT_FUSED");
-    const bool fused_keys = !(fused_env && fused_env[0] == '0') && PB_SORT_OCTANT == 0;
+    // shooting from the camera rays' hit points, which are already in pixel order (AO: -6 % with the sort).
+    // PbrtRenderParams.ray_order = 1 leaves the queues as the shading kernel filled them (results do not depend on it).
+    if (rp.ray_order < 0 || rp.ray_order > 1) return invalid("ray_order must be 0 (Morton order from the second bounce on) or 1 (queue order)");
+    const bool sort_rays = rp.ray_order == 0 && rp.integrator == PBRT_INTEGRATOR_PATH;
+    constexpr int sort_from = 2;  // first sorted wavefront: the first bounce still follows the pixel order of its camera rays
     uint32_t *sort_keys[2] = {nullptr, nullptr}, *sort_vals = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
@@ -824,13 +818,8 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                 const uint32_t* trace_queue = q[cur].trace;
                 if (sort_rays && wavefront >= sort_from && n_trace >= (1u << 20)) {
                     // from the second bounce on the rays of a wavefront start all over the scene (the first bounce still
-                    // follows the pixel order of its camera rays): trace them in Morton order of their origins
-                    if (!fused_keys) {
-                        float3 lo = make_float3(q[cur].key_lo[0], q[cur].key_lo[1], q[cur].key_lo[2]);
-                        float3 inv = make_float3(q[cur].key_inv[0], q[cur].key_inv[1], q[cur].key_inv[2]);
-                        hipLaunchKernelGGL(k_ray_sort_keys, dim3((n_trace + 255) / 256), dim3(256), 0, st, ps, q[cur].trace, n_trace, lo,
-                                           inv, sort_keys[0]);
-                    }
+                    // follows the pixel order of its camera rays): trace them in Morton order of their origins (the keys were
+                    // written by k_shade together with the queue entries)
                     size_t tb = sort_tmp_bytes;
                     if (pb::sort_pairs_u32(st, sort_tmp, &tb, sort_keys[0], sort_keys[1], q[cur].trace, sort_vals, n_trace, kSortKeyBits) != 0 &&
                         rc == PBRT_HIP_OK) {
@@ -844,7 +833,6 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                     dim3 grid(persistent_grid(s)), block(kTraceBlock);
                     const int inst = s->d.bvh.instanced ? (s->d.bvh.general_top ? 2 : 1) : 0;  // trace_persistent.h: INST
                     int segments = (wavefront == 0 && !inst) ? kQueueSegments : 1;  // see trace.h
-                    if (seg_all && !inst) segments = kQueueSegments;
                     const bool count_ref = ctx->count_traversal == 1, count_wide = ctx->count_traversal == 2;
 #define PB_LAUNCH_BINARY(COUNT, INST, SPH) \
     hipLaunchKernelGGL((k_trace<COUNT, INST, SPH>), grid, block, 0, st, s->d.bvh, ps, trace_queue, n_trace, ctx->d_work_counter, ctx->d_counters, segments)
@@ -890,7 +878,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             int nxt = cur ^ 1;
             RENDER_TRY(hipMemsetAsync(q[nxt].counts64, 0, 2 * sizeof(unsigned long long), st));
             // the wavefront this launch of k_shade fills is traced in Morton order: have it write the keys as well
-            q[nxt].keys = (sort_rays && fused_keys && wavefront + 1 >= sort_from) ? sort_keys[0] : nullptr;
+            q[nxt].keys = (sort_rays && wavefront + 1 >= sort_from) ? sort_keys[0] : nullptr;
             if (direct)
 {
                 dim3 sg((n_shade + 255) / 256), sb(256);

@@ -48,6 +48,7 @@ struct PbrtHipContext {
     // record / leaf / triangle fetches (pbrt_hip_set_counting)
     int count_traversal = 0;
     int traversal = 0;  // PBRT_TRAVERSAL_*: pbrt_hip_context_set_traversal
+    int wide_build = 0;  // PBRT_WIDE_BUILD_*: pbrt_hip_context_set_wide_build
     unsigned long long* d_counters = nullptr;  // [0..3] mode 1: node, prim, rays, instance tests; [4..7] mode 2
     uint64_t counted_rays = 0;
     // ray-queue heads of the persistent traversal kernels: [0, kQueueSegments) the launch's segments,
@@ -184,8 +185,8 @@ struct DeviceTree {
     int root_ref = 0, count_bits = 0, n_interior = 0, n_nodes = 0;
     std::vector<int32_t> light_slot;  // per light: leaf slot of an area light's triangle, -1 otherwise
     // the 4-wide records (wide_bvh.h) laid over the device-built tree, on the device as well (wide_gpu.hip);
-    // wide.n_records < 0: not built (wide_reason says why: PBRT_HIP_WIDE=0, PBRT_HIP_WIDE_DEVICE_TREES=0, or the tree does not
-    // qualify). PBRT_HIP_WIDE_BUILD=host: the host builder instead, on copies of the tree (the test of host == device).
+    // wide.n_records < 0: not built (wide_reason says why: PBRT_WIDE_BUILD_NONE, or the tree does not qualify).
+    // PBRT_WIDE_BUILD_HOST: the host builder instead, on copies of the tree (the test of host == device).
     WideDeviceTree wide;
     const char* wide_reason = nullptr;
     std::vector<PbrtLinearBVHNode> h_nodes;

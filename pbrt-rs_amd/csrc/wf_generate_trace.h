@@ -200,24 +200,7 @@ struct WavefrontRayIO {
 // Sort key of a queued ray: any-hit flag, then a 15-bit Morton code of the origin inside the scene bounds. Rays that
 // start close together walk the same part of the tree: in cache order the traversal kernel runs 20 % faster on
 // incoherent bounce rays (tools/probe_sorting.py), which pays for the two 8-bit radix passes.
-// The stand-alone form of the key (the fused one is written by k_shade's block_append): PBRT_HIP_SORT_FUSED=0, and
-// the builds with direction-octant bits.
-__global__ void k_ray_sort_keys(PathState ps, const uint32_t* __restrict__ queue, uint32_t n, float3 lo, float3 inv_extent,
-                                uint32_t* __restrict__ keys) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t e = queue[i];
-    uint32_t p = e >> 2, slot = e & 3u;
-    const uint32_t rslot = slot == RS_MIS_BOOL ? (uint32_t)RS_MIS : slot;
-    float4 a = ps.ray[ray_index(ps, p, rslot)];
-    const float l[3] = {lo.x, lo.y, lo.z}, iv[3] = {inv_extent.x, inv_extent.y, inv_extent.z};
-    uint32_t code = ray_sort_cell(a.x, a.y, a.z, l, iv);
-#if PB_SORT_OCTANT
-    float4 d = ps.ray[ray_index(ps, p, rslot) + 1];  // (d.y, d.z, t_max, -); d.x rides in a.w
-    code = (code << 3) | (a.w < 0.0f ? 1u : 0u) | (d.x < 0.0f ? 2u : 0u) | (d.y < 0.0f ? 4u : 0u);
-#endif
-    keys[i] = code | ((slot >= RS_SHADOW ? 1u : 0u) << (kSortKeyBits - 1));
-}
+// (the key is written by k_shade's block_append together with the queue entry, wf_state.h)
 
 template <bool COUNT, int INST, bool SPH = false>
 __global__ void __launch_bounds__(kTraceBlock, (COUNT || SPH) ? 4 : (INST ? PB_INST_WAVES : PB_TRACE_WAVES))

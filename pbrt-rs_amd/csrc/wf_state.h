@@ -124,10 +124,7 @@ struct Queues {
 #ifndef PB_SORT_AXIS_BITS
 #define PB_SORT_AXIS_BITS 5
 #endif
-#ifndef PB_SORT_OCTANT
-#define PB_SORT_OCTANT 0
-#endif
-constexpr int kSortKeyBits = 3 * PB_SORT_AXIS_BITS + 3 * PB_SORT_OCTANT + 1;
+constexpr int kSortKeyBits = 3 * PB_SORT_AXIS_BITS + 1;
 // Morton code of the cell of `o` in the scene bounds, PB_SORT_AXIS_BITS bits per axis
 PB_DEV uint32_t ray_sort_cell(float ox, float oy, float oz, const float* lo, const float* inv) {
     constexpr float kCells = (float)(1 << PB_SORT_AXIS_BITS);
@@ -200,7 +197,6 @@ PB_DEV void block_append(BlockAppend& sh, const Queues& q, uint32_t p, bool cont
     if (mis) q.trace[im] = p * 4u + (mis_bool ? RS_MIS_BOOL : (uint32_t)RS_MIS);
     if (shadow) q.trace[is] = p * 4u + RS_SHADOW;
     if (q.keys) {  // the three rays leave from the same surface point: one cell, the any-hit flag on top
-        if (PB_SORT_OCTANT) cell <<= 3;
         if (cont) q.keys[ic] = cell;
         if (mis) q.keys[im] = mis_bool ? (cell | (1u << (kSortKeyBits - 1))) : cell;
         if (shadow) q.keys[is] = cell | (1u << (kSortKeyBits - 1));

@@ -23,13 +23,14 @@ SPLIT_SAH, SPLIT_HLBVH, SPLIT_MIDDLE, SPLIT_EQUAL_COUNTS = 0, 1, 2, 3
 INTEGRATOR_PATH, INTEGRATOR_DIRECT, INTEGRATOR_WHITTED, INTEGRATOR_AO = 0, 1, 2, 3
 SAMPLER_RANDOM, SAMPLER_STRATIFIED, SAMPLER_ZEROTWO, SAMPLER_HALTON = 0, 1, 2, 3
 TRAVERSAL_AUTO, TRAVERSAL_STACK, TRAVERSAL_STACKLESS = 0, 1, 2   # pbrt_hip_context_set_traversal
+WIDE_BUILD_DEVICE, WIDE_BUILD_HOST, WIDE_BUILD_NONE = 0, 1, 2       # pbrt_hip_context_set_wide_build
 
 EXPORTS = [
     "pbrt_hip_context_create", "pbrt_hip_context_destroy", "pbrt_hip_last_error", "pbrt_hip_bvh_build",
     "pbrt_hip_free", "pbrt_hip_bvh_build_boxes", "pbrt_hip_instance_bounds", "pbrt_hip_scene_create",
     "pbrt_hip_scene_create_instanced", "pbrt_hip_scene_create_with_spheres", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
     "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
-    "pbrt_hip_context_set_deadline", "pbrt_hip_context_set_traversal", "pbrt_hip_context_is_lost",
+    "pbrt_hip_context_set_deadline", "pbrt_hip_context_set_traversal", "pbrt_hip_context_is_lost", "pbrt_hip_context_set_wide_build",
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
     "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png", "pbrt_hip_write_exr",
     "pbrt_hip_comm_unique_id", "pbrt_hip_comm_create", "pbrt_hip_comm_destroy", "pbrt_hip_film_reduce",
@@ -47,7 +48,7 @@ class RenderParams(ctypes.Structure):
                 ("filter_radius", ctypes.c_float * 2), ("filter_table", ctypes.c_void_p),
                 ("sampler", ctypes.c_int32), ("sampler_x", ctypes.c_int32), ("sampler_y", ctypes.c_int32),
                 ("sampler_jitter", ctypes.c_int32), ("sampler_dims", ctypes.c_int32), ("max_sample_luminance", ctypes.c_float),
-                ("shade_order", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("shade_order", ctypes.c_int32), ("ray_order", ctypes.c_int32)]
 
 
 class PbrtObject(ctypes.Structure):
@@ -127,6 +128,7 @@ def lib():
                                             ctypes.POINTER(ctypes.c_uint64)]
         L.pbrt_hip_set_counting.argtypes = [vp, ctypes.c_int]
         L.pbrt_hip_context_set_traversal.argtypes = [vp, ctypes.c_int]
+        L.pbrt_hip_context_set_wide_build.argtypes = [vp, ctypes.c_int]
         L.pbrt_hip_get_counters.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64 * 4)]
         L.pbrt_hip_get_wide_counters.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64 * 4)]
         L.pbrt_hip_probe_gather.argtypes = [vp, i64, i32, i32, i32, ctypes.POINTER(ctypes.c_double)]
@@ -187,6 +189,11 @@ class Context:
         """TRAVERSAL_AUTO (4-wide records where the scene has them), TRAVERSAL_STACK (binary records, per-lane stack) or
         TRAVERSAL_STACKLESS (binary records, parent links + bit trail; single-level triangle scenes only)."""
         self.check(lib().pbrt_hip_context_set_traversal(self.h, int(traversal)), "context_set_traversal")
+
+    def set_wide_build(self, where):
+        """Where scenes created from now on get their 4-wide records: WIDE_BUILD_DEVICE (default), WIDE_BUILD_HOST (the host
+        builder: same bytes) or WIDE_BUILD_NONE (binary records only)."""
+        self.check(lib().pbrt_hip_context_set_wide_build(self.h, int(where)), "context_set_wide_build")
 
     def set_counting(self, enable):
         """Instrumented traversal. True / 1: box / triangle test counts of the reference's loops (binary kernels);
@@ -521,7 +528,7 @@ class Scene:
 
     def _params(self, width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
                 tile_rank, tile_world, spp_per_pass, filter=None, ao_samples=64, sampler=None, max_sample_luminance=0.0,
-                shade_order=0):
+                shade_order=0, ray_order=0):
         rx, ry, table = (0.5, 0.5, None) if filter is None else filter
         if table is not None:
             table = np.ascontiguousarray(table, dtype=np.float32)
@@ -539,22 +546,23 @@ class Scene:
             raise ValueError(sampler)
         return RenderParams(integrator, max_depth, rr_threshold, light_strategy, spp, width, height, x0, y0, x1, y1,
                             seed, tile_rank, tile_world, spp_per_pass, ao_samples, (ctypes.c_float * 2)(rx, ry),
-                            None if table is None else table.ctypes.data, *smp, float(max_sample_luminance), int(shade_order), 0)
+                            None if table is None else table.ctypes.data, *smp, float(max_sample_luminance), int(shade_order), int(ray_order))
 
     def render(self, camera, width, height, spp, integrator=INTEGRATOR_PATH, max_depth=5, rr_threshold=1.0,
                light_strategy=1, seed=0, bounds=None, tile_rank=0, tile_world=1, spp_per_pass=0, d_film_ptr=None,
-               filter=None, ao_samples=64, cos_sample=True, sampler=None, max_sample_luminance=0.0, shade_order=0):
+               filter=None, ao_samples=64, cos_sample=True, sampler=None, max_sample_luminance=0.0, shade_order=0, ray_order=0):
         """Integrator::render. Returns (film[h,w,4] or None when d_film_ptr is given, stats dict).
         integrator: INTEGRATOR_PATH / _DIRECT / _WHITTED / _AO (ao_samples, cos_sample: AOIntegrator::new).
         sampler: None (RandomSampler), ("stratified", nx, ny, jitter, n_dims) or ("zerotwo", n_dims); the samples
         per pixel then become nx * ny / the next power of two of spp.
         filter = (radius_x, radius_y, table256) from filter_table(), None = 0.5 box.
-        shade_order: 0 queue order, 1 by material inside blocks, 2 sorted queue (PbrtRenderParams.shade_order)."""
+        shade_order: 0 queue order, 1 by material inside blocks, 2 sorted queue (PbrtRenderParams.shade_order).
+        ray_order: 0 ray queues in Morton order from the second bounce on, 1 queue order (PbrtRenderParams.ray_order)."""
         camera = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
         if integrator == INTEGRATOR_AO:
             light_strategy = int(bool(cos_sample))
         rp = self._params(width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
-                          tile_rank, tile_world, spp_per_pass, filter, ao_samples, sampler, max_sample_luminance, shade_order)
+                          tile_rank, tile_world, spp_per_pass, filter, ao_samples, sampler, max_sample_luminance, shade_order, ray_order)
         st = RenderStats()
         if d_film_ptr is None:
             film = np.zeros((height, width, 4), dtype=np.float32)

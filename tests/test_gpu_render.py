@@ -490,22 +490,19 @@ def test_world_space_instances(hip_ctx):
         s_.close()
 
 
-def test_ray_queue_sorting_does_not_change_the_film(hip_ctx, monkeypatch):
-    """The render loop puts the ray queue into Morton order from the second bounce on (PBRT_HIP_SORT_RAYS, default
-    on; only queues of >= 2^20 rays are sorted): the film and the ray counts are identical either way."""
+def test_ray_queue_sorting_does_not_change_the_film(hip_ctx):
+    """The render loop puts the ray queue into Morton order from the second bounce on (PbrtRenderParams.ray_order 0, the
+    default; only queues of >= 2^20 rays are sorted): the film and the ray counts are identical in queue order (1)."""
     w, h = 512, 288
     sc, cam = scenes.random_triangles(100_000, seq=4, size=0.03), scenes.random_triangles_camera(w, h)
     g = pbrt_hip.Scene(hip_ctx, sc)
     a, st_a = g.render(cam, w, h, 16, max_depth=5, seed=9)
-    monkeypatch.setenv("PBRT_HIP_SORT_RAYS", "0")
-    b, st_b = g.render(cam, w, h, 16, max_depth=5, seed=9)
+    b, st_b = g.render(cam, w, h, 16, max_depth=5, seed=9, ray_order=1)
     assert a.tobytes() == b.tobytes()
     assert (st_a["rays_closest"], st_a["rays_shadow"]) == (st_b["rays_closest"], st_b["rays_shadow"])
-    monkeypatch.setenv("PBRT_HIP_SORT_RAYS", "1")
-    monkeypatch.setenv("PBRT_HIP_SORT_FUSED", "0")          # keys from the stand-alone pass instead of k_shade
-    c, st_c = g.render(cam, w, h, 16, max_depth=5, seed=9)
-    assert a.tobytes() == c.tobytes()
-    assert (st_a["rays_closest"], st_a["rays_shadow"]) == (st_c["rays_closest"], st_c["rays_shadow"])
+    assert st_b["trace_ms"] > 0 and st_a["trace_ms"] > 0
+    with pytest.raises(pbrt_hip.PbrtHipError, match="ray_order"):
+        g.render(cam, w, h, 1, max_depth=1, ray_order=2)
     g.close()
 
 

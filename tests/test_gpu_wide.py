@@ -200,9 +200,9 @@ def test_visiting_order_decides_ties(hip_ctx, split, max_prims):
 
 @pytest.mark.parametrize("tree", ["built_on_device", "from_host"])
 @pytest.mark.parametrize("which", ["cloud", "cornell", "mixed", "one_leaf"])
-def test_device_builder_of_the_wide_records_equals_the_host_builder(hip_ctx, monkeypatch, which, tree):
+def test_device_builder_of_the_wide_records_equals_the_host_builder(hip_ctx, which, tree):
     """Single-level scenes get their wide records on the device (csrc/wide_gpu.hip, level by level): over a tree built there
-    (pbrt_hip_scene_create_hlbvh) and over a tree the caller built (its flat nodes go up once). PBRT_HIP_WIDE_BUILD=host
+    (pbrt_hip_scene_create_hlbvh) and over a tree the caller built (its flat nodes go up once). PBRT_WIDE_BUILD_HOST (pbrt_hip_context_set_wide_build)
     runs the host builder (csrc/host_wide.cpp) instead. Same source for the arithmetic (csrc/wide_build.h), same order:
     the three arrays are equal byte for byte, and so is everything traced."""
     kw = dict(device_build=True) if tree == "built_on_device" else dict(split_method=pbrt_hip.SPLIT_SAH)
@@ -217,18 +217,23 @@ def test_device_builder_of_the_wide_records_equals_the_host_builder(hip_ctx, mon
         sc = dict(base, indices=base["indices"][:1].copy(), tri_material=base["tri_material"][:1].copy(), tri_light=base["tri_light"][:1].copy())
         sc = scenes.with_lights(sc, [scenes.point_light((278.0, 400.0, 278.0), (1e5, 1e5, 1e5))], keep_existing=False)
     n = len(sc["indices"])
-    monkeypatch.delenv("PBRT_HIP_WIDE_BUILD", raising=False)
     g_dev = pbrt_hip.Scene(hip_ctx, sc, **kw)
-    monkeypatch.setenv("PBRT_HIP_WIDE_BUILD", "host")
-    g_host = pbrt_hip.Scene(hip_ctx, sc, **kw)
-    monkeypatch.delenv("PBRT_HIP_WIDE_BUILD")
+    hip_ctx.set_wide_build(pbrt_hip.WIDE_BUILD_HOST)
+    try:
+        g_host = pbrt_hip.Scene(hip_ctx, sc, **kw)
+        hip_ctx.set_wide_build(pbrt_hip.WIDE_BUILD_NONE)
+        g_none = pbrt_hip.Scene(hip_ctx, sc, **kw)
+    finally:
+        hip_ctx.set_wide_build(pbrt_hip.WIDE_BUILD_DEVICE)      # the context is shared by the session
+    assert g_none.wide_records() == (-1, "disabled by PBRT_WIDE_BUILD_NONE")
     assert g_dev.wide_records() == g_host.wide_records() and g_dev.wide_records()[0] >= 0, (g_dev.wide_records(), g_host.wide_records())
     for a, b, what in zip(g_dev.debug_wide_export(n), g_host.debug_wide_export(n), ("records", "triangles", "leaf boxes")):
         assert a.tobytes() == b.tobytes(), what
     if which == "one_leaf":
         assert g_dev.wide_records()[0] == 0
     rays = scenes.random_rays(50_000, 77, origin_extent=600.0 if which in ("cornell", "one_leaf") else 1.3)
-    assert g_dev.intersect(rays).tobytes() == g_host.intersect(rays).tobytes()
+    assert g_dev.intersect(rays).tobytes() == g_host.intersect(rays).tobytes() == g_none.intersect(rays).tobytes()
+    g_none.close()
     g_dev.close()
     g_host.close()
 

@@ -167,11 +167,11 @@ def main():
                     ctx.set_traversal(pbrt_hip.TRAVERSAL_AUTO)
             if n_rec >= 0 and "instances" not in sc and "objects" not in sc and seed % 3 == 0:
                 # the device builder of the wide records (wide_gpu.hip) against the host builder (host_wide.cpp): same bytes
-                os.environ["PBRT_HIP_WIDE_BUILD"] = "host"
+                ctx.set_wide_build(pbrt_hip.WIDE_BUILD_HOST)
                 try:
                     hsc = pbrt_hip.Scene(ctx, sc, max_prims_in_node=max_prims, split_method=split, **kw)
                 finally:
-                    del os.environ["PBRT_HIP_WIDE_BUILD"]
+                    ctx.set_wide_build(pbrt_hip.WIDE_BUILD_DEVICE)
                 n_t = len(sc["indices"])
                 same = hsc.wide_records() == (n_rec, why) and all(a.tobytes() == b.tobytes() for a, b in zip(gsc.debug_wide_export(n_t), hsc.debug_wide_export(n_t)))
                 hsc.close()
