@@ -29,8 +29,9 @@ sys.path.insert(0, os.path.join(ROOT, "pbrt-rs_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 DEFAULTS = dict(width=1920, height=1080, tris=1_000_000, max_depth=5)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
-KERNEL_SOURCES = ("pbrt-rs_amd/csrc", "pbrt-rs_amd/build.sh")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
+# what a stamped counter profile was measured on: the kernels, and what decides the workload they were given
+KERNEL_SOURCES = ("pbrt-rs_amd/csrc", "pbrt-rs_amd/build.sh", "bench.py", "pbrt-rs_amd/pbrt_hip/scenes.py")
 
 
 def parse():
@@ -91,7 +92,8 @@ def algorithmic_bytes(rays_closest, rays_shadow, node_tests, prim_tests):
 
 
 def kernel_source_hash():
-    """sha1 over the kernel sources (pbrt-rs_amd/csrc/*, build.sh): what the stamped counter profile was measured on."""
+    """sha1 over the kernel sources (pbrt-rs_amd/csrc/*, build.sh), this file and the scene generator: what the stamped counter
+    profile was measured on."""
     import hashlib
     h = hashlib.sha1()
     files = []
@@ -108,14 +110,14 @@ def kernel_source_hash():
 
 
 def measured_traffic(args, world, spp_total, kernel):
-    """The stamped counter profile of this very command (profiles/r03_traffic.json, written by tools/measure_traffic.sh:
+    """The stamped counter profile of this very command (profiles/r04_traffic.json, written by tools/measure_traffic.sh:
     rocprofv3 --kernel-trace --stats and separate --pmc passes). It was measured for ONE configuration and ONE state of
     the kernel sources: returned only when this run is that configuration (otherwise None and the reason); `stale` says
     that the kernel sources have changed since (the figures are then reported as measured, flagged)."""
     try:
         rec = json.load(open(TRAFFIC_FILE))
     except Exception:
-        return None, "profiles/r03_traffic.json missing", False
+        return None, "profiles/r04_traffic.json missing", False
     mine = dict(n_gpus=world, tris=args.tris, width=args.width, height=args.height, spp=spp_total, max_depth=args.max_depth, kernel=kernel)
     diff = {k: (v, rec["config"].get(k)) for k, v in mine.items() if rec["config"].get(k) != v}
     if diff:
@@ -136,6 +138,49 @@ def loaded_runtime_libs():
     except OSError:
         pass
     return sorted(libs)
+
+
+def rank_report(torch, device, local_rank, rank, stats, elapsed_s):
+    """What one rank of the N-GPU job knows about itself (gathered into config.ranks): which device it really ran on, how
+    long ITS renders took (HIP events around the whole render call, per step) and how many rays it traced — load balance
+    is what bounds the N-GPU rate, and a line built on N ranks that shared one device would not be a scaling number."""
+    props = torch.cuda.get_device_properties(device)
+    free_b, total_b = torch.cuda.mem_get_info(device)
+    ms = [st["total_ms"] for st in stats] or [0.0]
+    return {
+        "rank": rank, "local_rank": local_rank, "device": props.name,
+        "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": f"{getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', 0):02x}:{getattr(props, 'pci_device_id', 0):02x}",
+        "hbm_free_GB": round(free_b / 1e9, 1), "hbm_total_GB": round(total_b / 1e9, 1),
+        "render_ms_per_step": {"mean": round(sum(ms) / len(ms), 2), "max": round(max(ms), 2)},
+        "trace_ms_per_step": round(sum(st["trace_ms"] for st in stats) / max(len(stats), 1), 2),
+        "rays_per_step": int(sum(st["rays_closest"] + st["rays_shadow"] for st in stats) / max(len(stats), 1)),
+        "wall_s": round(elapsed_s, 4), "runtime_libs": loaded_runtime_libs(), "pid": os.getpid(),
+    }
+
+
+def gather_rank_reports(dist, use_dist, world, report):
+    """Collective (all_gather_object): every rank's report, in rank order, on every rank."""
+    if not use_dist:
+        return [report]
+    reports = [None] * world
+    dist.all_gather_object(reports, report)
+    return reports
+
+
+def check_distinct_devices(reports, one_gpu):
+    """N ranks must be N devices (uuid, or PCI bus id where the runtime reports no uuid) unless the job was started as the
+    one-GPU rehearsal (--one-gpu)."""
+    ids = [r.get("uuid") or r.get("pci_bus_id") for r in reports]
+    if len(set(ids)) != len(ids) and not one_gpu:
+        raise RuntimeError(f"{len(ids)} ranks on {len(set(ids))} distinct device(s): {ids} (use --one-gpu for the one-GPU rehearsal)")
+    return len(set(ids))
+
+
+def load_balance(reports):
+    """max / mean of the ranks' own render time per step: 1.0 = perfectly even; the N-GPU rate is bounded by 1 / this."""
+    ms = [r["render_ms_per_step"]["mean"] for r in reports]
+    mean = sum(ms) / len(ms)
+    return round(max(ms) / mean, 4) if mean > 0 else None
 
 
 class Stage:
@@ -341,10 +386,14 @@ def main():
             if args.save_film and rank == 0:
                 np.save(args.save_film, last.cpu().numpy())
             return (seconds, sum(st["rays_closest"] + st["rays_shadow"] for st in stats), sum(st["trace_ms"] for st in stats),
-                    sum(st["trace_launches"] for st in stats))
+                    sum(st["trace_launches"] for st in stats), stats)
 
-        elapsed, rays, trace_ms, trace_launches = timed()   # carries its own agreement points (run_steps)
+        elapsed, rays, trace_ms, trace_launches, step_stats = timed()   # carries its own agreement points (run_steps)
         my_rays, my_elapsed = rays, elapsed
+        # every rank's own account of the run (device identity, its render times, its rays): config.ranks
+        report = stage.run("rank report", lambda: rank_report(torch, device, local_rank, rank, step_stats, elapsed))
+        reports = stage.collective("gather rank reports", lambda: gather_rank_reports(dist, use_dist, world, report))
+        n_devices = stage.run("distinct devices", lambda: check_distinct_devices(reports, args.one_gpu))
         if use_dist:
             def gather_times():
                 tt = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=coll_device)
@@ -395,8 +444,15 @@ def main():
             compulsory_per_launch = compulsory / max(launches_per_frame, 1) + (table_bytes + tri_bytes)          # + the tree, once
             rec, why_not, stale = measured_traffic(args, world, spp_total, kernel)
             tr = rec["trace"] if rec else None
+            # the stamped counters belong to the launches they were collected on: a run whose own launches take a different time
+            # (another box, clock, driver) is not described by them either
+            stamped_launch_ms = tr["avg_launch_ns_under_kernel_trace"] * 1e-6 if tr and tr.get("avg_launch_ns_under_kernel_trace") else None
+            drift = (trace_s_per_launch * 1e3 / stamped_launch_ms - 1.0) if stamped_launch_ms else None
+            if rec and drift is not None and abs(drift) > 0.05:
+                stale = True
             source = (f"{os.path.relpath(TRAFFIC_FILE, ROOT)}: rocprofv3 --pmc passes over this command, commit {rec['commit']}, "
-                      f"kernel sources {rec.get('source_hash')}" + (" (STALE: the kernel sources have changed since)" if stale else "")) if rec else why_not
+                      f"sources {rec.get('source_hash')}" + (" (STALE: the sources have changed since, or this run's launches take "
+                      f"{drift * 100:+.1f} % of the profiled ones')" if stale else "")) if rec else why_not
             traffic = tr["bytes_per_launch"] if tr else None
             hbm_frac = traffic / trace_s_per_launch / 1e9 / HBM_PEAK_GBS if traffic else None
             peak_ips = 256 * 4 * 2.4e9 / 2   # one wave64 vector instruction per two cycles per SIMD, 1024 SIMDs at 2.4 GHz
@@ -422,6 +478,11 @@ def main():
                 "kernel": kernel,
                 "bound": bound, **head, "frac": round(known[bound], 4) if bound else None,
                 "definition": "busiest hardware unit of the dominant kernel = max(TA busy, VALU issue, HBM bytes / 8 TB/s), stamped rocprofv3 counters",
+                # bound / achieved / peak / frac / traffic / units come from the STAMPED profile (counters cannot be read inside a
+                # run); what this run itself measured is launch time (HIP events) and the gather / algorithmic / wide blocks below
+                "measured_in_this_run": False, "stamped_avg_launch_ms": round(stamped_launch_ms, 4) if stamped_launch_ms else None,
+                "launch_time_vs_stamped": round(drift, 4) if drift is not None else None,
+                "counter_derived": None if rec else f"null: {why_not} (bound, achieved, peak, frac, traffic, units, hbm.frac); gather / algorithmic / wide are this run's own, rank 0's tile share",
                 "traffic": traffic, "stale": stale if rec else None, "source": source,
                 "units": {k: (round(v, 4) if v is not None else None) for k, v in units.items()},
                 "valu_lane_utilisation": round(tr["valu_lane_utilisation"], 3) if tr and tr.get("valu_lane_utilisation") else None,
@@ -455,9 +516,14 @@ def main():
             if sh and sh.get("avg_launch_ns_under_kernel_trace"):
                 # the second kernel of the frame: k_shade streams the path state (stamped profile; its launch time is the
                 # profile's own, the library times only the traversal launches)
-                gbps = sh["bytes_per_launch"] / sh["avg_launch_ns_under_kernel_trace"]
+                # FETCH_SIZE under-counts the coalesced SoA streams k_shade reads: calibrated on that pattern (factor and file below)
+                shade_bytes = sh.get("bytes_per_launch_calibrated") or sh["bytes_per_launch"]
+                gbps = shade_bytes / sh["avg_launch_ns_under_kernel_trace"]
                 roofline["shade"] = {"kernel": "k_shade", "bound": "HBM", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": round(gbps / HBM_PEAK_GBS, 4), "traffic": sh["bytes_per_launch"],
+                                     "frac": round(gbps / HBM_PEAK_GBS, 4), "traffic": shade_bytes, "traffic_counters_at_face_value": sh["bytes_per_launch"],
+                                     "source": (f"FETCH_SIZE / {sh['fetch_calibration']['factor']} + WRITE_SIZE: {sh['fetch_calibration']['source']}"
+                                                if sh.get("fetch_calibration") else "counters at face value (uncalibrated)"),
+                                     "measured_in_this_run": False,
                                      "avg_launch_ms": round(sh["avg_launch_ns_under_kernel_trace"] * 1e-6, 4), "launches_per_step": sh.get("launches_per_step"),
                                      "valu_lane_utilisation": sh.get("valu_lane_utilisation"), "stale": stale}
             if wc is not None:
@@ -466,11 +532,26 @@ def main():
                                     "triangles_per_ray": round(wc["triangles"] / max(frame_rays, 1), 2),
                                     "rays_left_to_binary_kernel": wc["special_rays"], "n_records": n_wide}
             secondary = None
+            config4_n1 = None
             if world == 1 and not args.no_secondary:
                 try:   # reported beside the measurement, never instead of it
                     secondary = secondary_config5(torch, pbrt_hip, scenes, ctx, device, peak_rec)
                 except Exception as e:  # noqa: BLE001
                     secondary = {"error": f"{type(e).__name__}: {e}"}
+                if config_name == "config3":
+                    # The N > 1 job is BASELINE config 4 (256 spp, the tiles of the one frame split over the ranks): its
+                    # one-GPU point, so that the 1 / 2 / 4 / 8 curve has an anchor on the same workload. Untimed for `value`.
+                    try:
+                        runs4 = [scene.render(cam, W, H, 256, max_depth=args.max_depth, rr_threshold=1.0, light_strategy=1, seed=0,
+                                              d_film_ptr=films[0].data_ptr())[1] for _ in range(2)]
+                        ms4 = [r["total_ms"] for r in runs4]
+                        rays4 = runs4[0]["rays_closest"] + runs4[0]["rays_shadow"]
+                        config4_n1 = {"workload": f"config4 on ONE GPU: the same scene, {W}x{H}x256spp (what --gpus N splits over N ranks); "
+                                                  f"mean of {len(ms4)} frames, HIP-event time of the render call, no film reduce; not part of `value`",
+                                      "value": round(rays4 / (sum(ms4) / len(ms4)) / 1e3, 1), "unit": "Mrays/s",
+                                      "ms_per_frame": round(sum(ms4) / len(ms4), 2), "rays_per_frame": int(rays4)}
+                    except Exception as e:  # noqa: BLE001
+                        config4_n1 = {"error": f"{type(e).__name__}: {e}"}
             cpu_baseline = None
             if world == 1 and not args.no_cpu_baseline:
                 # ---- CPU baseline: the oracle (C++ restatement; the Rust reference cannot be built) on a
@@ -508,10 +589,14 @@ def main():
                     "bvh_build_s_host": round(t_bvh, 2),
                     "traversal": f"{kernel}" + (f" ({n_wide} 4-wide records)" if n_wide >= 0 else f" (binary records: {wide_reason})"),
                 },
-                "roofline": roofline, "cpu_baseline": cpu_baseline, "secondary": secondary,
+                "roofline": roofline, "cpu_baseline": cpu_baseline, "secondary": secondary, "config4_n1": config4_n1,
             })
             out["config"]["dist_backend"] = args.dist_backend if use_dist else None
             out["config"]["runtime_libs"] = loaded_runtime_libs()
+            # per rank: device identity, its own render time per step, its rays (DESIGN.md section 6 says how to read them)
+            out["config"]["ranks"] = reports
+            out["config"]["n_devices"] = n_devices
+            out["config"]["load_balance_max_over_mean"] = load_balance(reports)
 
         if args.abi_reduce_check and use_dist and not staged:
             # Untimed: the same film merge through the C ABI's own RCCL communicator (pbrt_hip_comm_create /
@@ -574,13 +659,15 @@ def secondary_config5(torch, pbrt_hip, scenes, ctx, device, peak_rec):
         return scene5.render(cam5, W5, H5, SPP5, max_depth=DEPTH5, rr_threshold=1.0, light_strategy=1, seed=0, d_film_ptr=film5.data_ptr())[1]
     go()
     runs = [go() for _ in range(3)]
-    st = min(runs, key=lambda r: r["total_ms"])
+    best = min(runs, key=lambda r: r["total_ms"])
+    st = dict(best, total_ms=sum(r["total_ms"] for r in runs) / len(runs), trace_ms=sum(r["trace_ms"] for r in runs) / len(runs))   # the MEAN frame
     rays = st["rays_closest"] + st["rays_shadow"]
     n_wide, why = scene5.wide_records()
     out = {
         "workload": f"config5 scene: 10000 base triangles x 1000 instances (10 M instanced), matte/mirror/glass by instance, env light, "
-                    f"PathIntegrator max_depth {DEPTH5}, {W5}x{H5}x{SPP5}spp of the 128 (one GPU; best of 3 frames; not part of `value`)",
+                    f"PathIntegrator max_depth {DEPTH5}, {W5}x{H5}x{SPP5}spp of the 128 (one GPU; mean of 3 frames after one warm-up; not part of `value`)",
         "value": round(rays / st["total_ms"] / 1e3, 1), "unit": "Mrays/s", "ms_per_frame": round(st["total_ms"], 2),
+        "best_frame_Mrays_per_s": round(rays / best["total_ms"] / 1e3, 1),
         "rays_per_frame": int(rays), "trace_only_Mrays_per_s": round(rays / st["trace_ms"] / 1e3, 1),
         "trace_launches": int(st["trace_launches"]), "trace_fraction_of_frame": round(st["trace_ms"] / st["total_ms"], 3),
         "kernel": "k_trace_wide<false, 1>" if n_wide >= 0 else f"k_trace<false, 1> (binary records: {why})",

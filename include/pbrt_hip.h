@@ -376,6 +376,13 @@ int pbrt_hip_get_wide_counters(PbrtHipContext* ctx, int reset, uint64_t counters
  * Returns records per second. Measurement only. */
 int pbrt_hip_probe_gather(PbrtHipContext* ctx, int64_t table_bytes, int32_t record_bytes, int32_t waves_per_simd, int32_t iters,
                           double* records_per_second);
+/* The shading kernel's access pattern with a known byte count, for calibrating a profiler's memory counters on it
+ * (profiles/r04_fetch_size_calibration_shade.txt): a shade queue of ascending path numbers (density_permille of n_paths) and,
+ * per queued path, `parts` of: 1 nine 16-B SoA records, 2 two 32-B ray records (slot-major, 32-B stride), 4 one 8-B and two
+ * 4-B scalars, 8 one random 48-B record of a gather_table_bytes table, 16 the stores (five 16-B, three 32-B, 8 + 4 + 4 B and
+ * seven 4-B queue words). Three launches; bytes_read / bytes_written = what the lanes of ONE launch ask for. Measurement only. */
+int pbrt_hip_probe_state_stream(PbrtHipContext* ctx, int64_t n_paths, int32_t density_permille, int64_t gather_table_bytes,
+                                int32_t parts, int64_t* bytes_read, int64_t* bytes_written, double* ms);
 
 /* ---- Integrator::render (src/core/integrator.rs:29-42, 399-480) for this GPU's tile set ----
  * film_xyzw: width*height*4 floats {xyz[3], filter_weight_sum} = the first 16 bytes of the

@@ -34,7 +34,7 @@ EXPORTS = [
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
     "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png", "pbrt_hip_write_exr",
     "pbrt_hip_comm_unique_id", "pbrt_hip_comm_create", "pbrt_hip_comm_destroy", "pbrt_hip_film_reduce",
-    "pbrt_hip_comm_last_error", "pbrt_hip_scene_wide_records", "pbrt_hip_get_wide_counters", "pbrt_hip_probe_gather",
+    "pbrt_hip_comm_last_error", "pbrt_hip_scene_wide_records", "pbrt_hip_get_wide_counters", "pbrt_hip_probe_gather", "pbrt_hip_probe_state_stream",
     "pbrt_hip_li", "pbrt_hip_li_device", "pbrt_hip_camera_rays", "pbrt_hip_scene_create_two_level",
 ]
 
@@ -132,6 +132,7 @@ def lib():
         L.pbrt_hip_get_counters.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64 * 4)]
         L.pbrt_hip_get_wide_counters.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64 * 4)]
         L.pbrt_hip_probe_gather.argtypes = [vp, i64, i32, i32, i32, ctypes.POINTER(ctypes.c_double)]
+        L.pbrt_hip_probe_state_stream.argtypes = [vp, i64, i32, i64, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double)]
         L.pbrt_hip_render.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
         L.pbrt_hip_render_device.argtypes = [vp, vp, ctypes.POINTER(RenderParams), vp, ctypes.POINTER(RenderStats)]
         L.pbrt_hip_li.argtypes = [vp, ctypes.POINTER(LiParams), vp, vp, i64, vp, ctypes.POINTER(RenderStats)]
@@ -204,6 +205,13 @@ class Context:
         c = (ctypes.c_uint64 * 4)()
         self.check(lib().pbrt_hip_get_wide_counters(self.h, int(reset), ctypes.byref(c)), "get_wide_counters")
         return dict(records=int(c[0]), leaf_candidates=int(c[1]), triangles=int(c[2]), special_rays=int(c[3]))
+
+    def probe_state_stream(self, n_paths, density=0.7, gather_table_bytes=48 << 20, parts=31):
+        """k_shade's access pattern with a known byte count (pbrt_hip_probe_state_stream): (bytes read, bytes written, ms) per launch."""
+        rd, wr, ms = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_double()
+        self.check(lib().pbrt_hip_probe_state_stream(self.h, int(n_paths), int(round(density * 1000)), int(gather_table_bytes), int(parts),
+                                                     ctypes.byref(rd), ctypes.byref(wr), ctypes.byref(ms)), "probe_state_stream")
+        return rd.value, wr.value, ms.value
 
     def probe_gather(self, table_bytes, record_bytes=48, waves_per_simd=5, iters=256):
         """Measured rate (records / s) of dependent random record fetches from a table of table_bytes."""

@@ -53,6 +53,21 @@ def test_two_ranks_on_one_gpu_reduce_to_the_one_process_frame(hip_ctx, tmp_path)
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["dist_backend"] == "gloo" and "error" not in line
     assert any("libpbrt_hip" in p for p in line["config"]["runtime_libs"])   # the HIP path is what rendered
+    # what makes the first real N-GPU line diagnosable: every rank's own account of the run ...
+    ranks = line["config"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and len({r["pid"] for r in ranks}) == 2
+    for r in ranks:
+        assert r["device"] and (r["uuid"] or r["pci_bus_id"]) and r["hbm_total_GB"] > 100 and 0 < r["hbm_free_GB"] <= r["hbm_total_GB"]
+        assert 0 < r["render_ms_per_step"]["mean"] <= r["render_ms_per_step"]["max"] and r["trace_ms_per_step"] > 0
+        assert any("libpbrt_hip" in p for p in r["runtime_libs"])
+    # ... the two ranks share the one device of this box, which the line says and --one-gpu permits ...
+    assert line["config"]["n_devices"] == 1 and len({r["uuid"] or r["pci_bus_id"] for r in ranks}) == 1
+    assert line["config"]["load_balance_max_over_mean"] >= 1.0
+    # ... and a roofline block whose run-measured parts are filled in; only the counter-derived part is null, and says why
+    roof = line["roofline"]
+    assert roof["bound"] is None and roof["measured_in_this_run"] is False and "null:" in roof["counter_derived"]
+    assert roof["gather"]["achieved"] > 0 and roof["algorithmic"]["node_tests_per_ray"] > 1 and roof["avg_launch_ms"] > 0
+    assert roof["wide"]["records_per_ray"] > 1
     # the same frame in this process, all tiles on one rank
     sc = scenes.random_triangles(TRIS, seq=1)
     g = pbrt_hip.Scene(hip_ctx, sc, bvh=pbrt_hip.bvh_build(sc["positions"], sc["indices"], 4, pbrt_hip.SPLIT_SAH))
@@ -61,7 +76,25 @@ def test_two_ranks_on_one_gpu_reduce_to_the_one_process_frame(hip_ctx, tmp_path)
     film = np.load(film_path)
     assert film.shape == ref.shape
     assert film.tobytes() == ref.tobytes()   # non-owned pixels are zero on every rank: the sum is a pure gather
-    assert line["config"]["rays_per_frame"] == st["rays_closest"] + st["rays_shadow"]
+    assert line["config"]["rays_per_frame"] == st["rays_closest"] + st["rays_shadow"] == sum(r["rays_per_step"] for r in ranks)
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_device_are_refused_without_one_gpu():
+    """The same job WITHOUT --one-gpu is what a mis-launched 2-GPU run on this box would be (LOCAL_RANK 0 for both): the ranks
+    gather their device ids, find one device behind two ranks and stop, exit code 4 — a line from such a run would not be a
+    scaling number."""
+    port = _free_port()
+    args = [a for a in ARGS if a != "--one-gpu"]
+    procs = []
+    for rank in range(2):
+        env = _env()
+        env.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=540) for p in procs]
+    assert [p.returncode for p in procs] == [4, 4], [o[1][-1500:] for o in outs]
+    assert "distinct device" in outs[0][1] + outs[1][1]
 
 
 @pytest.mark.timeout(600)

@@ -77,6 +77,18 @@ def _bench_worker(rank, world, port, out_path, fail):
     try:
         seconds, stats, last = bench.run_steps(render_into, films, 2, 1, dist, True, lambda: None, None, stage)
         rays = stage.collective("sum over ranks", lambda: _sum(dist, torch, sum(st["rays"] for st in stats)))
+        # bench.py's per-rank report gather (config.ranks): all_gather_object over gloo, in rank order, the same on every rank
+        mine = {"rank": rank, "uuid": f"fake-device-{rank}", "pci_bus_id": "", "render_ms_per_step": {"mean": 10.0 * (rank + 1), "max": 12.0 * (rank + 1)},
+                "rays_per_step": sum(st["rays"] for st in stats) // 2, "pid": os.getpid()}
+        reports = stage.collective("gather rank reports", lambda: bench.gather_rank_reports(dist, True, world, mine))
+        assert [r["rank"] for r in reports] == list(range(world)) and reports[rank] == mine
+        assert bench.check_distinct_devices(reports, one_gpu=False) == world
+        assert bench.load_balance(reports) == pytest.approx(20.0 / 15.0, abs=1e-3)
+        same = [dict(r, uuid="one-device") for r in reports]
+        assert bench.check_distinct_devices(same, one_gpu=True) == 1
+        with pytest.raises(RuntimeError, match="distinct device"):
+            bench.check_distinct_devices(same, one_gpu=False)
+        assert sum(r["rays_per_step"] for r in reports) == rays // 2
     except bench.StageFailed:
         os._exit(4)   # what bench.py's main() does: leave, non-zero, without waiting for the others
     if rank == 0:
