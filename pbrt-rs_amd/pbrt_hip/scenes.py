@@ -176,6 +176,74 @@ def cornell_box():
     return scene
 
 
+def _assemble(quads, materials):
+    """quads: (corners a b c d, material id, Le or None, two_sided). The geometric normal normalize(dp02 x dp12)
+    (triangle.rs:232) of corners going +x then +z in the plane y = const points to -y (as the Cornell light does)."""
+    positions, indices, tri_mat, tri_light, lights = [], [], [], [], []
+    for q, mat, le, two_sided in quads:
+        base = len(positions)
+        verts, tris = _quad(*q)
+        positions.extend(verts)
+        for t in tris:
+            if le is not None:
+                tri_light.append(len(lights))
+                lights.append((LIGHT_DIFFUSE_AREA, le, len(indices), int(two_sided), 1))
+            else:
+                tri_light.append(-1)
+            indices.append([base + t[0], base + t[1], base + t[2]])
+            tri_mat.append(mat)
+    return dict(positions=np.asarray(positions, dtype=np.float32), indices=np.asarray(indices, dtype=np.int32),
+                tri_material=np.asarray(tri_mat, dtype=np.int32), materials=_materials(materials),
+                tri_light=np.asarray(tri_light, dtype=np.int32), lights=_lights(lights))
+
+
+def glass_slab_scene(eta=1.5, thickness=0.2):
+    """Closed-form pin of the specular chain (tests/test_oracle_render.py): a glass slab (FresnelSpecular, Kr = Kt = 1) in
+    y in [0, thickness], outward normals; a RED one-sided emitter below it facing up (what a camera above the slab sees
+    THROUGH it), a GREEN one facing down above the camera (what it sees reflected IN it). Black emitters, no other light."""
+    e = 200.0
+    quads = [(q, 0, None, False) for q in _box([(-e, 0, -e), (-e, 0, e), (e, 0, e), (e, 0, -e)], thickness)]
+    quads.append((((-e, -1, -e), (-e, -1, e), (e, -1, e), (e, -1, -e)), 1, (1.0, 0.0, 0.0), False))     # faces +y
+    quads.append((((-e, 9, -e), (e, 9, -e), (e, 9, e), (-e, 9, e)), 1, (0.0, 1.0, 0.0), False))         # faces -y
+    return _assemble(quads, [(MAT_GLASS, (1.0, 1.0, 1.0), (1.0, 1.0, 1.0), eta), (MAT_MATTE, (0, 0, 0), (0, 0, 0), 1.0)])
+
+
+def glass_slab_camera(theta_deg, width, height):
+    """Looks down at the slab's top face at `theta_deg` from its normal, from y = 4 (below the green emitter)."""
+    t = np.radians(theta_deg)
+    eye = np.array([-4.0 * np.tan(t), 4.0 + 0.2, 0.0])
+    return perspective_camera(tuple(eye), (0.0, 0.2, 0.0), (0, 0, 1), 0.2, width, height)
+
+
+def mirror_corridor_scene(kr=0.9, Le=3.0):
+    """Two facing mirrors x = -1 and x = +1 (SpecularReflection, FresnelNoOp, Kr = kr) and a one-sided emitter that closes the
+    corridor at z = 10: a ray from the origin with lateral travel D = 10 tan(phi) is reflected floor((D + 1) / 2) times."""
+    h = 100.0
+    quads = [(((-1, -h, -2), (-1, h, -2), (-1, h, 14), (-1, -h, 14)), 0, None, False),
+             (((1, -h, -2), (1, -h, 14), (1, h, 14), (1, h, -2)), 0, None, False),
+             (((-1, -h, 10), (-1, h, 10), (1, h, 10), (1, -h, 10)), 1, (Le, Le, Le), True)]
+    return _assemble(quads, [(MAT_MIRROR, (kr, kr, kr), (0, 0, 0), 1.0), (MAT_MATTE, (0, 0, 0), (0, 0, 0), 1.0)])
+
+
+def mirror_corridor_camera(lateral_travel, width, height):
+    return perspective_camera((0, 0, 0), (lateral_travel, 0.0, 10.0), (0, 1, 0), 0.05, width, height)
+
+
+def two_unequal_lights_scene(rho=0.6):
+    """A Lambertian floor under two very unequal one-sided emitters facing down: a large dim one (4 x 4 at y = 3, Le 1) and a
+    small bright one (0.2 x 0.2 at y = 1, off to the side, Le 4000: ten times the other's power) — every light-pick strategy must
+    find the same mean."""
+    e = 100.0
+    quads = [(((-e, 0, -e), (-e, 0, e), (e, 0, e), (e, 0, -e)), 0, None, False),
+             (((-2, 3, -2), (2, 3, -2), (2, 3, 2), (-2, 3, 2)), 1, (1.0, 1.0, 1.0), False),
+             (((1.4, 1, -0.1), (1.6, 1, -0.1), (1.6, 1, 0.1), (1.4, 1, 0.1)), 1, (4000.0, 4000.0, 4000.0), False)]
+    return _assemble(quads, [(MAT_MATTE, (rho, rho, rho), (0, 0, 0), 1.0), (MAT_MATTE, (0, 0, 0), (0, 0, 0), 1.0)])
+
+
+def two_unequal_lights_camera(width, height):
+    return perspective_camera((-5.0, 2.5, 0.0), (0.7, 0.0, 0.0), (0, 1, 0), 28.0, width, height)
+
+
 def with_lights(scene, extra, keep_existing=True):
     """Copy of `scene` with the LIGHT_DTYPE records `extra` appended to (or replacing) its light table."""
     out = dict(scene)

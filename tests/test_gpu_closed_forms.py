@@ -1,0 +1,100 @@
+"""The HIP path held to the closed forms of tests/test_oracle_render.py (round 4): glass-slab transmission / reflection series,
+Kr^n between facing mirrors, agreement of the light-pick strategies and of Russian roulette on / off in the mean — and, scene by
+scene, to the oracle's film at the same seed (per-pixel tolerance of the render tests)."""
+import numpy as np
+import pytest
+
+import oracle
+import pbrt_hip
+from pbrt_hip import scenes
+from test_oracle_render import CORRIDOR_CASES, INDEPENDENT_SEEDS, SLAB_ANGLES, slab_expectation
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_as_oracle(g, osc, cam, w, h, spp, **kw):
+    film_g, st_g = g.render(cam, w, h, spp, **kw)
+    film_c, st_c = osc.render(scenes.camera_dict_to_floats(cam), w, h, spp, **kw)
+    assert np.array_equal(film_g[..., 3], film_c[..., 3])
+    rgb_g, rgb_c = pbrt_hip.film_to_rgb(film_g), oracle.film_to_rgb(film_c)
+    assert np.all(np.abs(rgb_g - rgb_c) <= 1e-5 * np.maximum(1.0, np.abs(rgb_c))), np.abs(rgb_g - rgb_c).max()
+    assert st_g["rays_closest"] + st_g["rays_shadow"] == st_c["rays"]
+    return rgb_g, st_g
+
+
+def test_glass_slab_series_on_the_device(hip_ctx):
+    w = h = 8
+    sc = scenes.glass_slab_scene()
+    g, osc = pbrt_hip.Scene(hip_ctx, sc), oracle.OracleScene(sc)
+    for theta in SLAB_ANGLES:
+        cam = scenes.glass_slab_camera(theta, w, h)
+        t_exp, r_exp = slab_expectation(theta)
+        for integrator in (1, 2):
+            rgb, st = _same_as_oracle(g, osc, cam, w, h, 1, integrator=integrator, max_depth=12, light_strategy=0, seed=1)
+            m = rgb.reshape(-1, 3).mean(0)
+            assert abs(m[0] - t_exp) < 2e-4 and abs(m[1] - r_exp) < 2e-4 and abs(m[2]) < 1e-5, (theta, integrator, m)
+            assert st["rays_shadow"] == 0              # nothing but specular vertices and black emitters: no light is ever sampled
+        spp = 2048
+        rgb, _ = _same_as_oracle(g, osc, cam, w, h, spp, integrator=0, max_depth=64, rr_threshold=0.0, seed=5)
+        m = rgb.reshape(-1, 3).mean(0)
+        sigma = np.sqrt(t_exp * (1.0 - t_exp) / (w * h * spp))
+        assert abs(m[0] - t_exp) < 4 * sigma + 2e-4 and abs(m[1] - r_exp) < 4 * sigma + 2e-4, (theta, m, t_exp, r_exp)
+    g.close()
+    osc.close()
+
+
+def test_facing_mirrors_on_the_device(hip_ctx):
+    kr, le = 0.9, 3.0
+    w = h = 4
+    sc = scenes.mirror_corridor_scene(kr, le)
+    g, osc = pbrt_hip.Scene(hip_ctx, sc), oracle.OracleScene(sc)
+    for travel, n in CORRIDOR_CASES:
+        cam = scenes.mirror_corridor_camera(travel, w, h)
+        for integrator, kw in ((0, dict(max_depth=8, rr_threshold=0.0)), (1, dict(max_depth=8, light_strategy=0)), (2, dict(max_depth=8))):
+            rgb, _ = _same_as_oracle(g, osc, cam, w, h, 2, integrator=integrator, seed=1, **kw)
+            assert np.all(np.abs(rgb - le * kr ** n) < 2e-5 * le * kr ** n), (travel, n, integrator)
+    travel, n = CORRIDOR_CASES[-1]
+    rgb, _ = _same_as_oracle(g, osc, scenes.mirror_corridor_camera(travel, w, h), w, h, 4096, integrator=0, max_depth=8, rr_threshold=1.0, seed=3)
+    q = 1.0 - kr ** 5
+    assert abs(rgb.mean() - le * kr ** n) < 4 * le * kr ** n * np.sqrt(q / (1.0 - q) / (w * h * 4096)) and rgb.std() > 0.0
+    g.close()
+    osc.close()
+
+
+def _mean_and_sigma(g, cam, w, h, spp, **kw):
+    m = [float(pbrt_hip.film_to_rgb(g.render(cam, w, h, spp, seed=s, **kw)[0]).astype(np.float64).mean()) for s in INDEPENDENT_SEEDS]
+    return float(np.mean(m)), float(np.std(m, ddof=1) / np.sqrt(len(m)))
+
+
+def test_light_pick_strategies_and_roulette_on_the_device(hip_ctx):
+    """Larger sample counts than the CPU test affords (the estimators' agreement gets tighter), one frame of each against the oracle."""
+    w, h, spp = 48, 32, 256
+    sc = scenes.two_unequal_lights_scene()
+    g, osc = pbrt_hip.Scene(hip_ctx, sc), oracle.OracleScene(sc)
+    cam = scenes.two_unequal_lights_camera(w, h)
+    settings = {
+        "direct, all lights": dict(integrator=1, max_depth=1, light_strategy=0),
+        "direct, one light": dict(integrator=1, max_depth=1, light_strategy=1),
+        "path, uniform": dict(integrator=0, max_depth=1, light_strategy=0),
+        "path, power": dict(integrator=0, max_depth=1, light_strategy=1),
+        "path, spatial": dict(integrator=0, max_depth=1, light_strategy=2),
+    }
+    est = {}
+    for name, kw in settings.items():
+        _same_as_oracle(g, osc, cam, w, h, 8, seed=11, **kw)
+        est[name] = _mean_and_sigma(g, cam, w, h, spp, **kw)
+    g.close()
+    osc.close()
+    names = list(est)
+    for i, a in enumerate(names):
+        for b in names[i + 1:]:
+            assert abs(est[a][0] - est[b][0]) <= 4.0 * np.hypot(est[a][1], est[b][1]) + 1e-9, (a, est[a], b, est[b])
+    assert est["direct, all lights"][1] < est["path, power"][1] < est["path, uniform"][1], est
+    w = h = 64
+    sc = scenes.cornell_box()
+    g = pbrt_hip.Scene(hip_ctx, sc)
+    cam = scenes.cornell_camera(w, h)
+    off = _mean_and_sigma(g, cam, w, h, 256, max_depth=8, rr_threshold=0.0)
+    on = _mean_and_sigma(g, cam, w, h, 256, max_depth=8, rr_threshold=1.0)
+    g.close()
+    assert abs(on[0] - off[0]) <= 4.0 * np.hypot(on[1], off[1]), (on, off)

@@ -274,3 +274,130 @@ def test_spatial_light_distribution_same_mean_lower_error():
         assert abs(mean[strategy] - ref.mean()) < 0.01 * ref.mean()
     assert err[2] < err[1] < err[0]                     # measured 0.064 < 0.081 < 0.124
     osc.close()
+
+
+# ---- round 4: the integrator-level logic against closed forms. Geometry has an exact-arithmetic pin
+# (test_exact_rational_pin.py); what follows pins specular chains, MIS / light-pick weights and Russian roulette, none of
+# which the furnace, AO, irradiance and delta-light forms above reach. tests/test_gpu_closed_forms.py holds the HIP path to
+# the same numbers. ----
+def fresnel_dielectric_f64(cos_i, eta_i, eta_t):
+    """The Fresnel equations for unpolarised light in float64 (physics, not reflection.rs:19-40)."""
+    sin_t = eta_i / eta_t * np.sqrt(max(0.0, 1.0 - cos_i * cos_i))
+    if sin_t >= 1.0:
+        return 1.0
+    cos_t = np.sqrt(1.0 - sin_t * sin_t)
+    r_par = (eta_t * cos_i - eta_i * cos_t) / (eta_t * cos_i + eta_i * cos_t)
+    r_per = (eta_i * cos_i - eta_t * cos_t) / (eta_i * cos_i + eta_t * cos_t)
+    return 0.5 * (r_par * r_par + r_per * r_per)
+
+
+SLAB_ANGLES = (0.001, 30.0, 60.0, 75.0)
+INDEPENDENT_SEEDS = [(k + 1) * 1_000_003 for k in range(8)]   # (seeds that differ in the low bits only permute a pixel's samples)
+
+
+def slab_expectation(theta_deg, eta=1.5):
+    """What a camera sees through / in a glass slab at theta from its normal: both faces reflect R = F(theta) (the refracted ray
+    meets the second face at the conjugate angle), so sum_k (1 - R)^2 R^(2k) = (1 - R) / (1 + R) of the radiance behind the slab
+    is transmitted and R + (1 - R)^2 R sum_k R^(2k) = 2 R / (1 + R) of the radiance in front of it is reflected (the radiance
+    scalings 1 / eta^2 and eta^2 of entering and leaving cancel)."""
+    R = fresnel_dielectric_f64(np.cos(np.radians(theta_deg)), 1.0, eta)
+    return (1.0 - R) / (1.0 + R), 2.0 * R / (1.0 + R)
+
+
+def test_glass_slab_transmission_and_reflection_series():
+    """FresnelSpecular / SpecularReflection + SpecularTransmission (reflection.rs:614-819), fr_dielectric, refract, eta_scale, the
+    specular-bounce emission rule (path.rs:80-88) and specular_reflect / transmit (integrator.rs:294-392): a red emitter behind a
+    glass slab and a green one in front of it, seen at four angles. The path integrator picks reflection or transmission at random
+    (mean within 4 sigma of the series); direct lighting and Whitted follow both branches (deterministic, max_depth 12: the
+    dropped terms are below R^10)."""
+    w = h = 8
+    osc = oracle.OracleScene(scenes.glass_slab_scene())
+    for theta in SLAB_ANGLES:
+        cam = _cam(scenes.glass_slab_camera(theta, w, h))
+        t_exp, r_exp = slab_expectation(theta)
+        for integrator in (1, 2):
+            film, _ = osc.render(cam, w, h, 1, integrator=integrator, max_depth=12, light_strategy=0, seed=1)
+            rgb = oracle.film_to_rgb(film).reshape(-1, 3).mean(0)
+            assert abs(rgb[0] - t_exp) < 2e-4 and abs(rgb[1] - r_exp) < 2e-4 and abs(rgb[2]) < 1e-5, (theta, integrator, rgb, t_exp, r_exp)
+        spp = 2048
+        film, _ = osc.render(cam, w, h, spp, integrator=0, max_depth=64, rr_threshold=0.0, seed=5)
+        rgb = oracle.film_to_rgb(film).reshape(-1, 3).mean(0)
+        sigma = np.sqrt(t_exp * (1.0 - t_exp) / (w * h * spp))     # each sample ends on the red side or on the green side
+        assert abs(rgb[0] - t_exp) < 4 * sigma + 2e-4 and abs(rgb[1] - r_exp) < 4 * sigma + 2e-4, (theta, rgb, t_exp, r_exp, sigma)
+    osc.close()
+
+
+CORRIDOR_CASES = ((0.5, 0), (1.5, 1), (3.5, 2), (5.5, 3), (9.5, 5))      # lateral travel, reflections
+
+
+def test_facing_mirrors_attenuate_by_kr_per_reflection():
+    """Two facing mirrors (SpecularReflection with FresnelNoOp: f cos / pdf = Kr exactly) and an emitter at the end of the corridor:
+    after n reflections the camera sees Kr^n Le — in all three integrators, and with Russian roulette switched on (the default
+    threshold 1 plays it from the fifth vertex on, path.rs:199-209) in the mean."""
+    kr, le = 0.9, 3.0
+    w = h = 4
+    osc = oracle.OracleScene(scenes.mirror_corridor_scene(kr, le))
+    for travel, n in CORRIDOR_CASES:
+        cam = _cam(scenes.mirror_corridor_camera(travel, w, h))
+        expect = le * kr ** n
+        for integrator, kw in ((0, dict(max_depth=8, rr_threshold=0.0)), (1, dict(max_depth=8, light_strategy=0)), (2, dict(max_depth=8))):
+            film, _ = osc.render(cam, w, h, 2, integrator=integrator, seed=1, **kw)
+            rgb = oracle.film_to_rgb(film)
+            assert np.all(np.abs(rgb - expect) < 2e-5 * expect), (travel, n, integrator, rgb.min(), rgb.max(), expect)
+        # one reflection too few in the budget: the emitter is never reached
+        if n > 0:
+            film, _ = osc.render(cam, w, h, 2, integrator=0, max_depth=n - 1, rr_threshold=0.0, seed=1)
+            assert np.all(oracle.film_to_rgb(film) == 0.0)
+    travel, n = CORRIDOR_CASES[-1]
+    film, _ = osc.render(_cam(scenes.mirror_corridor_camera(travel, w, h)), w, h, 4096, integrator=0, max_depth=8, rr_threshold=1.0, seed=3)
+    rgb = oracle.film_to_rgb(film)
+    q = 1.0 - kr ** 5                                  # the one roulette of this path (bounces = 4): survive with 1 - q, weight 1 / (1 - q)
+    sigma = le * kr ** n * np.sqrt(q / (1.0 - q) / (w * h * 4096))
+    assert abs(rgb.mean() - le * kr ** n) < 4 * sigma, (rgb.mean(), le * kr ** n, sigma)
+    assert rgb.std() > 0.0
+    osc.close()
+
+
+def _mean_and_sigma(osc, cam, w, h, spp, **kw):
+    m = [float(oracle.film_to_rgb(osc.render(cam, w, h, spp, seed=s, **kw)[0]).astype(np.float64).mean()) for s in INDEPENDENT_SEEDS]
+    return float(np.mean(m)), float(np.std(m, ddof=1) / np.sqrt(len(m)))
+
+
+def test_light_pick_strategies_and_mis_agree_in_the_mean():
+    """uniform_sample_all_lights, uniform_sample_one_light with the "uniform", "power" and "spatial" distributions
+    (integrator.rs:44-134, lightdistrib.rs) and the power-heuristic MIS inside estimate_direct are different estimators of ONE
+    integral: on a floor under a large dim and a small bright emitter (powers 1 : 10) their means agree within 4 sigma (sigma of
+    the mean from eight independent seeds), and the errors rank as the theory says (all lights < power-proportional < uniform pick)."""
+    w, h, spp = 24, 16, 64
+    osc = oracle.OracleScene(scenes.two_unequal_lights_scene())
+    cam = _cam(scenes.two_unequal_lights_camera(w, h))
+    est = {
+        "direct, all lights": _mean_and_sigma(osc, cam, w, h, spp, integrator=1, max_depth=1, light_strategy=0),
+        "direct, one light": _mean_and_sigma(osc, cam, w, h, spp, integrator=1, max_depth=1, light_strategy=1),
+        "path, uniform": _mean_and_sigma(osc, cam, w, h, spp, integrator=0, max_depth=1, light_strategy=0),
+        "path, power": _mean_and_sigma(osc, cam, w, h, spp, integrator=0, max_depth=1, light_strategy=1),
+        "path, spatial": _mean_and_sigma(osc, cam, w, h, spp, integrator=0, max_depth=1, light_strategy=2),
+    }
+    osc.close()
+    names = list(est)
+    for i, a in enumerate(names):
+        for b in names[i + 1:]:
+            (ma, sa), (mb, sb) = est[a], est[b]
+            assert abs(ma - mb) <= 4.0 * np.hypot(sa, sb) + 1e-9, (a, est[a], b, est[b])
+    assert est["direct, all lights"][1] < est["path, power"][1] < est["path, uniform"][1], est
+    assert est["direct, all lights"][0] > 0.05
+
+
+def test_russian_roulette_keeps_the_mean():
+    """path.rs:199-209: with rr_threshold 1 paths are cut at random from the fifth vertex on and the survivors re-weighted by
+    1 / (1 - q); with 0 nothing is cut. Same mean within 4 sigma at depth 8 in the Cornell box; fewer rays with the roulette."""
+    w = h = 24
+    osc = oracle.OracleScene(scenes.cornell_box())
+    cam = _cam(scenes.cornell_camera(w, h))
+    off = _mean_and_sigma(osc, cam, w, h, 64, max_depth=8, rr_threshold=0.0)
+    on = _mean_and_sigma(osc, cam, w, h, 64, max_depth=8, rr_threshold=1.0)
+    _, st_off = osc.render(cam, w, h, 16, max_depth=8, rr_threshold=0.0, seed=9)
+    _, st_on = osc.render(cam, w, h, 16, max_depth=8, rr_threshold=1.0, seed=9)
+    osc.close()
+    assert abs(on[0] - off[0]) <= 4.0 * np.hypot(on[1], off[1]), (on, off)
+    assert st_on["rays"] < 0.97 * st_off["rays"]
