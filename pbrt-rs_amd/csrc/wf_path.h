@@ -44,8 +44,11 @@ struct ShadeBins {
     uint32_t path[256];
 };
 
+#ifndef PB_SHADE_WAVES
+#define PB_SHADE_WAVES 3  // 162 VGPRs; 4 waves (128 VGPRs, spills) measured in profiles/r04_wide_kernel_ladder.txt
+#endif
 template <bool BIN>
-__global__ void __launch_bounds__(256) k_shade(ShadeConsts sc, PathState ps, Queues qin, Queues qout, PassParams pp,
+__global__ void __launch_bounds__(256, PB_SHADE_WAVES) k_shade(ShadeConsts sc, PathState ps, Queues qin, Queues qout, PassParams pp,
                                                  TileList tiles, uint32_t n_in) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool active = i < n_in;
