@@ -154,7 +154,7 @@ def make_case(seed):
         kw["sampler"] = ("zerotwo", int(rng.integers(0, 5)))
     elif smp == "halton":
         kw["sampler"] = ("halton",)
-    gpu_only = dict(shade_order=int(rng.integers(0, 3)), spp_per_pass=int(rng.integers(0, 3)))   # must not change the film
+    gpu_only = dict(shade_order=int(rng.integers(0, 3)), spp_per_pass=int(rng.integers(0, 3)), ray_order=int(rng.integers(0, 2)))   # must not change the film
     plain = "spheres" not in sc and "instances" not in sc and "objects" not in sc and "normals" not in sc and "uvs" not in sc and "tangents" not in sc
     opts = dict(device_build=bool(plain and rng.random() < 0.2),     # the tree built on the device (HLBVH) against the oracle's HLBVH
                 tile_split=int(rng.choice([1, 1, 2, 3])),              # the frame as the sum of the ranks' tile shares
