@@ -23,11 +23,23 @@ def test_kernel_source_hash_covers_the_kernel_sources(tmp_path, monkeypatch):
     root = tmp_path / "repo"
     shutil.copytree(os.path.join(ROOT, "pbrt-rs_amd", "csrc"), root / "pbrt-rs_amd" / "csrc")
     shutil.copy(os.path.join(ROOT, "pbrt-rs_amd", "build.sh"), root / "pbrt-rs_amd" / "build.sh")
+    # ... and what decides the workload the kernels are given: bench.py itself and the scene generator
+    os.makedirs(root / "pbrt-rs_amd" / "pbrt_hip")
+    shutil.copy(os.path.join(ROOT, "pbrt-rs_amd", "pbrt_hip", "scenes.py"), root / "pbrt-rs_amd" / "pbrt_hip" / "scenes.py")
+    shutil.copy(os.path.join(ROOT, "bench.py"), root / "bench.py")
     monkeypatch.setattr(bench, "ROOT", str(root))
     assert bench.kernel_source_hash() == h
     with open(root / "pbrt-rs_amd" / "csrc" / "trace_wide.h", "a") as f:
         f.write("\n// changed\n")
-    assert bench.kernel_source_hash() != h
+    h2 = bench.kernel_source_hash()
+    assert h2 != h
+    with open(root / "pbrt-rs_amd" / "pbrt_hip" / "scenes.py", "a") as f:
+        f.write("\n# changed\n")
+    h3 = bench.kernel_source_hash()
+    assert h3 not in (h, h2)
+    with open(root / "bench.py", "a") as f:
+        f.write("\n# changed\n")
+    assert bench.kernel_source_hash() not in (h, h2, h3)
 
 
 def test_stamped_profile_is_used_only_for_its_configuration_and_flags_stale_sources(tmp_path, monkeypatch):

@@ -318,3 +318,19 @@ def test_adversarial_meshes_and_rays_through_vertices_and_edges(hip_ctx):
             osc.close()
 
     check()
+
+
+def test_state_stream_probe_reports_what_its_lanes_ask_for(hip_ctx):
+    """pbrt_hip_probe_state_stream (the calibration probe behind bench.py's roofline.shade, profiles/r04_fetch_size_calibration_shade.txt):
+    the byte counts it reports are the per-path widths of include/pbrt_hip.h times the queue length, for every part mask."""
+    n, density = 1 << 20, 0.7
+    keep = -(-1024 * 700 // 1000)
+    q = n // 1024 * keep
+    widths = {1: 9 * 16, 2: 2 * 32, 4: 16, 8: 48}
+    for parts in (1, 2, 4, 8, 15, 16, 31):
+        rd, wr, ms = hip_ctx.probe_state_stream(n, density, 1 << 20, parts)
+        assert rd == q * (4 + sum(w for bit, w in widths.items() if parts & bit)), parts
+        assert wr == (q * (5 * 16 + 3 * 32 + 16 + 7 * 4) if parts & 16 else 0), parts
+        assert ms > 0
+    with pytest.raises(pbrt_hip.PbrtHipError):
+        hip_ctx.probe_state_stream(100, 0.5, 1 << 20, 1)
