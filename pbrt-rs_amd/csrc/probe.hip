@@ -170,14 +170,12 @@ __global__ void __launch_bounds__(256) k_probe_state_stream(StateStreamArrays a,
         a.out_queue[i] = p;  // keeps the loads alive
     }
 }
-__global__ void k_probe_queue(uint32_t* queue, const uint32_t* __restrict__ prefix_unused, size_t n_paths, uint32_t keep_of_1024, uint32_t n_queue) {
+__global__ void k_probe_queue(uint32_t* queue, uint32_t keep_of_1024, uint32_t n_queue) {
     // queue entry i = the i-th kept path: paths are kept in a fixed pattern of keep_of_1024 per 1024 (ascending, as a shade queue is)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_queue) return;
     const uint32_t block = i / keep_of_1024, within = i % keep_of_1024;
     queue[i] = block * 1024u + (uint32_t)(((uint64_t)within * 1024u) / keep_of_1024);
-    (void)prefix_unused;
-    (void)n_paths;
 }
 }  // namespace
 
@@ -210,7 +208,7 @@ extern "C" int pbrt_hip_probe_state_stream(PbrtHipContext* ctx, int64_t n_paths,
         a.tris = (const float4*)blocks[5];
         a.out_queue = (uint32_t*)blocks[6];
         for (int k = 1; k < 6; ++k) (void)hipMemsetAsync(blocks[k], 0, sizes[k], st);
-        hipLaunchKernelGGL(k_probe_queue, dim3((n_queue + 255) / 256), dim3(256), 0, st, (uint32_t*)blocks[0], nullptr, (size_t)n_paths, keep, n_queue);
+        hipLaunchKernelGGL(k_probe_queue, dim3((n_queue + 255) / 256), dim3(256), 0, st, (uint32_t*)blocks[0], keep, n_queue);
         float best = 1e30f;
         for (int rep = 0; rep < 3 && rc == PBRT_HIP_OK; ++rep) {
             if (!pb::hip_ok(ctx, hipEventRecord(ctx->ev0, st), "hipEventRecord")) rc = PBRT_HIP_ERR_DEVICE;

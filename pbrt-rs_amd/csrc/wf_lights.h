@@ -385,8 +385,6 @@ PB_DEV V3 estimate_direct_resolve(const ShadeConsts& sc, const PathState& ps, ui
     }
     if (flags & PF_NEE_MIS) {
         int hslot = __float_as_int(ps.hit[hit_index(ps, p, RS_MIS)].x);
-        float4 r0 = ps.ray[ray_index(ps, p, RS_MIS)], r1 = ps.ray[ray_index(ps, p, RS_MIS) + 1];
-        V3 wi = V3{r0.w, r1.x, r1.y};
         DevLight lt = sc.lights[light_id];
         V3 li = V3{0.0f, 0.0f, 0.0f};
         if (hslot >= 0) {
@@ -394,6 +392,9 @@ PB_DEV V3 estimate_direct_resolve(const ShadeConsts& sc, const PathState& ps, ui
             // "found" here, not a leaf slot: it is never queued for an area light)
             int hl = lt.type == PBRT_LIGHT_DIFFUSE_AREA ? (__float_as_int(sc.bvh.tris[3 * (size_t)hslot + 2].w) & kPrimLightMask) - 1 : -2;
             if (hl == light_id) {
+                // (the MIS ray's direction and the hit's barycentrics are read only here: an area light's emitter was hit)
+                float4 r0 = ps.ray[ray_index(ps, p, RS_MIS)], r1 = ps.ray[ray_index(ps, p, RS_MIS) + 1];
+                V3 wi = V3{r0.w, r1.x, r1.y};
                 float4 hb = ps.hit[hit_index(ps, p, RS_MIS)];
                 V3 n = tri_interaction_normal(sc.bvh, hslot, hb.y, hb.z, hb.w);
                 if (lt.two_sided || dot(n, -wi) > 0.0f) li = V3{lt.L[0], lt.L[1], lt.L[2]};
