@@ -201,7 +201,7 @@ typedef struct PbrtRenderStats {
  * leaves the context LOST: every later call on it fails with PBRT_HIP_ERR_DEVICE, its device buffers are never
  * reused, and pbrt_hip_context_destroy then releases the host side only. What a lost context held on the device — its
  * block cache (tens of GB after a large frame), the buffers of the abandoned call, its scenes (pbrt_hip_scene_destroy and
- * pbrt_hip_comm_destroy after the loss release their host side only, in either order with the context) — goes back
+ * pbrt_hip_comm_destroy after the loss release their host side only; the order above still holds: before the context) — goes back
  * with the PROCESS, not before: a long-lived host should ask pbrt_hip_context_is_lost after a PBRT_HIP_ERR_DEVICE and,
  * if so, finish in a fresh child process or exit non-zero. The caller's own device buffers of the abandoned *_device
  * call (d_film, d_rgb, d_rays, d_stream_keys) may still be written or read by the kernel that never finished: they must
