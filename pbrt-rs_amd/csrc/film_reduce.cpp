@@ -166,7 +166,8 @@ extern "C" void pbrt_hip_comm_destroy(PbrtHipComm* comm) {
     {
         PB_LOCK(comm->ctx);  // not while a reduce of this context is in flight, and on the context's device
         (void)hipSetDevice(comm->ctx->device);
-        if (r && comm->comm) (void)r->CommDestroy(comm->comm);
+        // a lost context (scene.h): the abandoned stream may never drain and ncclCommDestroy waits for it — the communicator stays
+        if (r && comm->comm && !comm->ctx->lost) (void)r->CommDestroy(comm->comm);
     }
     delete comm;
 }
