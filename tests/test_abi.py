@@ -132,6 +132,16 @@ def test_comm_without_a_gpu_is_an_error():
     L.pbrt_hip_comm_destroy(None)                                                                   # a no-op
 
 
+def test_null_handles_are_errors_on_the_round4_entry_points():
+    """pbrt_hip_context_is_lost / set_wide_build / probe_state_stream (round 4) with no context: error codes, no dereference."""
+    L = pbrt_hip.lib()
+    assert L.pbrt_hip_context_is_lost(None) == -1
+    assert L.pbrt_hip_context_set_wide_build(None, 0) == 1
+    rd, wr, ms = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_double()
+    assert L.pbrt_hip_probe_state_stream(None, 1 << 20, 700, 1 << 20, 31, ctypes.byref(rd), ctypes.byref(wr), ctypes.byref(ms)) == 1
+    assert (pbrt_hip.TRAVERSAL_AUTO, pbrt_hip.WIDE_BUILD_DEVICE, pbrt_hip.WIDE_BUILD_HOST, pbrt_hip.WIDE_BUILD_NONE) == (0, 0, 1, 2)
+
+
 @pytest.mark.parametrize("kind,rx,ry,a,b", [("box", 0.5, 0.5, 0, 0), ("gaussian", 2.0, 2.0, 2.0, 0),
                                             ("mitchell", 2.0, 2.0, 1 / 3, 1 / 3), ("lanczos", 4.0, 4.0, 3.0, 0),
                                             ("triangle", 2.0, 1.5, 0, 0)])
