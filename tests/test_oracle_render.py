@@ -401,3 +401,24 @@ def test_russian_roulette_keeps_the_mean():
     osc.close()
     assert abs(on[0] - off[0]) <= 4.0 * np.hypot(on[1], off[1]), (on, off)
     assert st_on["rays"] < 0.97 * st_off["rays"]
+
+
+def test_found_of_intersect_is_the_boolean_of_an_order_free_walk():
+    """What RS_MIS_BOOL rests on (csrc/wf_state.h, DESIGN 4.5): `found` of BVHAccel::intersect (bvh.rs:828-879) equals
+    BVHAccel::intersect_p (bvh.rs:881-932) for the same ray — the first hit is found under the ray's original t_max, walking as
+    intersect_p walks — on one-level and instanced scenes, with finite and infinite t_max, rays through shared vertices among them;
+    and fewer boxes are tested on the way (the early exit is what the boolean buys)."""
+    for sc, extent in ((scenes.random_triangles(20_000, seq=5, size=0.05), 1.3), (scenes.cornell_box(), 600.0),
+                       (scenes.instanced_scene(1500, 40, extent=1.5), 2.0)):
+        osc = oracle.OracleScene(sc)
+        for t_max in (np.inf, 0.7 * extent):
+            rays = scenes.random_rays(30_000, 13, origin_extent=extent, t_max=t_max)
+            if "instances" not in sc:      # aim a third of the rays exactly at vertices (ties, t_max moving by an ulp)
+                v = sc["positions"][np.arange(10_000) % len(sc["positions"])]
+                rays["d"][:10_000] = (v - rays["o"][:10_000]).astype(np.float32)
+            hits, c_hit = osc.intersect(rays)
+            occl, c_any = osc.intersect_p(rays)
+            assert np.array_equal(hits["prim_id"] >= 0, occl.astype(bool))
+            assert 0.05 < occl.mean() < 0.999
+            assert c_any["node_tests"] < c_hit["node_tests"]
+        osc.close()
