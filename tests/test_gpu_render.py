@@ -691,3 +691,30 @@ def test_instances_without_an_override_keep_the_triangles_own_materials(hip_ctx)
     flat = dict(sc, tri_material=np.zeros(n, dtype=np.int32))
     _, st_flat, _, st_flat_c = _render_both(hip_ctx, flat, cam, w, h, 4, max_depth=6, seed=17)
     assert st_flat["rays_closest"] + st_flat["rays_shadow"] == st_flat_c["rays"] != st_c["rays"]
+
+
+def test_boolean_mis_rays_leave_the_film_and_the_ray_counts_alone(hip_ctx):
+    """RS_MIS_BOOL: under an environment light the BSDF-sampled MIS ray of estimate_direct is traced as a boolean query.
+    While the reference's loops are being counted (pbrt_hip_set_counting(1)) the same rays are walked to their closest hit, as the
+    reference walks them: the two films are the same bits, the ray counts are equal — on one-level, instanced and mixed-light
+    scenes (an area light beside the environment keeps ITS MIS rays closest-hit) — and the counted walk tests more boxes than
+    the oracle's count of the boolean walk would (it is the reference's figure)."""
+    w, h, spp = 160, 96, 4
+    cornell_env = scenes.with_lights(scenes.cornell_box(), [scenes._lights([(scenes.LIGHT_INFINITE, (0.4, 0.5, 0.6), -1, 0, 1)])[0]])
+    cases = [(scenes.random_triangles(60_000, seq=8, size=0.04), scenes.random_triangles_camera(w, h), 5),
+             (scenes.instanced_scene(2000, 50, extent=1.5), scenes.instanced_camera(w, h, 1.5), 12),
+             (cornell_env, scenes.cornell_camera(w, h), 6)]
+    for sc, cam, depth in cases:
+        g = pbrt_hip.Scene(hip_ctx, sc)
+        film, st = g.render(cam, w, h, spp, max_depth=depth, seed=77)
+        hip_ctx.set_counting(1)
+        try:
+            hip_ctx.counters(reset=True)
+            counted, st_c = g.render(cam, w, h, spp, max_depth=depth, seed=77)
+            c = hip_ctx.counters(reset=True)
+        finally:
+            hip_ctx.set_counting(0)
+        assert film.tobytes() == counted.tobytes()
+        assert (st["rays_closest"], st["rays_shadow"]) == (st_c["rays_closest"], st_c["rays_shadow"])
+        assert c["rays"] == st["rays_closest"] + st["rays_shadow"] and c["node_tests"] > 10 * c["rays"]
+        g.close()
