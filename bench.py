@@ -647,9 +647,10 @@ def main():
 
 def secondary_config5(torch, pbrt_hip, scenes, ctx, device, peak_rec):
     """Untimed for `value`: BASELINE config 5's scene (10 000 base triangles x 1000 rigid instances, matte / mirror / glass by
-    instance, env light, PathIntegrator depth 16) at its stated 3840x2160, 8 of the 128 spp (Mrays/s does not depend on spp),
-    through pbrt_hip_render_device — the two-level traversal kernel k_trace_wide<false, 1> (primitive.rs:136-159)."""
-    W5, H5, SPP5, DEPTH5 = 3840, 2160, 8, 16
+    instance, env light, PathIntegrator depth 16) at its stated 3840x2160, 32 of the 128 spp = ONE PASS of the full job (2^28
+    concurrent paths: the 128-spp frame is four such passes; with 8 spp the wavefronts are a quarter as long and the rate reads
+    5 % lower, profiles/r04_wide_kernel_ladder.txt), through pbrt_hip_render_device — the two-level traversal kernel k_trace_wide<false, 1> (primitive.rs:136-159)."""
+    W5, H5, SPP5, DEPTH5 = 3840, 2160, 32, 16
     sc5 = scenes.instanced_scene(10_000, 1000)
     scene5 = pbrt_hip.Scene(ctx, sc5, bvh=pbrt_hip.build_two_level(sc5))
     cam5 = scenes.instanced_camera(W5, H5)
@@ -665,7 +666,7 @@ def secondary_config5(torch, pbrt_hip, scenes, ctx, device, peak_rec):
     n_wide, why = scene5.wide_records()
     out = {
         "workload": f"config5 scene: 10000 base triangles x 1000 instances (10 M instanced), matte/mirror/glass by instance, env light, "
-                    f"PathIntegrator max_depth {DEPTH5}, {W5}x{H5}x{SPP5}spp of the 128 (one GPU; mean of 3 frames after one warm-up; not part of `value`)",
+                    f"PathIntegrator max_depth {DEPTH5}, {W5}x{H5}x{SPP5}spp of the 128 = one pass of the full job (one GPU; mean of 3 frames after one warm-up; not part of `value`)",
         "value": round(rays / st["total_ms"] / 1e3, 1), "unit": "Mrays/s", "ms_per_frame": round(st["total_ms"], 2),
         "best_frame_Mrays_per_s": round(rays / best["total_ms"] / 1e3, 1),
         "rays_per_frame": int(rays), "trace_only_Mrays_per_s": round(rays / st["trace_ms"] / 1e3, 1),
