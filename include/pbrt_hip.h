@@ -140,6 +140,7 @@ enum PbrtIntegratorKind {
 /* Constructor arguments of PathIntegrator (src/integrators/path.rs:31-46) /
  * DirectLightingIntegrator (src/integrators/directlighting.rs:33-46) plus the sampler and film
  * plumbing of SamplerIntegrator::render (src/core/integrator.rs:399-480). */
+enum PbrtTileOrder { PBRT_TILE_ORDER_MORTON = 0, PBRT_TILE_ORDER_ROW_MAJOR = 1 };
 enum PbrtSamplerKind { PBRT_SAMPLER_RANDOM = 0, PBRT_SAMPLER_STRATIFIED = 1, PBRT_SAMPLER_ZEROTWO = 2, PBRT_SAMPLER_HALTON = 3 };
 typedef struct PbrtRenderParams {
     int32_t integrator;     /* PbrtIntegratorKind */
@@ -153,7 +154,8 @@ typedef struct PbrtRenderParams {
     int32_t x0, y0, x1, y1; /* pixel_bounds [x0,x1) x [y0,y1) */
     uint64_t seed;          /* stream of (pixel, sample) = seed ^ (pixel_number * spp + s), pixel_number = the pixel's
                              * row-major number over the film's sample bounds: y * width + x with the 0.5 box filter */
-    int32_t tile_rank;      /* this GPU renders the 16x16 tiles whose index % tile_world == tile_rank */
+    int32_t tile_rank;      /* this GPU renders the 16x16 tiles whose position in the dealing order (tile_order below)
+                             * is tile_rank modulo tile_world */
     int32_t tile_world;     /* 1 = all tiles */
     int32_t spp_per_pass;   /* 0 = library default; samples of one pixel traced concurrently. Queue entries are 32 bits
                              * (path << 2 | ray slot): pixels x spp_per_pass of one pass must stay below 2^30, larger values
@@ -184,6 +186,10 @@ typedef struct PbrtRenderParams {
     int32_t shade_order;
     int32_t ray_order; /* 0: the path integrator's ray queues are put into Morton order of the ray origins from the second bounce on
                         * (cache order: the rays of a wave walk the same part of the tree); 1: queue order. Same film either way. */
+    int32_t tile_order; /* PbrtTileOrder: the order in which the 16x16 tiles (src/core/integrator.rs:404-409) are dealt to the
+                         * tile_world ranks, and in which a rank walks its own. 0 = Morton order of the tile grid (every
+                         * rank's tiles are spread over the whole frame in both directions), 1 = row-major (with 120 or 240 tiles per
+                         * row and 2 / 4 / 8 ranks a rank then owns whole tile COLUMNS). The merged film does not depend on it. */
 } PbrtRenderParams;
 
 typedef struct PbrtRenderStats {
@@ -208,12 +214,14 @@ typedef struct PbrtRenderStats {
  * not be freed (hipFree waits for the device) or reused either. */
 int pbrt_hip_context_create(int device_id, PbrtHipContext** out);
 void pbrt_hip_context_destroy(PbrtHipContext* ctx);
-/* 1 when a call on this context ran into the wavefront deadline (see above), else 0; -1 for NULL. Takes no lock. */
+/* 1 when a call on this context ran into the wavefront deadline (see above), else 0; -1 for NULL. Takes no lock (the flag is
+ * atomic): safe to poll from any thread while another one is inside a call on the context. */
 int pbrt_hip_context_is_lost(const PbrtHipContext* ctx);
 /* How long pbrt_hip_render / pbrt_hip_li wait for one wavefront before they give the context up for lost (default 120 s; a
  * profiler or a debug build may need more, a service less). seconds > 0. */
 int pbrt_hip_context_set_deadline(PbrtHipContext* ctx, double seconds);
-/* Last error text for this context (or for context creation when ctx == NULL). */
+/* Last error text for this context; ctx == NULL: why the CALLING THREAD's last pbrt_hip_context_create failed (contexts may
+ * be created from several host threads at once; the text is thread-local and lives until that thread's next failed creation). */
 const char* pbrt_hip_last_error(const PbrtHipContext* ctx);
 
 /* ---- host side: BVHAccel::new (src/accelerators/bvh.rs:216-271) ----
@@ -326,6 +334,12 @@ void pbrt_hip_scene_destroy(PbrtHipScene* scene);
  * (spheres, a leaf with more than 4 primitives, coordinates beyond 2^20, PBRT_WIDE_BUILD_NONE ...). The string lives as long
  * as the scene. */
 int pbrt_hip_scene_wide_records(const PbrtHipScene* scene, int32_t* n_records, const char** reason);
+/* Diagnostic (not needed by a renderer; the test that the device builder and the host builder of those records produce the
+ * same bytes reads them through it): copies a single-level scene's wide records back to the host — n_records x 12 dwords,
+ * n_slots x 12 floats (triangles in the records' order), n_slots x 8 floats (exact leaf boxes); n_slots must be the scene's
+ * triangle count, any of the three pointers may be NULL. PBRT_HIP_ERR_INVALID for scenes without wide records and for
+ * two-level scenes. */
+int pbrt_hip_debug_wide_export(PbrtHipScene* scene, uint32_t* nodes, float* tris, float* boxes, int32_t n_slots);
 /* Where the scenes created on this context from now on get those records:
  *   PBRT_WIDE_BUILD_DEVICE  laid out on the device from the flat tree (csrc/wide_gpu.hip; two-level scenes: on the host) — the default;
  *   PBRT_WIDE_BUILD_HOST    by the host builder (csrc/host_wide.cpp): the same bytes, tens of ms per million triangles slower
@@ -441,12 +455,16 @@ void pbrt_hip_comm_destroy(PbrtHipComm* comm); /* before pbrt_hip_context_destro
 int pbrt_hip_film_reduce(PbrtHipComm* comm, float* d_film_xyzw, int64_t n_pixels, int32_t root);
 const char* pbrt_hip_comm_last_error(void);
 
-/* Tile partition used by pbrt_hip_render (host only, no GPU needed): the 16x16 tiles of the pixel
- * bounds (src/core/integrator.rs:402-409) in row-major order; tile t belongs to rank t % world.
- * Writes this rank's tile origins (x, y pairs) to origins_xy (capacity in tiles) and their count
- * to n_out; returns PBRT_HIP_ERR_INVALID if the capacity is too small (n_out then holds the need). */
+/* Tile partition used by pbrt_hip_render (host only, no GPU needed) — what replaces the tile loop of
+ * parallel_for_2d! (src/core/parallel.rs:4-21, src/core/integrator.rs:402-416) across GPUs: the 16x16 tiles of the pixel
+ * bounds are put into `order` (PbrtTileOrder: Morton order of the tile grid, or row-major) and the k-th tile of that order
+ * belongs to rank k % world. Writes this rank's tile origins (x, y pairs, in that order) to origins_xy (capacity in tiles)
+ * and their count to n_out; returns PBRT_HIP_ERR_INVALID if the capacity is too small (n_out then holds the need).
+ * pbrt_hip_tile_partition is the Morton deal (PbrtRenderParams.tile_order = 0, the default). */
 int pbrt_hip_tile_partition(int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t rank, int32_t world,
                             int32_t* origins_xy, int32_t capacity, int32_t* n_out);
+int pbrt_hip_tile_partition_order(int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t rank, int32_t world, int32_t order,
+                                  int32_t* origins_xy, int32_t capacity, int32_t* n_out);
 
 /* Reconstruction filters of src/filters/{boxf,gaussian,mitchell,sinc,triangle}.rs tabulated as Film::new
  * does (src/core/film.rs:52-63). a, b: gaussian alpha / mitchell B, C / lanczos tau. Host only. */

@@ -263,19 +263,53 @@ extern "C" void pbrt_hip_film_to_rgb(const float* film, int64_t n_pixels, float*
     }
 }
 
+// Morton (Z-order) code of a tile's grid position: x in the even bits, y in the odd ones.
+static inline uint64_t tile_morton(uint32_t tx, uint32_t ty) {
+    auto spread = [](uint64_t v) {
+        v &= 0xffffffffull;
+        v = (v | (v << 16)) & 0x0000ffff0000ffffull;
+        v = (v | (v << 8)) & 0x00ff00ff00ff00ffull;
+        v = (v | (v << 4)) & 0x0f0f0f0f0f0f0f0full;
+        v = (v | (v << 2)) & 0x3333333333333333ull;
+        v = (v | (v << 1)) & 0x5555555555555555ull;
+        return v;
+    };
+    return spread(tx) | (spread(ty) << 1);
+}
+
+extern "C" int pbrt_hip_tile_partition_order(int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t rank, int32_t world,
+                                             int32_t order, int32_t* origins_xy, int32_t capacity, int32_t* n_out) {
+    if (!n_out || x0 > x1 || y0 > y1 || world <= 0 || rank < 0 || rank >= world) return PBRT_HIP_ERR_INVALID;
+    if (order != PBRT_TILE_ORDER_MORTON && order != PBRT_TILE_ORDER_ROW_MAJOR) return PBRT_HIP_ERR_INVALID;
+    const int64_t ntx = ((int64_t)x1 - x0 + kTile - 1) / kTile, nty = ((int64_t)y1 - y0 + kTile - 1) / kTile;
+    const int64_t total = ntx * nty;
+    if (total > INT32_MAX) return PBRT_HIP_ERR_INVALID;
+    // the k-th tile of the dealing order belongs to rank k % world (round-robin in Morton order)
+    const int64_t n = total <= rank ? 0 : (total - rank + world - 1) / world;
+    *n_out = (int32_t)n;
+    if (!origins_xy) return PBRT_HIP_OK;
+    if (n > capacity) return PBRT_HIP_ERR_INVALID;
+    if (order == PBRT_TILE_ORDER_ROW_MAJOR) {
+        int64_t k = 0;
+        for (int64_t t = rank; t < total; t += world, ++k) {
+            origins_xy[2 * k] = x0 + (int32_t)(t % ntx) * kTile;
+            origins_xy[2 * k + 1] = y0 + (int32_t)(t / ntx) * kTile;
+        }
+        return PBRT_HIP_OK;
+    }
+    std::vector<std::pair<uint64_t, int32_t>> keyed((size_t)total);
+    for (int64_t t = 0; t < total; ++t) keyed[(size_t)t] = {tile_morton((uint32_t)(t % ntx), (uint32_t)(t / ntx)), (int32_t)t};
+    std::sort(keyed.begin(), keyed.end());
+    int64_t k = 0;
+    for (int64_t i = rank; i < total; i += world, ++k) {
+        const int64_t t = keyed[(size_t)i].second;
+        origins_xy[2 * k] = x0 + (int32_t)(t % ntx) * kTile;
+        origins_xy[2 * k + 1] = y0 + (int32_t)(t / ntx) * kTile;
+    }
+    return PBRT_HIP_OK;
+}
+
 extern "C" int pbrt_hip_tile_partition(int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t rank, int32_t world,
                                        int32_t* origins_xy, int32_t capacity, int32_t* n_out) {
-    if (!n_out || x0 > x1 || y0 > y1 || world <= 0 || rank < 0 || rank >= world) return PBRT_HIP_ERR_INVALID;
-    int ntx = (x1 - x0 + kTile - 1) / kTile, nty = (y1 - y0 + kTile - 1) / kTile;
-    int n = 0;
-    for (int t = 0; t < ntx * nty; ++t) {
-        if (t % world != rank) continue;
-        if (origins_xy && n < capacity) {
-            origins_xy[2 * n] = x0 + (t % ntx) * kTile;
-            origins_xy[2 * n + 1] = y0 + (t / ntx) * kTile;
-        }
-        ++n;
-    }
-    *n_out = n;
-    return (origins_xy && n > capacity) ? PBRT_HIP_ERR_INVALID : PBRT_HIP_OK;
+    return pbrt_hip_tile_partition_order(x0, y0, x1, y1, rank, world, PBRT_TILE_ORDER_MORTON, origins_xy, capacity, n_out);
 }

@@ -22,7 +22,9 @@
 
 using namespace pb;
 
-static std::string g_create_error;
+// why the calling THREAD's last pbrt_hip_context_create failed (pbrt_hip_last_error(NULL)): contexts may be created from several
+// host threads at once, and a failed creation has no context to carry its message
+static thread_local std::string g_create_error;
 
 
 
@@ -55,6 +57,7 @@ extern "C" int pbrt_hip_context_create(int device_id, PbrtHipContext** out) {
         return PBRT_HIP_ERR_DEVICE;
     }
     ctx->n_cus = prop.multiProcessorCount;
+    ctx->trace_log = std::getenv("PBRT_HIP_TRACE_LOG") != nullptr;  // read once, here: the render loop asks per wavefront
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipMalloc((void**)&ctx->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
@@ -98,7 +101,9 @@ extern "C" void pbrt_hip_context_destroy(PbrtHipContext* ctx) {
     delete ctx;
 }
 
-extern "C" int pbrt_hip_context_is_lost(const PbrtHipContext* ctx) { return ctx ? (ctx->lost ? 1 : 0) : -1; }
+extern "C" int pbrt_hip_context_is_lost(const PbrtHipContext* ctx) {
+    return ctx ? (ctx->lost.load(std::memory_order_acquire) ? 1 : 0) : -1;  // no lock: `lost` is atomic (polled from other threads)
+}
 
 extern "C" int pbrt_hip_context_set_deadline(PbrtHipContext* ctx, double seconds) {
     if (!ctx || !(seconds > 0.0)) return PBRT_HIP_ERR_INVALID;
@@ -1034,8 +1039,8 @@ extern "C" int pbrt_hip_scene_wide_records(const PbrtHipScene* s, int32_t* n_rec
 }
 
 // Copies a single-level scene's wide records back: n_records x 12 dwords, n_slots x 12 floats (wide-order triangles),
-// n_slots x 8 floats (leaf boxes). Not part of the boundary (not in include/pbrt_hip.h): the test that the device builder
-// (wide_gpu.hip) and the host builder (host_wide.cpp) produce the same bytes reads the arrays through it.
+// n_slots x 8 floats (leaf boxes). A diagnostic entry point (declared as such in include/pbrt_hip.h): the test that the device
+// builder (wide_gpu.hip) and the host builder (host_wide.cpp) produce the same bytes reads the arrays through it.
 extern "C" int pbrt_hip_debug_wide_export(PbrtHipScene* s, uint32_t* nodes, float* tris, float* boxes, int32_t n_slots) {
     if (!s || !s->has_wide || s->d.bvh.instanced || n_slots != s->d.bvh.n_slots) return PBRT_HIP_ERR_INVALID;
     PbrtHipContext* ctx = s->ctx;

@@ -126,7 +126,11 @@ extern "C" int pbrt_hip_camera_rays(PbrtHipScene* s, const PbrtCamera* camera, c
         return PBRT_HIP_ERR_INVALID;
     int32_t n_tiles = 0;
     const int world = params->tile_world <= 0 ? 1 : params->tile_world;
-    pbrt_hip_tile_partition(params->x0, params->y0, params->x1, params->y1, params->tile_rank, world, nullptr, 0, &n_tiles);
+    if (pbrt_hip_tile_partition_order(params->x0, params->y0, params->x1, params->y1, params->tile_rank, world, params->tile_order, nullptr, 0,
+                                      &n_tiles) != PBRT_HIP_OK) {
+        ctx->last_error = "camera rays: bad tile_rank / tile_world / tile_order";
+        return PBRT_HIP_ERR_INVALID;
+    }
     const int64_t n = (int64_t)n_tiles * kTile * kTile * params->spp;  // whole tiles: pixels outside the bounds carry pixel = (-1, -1)
     *n_out = n;
     if (n == 0) return PBRT_HIP_OK;
@@ -467,20 +471,23 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     int world = rp.tile_world <= 0 ? 1 : rp.tile_world;
     int rank = rp.tile_rank;
     if (rank < 0 || rank >= world) return invalid("tile_rank outside [0, tile_world)");
+    if (rp.tile_order != PBRT_TILE_ORDER_MORTON && rp.tile_order != PBRT_TILE_ORDER_ROW_MAJOR)
+        return invalid("tile_order must be a PbrtTileOrder");
     hipStream_t st = ctx->stream;
 
     size_t film_bytes = (size_t)rp.width * rp.height * 4 * sizeof(float);
     if (d_film) HIP_TRY(ctx, hipMemsetAsync(d_film, 0, film_bytes, st));
 
-    // tiles of the sample bounds (integrator.rs:402-409), dealt round-robin to the GPUs
+    // tiles of the sample bounds (integrator.rs:402-409), dealt round-robin in rp.tile_order to the GPUs
     std::vector<int2> origins;
     if (li_mode) {
         origins.assign((size_t)((li->n + kTile * kTile - 1) / (kTile * kTile)), make_int2(0, 0));  // 256 rays per "tile"
     } else {
         int32_t n_mine = 0;
-        pbrt_hip_tile_partition(rp.x0, rp.y0, rp.x1, rp.y1, rank, world, nullptr, 0, &n_mine);
+        if (pbrt_hip_tile_partition_order(rp.x0, rp.y0, rp.x1, rp.y1, rank, world, rp.tile_order, nullptr, 0, &n_mine) != PBRT_HIP_OK)
+            return invalid("tile partition: too many tiles");
         origins.resize(n_mine);
-        pbrt_hip_tile_partition(rp.x0, rp.y0, rp.x1, rp.y1, rank, world, (int32_t*)origins.data(), n_mine, &n_mine);
+        pbrt_hip_tile_partition_order(rp.x0, rp.y0, rp.x1, rp.y1, rank, world, rp.tile_order, (int32_t*)origins.data(), n_mine, &n_mine);
     }
     PbrtRenderStats local{};
     if (origins.empty()) {
@@ -937,7 +944,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
                 RENDER_TRY(hipEventElapsedTime(&ms, e_t0, e_t1));
                 local.trace_ms += ms;
                 local.trace_launches += 1;
-                if (std::getenv("PBRT_HIP_TRACE_LOG"))
+                if (ctx->trace_log)
                     std::fprintf(stderr, "[pbrt_hip] k_trace: %u rays %.3f ms (%.0f Mrays/s)\n", n_trace, ms, n_trace / ms * 1e-3);
                 ctx->trace_ms += ms;
                 ctx->trace_launches += 1;

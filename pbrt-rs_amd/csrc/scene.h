@@ -4,6 +4,7 @@
 // BVHAccel's flat node array (src/accelerators/bvh.rs:129-135, 774-811), re-laid out for the
 // gfx950 traversal kernel (layout described in trace.h).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -37,7 +38,9 @@ struct PbrtHipContext {
     int n_cus = 0;
     std::string last_error;
     // sticky: set when a call gave up on a kernel that did not finish (render.hip); every entry point then fails
-    bool lost = false;
+    // (atomic: pbrt_hip_context_is_lost polls it from other threads without the lock)
+    std::atomic<bool> lost{false};
+    bool trace_log = false;  // PBRT_HIP_TRACE_LOG was set when the context was created: one stderr line per traversal launch
     double wavefront_deadline_s = 120.0;  // no wavefront of a render takes this long (pbrt_hip_context_set_deadline)
     // traversal-kernel timing (HIP events on `stream`)
     double trace_ms = 0.0;

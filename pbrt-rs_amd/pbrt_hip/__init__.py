@@ -24,6 +24,7 @@ INTEGRATOR_PATH, INTEGRATOR_DIRECT, INTEGRATOR_WHITTED, INTEGRATOR_AO = 0, 1, 2,
 SAMPLER_RANDOM, SAMPLER_STRATIFIED, SAMPLER_ZEROTWO, SAMPLER_HALTON = 0, 1, 2, 3
 TRAVERSAL_AUTO, TRAVERSAL_STACK, TRAVERSAL_STACKLESS = 0, 1, 2   # pbrt_hip_context_set_traversal
 WIDE_BUILD_DEVICE, WIDE_BUILD_HOST, WIDE_BUILD_NONE = 0, 1, 2       # pbrt_hip_context_set_wide_build
+TILE_ORDER_MORTON, TILE_ORDER_ROW_MAJOR = 0, 1                     # PbrtRenderParams.tile_order
 
 EXPORTS = [
     "pbrt_hip_context_create", "pbrt_hip_context_destroy", "pbrt_hip_last_error", "pbrt_hip_bvh_build",
@@ -32,10 +33,10 @@ EXPORTS = [
     "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
     "pbrt_hip_context_set_deadline", "pbrt_hip_context_set_traversal", "pbrt_hip_context_is_lost", "pbrt_hip_context_set_wide_build",
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
-    "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png", "pbrt_hip_write_exr",
+    "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_tile_partition_order", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png", "pbrt_hip_write_exr",
     "pbrt_hip_comm_unique_id", "pbrt_hip_comm_create", "pbrt_hip_comm_destroy", "pbrt_hip_film_reduce",
     "pbrt_hip_comm_last_error", "pbrt_hip_scene_wide_records", "pbrt_hip_get_wide_counters", "pbrt_hip_probe_gather", "pbrt_hip_probe_state_stream",
-    "pbrt_hip_li", "pbrt_hip_li_device", "pbrt_hip_camera_rays", "pbrt_hip_scene_create_two_level",
+    "pbrt_hip_li", "pbrt_hip_li_device", "pbrt_hip_camera_rays", "pbrt_hip_scene_create_two_level", "pbrt_hip_debug_wide_export",
 ]
 
 
@@ -48,7 +49,7 @@ class RenderParams(ctypes.Structure):
                 ("filter_radius", ctypes.c_float * 2), ("filter_table", ctypes.c_void_p),
                 ("sampler", ctypes.c_int32), ("sampler_x", ctypes.c_int32), ("sampler_y", ctypes.c_int32),
                 ("sampler_jitter", ctypes.c_int32), ("sampler_dims", ctypes.c_int32), ("max_sample_luminance", ctypes.c_float),
-                ("shade_order", ctypes.c_int32), ("ray_order", ctypes.c_int32)]
+                ("shade_order", ctypes.c_int32), ("ray_order", ctypes.c_int32), ("tile_order", ctypes.c_int32)]
 
 
 class PbrtObject(ctypes.Structure):
@@ -139,6 +140,7 @@ def lib():
         L.pbrt_hip_li_device.argtypes = [vp, ctypes.POINTER(LiParams), vp, vp, i64, vp, ctypes.POINTER(RenderStats)]
         L.pbrt_hip_camera_rays.argtypes = [vp, vp, ctypes.POINTER(RenderParams), i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
         L.pbrt_hip_tile_partition.argtypes = [i32, i32, i32, i32, i32, i32, vp, i32, ctypes.POINTER(i32)]
+        L.pbrt_hip_tile_partition_order.argtypes = [i32, i32, i32, i32, i32, i32, i32, vp, i32, ctypes.POINTER(i32)]
         L.pbrt_hip_filter_table.argtypes = [i32, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]
         L.pbrt_hip_sample_bounds.argtypes = [i32, i32, ctypes.c_float, ctypes.c_float, vp]
         L.pbrt_hip_write_pfm.argtypes = [ctypes.c_char_p, vp, i32, i32]
@@ -413,7 +415,7 @@ class Scene:
 
     def debug_wide_export(self, n_slots):
         """(records (n, 12) uint32, wide-order triangles (n_slots, 12) float32, leaf boxes (n_slots, 8) float32) of a
-        single-level scene, copied back from the device (pbrt_hip_debug_wide_export: a test hook, not part of the boundary)."""
+        single-level scene, copied back from the device (pbrt_hip_debug_wide_export: the header's diagnostic entry point)."""
         n, _ = self.wide_records()
         nodes = np.zeros((max(n, 0), 12), dtype=np.uint32)
         tris = np.zeros((n_slots, 12), dtype=np.float32)
@@ -536,7 +538,7 @@ class Scene:
 
     def _params(self, width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
                 tile_rank, tile_world, spp_per_pass, filter=None, ao_samples=64, sampler=None, max_sample_luminance=0.0,
-                shade_order=0, ray_order=0):
+                shade_order=0, ray_order=0, tile_order=0):
         rx, ry, table = (0.5, 0.5, None) if filter is None else filter
         if table is not None:
             table = np.ascontiguousarray(table, dtype=np.float32)
@@ -554,23 +556,27 @@ class Scene:
             raise ValueError(sampler)
         return RenderParams(integrator, max_depth, rr_threshold, light_strategy, spp, width, height, x0, y0, x1, y1,
                             seed, tile_rank, tile_world, spp_per_pass, ao_samples, (ctypes.c_float * 2)(rx, ry),
-                            None if table is None else table.ctypes.data, *smp, float(max_sample_luminance), int(shade_order), int(ray_order))
+                            None if table is None else table.ctypes.data, *smp, float(max_sample_luminance), int(shade_order), int(ray_order),
+                            int(tile_order))
 
     def render(self, camera, width, height, spp, integrator=INTEGRATOR_PATH, max_depth=5, rr_threshold=1.0,
                light_strategy=1, seed=0, bounds=None, tile_rank=0, tile_world=1, spp_per_pass=0, d_film_ptr=None,
-               filter=None, ao_samples=64, cos_sample=True, sampler=None, max_sample_luminance=0.0, shade_order=0, ray_order=0):
+               filter=None, ao_samples=64, cos_sample=True, sampler=None, max_sample_luminance=0.0, shade_order=0, ray_order=0,
+               tile_order=0):
         """Integrator::render. Returns (film[h,w,4] or None when d_film_ptr is given, stats dict).
         integrator: INTEGRATOR_PATH / _DIRECT / _WHITTED / _AO (ao_samples, cos_sample: AOIntegrator::new).
         sampler: None (RandomSampler), ("stratified", nx, ny, jitter, n_dims) or ("zerotwo", n_dims); the samples
         per pixel then become nx * ny / the next power of two of spp.
         filter = (radius_x, radius_y, table256) from filter_table(), None = 0.5 box.
         shade_order: 0 queue order, 1 by material inside blocks, 2 sorted queue (PbrtRenderParams.shade_order).
-        ray_order: 0 ray queues in Morton order from the second bounce on, 1 queue order (PbrtRenderParams.ray_order)."""
+        ray_order: 0 ray queues in Morton order from the second bounce on, 1 queue order (PbrtRenderParams.ray_order).
+        tile_order: TILE_ORDER_MORTON (0) / TILE_ORDER_ROW_MAJOR (1): how the 16x16 tiles are dealt to the tile_world ranks."""
         camera = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
         if integrator == INTEGRATOR_AO:
             light_strategy = int(bool(cos_sample))
         rp = self._params(width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
-                          tile_rank, tile_world, spp_per_pass, filter, ao_samples, sampler, max_sample_luminance, shade_order, ray_order)
+                          tile_rank, tile_world, spp_per_pass, filter, ao_samples, sampler, max_sample_luminance, shade_order, ray_order,
+                          tile_order)
         st = RenderStats()
         if d_film_ptr is None:
             film = np.zeros((height, width, 4), dtype=np.float32)
@@ -596,10 +602,11 @@ class Scene:
         self.ctx.check(lib().pbrt_hip_li(self.h, ctypes.byref(lp), _p(rays), _p(keys), len(rays), _p(rgb), ctypes.byref(st)), "pbrt_hip_li")
         return rgb, {name: getattr(st, name) for name, _ in RenderStats._fields_}
 
-    def camera_rays(self, camera, width, height, spp, seed=0, bounds=None, tile_rank=0, tile_world=1):
+    def camera_rays(self, camera, width, height, spp, seed=0, bounds=None, tile_rank=0, tile_world=1, tile_order=0):
         """The camera-ray stage of render(): (rays[RAY_DTYPE], stream_keys[uint64], p_film[n, 2], pixel_sample[n, 3])."""
         camera = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
-        rp = self._params(width, height, spp, INTEGRATOR_PATH, 5, 1.0, 1, seed, bounds, tile_rank, tile_world, 0, None, 64, None, 0.0)
+        rp = self._params(width, height, spp, INTEGRATOR_PATH, 5, 1.0, 1, seed, bounds, tile_rank, tile_world, 0, None, 64, None, 0.0,
+                          tile_order=tile_order)
         n = ctypes.c_int64()
         lib().pbrt_hip_camera_rays(self.h, _p(camera), ctypes.byref(rp), 0, None, None, None, None, ctypes.byref(n))
         rays = np.zeros(n.value, dtype=RAY_DTYPE)
@@ -667,17 +674,18 @@ class Comm:
             pass
 
 
-def tile_partition(bounds, rank, world):
-    """16x16 tile origins of `bounds` = (x0, y0, x1, y1) owned by `rank` (tile t -> rank t % world). Host only."""
+def tile_partition(bounds, rank, world, order=0):
+    """16x16 tile origins of `bounds` = (x0, y0, x1, y1) owned by `rank`: the k-th tile of the dealing order (TILE_ORDER_MORTON,
+    the default, or TILE_ORDER_ROW_MAJOR) belongs to rank k % world; returned in that order. Host only."""
     x0, y0, x1, y1 = bounds
     n = ctypes.c_int32()
-    rc = lib().pbrt_hip_tile_partition(x0, y0, x1, y1, rank, world, None, 0, ctypes.byref(n))
+    rc = lib().pbrt_hip_tile_partition_order(x0, y0, x1, y1, rank, world, order, None, 0, ctypes.byref(n))
     if rc != 0:
-        raise PbrtHipError(f"pbrt_hip_tile_partition failed ({rc})")
+        raise PbrtHipError(f"pbrt_hip_tile_partition_order failed ({rc})")
     out = np.zeros((n.value, 2), dtype=np.int32)
-    rc = lib().pbrt_hip_tile_partition(x0, y0, x1, y1, rank, world, _p(out), n.value, ctypes.byref(n))
+    rc = lib().pbrt_hip_tile_partition_order(x0, y0, x1, y1, rank, world, order, _p(out), n.value, ctypes.byref(n))
     if rc != 0:
-        raise PbrtHipError(f"pbrt_hip_tile_partition failed ({rc})")
+        raise PbrtHipError(f"pbrt_hip_tile_partition_order failed ({rc})")
     return out
 
 

@@ -3,6 +3,7 @@ without a GPU, compute entry points fail loudly (no CPU fallback)."""
 import ctypes
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -24,8 +25,18 @@ def test_header_symbols_exported():
     assert declared == set(pbrt_hip.EXPORTS)
 
 
-def test_struct_sizes_match_header():
-    assert ctypes.sizeof(pbrt_hip.RenderParams) == 120  # 11 x i32, pad, u64 seed, 4 x i32, 2 x f32, pointer, 8 x i32
+def test_struct_sizes_match_header(tmp_path):
+    assert ctypes.sizeof(pbrt_hip.RenderParams) == 128  # 11 x i32, pad, u64 seed, 4 x i32, 2 x f32, pointer, 9 x i32, pad
+    # ... and against the header itself: a C99 translation unit prints what the compiler lays out
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "pbrt_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu\\n", '
+                   'sizeof(PbrtRenderParams), offsetof(PbrtRenderParams, seed), offsetof(PbrtRenderParams, filter_table), '
+                   'offsetof(PbrtRenderParams, tile_order), sizeof(PbrtRenderStats)); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)], text=True).split()]
+    P = pbrt_hip.RenderParams
+    assert got == [ctypes.sizeof(P), P.seed.offset, P.filter_table.offset, P.tile_order.offset, ctypes.sizeof(pbrt_hip.RenderStats)]
     assert ctypes.sizeof(pbrt_hip.RenderStats) == 48
     assert scenes.CAMERA_DTYPE.itemsize == 160
 

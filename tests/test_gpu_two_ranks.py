@@ -61,13 +61,15 @@ def test_two_ranks_on_one_gpu_reduce_to_the_one_process_frame(hip_ctx, tmp_path)
         assert 0 < r["render_ms_per_step"]["mean"] <= r["render_ms_per_step"]["max"] and r["trace_ms_per_step"] > 0
         assert any("libpbrt_hip" in p for p in r["runtime_libs"])
     # ... the two ranks share the one device of this box, which the line says and --one-gpu permits ...
-    assert line["config"]["n_devices"] == 1 and len({r["uuid"] or r["pci_bus_id"] for r in ranks}) == 1
+    assert line["config"]["n_devices"] == 1 and len({(r["host"], r["uuid"] or r["pci_bus_id"]) for r in ranks}) == 1
     assert line["config"]["load_balance_max_over_mean"] >= 1.0
     # ... and a roofline block whose run-measured parts are filled in; only the counter-derived part is null, and says why
     roof = line["roofline"]
-    assert roof["bound"] is None and roof["measured_in_this_run"] is False and "null:" in roof["counter_derived"]
-    assert roof["gather"]["achieved"] > 0 and roof["algorithmic"]["node_tests_per_ray"] > 1 and roof["avg_launch_ms"] > 0
-    assert roof["wide"]["records_per_ray"] > 1
+    assert roof["bound"] == "HBM" and roof["achieved"] is None and roof["frac"] is None and "null:" in roof["counter_derived"]
+    assert roof["measured_in_this_run"]["gather_frac"] is True and roof["measured_in_this_run"]["achieved"] is False
+    assert roof["gather"]["achieved"] > 0 and roof["gather_frac"] > 0 and roof["algorithmic_frac"] > 0
+    assert roof["algorithmic"]["node_tests_per_ray"] > 1 and roof["avg_launch_ms"] > 0 and roof["wide"]["records_per_ray"] > 1
+    assert line["config"]["launcher"] == "torch.distributed.run" and line["config"]["tile_order"] == "morton"
     # the same frame in this process, all tiles on one rank
     sc = scenes.random_triangles(TRIS, seq=1)
     g = pbrt_hip.Scene(hip_ctx, sc, bvh=pbrt_hip.bvh_build(sc["positions"], sc["indices"], 4, pbrt_hip.SPLIT_SAH))
@@ -79,11 +81,76 @@ def test_two_ranks_on_one_gpu_reduce_to_the_one_process_frame(hip_ctx, tmp_path)
     assert line["config"]["rays_per_frame"] == st["rays_closest"] + st["rays_shadow"] == sum(r["rays_per_step"] for r in ranks)
 
 
+def _one_process_frame(hip_ctx, sc, bvh, cam, w, h, spp, depth, **kw):
+    g = pbrt_hip.Scene(hip_ctx, sc, bvh=bvh)
+    ref, st = g.render(cam, w, h, spp, max_depth=depth, rr_threshold=1.0, light_strategy=1, seed=0, **kw)
+    g.close()
+    return ref, st
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks(hip_ctx, tmp_path):
+    """`python bench.py --gpus 2 ...` exactly as the driver starts the one-GPU job — no torch.distributed.run, no WORLD_SIZE:
+    the process becomes the parent of two rank processes (before it touches the GPU), rank 0's one line arrives on its stdout,
+    its exit code is the job's. Same bit-identical film, same per-rank reports; row-major dealing for once, so that both
+    tile orders have gone through the two-process job."""
+    film_path = str(tmp_path / "film.npy")
+    env = _env()
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + ARGS + ["--save-film", film_path, "--tile-order", "row-major"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and "error" not in line and line["config"]["launcher"].startswith("bench.py --gpus N")
+    assert line["config"]["tile_order"] == "row-major" and "row-major" in line["config"]["parallelism"]
+    ranks = line["config"]["ranks"]
+    assert [x["rank"] for x in ranks] == [0, 1] and len({x["pid"] for x in ranks}) == 2 and os.getpid() not in {x["pid"] for x in ranks}
+    assert all(any("libpbrt_hip" in p for p in x["runtime_libs"]) for x in ranks)
+    sc = scenes.random_triangles(TRIS, seq=1)
+    ref, st = _one_process_frame(hip_ctx, sc, pbrt_hip.bvh_build(sc["positions"], sc["indices"], 4, pbrt_hip.SPLIT_SAH),
+                                 scenes.random_triangles_camera(W, H), W, H, SPP, DEPTH)
+    assert np.load(film_path).tobytes() == ref.tobytes()
+    assert line["config"]["rays_per_frame"] == st["rays_closest"] + st["rays_shadow"] == sum(x["rays_per_step"] for x in ranks)
+    # a rank that fails: the parent's exit code is the ranks' (4), not a launcher's 1
+    env["PBRT_BENCH_FAIL"] = "render@1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + ARGS, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 4, r.stderr[-3000:]
+
+
+@pytest.mark.timeout(600)
+def test_config5_job_on_two_ranks_equals_the_one_process_frame(hip_ctx, tmp_path):
+    """bench.py --config 5 --gpus 2: BASELINE config 5's job (instanced scene, matte / mirror / glass, depth 16, several passes
+    of spp_per_pass samples, the tiles of the one frame dealt to the ranks in Morton order) at reduced size — two-level
+    traversal kernel in both ranks, film merged on rank 0 == the one-process frame bit for bit."""
+    w, h, spp, tris, inst = 320, 180, 8, 2000, 60
+    film_path = str(tmp_path / "film5.npy")
+    args = ["--config", "5", "--gpus", "2", "--steps", "1", "--warmup", "1", "--dist-backend", "gloo", "--one-gpu", "--width", str(w),
+            "--height", str(h), "--spp", str(spp), "--spp-per-pass", "2", "--tris", str(tris), "--instances", str(inst), "--no-cpu-baseline",
+            "--watchdog-s", "240", "--save-film", film_path]
+    env = _env()
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["config"]["workload"].startswith("config5 variant") and "instances" in line["config"]["workload"]
+    assert line["roofline"]["kernel"] == "k_trace_wide<false, 1>" and line["roofline"]["wide"]["records_per_ray"] > 1
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2
+    sc = scenes.instanced_scene(tris, inst)
+    ref, st = _one_process_frame(hip_ctx, sc, pbrt_hip.build_two_level(sc), scenes.instanced_camera(w, h), w, h, spp, 16, spp_per_pass=2)
+    assert np.load(film_path).tobytes() == ref.tobytes()
+    ranks = line["config"]["ranks"]
+    assert line["config"]["rays_per_frame"] == st["rays_closest"] + st["rays_shadow"] == sum(x["rays_per_step"] for x in ranks)
+
+
 @pytest.mark.timeout(600)
 def test_two_ranks_on_one_device_are_refused_without_one_gpu():
     """The same job WITHOUT --one-gpu is what a mis-launched 2-GPU run on this box would be (LOCAL_RANK 0 for both): the ranks
-    gather their device ids, find one device behind two ranks and stop, exit code 4 — a line from such a run would not be a
-    scaling number."""
+    gather their device ids right after device selection — before the scene is built or a step is timed — find one device
+    behind two ranks and stop, exit code 4: a line from such a run would not be a scaling number."""
     port = _free_port()
     args = [a for a in ARGS if a != "--one-gpu"]
     procs = []
@@ -95,6 +162,7 @@ def test_two_ranks_on_one_device_are_refused_without_one_gpu():
     outs = [p.communicate(timeout=540) for p in procs]
     assert [p.returncode for p in procs] == [4, 4], [o[1][-1500:] for o in outs]
     assert "distinct device" in outs[0][1] + outs[1][1]
+    assert not any(ln.startswith("{") for o in outs for ln in o[0].splitlines())   # stopped before anything was measured
 
 
 @pytest.mark.timeout(600)

@@ -167,3 +167,35 @@ def test_two_rank_tile_sharding_and_film_reduce(tmp_path):
     osc.close()
     assert n_owned == (BOUNDS[2] - BOUNDS[0]) * (BOUNDS[3] - BOUNDS[1])   # every pixel owned by exactly one rank
     assert film.tobytes() == ref.tobytes()
+
+
+@pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160)])
+def test_morton_deal_spreads_every_rank_over_the_frame_in_both_directions(w, h):
+    """the 16x16 tiles are dealt round-robin in MORTON order. With 120 (1080p) or 240 (4K) tiles per row the
+    row-major deal gives a rank whole tile COLUMNS at N = 2, 4, 8 (16-px stripes every 16 N px); the Morton deal gives every
+    rank a 2-D lattice from N = 4 on (N = 4: every other tile of every other row, N = 8: a 4 x 2 lattice). At N = 2 the low bit
+    of a Z-order index IS the column parity, so the two deals coincide there — stated, not hidden. Either way the shares are
+    a partition of the frame into equal counts (+-1) and each rank walks its tiles in the dealing order."""
+    import pbrt_hip
+    bounds = (0, 0, w, h)
+    ntx, nty = (w + 15) // 16, (h + 15) // 16
+    for world in (2, 4, 8):
+        for order in (pbrt_hip.TILE_ORDER_MORTON, pbrt_hip.TILE_ORDER_ROW_MAJOR):
+            shares = [pbrt_hip.tile_partition(bounds, r, world, order) // 16 for r in range(world)]
+            owner = np.full((nty, ntx), -1)
+            for r, t in enumerate(shares):
+                assert (owner[t[:, 1], t[:, 0]] == -1).all()
+                owner[t[:, 1], t[:, 0]] = r
+            assert (owner >= 0).all() and max(len(t) for t in shares) - min(len(t) for t in shares) <= 1
+            whole_columns = all((owner[:, x] == owner[0, x]).all() for x in range(ntx))
+            if order == pbrt_hip.TILE_ORDER_ROW_MAJOR or world == 2:
+                assert whole_columns            # what the Morton deal is there to avoid (N = 2: inherent to a mod-2 deal of a Z curve)
+            else:
+                assert not whole_columns
+                for r, t in enumerate(shares):
+                    # every rank has tiles in (nearly) every tile row and in every second tile column at least: no stripes
+                    assert len(set(t[:, 1].tolist())) >= nty // 2 and len(set(t[:, 0].tolist())) >= ntx // 4
+                    # ... and any 4 x 4 block of tiles inside the frame holds a tile of every rank (N <= 8)
+                for y in range(0, nty - 3, 4):
+                    for x in range(0, ntx - 3, 4):
+                        assert len(set(owner[y:y + 4, x:x + 4].ravel().tolist())) == world

@@ -1,6 +1,8 @@
 """Property-based checks (hypothesis) of the host-side logic against the oracle: BVH builders on adversarial small
 meshes (coincident vertices, zero-area triangles, collinear centroids, huge / tiny coordinates), the tile partition,
 the sample bounds."""
+import ctypes
+
 import numpy as np
 from hypothesis import given, settings, strategies as st
 
@@ -40,22 +42,43 @@ def test_host_builders_equal_oracle_on_adversarial_meshes(mesh, split, max_prims
     assert int(nodes["n_primitives"].sum()) == len(idx) and leaf.sum() == (len(nodes) + 1) // 2
 
 
+def _morton(tx, ty):
+    code = 0
+    for b in range(16):
+        code |= ((tx >> b) & 1) << (2 * b) | ((ty >> b) & 1) << (2 * b + 1)
+    return code
+
+
 @settings(max_examples=200, deadline=None)
 @given(x0=st.integers(-40, 40), y0=st.integers(-40, 40), dx=st.integers(0, 300), dy=st.integers(0, 200),
-       world=st.integers(1, 9))
-def test_tile_partition_is_a_partition(x0, y0, dx, dy, world):
+       world=st.integers(1, 9), order=st.sampled_from([pbrt_hip.TILE_ORDER_MORTON, pbrt_hip.TILE_ORDER_ROW_MAJOR]))
+def test_tile_partition_is_a_partition(x0, y0, dx, dy, world, order):
     bounds = (x0, y0, x0 + dx, y0 + dy)
     seen = {}
     for rank in range(world):
-        for (tx, ty) in pbrt_hip.tile_partition(bounds, rank, world):
+        mine = [tuple(t) for t in pbrt_hip.tile_partition(bounds, rank, world, order).tolist()]
+        for (tx, ty) in mine:
             assert (tx, ty) not in seen
             seen[(tx, ty)] = rank
             assert (tx - x0) % 16 == 0 and (ty - y0) % 16 == 0 and x0 <= tx < x0 + dx and y0 <= ty < y0 + dy
+        # a rank walks its tiles in the dealing order
+        key = (lambda t: _morton((t[0] - x0) // 16, (t[1] - y0) // 16)) if order == pbrt_hip.TILE_ORDER_MORTON else (lambda t: (t[1], t[0]))
+        assert mine == sorted(mine, key=key)
     n_tiles = ((dx + 15) // 16) * ((dy + 15) // 16)
     assert len(seen) == n_tiles
-    # round-robin in row-major tile order
-    order = sorted(seen, key=lambda t: (t[1], t[0]))
-    assert [seen[t] for t in order] == [i % world for i in range(n_tiles)]
+    # round-robin over the tiles in Morton order of the tile grid / in row-major order
+    if order == pbrt_hip.TILE_ORDER_MORTON:
+        dealt = sorted(seen, key=lambda t: _morton((t[0] - x0) // 16, (t[1] - y0) // 16))
+    else:
+        dealt = sorted(seen, key=lambda t: (t[1], t[0]))
+    assert [seen[t] for t in dealt] == [i % world for i in range(n_tiles)]
+    if order == pbrt_hip.TILE_ORDER_MORTON:   # pbrt_hip_tile_partition (no order argument) is the Morton deal
+        for rank in range(world):
+            n = ctypes.c_int32()
+            assert pbrt_hip.lib().pbrt_hip_tile_partition(*bounds, rank, world, None, 0, ctypes.byref(n)) == 0
+            out = np.zeros((n.value, 2), dtype=np.int32)
+            assert pbrt_hip.lib().pbrt_hip_tile_partition(*bounds, rank, world, out.ctypes.data, n.value, ctypes.byref(n)) == 0
+            assert out.tolist() == pbrt_hip.tile_partition(bounds, rank, world, order).tolist()
 
 
 @settings(max_examples=200, deadline=None)

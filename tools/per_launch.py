@@ -8,13 +8,13 @@ if sys.argv[1] == "render":
     import pbrt_hip
     from pbrt_hip import scenes
     W, H = 1920, 1080
+    os.environ["PBRT_HIP_TRACE_LOG"] = "1"   # read once, by pbrt_hip_context_create: both frames are logged, the second follows "FRAME"
     ctx = pbrt_hip.Context(0)
     g = pbrt_hip.Scene(ctx, scenes.random_triangles(1_000_000, seq=1))
     cam = scenes.random_triangles_camera(W, H)
     for it in range(2):
         if it == 1:
-            os.environ["PBRT_HIP_TRACE_LOG"] = "1"
-            print("FRAME", flush=True)
+            print("FRAME", file=sys.stderr, flush=True)
         _, st = g.render(cam, W, H, 64, max_depth=5, rr_threshold=1.0, light_strategy=1, seed=0,
                          tile_rank=0, tile_world=int(os.environ.get("TILE_WORLD", "1")))
     print(st, flush=True)
