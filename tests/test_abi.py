@@ -118,6 +118,31 @@ def test_tile_partition_covers_bounds_once():
     assert len(seen[1]) == ntx * nty
 
 
+def test_failed_context_creation_from_several_threads():
+    """pbrt_hip_last_error(NULL) is thread-local (the text of the calling thread's last failed pbrt_hip_context_create): many
+    threads failing at once neither crash nor read a torn string. (With a GPU: tests/test_gpu_intersect.py, distinct reasons.)"""
+    import threading
+    L = pbrt_hip.lib()
+    L.pbrt_hip_last_error.restype = ctypes.c_char_p
+    bad = []
+
+    def worker():
+        for _ in range(500):
+            h = ctypes.c_void_p()
+            rc = L.pbrt_hip_context_create(1 << 20, ctypes.byref(h))
+            txt = L.pbrt_hip_last_error(None)
+            if rc == 0 or h.value or txt not in (b"device_id out of range",
+                                                 b"no HIP device visible: the MI355X kernels cannot run (there is no CPU fallback)"):
+                bad.append((rc, txt))
+    threads = [threading.Thread(target=worker) for _ in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not bad, bad[:3]
+    assert L.pbrt_hip_context_is_lost(None) == -1
+
+
 def test_no_gpu_is_an_error_not_a_fallback():
     import torch
     if torch.cuda.is_available():

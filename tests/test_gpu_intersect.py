@@ -440,6 +440,44 @@ def test_error_behaviour_of_the_c_abi(hip_ctx):
     g.close()
 
 
+def test_context_creation_from_several_threads_keeps_each_threads_error(hip_ctx):
+    """pbrt_hip_context_create may be entered from several host threads at once; a creation that fails has no context to
+    carry its message, so pbrt_hip_last_error(NULL) is the CALLING thread's (it was one unlocked global). Two
+    threads keep failing with different reasons (device id out of range / a NULL out pointer leaves the text alone) while a
+    third creates and destroys good contexts: every thread reads its own text, every time."""
+    import ctypes
+    import threading
+    L = pbrt_hip.lib()
+    L.pbrt_hip_last_error.restype = ctypes.c_char_p
+    errors = []
+
+    def bad(device_id):
+        for _ in range(300):
+            h = ctypes.c_void_p()
+            rc = L.pbrt_hip_context_create(device_id, ctypes.byref(h))
+            txt = L.pbrt_hip_last_error(None)
+            if rc != 1 or txt != b"device_id out of range" or h.value:
+                errors.append((device_id, rc, txt))
+
+    def good():
+        for _ in range(20):
+            h = ctypes.c_void_p()
+            rc = L.pbrt_hip_context_create(0, ctypes.byref(h))
+            if rc != 0 or not h.value:
+                errors.append(("good", rc, L.pbrt_hip_last_error(None)))
+                continue
+            L.pbrt_hip_context_destroy(h)
+        if L.pbrt_hip_last_error(None) not in (b"", None):   # this thread never failed: its text is still empty
+            errors.append(("good thread sees another thread's text", L.pbrt_hip_last_error(None)))
+
+    threads = [threading.Thread(target=bad, args=(4096,)), threading.Thread(target=bad, args=(-1,)), threading.Thread(target=good)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors[:5]
+
+
 def test_handles_shared_between_host_threads(hip_ctx):
     """The reference's Primitive is Sync + Send and li() is entered from many rayon tasks at once
     (src/core/primitive.rs:179, integrator.rs:412-452): several host threads call intersect / intersect_p / render on

@@ -174,3 +174,75 @@ def test_stackless_refuses_what_it_does_not_cover(hip_ctx):
     for g in (inst, sph, plain):
         assert len(g.intersect(rays)) == 100          # back on TRAVERSAL_AUTO
         g.close()
+
+
+def _degenerate_above_matte(form):
+    """A matte triangle T of size 1e-9 through the origin and, 1e-12 above it, a triangle D with 5e-12 legs: D's geometric
+    normal (p2 - p0) x (p1 - p0) has squared length 6e-46, which is 0 in f32 — Triangle::intersect rejects it
+    (triangle.rs:212-216) while Triangle::intersect_p (= intersect_test alone, triangle.rs:318-321) accepts it. From T's hit
+    point D covers 43 % of a cosine-sampled hemisphere. Constant environment light. `form`: flat / instanced (one identity
+    instance, INST = 1) / two-level with D in world space beside an instance holding T / the other way round (INST = 2)."""
+    f = np.float32
+    s, d, h = f(1e-9), f(5e-12), f(1e-12)
+    T = np.array([[-s, -s, 0], [s, -s, 0], [0, s, 0]], dtype=np.float32)
+    D = np.array([[-d / 2, -d / 2, h], [d / 2, -d / 2, h], [-d / 2, d / 2, h]], dtype=np.float32)
+    tri = np.array([[0, 1, 2]], dtype=np.int32)
+    mats = scenes._materials([(scenes.MAT_MATTE, (0.5, 0.5, 0.5), (0, 0, 0), 1.0)])
+    env = scenes._lights([(scenes.LIGHT_INFINITE, (1.0, 1.0, 1.0), -1, 0, 1)])
+    ident = np.zeros((1, 2, 4, 4), dtype=np.float32)
+    ident[0, 0] = ident[0, 1] = np.eye(4)
+    both = dict(positions=np.concatenate([T, D]), indices=np.array([[0, 1, 2], [3, 4, 5]], dtype=np.int32),
+                tri_material=np.zeros(2, dtype=np.int32), tri_light=np.full(2, -1, dtype=np.int32))
+    if form == "flat":
+        return dict(both, materials=mats, lights=env)
+    if form == "instanced":
+        return dict(both, materials=mats, lights=env, instances=ident, instance_material=np.array([-1], dtype=np.int32))
+    inner, outer = (T, D) if form == "two-level, D in world space" else (D, T)
+    return dict(objects=[dict(positions=inner, indices=tri, tri_material=np.zeros(1, dtype=np.int32))], instances=ident,
+                instance_object=np.zeros(1, dtype=np.int32), instance_material=np.array([-1], dtype=np.int32),
+                world=dict(positions=outer, indices=tri, tri_material=np.zeros(1, dtype=np.int32), tri_light=np.full(1, -1, dtype=np.int32)),
+                materials=mats, lights=env)
+
+
+@pytest.mark.parametrize("form", ["flat", "instanced", "two-level, D in world space", "two-level, D inside the instance"])
+def test_boolean_mis_rays_skip_what_triangle_intersect_rejects(hip_ctx, form):
+    """the `strict` branches of RS_MIS_BOOL. estimate_direct's BSDF-sampled ray goes through
+    Scene::intersect (integrator.rs:232-262), so a triangle Triangle::intersect rejects must not make `found` true although the
+    any-hit walk that traces such a ray would stop at it. Here 43 % of the MIS rays can only hit such a triangle: a kernel that
+    lost a `strict` check would turn their environment contribution into 0. Every kernel (wide / stack / stackless) gives the
+    oracle's radiance, and the same numbers as the counted run in which the MIS rays are walked to their closest hit."""
+    sc = _degenerate_above_matte(form)
+    n = 2048
+    rays = np.zeros(n, dtype=scenes.RAY_DTYPE)
+    rays["o"], rays["d"], rays["t_max"] = (0.0, 0.0, 1e-6), (0.0, 0.0, -1.0), np.inf
+    keys = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    osc = oracle.OracleScene(sc)
+    cpu, st_c = osc.li(rays, keys, max_depth=1)
+    # the test has power: from just above T a large share of cosine-distributed directions hit D under intersect_p and nothing
+    # under intersect
+    u = scenes.pcg32_float(77, 2 * n).reshape(n, 2).astype(np.float64)
+    r, phi = np.sqrt(u[:, 0]), 2 * np.pi * u[:, 1]
+    probe = np.zeros(n, dtype=scenes.RAY_DTYPE)
+    probe["o"], probe["t_max"] = (0.0, 0.0, 1e-16), np.inf
+    probe["d"] = np.stack([r * np.cos(phi), r * np.sin(phi), np.sqrt(1 - u[:, 0])], 1).astype(np.float32)
+    any_c, closest_c = osc.intersect_p(probe)[0], osc.intersect(probe)[0]
+    assert 0.3 < any_c.mean() < 0.6 and (closest_c["prim_id"] < 0).all()
+    osc.close()
+    g = pbrt_hip.Scene(hip_ctx, sc)
+    modes = [pbrt_hip.TRAVERSAL_AUTO, pbrt_hip.TRAVERSAL_STACK] + ([pbrt_hip.TRAVERSAL_STACKLESS] if form == "flat" else [])
+    for mode in modes:
+        with traversal(hip_ctx, mode):
+            assert np.array_equal(g.intersect_p(probe), any_c) and (g.intersect(probe)["prim_id"] < 0).all()
+            gpu, st = g.li(rays, keys, max_depth=1)
+            assert st["rays_closest"] + st["rays_shadow"] == st_c["rays"]
+            assert np.all(np.abs(gpu - cpu) <= 1e-5 * np.maximum(1.0, np.abs(cpu))), (mode, np.abs(gpu - cpu).max())
+            if mode != pbrt_hip.TRAVERSAL_STACKLESS:   # (the stackless kernel has no counting variant)
+                hip_ctx.set_counting(1)
+                try:
+                    counted, st_n = g.li(rays, keys, max_depth=1)
+                finally:
+                    hip_ctx.set_counting(0)
+                assert counted.tobytes() == gpu.tobytes() and (st_n["rays_closest"], st_n["rays_shadow"]) == (st["rays_closest"], st["rays_shadow"])
+    # what a lost `strict` would give: every MIS ray that D stops contributes nothing -> the mean radiance drops by a third or more
+    assert cpu.mean() > 0.4
+    g.close()
