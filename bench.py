@@ -8,7 +8,7 @@
                                                           "scaling": "strong"), one RCCL reduce of the W*H*4 film to rank 0 inside
                                                           the timed step. --scaling weak renders 64 x N spp instead.
   python bench.py --config 5 --gpus N ...                config 5: 10 000 base triangles x 1000 instances, matte / mirror / glass,
-                                                          depth 16, 3840x2160x128 spp (four 32-spp passes), tiles split the same way
+                                                          depth 16, 3840x2160x128 spp (one GPU: four 32-spp passes), tiles split the same way
 
 Both launch forms work at N > 1: started plainly (`python bench.py --gpus N`, no WORLD_SIZE in the environment) this process
 starts the N ranks itself as CHILD processes — before it has imported torch.cuda or the HIP library, so nothing that has
@@ -39,7 +39,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 CONFIGS = {
     3: dict(scene="random_triangles", width=1920, height=1080, spp=64, max_depth=5, tris=1_000_000, instances=0, spp_per_pass=0),
     4: dict(scene="random_triangles", width=1920, height=1080, spp=256, max_depth=5, tris=1_000_000, instances=0, spp_per_pass=0),
-    5: dict(scene="instanced", width=3840, height=2160, spp=128, max_depth=16, tris=10_000, instances=1000, spp_per_pass=32),
+    # spp_per_pass 0 = as many samples of a pixel in flight as HBM and the 2^28-path bound allow: four 32-spp passes of the whole
+    # 4K frame on one GPU, one 128-spp pass of a rank's eighth of the tiles at N = 8 (profiles/r05_rank_of_world.txt)
+    5: dict(scene="instanced", width=3840, height=2160, spp=128, max_depth=16, tris=10_000, instances=1000, spp_per_pass=0),
 }
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
 # one-GPU anchors of the N-GPU curve (config4_n1 of a committed one-GPU line), newest first
@@ -714,7 +716,7 @@ def run_rank(args):
             rays_per_launch = my_rays / max(trace_launches, 1)
             # ---- untimed, instrumented renders of this rank's tile set (per-ray figures do not depend on spp: one pass of the
             # frame is enough where the frame has several) ----
-            instr_spp = min(spp_total, args.spp_per_pass) if args.spp_per_pass > 0 else spp_total
+            instr_spp = min(spp_total, args.spp_per_pass) if args.spp_per_pass > 0 else min(spp_total, 256 if not inst else 32)
             # (1) the reference's loops: box / triangle tests of BVHAccel::intersect for exactly these rays -> SURVEY 8(d)
             ctx.set_counting(1)
             ctx.counters(reset=True)

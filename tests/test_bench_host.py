@@ -237,7 +237,7 @@ def test_workload_table_is_baselines():
     assert bench.resolve_workload(a, 8) == (4, 256, "config4") and a.spp == 256
     a = bench.parse(["--gpus", "8", "--config", "5"])
     assert bench.resolve_workload(a, 8) == (5, 128, "config5")
-    assert (a.width, a.height, a.tris, a.instances, a.max_depth, a.spp_per_pass) == (3840, 2160, 10_000, 1000, 16, 32)
+    assert (a.width, a.height, a.tris, a.instances, a.max_depth, a.spp_per_pass) == (3840, 2160, 10_000, 1000, 16, 0)
     a = bench.parse(["--gpus", "4", "--scaling", "weak"])
     assert bench.resolve_workload(a, 4) == (4, 256, "config4 variant") and a.spp == 64
     a = bench.parse(["--gpus", "2", "--width", "256", "--height", "144"])

@@ -98,3 +98,50 @@ def test_light_pick_strategies_and_roulette_on_the_device(hip_ctx):
     on = _mean_and_sigma(g, cam, w, h, 256, max_depth=8, rr_threshold=1.0)
     g.close()
     assert abs(on[0] - off[0]) <= 4.0 * np.hypot(on[1], off[1]), (on, off)
+
+
+# ---- the film and the lens: the HIP path against the closed forms of tests/closed_forms_film.py ----
+import closed_forms_film as cf   # noqa: E402
+from test_oracle_render import (FILM_FILTERS, FILM_H, FILM_LE, FILM_SEED, FILM_SPP, FILM_W, LENS_EMITTER, LENS_FOCUS, LENS_H, LENS_W,   # noqa: E402
+                                check_constant_radiance_film, check_luminance_clamp, check_thin_lens)
+
+
+def test_film_reconstructs_a_constant_and_sums_the_analytic_table_on_the_device(hip_ctx):
+    """k_film_accumulate (0.5 box) and k_film_splat (wider filters, float atomics) — with the library's own filter table —
+    against the analytic weight sums and the constant; the sample positions the closed form assumes are the ones
+    pbrt_hip_camera_rays reports, bit for bit; tile splits and pass sizes leave the film where it is."""
+    g = pbrt_hip.Scene(hip_ctx, cf.sky_scene(FILM_LE))
+    cam = cf.sky_camera(FILM_W, FILM_H)
+    for kind, rx, a, b in FILM_FILTERS:
+        filt = None if (kind == "box" and rx == 0.5) else pbrt_hip.filter_table(kind, rx, rx, a, b)
+        film, st = g.render(cam, FILM_W, FILM_H, FILM_SPP, max_depth=5, seed=FILM_SEED, filter=filt, spp_per_pass=2)
+        n = check_constant_radiance_film(film, pbrt_hip.film_to_rgb(film), kind, rx, a, b)
+        assert st["camera_samples"] == n == st["rays_closest"] and st["rays_shadow"] == 0
+        parts = [g.render(cam, FILM_W, FILM_H, FILM_SPP, max_depth=5, seed=FILM_SEED, filter=filt, tile_rank=r, tile_world=3)[0] for r in range(3)]
+        merged = parts[0] + parts[1] + parts[2]
+        check_constant_radiance_film(merged, pbrt_hip.film_to_rgb(merged), kind, rx, a, b)
+    # where the closed form puts the samples is where the camera-ray stage puts them (0.5 box: sample bounds = the film)
+    _, _, p_film, pix = g.camera_rays(cam, FILM_W, FILM_H, FILM_SPP, seed=FILM_SEED)
+    px, py = cf.camera_sample_positions(FILM_W, FILM_H, FILM_SPP, FILM_SEED, 0.5, 0.5)
+    inside = pix[:, 0] >= 0
+    order = np.lexsort((pix[inside, 2], pix[inside, 0], pix[inside, 1]))   # row-major pixels, samples in order
+    assert np.array_equal(p_film[inside][order][:, 0], px) and np.array_equal(p_film[inside][order][:, 1], py)
+    g.close()
+
+
+def test_max_sample_luminance_clamps_exactly_at_the_stated_y_on_the_device(hip_ctx):
+    g = pbrt_hip.Scene(hip_ctx, cf.sky_scene(FILM_LE))
+    cam = cf.sky_camera(24, 16)
+    check_luminance_clamp(lambda bound: pbrt_hip.film_to_rgb(g.render(cam, 24, 16, 2, seed=3, max_sample_luminance=bound)[0]))
+    wide = pbrt_hip.filter_table("gaussian", 2.0, 2.0, 2.0)
+    check_luminance_clamp(lambda bound: pbrt_hip.film_to_rgb(g.render(cam, 24, 16, 2, seed=3, max_sample_luminance=bound, filter=wide)[0]))
+    g.close()
+
+
+def test_thin_lens_focus_and_blur_disc_on_the_device(hip_ctx):
+    def render(depth, lens_radius):
+        g = pbrt_hip.Scene(hip_ctx, cf.emitter_scene(depth, LENS_EMITTER))
+        film, _ = g.render(cf.lens_camera(LENS_W, LENS_H, lens_radius, LENS_FOCUS), LENS_W, LENS_H, 64, max_depth=1, seed=5)
+        g.close()
+        return pbrt_hip.film_to_rgb(film)
+    check_thin_lens(render)

@@ -422,3 +422,104 @@ def test_found_of_intersect_is_the_boolean_of_an_order_free_walk():
             assert 0.05 < occl.mean() < 0.999
             assert c_any["node_tests"] < c_hit["node_tests"]
         osc.close()
+
+
+# ---- closed forms for the film and the lens: the last stage every result passes through ----
+import closed_forms_film as cf   # noqa: E402  (numpy only: neither the oracle nor the kernels)
+
+FILM_W, FILM_H, FILM_SPP, FILM_SEED, FILM_LE = 40, 28, 3, 11, (0.7, 1.3, 2.1)
+FILM_FILTERS = [("box", 0.5, 0.0, 0.0), ("box", 1.5, 0.0, 0.0), ("gaussian", 2.0, 2.0, 0.0), ("mitchell", 2.0, 1.0 / 3.0, 1.0 / 3.0),
+                ("lanczos", 3.0, 3.0, 0.0), ("triangle", 2.0, 0.0, 0.0)]
+_RGB2XYZ = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+_XYZ2RGB = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]])
+
+
+def check_constant_radiance_film(film, rgb, kind, rx, a, b, le=FILM_LE, w=FILM_W, h=FILM_H, spp=FILM_SPP, seed=FILM_SEED):
+    """What a film of a constant-radiance scene must hold, whoever made it (film.rs:252-295, 93-123, 153-178):
+    (1) filter_weight_sum of every pixel = the sum of the 16 x 16 table entries (filter.evaluate in float64 at film.rs:52-63's
+        points) its samples select by add_sample's own index arithmetic, the samples being where the (pixel, sample) PCG32
+        streams put them — to 4e-6 relative (float32 sums of <= 120 terms);
+    (2) every pixel's colour = that constant: (xyz_to_rgb * rgb_to_xyz) le to 2e-6 of the largest channel (float32 sums of
+        products of magnitude 3 |le|, weights of both signs under Mitchell's and Lanczos' lobes), and le itself to the 4e-6
+        that adds what the reference's six-digit matrices lack of being inverses (2e-6)."""
+    table = cf.analytic_table(kind, rx, rx, a, b)
+    px, py = cf.camera_sample_positions(w, h, spp, seed, rx, rx)
+    want, n_terms = cf.expected_weight_sums(w, h, px, py, table, rx, rx)
+    assert n_terms.min() >= spp
+    assert np.all(np.abs(film[..., 3] - want) <= 4e-6 * np.maximum(1.0, np.abs(want))), np.abs(film[..., 3] - want).max()
+    through = _XYZ2RGB @ _RGB2XYZ @ np.array(le)
+    assert np.all(np.abs(rgb - through) <= 2e-6 * np.max(le)), np.abs(rgb - through).max()
+    assert np.all(np.abs(rgb - np.array(le)) <= 4e-6 * np.max(le))
+    return len(px)
+
+
+def test_film_reconstructs_a_constant_and_sums_the_analytic_table():
+    osc = oracle.OracleScene(cf.sky_scene(FILM_LE))
+    cam = _cam(cf.sky_camera(FILM_W, FILM_H))
+    for kind, rx, a, b in FILM_FILTERS:
+        table = oracle.filter_table(kind, rx, rx, a, b)
+        assert np.all(np.abs(table.reshape(16, 16) - cf.analytic_table(kind, rx, rx, a, b)) <= 4e-7 * np.abs(cf.analytic_table(kind, rx, rx, a, b)).max())
+        filt = None if (kind == "box" and rx == 0.5) else (rx, rx, table)
+        film, st = osc.render(cam, FILM_W, FILM_H, FILM_SPP, max_depth=5, seed=FILM_SEED, filter=filt)
+        n = check_constant_radiance_film(film, oracle.film_to_rgb(film), kind, rx, a, b)
+        assert st["camera_samples"] == n and st["rays"] == n   # every camera ray leaves the scene: one Scene::intersect each
+    osc.close()
+
+
+def check_luminance_clamp(render):
+    """Film::max_sample_luminance (film.rs:253-255): a sample brighter than the bound is scaled to carry exactly that
+    luminance (colour kept), one at or below it is left alone. render(max_sample_luminance) -> rgb of the constant scene."""
+    le = np.array(FILM_LE)
+    y = cf.luminance(le)
+    for bound in (1.0, 0.25):
+        rgb = render(bound)
+        assert np.all(np.abs(cf.luminance(rgb) - bound) <= 3e-6 * bound)
+        assert np.all(np.abs(rgb - le * (bound / y)) <= 6e-6 * bound)
+    for bound in (float(np.float32(y) * np.float32(1.0001)), 100.0, 0.0):   # 0 = no clamp (PbrtRenderParams / oracle convention)
+        assert np.all(np.abs(render(bound) - le) <= 4e-6 * le.max())
+
+
+def test_max_sample_luminance_clamps_exactly_at_the_stated_y():
+    osc = oracle.OracleScene(cf.sky_scene(FILM_LE))
+    cam = _cam(cf.sky_camera(24, 16))
+    check_luminance_clamp(lambda bound: oracle.film_to_rgb(osc.render(cam, 24, 16, 2, seed=3, max_sample_luminance=bound)[0]))
+    osc.close()
+
+
+LENS_W = LENS_H = 96
+LENS_RADIUS, LENS_FOCUS, LENS_EMITTER = 0.25, 4.0, 0.02
+
+
+def check_thin_lens(render):
+    """perspective.rs:100-106: p_lens = lens_radius * concentric disk sample, the ray goes through the pinhole ray's point at
+    depth focal_distance. render(depth, lens_radius) -> rgb of a small emitter on the axis at `depth`, 64 spp, camera of
+    cf.lens_camera. (1) At the focal distance the lens changes NOTHING: every lens sample's ray meets the pinhole ray on the
+    emitter's plane — the two images are equal and as sharp as the emitter's projection (within one pixel). (2) Off the focal
+    plane a point at depth d is seen through the disc of radius lens_radius |1 - d_focus / d| on the focal plane: the lit
+    region's radius = that disc through raster_to_camera + the emitter's own projected half-diagonal, within one pixel —
+    in front of the focal plane and behind it; without the lens it stays the pinhole image."""
+    cam = cf.lens_camera(LENS_W, LENS_H, LENS_RADIUS, LENS_FOCUS)
+    for depth in (LENS_FOCUS, 2.0 * LENS_FOCUS, 0.6 * LENS_FOCUS):
+        sharp, blurred = render(depth, 0.0), render(depth, LENS_RADIUS)
+        emitter_px = np.hypot(*(cf.raster_of_camera_point(cam, (LENS_EMITTER, LENS_EMITTER, depth)) - LENS_W / 2.0))
+        r_sharp, r_blur = cf.lit_radius_px(sharp, LENS_W, LENS_H, 1e-6), cf.lit_radius_px(blurred, LENS_W, LENS_H, 1e-6)
+        assert abs(r_sharp - emitter_px) <= 1.0, (depth, r_sharp, emitter_px)
+        coc = LENS_RADIUS * abs(1.0 - LENS_FOCUS / depth)
+        coc_px = abs(cf.raster_of_camera_point(cam, (coc, 0.0, LENS_FOCUS))[0] - LENS_W / 2.0)
+        assert abs(r_blur - (coc_px + emitter_px)) <= 1.0, (depth, r_blur, coc_px, emitter_px)
+        if depth == LENS_FOCUS:
+            assert coc_px < 1e-9 and np.array_equal(sharp, blurred)
+        else:
+            assert coc_px > 5.0   # the test has something to see
+            # the blurred image is centred where the sharp one is (the disc is symmetric about the axis)
+            ys, xs = np.nonzero(cf.luminance(blurred) > 1e-6)
+            assert abs(xs.mean() + 0.5 - LENS_W / 2.0) <= 0.75 and abs(ys.mean() + 0.5 - LENS_H / 2.0) <= 0.75
+
+
+def test_thin_lens_focus_and_blur_disc():
+    def render(depth, lens_radius):
+        osc = oracle.OracleScene(cf.emitter_scene(depth, LENS_EMITTER))
+        film, _ = osc.render(_cam(cf.lens_camera(LENS_W, LENS_H, lens_radius, LENS_FOCUS)), LENS_W, LENS_H, 64, max_depth=1, seed=5)
+        osc.close()
+        return oracle.film_to_rgb(film)
+    check_thin_lens(render)

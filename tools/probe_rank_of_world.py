@@ -20,11 +20,14 @@ ap.add_argument("--configs", type=int, nargs="+", default=[4, 5])
 ap.add_argument("--worlds", type=int, nargs="+", default=[1, 2, 4, 8])
 ap.add_argument("--orders", nargs="+", default=["morton", "row-major"])
 ap.add_argument("--repeats", type=int, default=2)
+ap.add_argument("--spp-per-pass", type=int, default=-1, help="override the configuration's pass size (0 = sized from free HBM)")
 a = ap.parse_args()
 ctx = pbrt_hip.Context(0)
 for cfg in a.configs:
     c = bench.CONFIGS[cfg]
     W, H = c["width"], c["height"]
+    if a.spp_per_pass >= 0:
+        c = dict(c, spp_per_pass=a.spp_per_pass)
     if c["scene"] == "instanced":
         sc = scenes.instanced_scene(c["tris"], c["instances"])
         scene = pbrt_hip.Scene(ctx, sc, bvh=pbrt_hip.build_two_level(sc))
