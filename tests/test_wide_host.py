@@ -241,3 +241,21 @@ def test_top_level_tree_over_opaque_primitives(chk):
         tris = _tri_records(np.asarray(o["positions"], dtype=np.float32), np.asarray(o["indices"], dtype=np.int32), order)
         rc, st, w = _structure(chk, nodes, tris)
         assert rc == 0, (rc, w)
+
+
+def test_record32_study_tool_runs_and_agrees_with_itself(tmp_path):
+    """tools/record32_study.py (profiles/r05_record32_study.txt: the 32-byte two-load record costed on the host, not built): on a
+    small tree both layouts are walked by the same rays; they must find the same hits (equal triangle-test counts up to the few
+    extra leaf candidates of a looser filter) and the candidate must save a third of the record loads — the tool still says what
+    the profile says it says."""
+    import re
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "record32_study.py"), "20000", "1500"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tail = r.stdout[r.stdout.index("all rays (the frame's mix)"):]
+    steps48, steps32 = float(re.search(r"48-B records:\s+([\d.]+) steps/ray", tail).group(1)), float(re.search(r"32-B records:\s+([\d.]+) steps/ray", tail).group(1))
+    tri48, tri32 = [float(v) for v in re.findall(r"([\d.]+) triangle tests", tail)[:2]]
+    assert 0.99 * steps48 <= steps32 <= 1.03 * steps48 and abs(tri48 - tri32) <= 0.02 * tri48
+    req = re.search(r"requests per ray:\s+([\d.]+) ->\s+([\d.]+)", tail)
+    assert 0.66 <= float(req.group(2)) / float(req.group(1)) <= 0.78   # between "every load is a record load" (2 / 3) and the full frame's 0.73
+    assert "frame origins that would not be exact floats: 0" in r.stdout
