@@ -43,7 +43,7 @@ CONFIGS = {
     # 4K frame on one GPU, one 128-spp pass of a rank's eighth of the tiles at N = 8 (profiles/r05_rank_of_world.txt)
     5: dict(scene="instanced", width=3840, height=2160, spp=128, max_depth=16, tris=10_000, instances=1000, spp_per_pass=0),
 }
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
 # one-GPU anchors of the N-GPU curve (config4_n1 of a committed one-GPU line), newest first
 ANCHOR_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r05_bench_line.json", "r04_bench_line.json")]
 # what a stamped counter profile was measured on: the kernels, and what decides the workload they were given
@@ -540,29 +540,30 @@ def roofline_block(kernel, trace_s_per_launch, launches_per_frame, rays_per_laun
 
 def shade_block(rec, stale):
     """roofline.shade: k_shade streams the SoA path state (stamped profile; its launch time is the profile's own, the library
-    times only the traversal launches). FETCH_SIZE under-counts the coalesced streams it reads; the calibration factor was
-    measured on ONE mix at shade-queue density 0.7 (profiles/r04_fetch_size_calibration_shade.txt: 0.62; the same mix at
-    density 1.0 reads 0.70), and a step's launches run from density 1.0 on the first bounce downwards — so the figure is a
-    RANGE: frac at factor 0.62 (upper) and at 0.70 (lower), WRITE_SIZE at face value (it reads up to 1.2x at density 0.7)."""
+    times only the traversal launches). FETCH_SIZE under-counts the coalesced streams it reads (counted at 1/2 per line) and
+    counts the triangle gathers per line touched: against the bytes MOVED it reads 0.62 at shade-queue density 0.7 and 0.633 at
+    density 1.0 (profiles/shade_fetch_calibration.json). A step's launches run from density 1.0 on the first bounce downwards,
+    so the figure is given as a RANGE over the two factors; WRITE_SIZE is the traffic at face value."""
     sh = rec.get("shade") if rec else None
     if not (sh and sh.get("avg_launch_ns_under_kernel_trace")):
         return None
     cal = sh.get("fetch_calibration") or {}
-    lo_f, hi_f = cal.get("factor"), cal.get("factor_dense", 0.70)
+    f_sparse, f_dense = cal.get("factor"), cal.get("factor_dense") or cal.get("factor")
     ns = sh["avg_launch_ns_under_kernel_trace"]
 
     def gbps(factor):
         return (sh["fetch_bytes_per_launch"] / factor + sh["write_bytes_per_launch"]) / ns
     face = sh["bytes_per_launch"] / ns
-    best = gbps(lo_f) if lo_f else face
-    return {"kernel": "k_shade", "bound": "HBM", "achieved": round(best, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(best / HBM_PEAK_GBS, 4),
-            "frac_range": [round((gbps(hi_f) if lo_f else face) / HBM_PEAK_GBS, 4), round(best / HBM_PEAK_GBS, 4)],
-            "traffic": round(best * ns), "traffic_counters_at_face_value": sh["bytes_per_launch"],
+    hi = gbps(f_sparse) if f_sparse else face
+    lo = gbps(f_dense) if f_sparse else face
+    return {"kernel": "k_shade", "bound": "HBM", "achieved": round(hi, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(hi / HBM_PEAK_GBS, 4), "frac_range": [round(lo / HBM_PEAK_GBS, 4), round(hi / HBM_PEAK_GBS, 4)],
+            "traffic": round(hi * ns), "traffic_counters_at_face_value": sh["bytes_per_launch"],
             "frac_counters_at_face_value": round(face / HBM_PEAK_GBS, 4),
-            "source": (f"FETCH_SIZE / f + WRITE_SIZE with f = {lo_f} (the probe's mix at shade-queue density 0.7) ... {hi_f} (density 1.0): "
-                       f"{cal.get('source')}; a step's launches run from density 1.0 downwards, so the fraction lies in frac_range"
-                       if lo_f else "counters at face value (uncalibrated)"),
+            "source": (f"FETCH_SIZE / f + WRITE_SIZE, f = FETCH_SIZE over the bytes MOVED on k_shade's access pattern: {f_sparse} at shade-queue "
+                       f"density {cal.get('density', 0.7)} ... {f_dense} at density {cal.get('density_dense', 1.0)} ({cal.get('source')}); "
+                       f"a step's launches run from density 1.0 downwards, so the fraction lies in frac_range"
+                       if f_sparse else "counters at face value (uncalibrated)"),
             "measured_in_this_run": False, "avg_launch_ms": round(ns * 1e-6, 4), "launches_per_step": sh.get("launches_per_step"),
             "valu_lane_utilisation": sh.get("valu_lane_utilisation"), "stale": stale}
 

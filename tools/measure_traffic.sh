@@ -1,7 +1,7 @@
 #!/bin/bash
-# Writes profiles/r04_traffic.json — the stamped counter profile behind bench.py's roofline block: per launch of the dominant
+# Writes profiles/r05_traffic.json — the stamped counter profile behind bench.py's roofline block: per launch of the dominant
 # traversal kernel and of k_shade, fabric-side bytes (FETCH_SIZE + WRITE_SIZE), vector instructions and lane utilisation,
-# texture-addresser busy cycles — and profiles/r04_bench_kernel_stats.csv, from rocprofv3 runs of the default bench.py
+# texture-addresser busy cycles — and profiles/r05_bench_kernel_stats.csv, from rocprofv3 runs of the default bench.py
 # command. Separate runs (--kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE; SQ counters; TA), as gpurun requires.
 # Stamped with the commit and with bench.py's hash of the kernel sources: bench.py flags the figures stale when they differ.
 set -o pipefail
@@ -49,7 +49,7 @@ avg = {}
 if stats:
     for row in csv.DictReader(open(stats[0], newline="")):
         avg[row["Name"]] = (float(row["AverageNs"]), int(row["Calls"]))
-    os.system(f"cp {stats[0]} profiles/r04_bench_kernel_stats.csv")
+    os.system(f"cp {stats[0]} profiles/r05_bench_kernel_stats.csv")
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("PB_COMMIT", "unknown")
 import sys
 sys.path.insert(0, ".")
@@ -76,26 +76,28 @@ def kernel_block(k):
     }
 trace, shade = kernel_block(kf), kernel_block(ks)
 shade["launches_per_step"] = 6
-# k_shade streams SoA path state through the shade queue: FETCH_SIZE reads 0.62 of the bytes that pattern moves
-# (profiles/r04_fetch_size_calibration_shade.txt: coalesced streams are counted at 1/2 per line at every lane width, the
-# triangle gathers at face value); WRITE_SIZE at face value
-SHADE_FETCH_FACTOR = 0.62
-shade["fetch_calibration"] = {"factor": SHADE_FETCH_FACTOR, "source": "profiles/r04_fetch_size_calibration_shade.txt"}
-shade["bytes_per_launch_calibrated"] = round(shade["fetch_bytes_per_launch"] / SHADE_FETCH_FACTOR + shade["write_bytes_per_launch"])
+# k_shade streams SoA path state through the shade queue: FETCH_SIZE reads 0.62 - 0.63 of the bytes that pattern MOVES
+# (profiles/shade_fetch_calibration.json, from r04_fetch_size_calibration_shade.txt: coalesced streams are counted at 1/2 per line
+# at every lane width, the triangle gathers at face value per line touched; density 0.7 -> 0.62, density 1.0 -> 0.633; a step's
+# launches run from density 1.0 on the first bounce downwards: bench.py reports the range); WRITE_SIZE at face value
+cal = json.load(open("profiles/shade_fetch_calibration.json"))
+shade["fetch_calibration"] = {"factor": cal["factor"], "density": cal["density"], "factor_dense": cal["factor_dense"],
+                              "density_dense": cal["density_dense"], "source": cal["source"]}
+shade["bytes_per_launch_calibrated"] = round(shade["fetch_bytes_per_launch"] / cal["factor"] + shade["write_bytes_per_launch"])
 rec = {
     "trace": trace, "shade": shade,
     "config": {"n_gpus": 1, "tris": 1000000, "width": 1920, "height": 1080, "spp": 64, "max_depth": 5,
                "kernel": "k_trace_wide" if "wide" in kf else "k_trace"},
     "commit": os.environ.get("PB_COMMIT", commit), "source_hash": bench.kernel_source_hash(),
-    "profile": "profiles/r04_bench_kernel_stats.csv + rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU "
+    "profile": "profiles/r05_bench_kernel_stats.csv + rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU "
                "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE; TA_TA_BUSY_sum GRBM_GUI_ACTIVE — one run each) on "
                "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary`; FETCH_SIZE = TCC_EA0_RDREQ x 64 B (Infinity-Cache hits "
                "included), used without the x2 of wide coalesced streams: calibrated on this gather pattern in "
                "profiles/r01_fetch_size_calibration.txt (0.986)",
 }
-json.dump(rec, open("profiles/r04_traffic.json", "w"), indent=1)
-json.dump(rec, open(f"{out}/r04_traffic.json", "w"), indent=1)
+json.dump(rec, open("profiles/r05_traffic.json", "w"), indent=1)
+json.dump(rec, open(f"{out}/r05_traffic.json", "w"), indent=1)
 print(json.dumps(rec, indent=1))
 PY
-cp profiles/r04_bench_kernel_stats.csv $OUT/ 2>/dev/null
+cp profiles/r05_bench_kernel_stats.csv $OUT/ 2>/dev/null
 find $OUT -name "*.csv" -size +2M -delete
