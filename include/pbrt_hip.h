@@ -187,9 +187,10 @@ typedef struct PbrtRenderParams {
     int32_t ray_order; /* 0: the path integrator's ray queues are put into Morton order of the ray origins from the second bounce on
                         * (cache order: the rays of a wave walk the same part of the tree); 1: queue order. Same film either way. */
     int32_t tile_order; /* PbrtTileOrder: the order in which the 16x16 tiles (src/core/integrator.rs:404-409) are dealt to the
-                         * tile_world ranks, and in which a rank walks its own. 0 = Morton order of the tile grid (every
-                         * rank's tiles are spread over the whole frame in both directions), 1 = row-major (with 120 or 240 tiles per
-                         * row and 2 / 4 / 8 ranks a rank then owns whole tile COLUMNS). The merged film does not depend on it. */
+                         * tile_world ranks. 0 = Morton order of the tile grid (every rank's tiles are spread over the
+                         * whole frame in both directions), 1 = row-major (with 120 or 240 tiles per row and 2 / 4 / 8 ranks a rank
+                         * then owns whole tile COLUMNS). A rank renders its own tiles in row-major order either way (with one rank
+                         * the two settings are the same job). The merged film does not depend on it. */
 } PbrtRenderParams;
 
 typedef struct PbrtRenderStats {
@@ -458,7 +459,7 @@ const char* pbrt_hip_comm_last_error(void);
 /* Tile partition used by pbrt_hip_render (host only, no GPU needed) — what replaces the tile loop of
  * parallel_for_2d! (src/core/parallel.rs:4-21, src/core/integrator.rs:402-416) across GPUs: the 16x16 tiles of the pixel
  * bounds are put into `order` (PbrtTileOrder: Morton order of the tile grid, or row-major) and the k-th tile of that order
- * belongs to rank k % world. Writes this rank's tile origins (x, y pairs, in that order) to origins_xy (capacity in tiles)
+ * belongs to rank k % world. Writes this rank's tile origins (x, y pairs, in row-major order) to origins_xy (capacity in tiles)
  * and their count to n_out; returns PBRT_HIP_ERR_INVALID if the capacity is too small (n_out then holds the need).
  * pbrt_hip_tile_partition is the Morton deal (PbrtRenderParams.tile_order = 0, the default). */
 int pbrt_hip_tile_partition(int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t rank, int32_t world,

@@ -676,7 +676,7 @@ class Comm:
 
 def tile_partition(bounds, rank, world, order=0):
     """16x16 tile origins of `bounds` = (x0, y0, x1, y1) owned by `rank`: the k-th tile of the dealing order (TILE_ORDER_MORTON,
-    the default, or TILE_ORDER_ROW_MAJOR) belongs to rank k % world; returned in that order. Host only."""
+    the default, or TILE_ORDER_ROW_MAJOR) belongs to rank k % world; returned in row-major order. Host only."""
     x0, y0, x1, y1 = bounds
     n = ctypes.c_int32()
     rc = lib().pbrt_hip_tile_partition_order(x0, y0, x1, y1, rank, world, order, None, 0, ctypes.byref(n))

@@ -175,7 +175,7 @@ def test_morton_deal_spreads_every_rank_over_the_frame_in_both_directions(w, h):
     row-major deal gives a rank whole tile COLUMNS at N = 2, 4, 8 (16-px stripes every 16 N px); the Morton deal gives every
     rank a 2-D lattice from N = 4 on (N = 4: every other tile of every other row, N = 8: a 4 x 2 lattice). At N = 2 the low bit
     of a Z-order index IS the column parity, so the two deals coincide there — stated, not hidden. Either way the shares are
-    a partition of the frame into equal counts (+-1) and each rank walks its tiles in the dealing order."""
+    a partition of the frame into equal counts (+-1)."""
     import pbrt_hip
     bounds = (0, 0, w, h)
     ntx, nty = (w + 15) // 16, (h + 15) // 16

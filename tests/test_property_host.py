@@ -61,9 +61,8 @@ def test_tile_partition_is_a_partition(x0, y0, dx, dy, world, order):
             assert (tx, ty) not in seen
             seen[(tx, ty)] = rank
             assert (tx - x0) % 16 == 0 and (ty - y0) % 16 == 0 and x0 <= tx < x0 + dx and y0 <= ty < y0 + dy
-        # a rank walks its tiles in the dealing order
-        key = (lambda t: _morton((t[0] - x0) // 16, (t[1] - y0) // 16)) if order == pbrt_hip.TILE_ORDER_MORTON else (lambda t: (t[1], t[0]))
-        assert mine == sorted(mine, key=key)
+        # whatever the deal, a rank walks its own tiles in row-major order
+        assert mine == sorted(mine, key=lambda t: (t[1], t[0]))
     n_tiles = ((dx + 15) // 16) * ((dy + 15) // 16)
     assert len(seen) == n_tiles
     # round-robin over the tiles in Morton order of the tile grid / in row-major order
