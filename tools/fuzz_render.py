@@ -155,6 +155,8 @@ def make_case(seed):
     elif smp == "halton":
         kw["sampler"] = ("halton",)
     gpu_only = dict(shade_order=int(rng.integers(0, 3)), spp_per_pass=int(rng.integers(0, 3)), ray_order=int(rng.integers(0, 2)))   # must not change the film
+    # round 5: the dealing order of the tiles (its own generator: the draws of the cases above stay what they were)
+    gpu_only["tile_order"] = int(np.random.default_rng(seed ^ 0x71e0).integers(0, 2))
     plain = "spheres" not in sc and "instances" not in sc and "objects" not in sc and "normals" not in sc and "uvs" not in sc and "tangents" not in sc
     opts = dict(device_build=bool(plain and rng.random() < 0.2),     # the tree built on the device (HLBVH) against the oracle's HLBVH
                 tile_split=int(rng.choice([1, 1, 2, 3])),              # the frame as the sum of the ranks' tile shares
