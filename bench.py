@@ -10,10 +10,10 @@
   python bench.py --config 5 --gpus N ...                config 5: 10 000 base triangles x 1000 instances, matte / mirror / glass,
                                                           depth 16, 3840x2160x128 spp (one GPU: four 32-spp passes), tiles split the same way
 
-Both launch forms work at N > 1: started plainly (`python bench.py --gpus N`, no WORLD_SIZE in the environment) this process
+Both launch forms work at N > 1: started plainly (`python bench.py --gpus N`, no RANK + WORLD_SIZE in the environment) this process
 starts the N ranks itself as CHILD processes — before it has imported torch.cuda or the HIP library, so nothing that has
 initialised the GPU is ever replaced — and leaves with their exit code; started under `python -m torch.distributed.run
---nproc-per-node N ... bench.py --gpus N` (WORLD_SIZE set) it is one of the ranks.
+--nproc-per-node N ... bench.py --gpus N` (RANK and WORLD_SIZE set) it is one of the ranks.
 
 A step = one frame through Integrator::render (scene + BVH resident in HBM, film left on the device). One ray = one
 Scene::intersect / intersect_p call. Prints ONE JSON line on rank 0. A rank that fails or hangs ends the job with a non-zero
@@ -590,8 +590,9 @@ def build_scene(args, cfg, pbrt_hip, scenes, local_rank):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # no launcher: be the parent of the ranks. Nothing has touched the GPU in this process (torch is not even imported).
+    if args.gpus > 1 and not ("WORLD_SIZE" in os.environ and "RANK" in os.environ):
+        # no launcher (a launcher sets RANK and WORLD_SIZE): be the parent of the ranks. Nothing has touched the GPU in this
+        # process (torch is not even imported).
         sys.exit(self_launch(args, argv))
     run_rank(args)
 
@@ -852,6 +853,7 @@ def run_rank(args):
             # Untimed, after the measured line is assembled: the same film merge through the C ABI's own RCCL communicator
             # (pbrt_hip_comm_create / pbrt_hip_film_reduce), checked against torch.distributed's reduce. The measurement does
             # not depend on it: a failure or a timeout of the CHECK goes into config.abi_film_reduce and the line is printed.
+            stage.collective("before the abi check", barrier)   # rank 0 has just spent seconds on its instrumented renders: the check's clock starts together
             abi_check(args, torch, dist, pbrt_hip, stage, ctx, render_into, device, rank, world, W, H, out, emit)
         emit()
         barrier()

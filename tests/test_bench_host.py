@@ -213,13 +213,17 @@ def test_main_becomes_the_parent_only_without_a_launcher(monkeypatch):
     monkeypatch.setattr(bench, "self_launch", lambda args, argv: calls.append(("parent", args.gpus)) or 0)
     monkeypatch.setattr(bench, "run_rank", lambda args: calls.append(("rank", args.gpus)))
     monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
     with pytest.raises(SystemExit) as e:
         bench.main(["--gpus", "8"])
     assert e.value.code == 0 and calls == [("parent", 8)]
     bench.main(["--gpus", "1"])
-    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("WORLD_SIZE", "8")          # a stray WORLD_SIZE without RANK is not a launcher
+    with pytest.raises(SystemExit):
+        bench.main(["--gpus", "8"])
+    monkeypatch.setenv("RANK", "3")
     bench.main(["--gpus", "8"])
-    assert calls == [("parent", 8), ("rank", 1), ("rank", 8)]
+    assert calls == [("parent", 8), ("rank", 1), ("parent", 8), ("rank", 8)]
     # the parent path imports neither torch nor the HIP binding: a fresh interpreter that starts ranks which do nothing
     code = ("import sys, bench; sys.modules_before = set(sys.modules); "
             "bench.launch_plan = lambda a, argv, env, port, script=None: [([sys.executable, '-c', 'pass'], dict(env))] * 2; "
