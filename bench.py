@@ -358,6 +358,20 @@ def load_balance(reports):
     return round(max(ms) / mean, 4) if mean > 0 else None
 
 
+def check_film_weights(weights, spp):
+    """A size-independent property of the merged film (0.5 box filter: FilmTile::add_sample film.rs:252-295 gives every sample
+    weight 1 in the one pixel it falls into): the filter_weight_sum channel of the frame rank 0 holds after the reduce must be
+    `spp` in every pixel and W x H x spp in total — every tile rendered by exactly one rank, every rank's share arrived. The
+    only slack: a sample whose random offset is exactly 0 on an axis lies on a pixel border and is added to both neighbours
+    (p0 = ceil(x - 1), p1 = floor(x) + 1; probability 2^-32 per draw, i.e. a handful of samples per 10^9), and a border sample of
+    the last row / column has no second neighbour inside the film."""
+    h, w = weights.shape
+    total, expected = float(weights.sum()), float(w) * h * spp
+    off = int((np.abs(weights - spp) > 2).sum())
+    return {"pixels": int(w * h), "spp": int(spp), "weight_sum": total, "expected": expected, "pixels_off_by_more_than_2": off,
+            "min": float(weights.min()), "max": float(weights.max()), "ok": bool(off == 0 and abs(total - expected) <= 64.0)}
+
+
 def scaling_anchor(config_name):
     """The one-GPU point of the workload the N-GPU job runs (config 4: `config4_n1` of a committed one-GPU bench line —
     another run, possibly another box: a diagnostic beside the driver's own curve, never `vs_baseline`)."""
@@ -689,11 +703,15 @@ def run_rank(args):
             if rank == 0:
                 film.copy_(host)
 
+        film_check = [None]
+
         def timed():
             seconds, stats, last = run_steps(render_into, films, args.steps, args.warmup, dist, use_dist, torch.cuda.synchronize, record_event, stage,
                                              reduce_staged if (staged and use_dist) else None)
             if args.save_film and rank == 0:
                 np.save(args.save_film, last.cpu().numpy())
+            if rank == 0:   # untimed: the merged film of the last step holds every sample of the frame exactly once
+                film_check[0] = check_film_weights(last[..., 3].double().cpu().numpy(), spp_total)
             return (seconds, sum(st["rays_closest"] + st["rays_shadow"] for st in stats), sum(st["trace_ms"] for st in stats),
                     sum(st["trace_launches"] for st in stats), stats)
 
@@ -842,6 +860,9 @@ def run_rank(args):
             out["config"]["ranks"] = reports
             out["config"]["n_devices"] = n_devices
             out["config"]["load_balance_max_over_mean"] = load_balance(reports)
+            out["config"]["film_check"] = film_check[0]
+            if film_check[0] and not film_check[0]["ok"]:
+                out.setdefault("warnings", []).append("film_check failed: the merged film does not hold every sample once")
             anchor = scaling_anchor(config_name) if world > 1 else None
             if anchor:
                 out["scaling_vs_config4_n1"] = dict(anchor, ratio=round(value / anchor["value"], 3),
