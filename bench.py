@@ -360,16 +360,18 @@ def load_balance(reports):
 
 def check_film_weights(weights, spp):
     """A size-independent property of the merged film (0.5 box filter: FilmTile::add_sample film.rs:252-295 gives every sample
-    weight 1 in the one pixel it falls into): the filter_weight_sum channel of the frame rank 0 holds after the reduce must be
+    weight 1 in the pixel it falls into): the filter_weight_sum channel of the frame rank 0 holds after the reduce must be
     `spp` in every pixel and W x H x spp in total — every tile rendered by exactly one rank, every rank's share arrived. The
-    only slack: a sample whose random offset is exactly 0 on an axis lies on a pixel border and is added to both neighbours
-    (p0 = ceil(x - 1), p1 = floor(x) + 1; probability 2^-32 per draw, i.e. a handful of samples per 10^9), and a border sample of
-    the last row / column has no second neighbour inside the film."""
+    slack is one-sided and small: p_film = pixel + u is rounded to float32, so a sample within half an ulp of a pixel border
+    (ulp(1900) = 1.2e-4: about one sample in 10^4 at 1080p, one in 4000 at 4K) lies ON the border and add_sample's footprint
+    p0 = ceil(x - 1), p1 = floor(x) + 1 gives it to both neighbours (the oracle does the same: the films are equal bit for bit).
+    So the total may exceed W x H x spp by up to 10^-3 of it, never fall short, and no pixel strays by more than 2 + spp / 32."""
     h, w = weights.shape
     total, expected = float(weights.sum()), float(w) * h * spp
-    off = int((np.abs(weights - spp) > 2).sum())
-    return {"pixels": int(w * h), "spp": int(spp), "weight_sum": total, "expected": expected, "pixels_off_by_more_than_2": off,
-            "min": float(weights.min()), "max": float(weights.max()), "ok": bool(off == 0 and abs(total - expected) <= 64.0)}
+    off = int((np.abs(weights - spp) > 2.0 + spp / 32.0).sum())
+    return {"pixels": int(w * h), "spp": int(spp), "weight_sum": total, "expected": expected, "excess": total - expected,
+            "pixels_off": off, "min": float(weights.min()), "max": float(weights.max()),
+            "ok": bool(off == 0 and 0.0 <= total - expected <= 1e-3 * expected)}
 
 
 def scaling_anchor(config_name):

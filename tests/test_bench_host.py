@@ -285,14 +285,16 @@ def test_scaling_anchor_reads_the_committed_one_gpu_line(tmp_path, monkeypatch):
 
 def test_film_check_sees_a_missing_and_a_doubled_tile():
     """bench.check_film_weights: the merged film's weight channel is spp everywhere (up to the few samples that fall exactly on a
-    pixel border); a tile no rank rendered, or one that arrived twice, is seen."""
+    pixel border and count in both neighbours); a tile no rank rendered, or one that arrived twice, is seen."""
     import numpy as np
     w = np.full((64, 96), 16.0)
     assert bench.check_film_weights(w, 16)["ok"]
     w[3, 5] += 1.0          # a border sample counted in both neighbours
     ok = bench.check_film_weights(w, 16)
-    assert ok["ok"] and ok["max"] == 17.0 and ok["weight_sum"] == 64 * 96 * 16 + 1
+    assert ok["ok"] and ok["max"] == 17.0 and ok["excess"] == 1.0
     missing = w.copy(); missing[16:32, 32:48] = 0.0
-    assert not bench.check_film_weights(missing, 16)["ok"] and bench.check_film_weights(missing, 16)["pixels_off_by_more_than_2"] == 256
+    assert not bench.check_film_weights(missing, 16)["ok"] and bench.check_film_weights(missing, 16)["pixels_off"] == 256
     doubled = w.copy(); doubled[0:16, 0:16] *= 2.0
     assert not bench.check_film_weights(doubled, 16)["ok"]
+    short = np.full((64, 96), 16.0); short[0, 0] = 15.0    # a lost sample: the total may exceed, never fall short
+    assert not bench.check_film_weights(short, 16)["ok"]
