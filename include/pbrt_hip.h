@@ -31,7 +31,9 @@ enum PbrtHipStatus {
     PBRT_HIP_ERR_INVALID = 1,   /* bad argument (null pointer, negative count, index out of range) */
     PBRT_HIP_ERR_DEVICE = 2,    /* a HIP runtime call failed; see pbrt_hip_last_error */
     PBRT_HIP_ERR_NO_DEVICE = 3, /* no gfx950 device visible */
-    PBRT_HIP_ERR_OOM = 4
+    PBRT_HIP_ERR_OOM = 4        /* a device allocation, or a host allocation inside the library (a tree being built, a scene re-laid
+                                 * out, the tiles of a frame being dealt), failed. No C++ exception ever crosses this boundary: every
+                                 * status-returning entry point catches what its body throws (csrc/abi_guard.h) */
 };
 
 /* src/accelerators/bvh.rs:129-135 LinearBVHNode, packed to pbrt-v3's 32 bytes (the reference's

@@ -4,6 +4,7 @@
 // One process per GPU; the 128-byte communicator id travels out of band (the host renderer's own launcher).
 // RCCL is loaded on first use (dlopen), so single-GPU callers never need it.
 #include <dlfcn.h>
+#include "abi_guard.h"
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -104,7 +105,7 @@ extern "C" const char* pbrt_hip_comm_last_error(void) {
     return mine.c_str();
 }
 
-extern "C" int pbrt_hip_comm_unique_id(uint8_t id[PBRT_HIP_COMM_ID_BYTES]) {
+extern "C" int pbrt_hip_comm_unique_id(uint8_t id[PBRT_HIP_COMM_ID_BYTES]) try {
     if (!id) return PBRT_HIP_ERR_INVALID;
     Rccl* r = rccl();
     if (!r) {
@@ -125,9 +126,10 @@ extern "C" int pbrt_hip_comm_unique_id(uint8_t id[PBRT_HIP_COMM_ID_BYTES]) {
     std::memcpy(id, &uid, sizeof(uid));
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
 extern "C" int pbrt_hip_comm_create(PbrtHipContext* ctx, int32_t world, int32_t rank, const uint8_t id[PBRT_HIP_COMM_ID_BYTES],
-                                    PbrtHipComm** out) {
+                                    PbrtHipComm** out) try {
     if (out) *out = nullptr;
     if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) {
         set_comm_error("pbrt_hip_comm_create: bad argument");
@@ -159,6 +161,7 @@ extern "C" int pbrt_hip_comm_create(PbrtHipContext* ctx, int32_t world, int32_t 
     *out = c;
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
 extern "C" void pbrt_hip_comm_destroy(PbrtHipComm* comm) {
     if (!comm) return;
@@ -174,7 +177,7 @@ extern "C" void pbrt_hip_comm_destroy(PbrtHipComm* comm) {
 
 // Sum of the ranks' films, in place, on the context's stream; root >= 0: only that rank's buffer holds the sum
 // afterwards (ncclReduce), root < 0: every rank's does (ncclAllReduce). Returns after the stream has drained.
-extern "C" int pbrt_hip_film_reduce(PbrtHipComm* comm, float* d_film_xyzw, int64_t n_pixels, int32_t root) {
+extern "C" int pbrt_hip_film_reduce(PbrtHipComm* comm, float* d_film_xyzw, int64_t n_pixels, int32_t root) try {
     if (!comm || !d_film_xyzw || n_pixels < 0 || root >= comm->world) {
         set_comm_error("pbrt_hip_film_reduce: bad argument");
         return PBRT_HIP_ERR_INVALID;
@@ -199,3 +202,4 @@ extern "C" int pbrt_hip_film_reduce(PbrtHipComm* comm, float* d_film_xyzw, int64
     }
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH

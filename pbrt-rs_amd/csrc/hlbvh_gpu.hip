@@ -22,6 +22,7 @@
 //   9. k_emit          LinearBVHNode records at (treelet offset + local index). The leaf order is the sorted
 //                      primitive list (the reference's ordered_prims_offset advances in DFS = Morton order).
 #include <hip/hip_runtime.h>
+#include "abi_guard.h"
 
 #include <cstring>
 
@@ -604,7 +605,7 @@ __global__ void __launch_bounds__(kBlock) k_light_slots(const int* __restrict__ 
 extern "C" int pbrt_hip_bvh_build_hlbvh_device(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
                                                const int32_t* indices, int32_t n_tris, int32_t max_prims_in_node,
                                                PbrtLinearBVHNode** nodes_out, int32_t* n_nodes_out,
-                                               int32_t** prim_order_out, double* build_ms) {
+                                               int32_t** prim_order_out, double* build_ms) try {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(ctx);
     auto invalid = [&](const char* m) {
@@ -664,6 +665,7 @@ extern "C" int pbrt_hip_bvh_build_hlbvh_device(PbrtHipContext* ctx, const float*
     *prim_order_out = order;
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
 // Stable radix sort of (key, value) pairs on `bits` key bits (rocPRIM), used by the render loop to put the ray queue
 // into spatial order. temp == nullptr: only reports the scratch size.

@@ -14,6 +14,7 @@
 // Implementation: the node array is emitted directly in pre-order (no build-node arena), over a
 // permutation of primitive indices with SoA bounds/centroids.
 #include <algorithm>
+#include "abi_guard.h"
 #include <cfloat>
 #include <cstdint>
 #include <cstdlib>
@@ -528,7 +529,7 @@ static int build_from_boxes(std::vector<float>& lo, std::vector<float>& hi, int3
 
 extern "C" int pbrt_hip_bvh_build(const float* positions, int32_t n_verts, const int32_t* indices, int32_t n_tris,
                                   int32_t max_prims_in_node, int32_t split_method, PbrtLinearBVHNode** nodes_out,
-                                  int32_t* n_nodes_out, int32_t** prim_order_out) {
+                                  int32_t* n_nodes_out, int32_t** prim_order_out) try {
     if (!nodes_out || !n_nodes_out || !prim_order_out) return PBRT_HIP_ERR_INVALID;
     *nodes_out = nullptr;
     *prim_order_out = nullptr;
@@ -556,10 +557,11 @@ extern "C" int pbrt_hip_bvh_build(const float* positions, int32_t n_verts, const
     }
     return build_from_boxes(lo, hi, n_tris, max_prims_in_node, split_method, nodes_out, n_nodes_out, prim_order_out);
 }
+PB_ABI_CATCH
 
 extern "C" int pbrt_hip_bvh_build_boxes(const float* bounds_min, const float* bounds_max, int32_t n,
                                         int32_t max_prims_in_node, int32_t split_method, PbrtLinearBVHNode** nodes_out,
-                                        int32_t* n_nodes_out, int32_t** prim_order_out) {
+                                        int32_t* n_nodes_out, int32_t** prim_order_out) try {
     if (!nodes_out || !n_nodes_out || !prim_order_out) return PBRT_HIP_ERR_INVALID;
     *nodes_out = nullptr;
     *prim_order_out = nullptr;
@@ -570,11 +572,12 @@ extern "C" int pbrt_hip_bvh_build_boxes(const float* bounds_min, const float* bo
     std::vector<float> lo(bounds_min, bounds_min + 3 * (size_t)n), hi(bounds_max, bounds_max + 3 * (size_t)n);
     return build_from_boxes(lo, hi, n, max_prims_in_node, split_method, nodes_out, n_nodes_out, prim_order_out);
 }
+PB_ABI_CATCH
 
 // Transform * Bounds3f (src/core/transform.rs:568-607): union of the 8 transformed corners
 extern "C" int pbrt_hip_instance_bounds(const float object_min[3], const float object_max[3],
                                         const PbrtInstance* instances, int32_t n_instances, float* bounds_min,
-                                        float* bounds_max) {
+                                        float* bounds_max) try {
     if (!object_min || !object_max || n_instances < 0 || (n_instances > 0 && (!instances || !bounds_min || !bounds_max)))
         return PBRT_HIP_ERR_INVALID;
     for (int32_t i = 0; i < n_instances; ++i) {
@@ -599,5 +602,6 @@ extern "C" int pbrt_hip_instance_bounds(const float object_min[3], const float o
     }
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
 extern "C" void pbrt_hip_free(void* p) { std::free(p); }

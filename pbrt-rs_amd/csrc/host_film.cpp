@@ -3,11 +3,13 @@
 // partition of SamplerIntegrator::render (src/core/integrator.rs:404-411), Film::write_image's XYZ -> RGB
 // (src/core/film.rs:153-178) and the image writers the reference leaves as todo!() (src/core/imageio.rs:3-5).
 #include <algorithm>
+#include "abi_guard.h"
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "../../include/pbrt_hip.h"
@@ -18,7 +20,7 @@ constexpr float kPi = 3.14159265358979323846f;
 }
 
 // Film::get_sample_bounds (film.rs:76-81, D42 intended) of the whole film
-extern "C" int pbrt_hip_sample_bounds(int32_t width, int32_t height, float rx, float ry, int32_t b[4]) {
+extern "C" int pbrt_hip_sample_bounds(int32_t width, int32_t height, float rx, float ry, int32_t b[4]) try {
     if (!b || width <= 0 || height <= 0 || !(rx > 0.0f) || !(ry > 0.0f)) return PBRT_HIP_ERR_INVALID;
     b[0] = (int32_t)std::floor(0.0f + 0.5f - rx);
     b[1] = (int32_t)std::floor(0.0f + 0.5f - ry);
@@ -26,9 +28,10 @@ extern "C" int pbrt_hip_sample_bounds(int32_t width, int32_t height, float rx, f
     b[3] = (int32_t)std::ceil((float)height - 0.5f + ry);
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
 // Filter::evaluate of src/filters/*.rs tabulated as Film::new does (film.rs:52-63)
-extern "C" int pbrt_hip_filter_table(int32_t type, float rx, float ry, float a, float b, float table[256]) {
+extern "C" int pbrt_hip_filter_table(int32_t type, float rx, float ry, float a, float b, float table[256]) try {
     if (!table || !(rx > 0.0f) || !(ry > 0.0f) || type < 0 || type > 4) return PBRT_HIP_ERR_INVALID;
     auto mitchell = [&](float x) {  // mitchell.rs:31-47
         x = std::fabs(2.0f * x);
@@ -70,8 +73,9 @@ extern "C" int pbrt_hip_filter_table(int32_t type, float rx, float ry, float a, 
         }
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
-extern "C" int pbrt_hip_write_pfm(const char* path, const float* rgb, int32_t width, int32_t height) {
+extern "C" int pbrt_hip_write_pfm(const char* path, const float* rgb, int32_t width, int32_t height) try {
     if (!path || !rgb || width <= 0 || height <= 0) return PBRT_HIP_ERR_INVALID;
     FILE* f = std::fopen(path, "wb");
     if (!f) return PBRT_HIP_ERR_INVALID;
@@ -81,6 +85,7 @@ extern "C" int pbrt_hip_write_pfm(const char* path, const float* rgb, int32_t wi
     bool ok = std::fclose(f) == 0;
     return ok ? PBRT_HIP_OK : PBRT_HIP_ERR_INVALID;
 }
+PB_ABI_CATCH
 
 // OpenEXR, the format pbrt-v3 writes by default: single-part scanline file, three 32-bit float channels (stored in
 // alphabetical order B, G, R), no compression, one scanline per chunk. Linear values, nothing clamped.
@@ -100,7 +105,7 @@ struct ExrBuf {
 };
 }  // namespace
 
-extern "C" int pbrt_hip_write_exr(const char* path, const float* rgb, int32_t width, int32_t height) {
+extern "C" int pbrt_hip_write_exr(const char* path, const float* rgb, int32_t width, int32_t height) try {
     if (!path || !rgb || width <= 0 || height <= 0) return PBRT_HIP_ERR_INVALID;
     ExrBuf h;
     h.i32(20000630);  // magic 0x76 0x2f 0x31 0x01
@@ -160,6 +165,7 @@ extern "C" int pbrt_hip_write_exr(const char* path, const float* rgb, int32_t wi
     bool ok = std::fclose(f) == 0;
     return ok ? PBRT_HIP_OK : PBRT_HIP_ERR_INVALID;
 }
+PB_ABI_CATCH
 
 // 8-bit sRGB PNG (what pbrt-v3's WriteImage does for ".png": gamma_correct, 255 * v + 0.5 clamped to [0, 255]);
 // the reference's own writer is todo!() (src/core/imageio.rs:3-5). zlib stream of stored (uncompressed) deflate
@@ -197,7 +203,7 @@ float gamma_correct(float v) {  // pbrt.rs GammaCorrect: sRGB transfer curve
 }
 }  // namespace
 
-extern "C" int pbrt_hip_write_png(const char* path, const float* rgb, int32_t width, int32_t height) {
+extern "C" int pbrt_hip_write_png(const char* path, const float* rgb, int32_t width, int32_t height) try {
     if (!path || !rgb || width <= 0 || height <= 0) return PBRT_HIP_ERR_INVALID;
     const size_t row = (size_t)width * 3 + 1;  // filter byte + pixels
     std::vector<unsigned char> raw(row * height);
@@ -244,6 +250,7 @@ extern "C" int pbrt_hip_write_png(const char* path, const float* rgb, int32_t wi
     bool ok = std::fclose(f) == 0;
     return ok ? PBRT_HIP_OK : PBRT_HIP_ERR_INVALID;
 }
+PB_ABI_CATCH
 
 extern "C" void pbrt_hip_film_to_rgb(const float* film, int64_t n_pixels, float* rgb) {
     for (int64_t i = 0; i < n_pixels; ++i) {
@@ -278,7 +285,7 @@ static inline uint64_t tile_morton(uint32_t tx, uint32_t ty) {
 }
 
 extern "C" int pbrt_hip_tile_partition_order(int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t rank, int32_t world,
-                                             int32_t order, int32_t* origins_xy, int32_t capacity, int32_t* n_out) {
+                                             int32_t order, int32_t* origins_xy, int32_t capacity, int32_t* n_out) try {
     if (!n_out || x0 > x1 || y0 > y1 || world <= 0 || rank < 0 || rank >= world) return PBRT_HIP_ERR_INVALID;
     if (order != PBRT_TILE_ORDER_MORTON && order != PBRT_TILE_ORDER_ROW_MAJOR) return PBRT_HIP_ERR_INVALID;
     const int64_t ntx = ((int64_t)x1 - x0 + kTile - 1) / kTile, nty = ((int64_t)y1 - y0 + kTile - 1) / kTile;
@@ -297,7 +304,7 @@ extern "C" int pbrt_hip_tile_partition_order(int32_t x0, int32_t y0, int32_t x1,
         }
         return PBRT_HIP_OK;
     }
-    std::vector<std::pair<uint64_t, int32_t>> keyed((size_t)total);
+    std::vector<std::pair<uint64_t, int32_t>> keyed((size_t)total);  // 16 bytes per tile of the frame while dealing (bad_alloc -> PB_ABI_CATCH)
     for (int64_t t = 0; t < total; ++t) keyed[(size_t)t] = {tile_morton((uint32_t)(t % ntx), (uint32_t)(t / ntx)), (int32_t)t};
     std::sort(keyed.begin(), keyed.end());
     // the rank's share of the deal, WALKED in row-major order: which tiles a rank owns is what balances the ranks; the order it
@@ -314,8 +321,10 @@ extern "C" int pbrt_hip_tile_partition_order(int32_t x0, int32_t y0, int32_t x1,
     }
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
 extern "C" int pbrt_hip_tile_partition(int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t rank, int32_t world,
-                                       int32_t* origins_xy, int32_t capacity, int32_t* n_out) {
+                                       int32_t* origins_xy, int32_t capacity, int32_t* n_out) try {
     return pbrt_hip_tile_partition_order(x0, y0, x1, y1, rank, world, PBRT_TILE_ORDER_MORTON, origins_xy, capacity, n_out);
 }
+PB_ABI_CATCH

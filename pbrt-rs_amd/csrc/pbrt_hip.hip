@@ -5,6 +5,7 @@
 //   pbrt_hip_intersect[_p]  Scene::intersect / intersect_p, src/core/scene.rs:40-46
 //   pbrt_hip_render         SamplerIntegrator::render, src/core/integrator.rs:399-480
 #include <hip/hip_runtime.h>
+#include "abi_guard.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -31,7 +32,7 @@ static thread_local std::string g_create_error;
 // ------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------
-extern "C" int pbrt_hip_context_create(int device_id, PbrtHipContext** out) {
+extern "C" int pbrt_hip_context_create(int device_id, PbrtHipContext** out) try {
     if (!out) return PBRT_HIP_ERR_INVALID;
     *out = nullptr;
     int n = 0;
@@ -72,6 +73,7 @@ extern "C" int pbrt_hip_context_create(int device_id, PbrtHipContext** out) {
     *out = ctx;
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
 extern "C" void pbrt_hip_context_destroy(PbrtHipContext* ctx) {
     if (!ctx) return;
@@ -101,29 +103,32 @@ extern "C" void pbrt_hip_context_destroy(PbrtHipContext* ctx) {
     delete ctx;
 }
 
-extern "C" int pbrt_hip_context_is_lost(const PbrtHipContext* ctx) {
+extern "C" int pbrt_hip_context_is_lost(const PbrtHipContext* ctx) try {
     return ctx ? (ctx->lost.load(std::memory_order_acquire) ? 1 : 0) : -1;  // no lock: `lost` is atomic (polled from other threads)
 }
+PB_ABI_CATCH
 
-extern "C" int pbrt_hip_context_set_deadline(PbrtHipContext* ctx, double seconds) {
+extern "C" int pbrt_hip_context_set_deadline(PbrtHipContext* ctx, double seconds) try {
     if (!ctx || !(seconds > 0.0)) return PBRT_HIP_ERR_INVALID;
     PB_LOCK(ctx);
     ctx->wavefront_deadline_s = seconds;
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
 extern "C" const char* pbrt_hip_last_error(const PbrtHipContext* ctx) {
     return ctx ? ctx->last_error.c_str() : g_create_error.c_str();
 }
 
-extern "C" int pbrt_hip_synchronize(PbrtHipContext* ctx) {
+extern "C" int pbrt_hip_synchronize(PbrtHipContext* ctx) try {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
-extern "C" int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* total_ms, uint64_t* launches) {
+extern "C" int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* total_ms, uint64_t* launches) try {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(ctx);
     if (total_ms) *total_ms = ctx->trace_ms;
@@ -134,15 +139,17 @@ extern "C" int pbrt_hip_trace_timing(PbrtHipContext* ctx, int reset, double* tot
     }
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
-extern "C" int pbrt_hip_set_counting(PbrtHipContext* ctx, int enable) {
+extern "C" int pbrt_hip_set_counting(PbrtHipContext* ctx, int enable) try {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(ctx);
     ctx->count_traversal = (enable == 1 || enable == 2) ? enable : 0;
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
-extern "C" int pbrt_hip_context_set_wide_build(PbrtHipContext* ctx, int where) {
+extern "C" int pbrt_hip_context_set_wide_build(PbrtHipContext* ctx, int where) try {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(ctx);
     if (where < PBRT_WIDE_BUILD_DEVICE || where > PBRT_WIDE_BUILD_NONE) {
@@ -152,8 +159,9 @@ extern "C" int pbrt_hip_context_set_wide_build(PbrtHipContext* ctx, int where) {
     ctx->wide_build = where;
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
-extern "C" int pbrt_hip_context_set_traversal(PbrtHipContext* ctx, int traversal) {
+extern "C" int pbrt_hip_context_set_traversal(PbrtHipContext* ctx, int traversal) try {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(ctx);
     if (traversal < PBRT_TRAVERSAL_AUTO || traversal > PBRT_TRAVERSAL_STACKLESS) {
@@ -163,8 +171,9 @@ extern "C" int pbrt_hip_context_set_traversal(PbrtHipContext* ctx, int traversal
     ctx->traversal = traversal;
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
-extern "C" int pbrt_hip_get_counters(PbrtHipContext* ctx, int reset, uint64_t counters[4]) {
+extern "C" int pbrt_hip_get_counters(PbrtHipContext* ctx, int reset, uint64_t counters[4]) try {
     if (!ctx || !counters) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -180,8 +189,9 @@ extern "C" int pbrt_hip_get_counters(PbrtHipContext* ctx, int reset, uint64_t co
     }
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
-extern "C" int pbrt_hip_get_wide_counters(PbrtHipContext* ctx, int reset, uint64_t counters[4]) {
+extern "C" int pbrt_hip_get_wide_counters(PbrtHipContext* ctx, int reset, uint64_t counters[4]) try {
     if (!ctx || !counters) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -194,6 +204,7 @@ extern "C" int pbrt_hip_get_wide_counters(PbrtHipContext* ctx, int reset, uint64
     }
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
 // ------------------------------------------------------------------------------------
 // scene
@@ -361,10 +372,11 @@ extern "C" int pbrt_hip_scene_create(PbrtHipContext* ctx, const float* positions
                                      const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
                                      const PbrtMaterial* materials, int32_t n_materials, const int32_t* tri_light,
                                      const PbrtLight* lights, int32_t n_lights, const PbrtLinearBVHNode* nodes,
-                                     int32_t n_nodes, const int32_t* prim_order, PbrtHipScene** out) {
+                                     int32_t n_nodes, const int32_t* prim_order, PbrtHipScene** out) try {
     return scene_create_impl(ctx, positions, n_verts, indices, n_tris, tri_material, materials, n_materials, tri_light,
                              lights, n_lights, nodes, n_nodes, prim_order, InstancingArgs(), out);
 }
+PB_ABI_CATCH
 
 namespace pb {
 int hlbvh_build_scene_tree(PbrtHipContext* ctx, const float* positions, int32_t n_verts, const int32_t* indices,
@@ -377,7 +389,7 @@ extern "C" int pbrt_hip_scene_create_hlbvh(PbrtHipContext* ctx, const float* pos
                                            const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
                                            const PbrtMaterial* materials, int32_t n_materials, const int32_t* tri_light,
                                            const PbrtLight* lights, int32_t n_lights, int32_t max_prims_in_node,
-                                           PbrtHipScene** out, double* build_ms, double* layout_ms) {
+                                           PbrtHipScene** out, double* build_ms, double* layout_ms) try {
     if (!ctx || !out) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(ctx);
     *out = nullptr;
@@ -415,6 +427,7 @@ extern "C" int pbrt_hip_scene_create_hlbvh(PbrtHipContext* ctx, const float* pos
     }
     return rc;
 }
+PB_ABI_CATCH
 
 extern "C" int pbrt_hip_scene_create_with_spheres(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
                                                   const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
@@ -422,7 +435,7 @@ extern "C" int pbrt_hip_scene_create_with_spheres(PbrtHipContext* ctx, const flo
                                                   const PbrtLight* lights, int32_t n_lights, const float* spheres,
                                                   const int32_t* sphere_material, const int32_t* sphere_light, int32_t n_spheres,
                                                   const PbrtLinearBVHNode* nodes, int32_t n_nodes, const int32_t* prim_order,
-                                                  PbrtHipScene** out) {
+                                                  PbrtHipScene** out) try {
     SphereArgs sa;
     sa.spheres = spheres;
     sa.material = sphere_material;
@@ -431,6 +444,7 @@ extern "C" int pbrt_hip_scene_create_with_spheres(PbrtHipContext* ctx, const flo
     return scene_create_impl(ctx, positions, n_verts, indices, n_tris, tri_material, materials, n_materials, tri_light,
                              lights, n_lights, nodes, n_nodes, prim_order, InstancingArgs(), out, nullptr, sa);
 }
+PB_ABI_CATCH
 
 extern "C" int pbrt_hip_scene_create_two_level(PbrtHipContext* ctx, const PbrtObject* objects, int32_t n_objects,
                                                const PbrtInstance* instances, const int32_t* instance_object, int32_t n_instances,
@@ -438,7 +452,7 @@ extern "C" int pbrt_hip_scene_create_two_level(PbrtHipContext* ctx, const PbrtOb
                                                int32_t n_world_tris, const int32_t* world_tri_material,
                                                const int32_t* world_tri_light, const PbrtMaterial* materials, int32_t n_materials,
                                                const PbrtLight* lights, int32_t n_lights, const PbrtLinearBVHNode* tlas_nodes,
-                                               int32_t n_tlas_nodes, const int32_t* tlas_order, PbrtHipScene** out) {
+                                               int32_t n_tlas_nodes, const int32_t* tlas_order, PbrtHipScene** out) try {
     if (!ctx || !out) return PBRT_HIP_ERR_INVALID;
     auto fail = [&](const char* msg) {
         ctx->last_error = msg;
@@ -511,6 +525,7 @@ extern "C" int pbrt_hip_scene_create_two_level(PbrtHipContext* ctx, const PbrtOb
     return scene_create_impl(ctx, pos.data(), (int32_t)n_verts, idx.data(), (int32_t)n_tris, mat.data(), materials, n_materials,
                              lgt.data(), lights, n_lights, nullptr, (int32_t)n_nodes, order.data(), ia, out);
 }
+PB_ABI_CATCH
 
 extern "C" int pbrt_hip_scene_create_instanced(PbrtHipContext* ctx, const float* positions, int32_t n_verts,
                                                const int32_t* indices, int32_t n_tris, const int32_t* tri_material,
@@ -519,7 +534,7 @@ extern "C" int pbrt_hip_scene_create_instanced(PbrtHipContext* ctx, const float*
                                                const PbrtLinearBVHNode* blas_nodes, int32_t n_blas_nodes,
                                                const int32_t* blas_order, const PbrtInstance* instances,
                                                int32_t n_instances, const PbrtLinearBVHNode* tlas_nodes,
-                                               int32_t n_tlas_nodes, const int32_t* tlas_order, PbrtHipScene** out) {
+                                               int32_t n_tlas_nodes, const int32_t* tlas_order, PbrtHipScene** out) try {
     if (!ctx || !out) return PBRT_HIP_ERR_INVALID;
     PbrtObject obj;
     obj.positions = positions;
@@ -533,6 +548,7 @@ extern "C" int pbrt_hip_scene_create_instanced(PbrtHipContext* ctx, const float*
     return pbrt_hip_scene_create_two_level(ctx, &obj, 1, instances, nullptr, n_instances, nullptr, 0, nullptr, 0, nullptr, nullptr,
                                            materials, n_materials, lights, n_lights, tlas_nodes, n_tlas_nodes, tlas_order, out);
 }
+PB_ABI_CATCH
 
 static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_t n_verts, const int32_t* indices,
                              int32_t n_tris, const int32_t* tri_material, const PbrtMaterial* materials,
@@ -1031,17 +1047,18 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     return PBRT_HIP_OK;
 }
 
-extern "C" int pbrt_hip_scene_wide_records(const PbrtHipScene* s, int32_t* n_records, const char** reason) {
+extern "C" int pbrt_hip_scene_wide_records(const PbrtHipScene* s, int32_t* n_records, const char** reason) try {
     if (!s) return PBRT_HIP_ERR_INVALID;
     if (n_records) *n_records = s->has_wide ? s->n_wide_records : -1;
     if (reason) *reason = s->wide_reason.c_str();
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
 // Copies a single-level scene's wide records back: n_records x 12 dwords, n_slots x 12 floats (wide-order triangles),
 // n_slots x 8 floats (leaf boxes). A diagnostic entry point (declared as such in include/pbrt_hip.h): the test that the device
 // builder (wide_gpu.hip) and the host builder (host_wide.cpp) produce the same bytes reads the arrays through it.
-extern "C" int pbrt_hip_debug_wide_export(PbrtHipScene* s, uint32_t* nodes, float* tris, float* boxes, int32_t n_slots) {
+extern "C" int pbrt_hip_debug_wide_export(PbrtHipScene* s, uint32_t* nodes, float* tris, float* boxes, int32_t n_slots) try {
     if (!s || !s->has_wide || s->d.bvh.instanced || n_slots != s->d.bvh.n_slots) return PBRT_HIP_ERR_INVALID;
     PbrtHipContext* ctx = s->ctx;
     PB_ENTER(ctx);
@@ -1053,6 +1070,7 @@ extern "C" int pbrt_hip_debug_wide_export(PbrtHipScene* s, uint32_t* nodes, floa
     if (boxes) HIP_TRY(ctx, hipMemcpy(boxes, s->wide.leaf_boxes, (size_t)n_slots * 32, hipMemcpyDeviceToHost));
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
 extern "C" void pbrt_hip_scene_destroy(PbrtHipScene* s) {
     if (!s) return;
@@ -1210,18 +1228,20 @@ static int launch_batch(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtH
     return PBRT_HIP_OK;
 }
 
-extern "C" int pbrt_hip_intersect_device(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtHit* d_out) {
+extern "C" int pbrt_hip_intersect_device(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, PbrtHit* d_out) try {
     if (!s || n < 0 || (n > 0 && (!d_rays || !d_out))) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(s->ctx);
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     return launch_batch<false>(s, d_rays, n, d_out, nullptr);
 }
-extern "C" int pbrt_hip_intersect_p_device(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, uint8_t* d_out) {
+PB_ABI_CATCH
+extern "C" int pbrt_hip_intersect_p_device(PbrtHipScene* s, const PbrtRay* d_rays, int64_t n, uint8_t* d_out) try {
     if (!s || n < 0 || (n > 0 && (!d_rays || !d_out))) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(s->ctx);
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     return launch_batch<true>(s, d_rays, n, nullptr, d_out);
 }
+PB_ABI_CATCH
 
 template <bool ANY>
 static int intersect_host(PbrtHipScene* s, const PbrtRay* rays, int64_t n, void* out) {
@@ -1250,9 +1270,11 @@ static int intersect_host(PbrtHipScene* s, const PbrtRay* rays, int64_t n, void*
     (void)hipFree(d_out);
     return rc;
 }
-extern "C" int pbrt_hip_intersect(PbrtHipScene* s, const PbrtRay* rays, int64_t n, PbrtHit* out) {
+extern "C" int pbrt_hip_intersect(PbrtHipScene* s, const PbrtRay* rays, int64_t n, PbrtHit* out) try {
     return intersect_host<false>(s, rays, n, out);
 }
-extern "C" int pbrt_hip_intersect_p(PbrtHipScene* s, const PbrtRay* rays, int64_t n, uint8_t* out) {
+PB_ABI_CATCH
+extern "C" int pbrt_hip_intersect_p(PbrtHipScene* s, const PbrtRay* rays, int64_t n, uint8_t* out) try {
     return intersect_host<true>(s, rays, n, out);
 }
+PB_ABI_CATCH

@@ -6,6 +6,7 @@
 // nothing else to do. The result is a measured ceiling, for bench.py's roofline line (measurement only: no part of
 // rendering calls this).
 #include <hip/hip_runtime.h>
+#include "abi_guard.h"
 
 #include <cstdint>
 #include <vector>
@@ -60,7 +61,7 @@ void launch(int waves, dim3 grid, hipStream_t st, const uint4* table, uint32_t n
 }  // namespace
 
 extern "C" int pbrt_hip_probe_gather(PbrtHipContext* ctx, int64_t table_bytes, int32_t record_bytes, int32_t waves_per_simd,
-                                     int32_t iters, double* records_per_second) {
+                                     int32_t iters, double* records_per_second) try {
     if (!ctx || !records_per_second || (record_bytes != 48 && record_bytes != 64) || table_bytes < record_bytes || iters <= 0 ||
         table_bytes > (64ll << 30))
         return PBRT_HIP_ERR_INVALID;
@@ -100,6 +101,7 @@ extern "C" int pbrt_hip_probe_gather(PbrtHipContext* ctx, int64_t table_bytes, i
     if (rc == PBRT_HIP_OK) *records_per_second = (double)blocks * 256.0 * (double)iters / ((double)best * 1e-3);
     return rc;
 }
+PB_ABI_CATCH
 
 // ------------------------------------------------------------------------------------
 // pbrt_hip_probe_state_stream: k_shade's access pattern with a known byte count, for calibrating rocprofv3's FETCH_SIZE /
@@ -180,7 +182,7 @@ __global__ void k_probe_queue(uint32_t* queue, uint32_t keep_of_1024, uint32_t n
 }  // namespace
 
 extern "C" int pbrt_hip_probe_state_stream(PbrtHipContext* ctx, int64_t n_paths, int32_t density_permille, int64_t gather_table_bytes,
-                                           int32_t parts, int64_t* bytes_read, int64_t* bytes_written, double* ms_out) {
+                                           int32_t parts, int64_t* bytes_read, int64_t* bytes_written, double* ms_out) try {
     if (!ctx || n_paths < 1024 || n_paths > (1ll << 28) || density_permille < 1 || density_permille > 1000 || gather_table_bytes < 48 ||
         gather_table_bytes > (8ll << 30) || !bytes_read || !bytes_written)
         return PBRT_HIP_ERR_INVALID;
@@ -236,3 +238,4 @@ extern "C" int pbrt_hip_probe_state_stream(PbrtHipContext* ctx, int64_t n_paths,
     *bytes_written = wr;
     return rc;
 }
+PB_ABI_CATCH

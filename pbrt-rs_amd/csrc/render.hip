@@ -3,6 +3,7 @@
 // wavefront.h; the per-vertex shading data of the TriangleMesh (pbrt_hip_scene_set_shading_data); the host side of the
 // HaltonSampler tables.
 #include <hip/hip_runtime.h>
+#include "abi_guard.h"
 
 #include <algorithm>
 #include <chrono>
@@ -23,15 +24,16 @@ using namespace pb;
 // render: see wavefront.h
 // ------------------------------------------------------------------------------------
 extern "C" int pbrt_hip_render_device(PbrtHipScene* s, const PbrtCamera* camera, const PbrtRenderParams* params,
-                                      float* d_film, PbrtRenderStats* stats) {
+                                      float* d_film, PbrtRenderStats* stats) try {
     if (!s || !camera || !params || !d_film) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(s->ctx);
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     return wavefront_render(s, *camera, *params, d_film, stats);
 }
+PB_ABI_CATCH
 
 extern "C" int pbrt_hip_render(PbrtHipScene* s, const PbrtCamera* camera, const PbrtRenderParams* params,
-                               float* film_xyzw, PbrtRenderStats* stats) {
+                               float* film_xyzw, PbrtRenderStats* stats) try {
     if (!s || !camera || !params || !film_xyzw) return PBRT_HIP_ERR_INVALID;
     PbrtHipContext* ctx = s->ctx;
     PB_ENTER(ctx);
@@ -47,6 +49,7 @@ extern "C" int pbrt_hip_render(PbrtHipScene* s, const PbrtCamera* camera, const 
     if (!ctx->lost) (void)hipFree(d_film);
     return rc;
 }
+PB_ABI_CATCH
 
 // ------------------------------------------------------------------------------------
 // Integrator::li in batch form (integrator.rs:29-42) and the camera-ray stage on its own
@@ -63,7 +66,7 @@ static int li_params_to_render(const PbrtLiParams* lp, PbrtRenderParams* rp) {
 }
 
 extern "C" int pbrt_hip_li_device(PbrtHipScene* s, const PbrtLiParams* lp, const PbrtRay* d_rays, const uint64_t* d_stream_keys,
-                                  int64_t n, float* d_rgb, PbrtRenderStats* stats) {
+                                  int64_t n, float* d_rgb, PbrtRenderStats* stats) try {
     if (!s || !lp || n < 0 || (n > 0 && (!d_rays || !d_stream_keys || !d_rgb))) return PBRT_HIP_ERR_INVALID;
     PbrtRenderStats zero{};
     if (stats) *stats = zero;
@@ -84,9 +87,10 @@ extern "C" int pbrt_hip_li_device(PbrtHipScene* s, const PbrtLiParams* lp, const
     PbrtCamera cam{};
     return wavefront_render(s, cam, rp, nullptr, stats, &b);
 }
+PB_ABI_CATCH
 
 extern "C" int pbrt_hip_li(PbrtHipScene* s, const PbrtLiParams* lp, const PbrtRay* rays, const uint64_t* stream_keys, int64_t n,
-                           float* rgb, PbrtRenderStats* stats) {
+                           float* rgb, PbrtRenderStats* stats) try {
     if (!s || !lp || n < 0 || (n > 0 && (!rays || !stream_keys || !rgb))) return PBRT_HIP_ERR_INVALID;
     PbrtRenderStats zero{};
     if (stats) *stats = zero;
@@ -115,9 +119,10 @@ extern "C" int pbrt_hip_li(PbrtHipScene* s, const PbrtLiParams* lp, const PbrtRa
     }
     return rc;
 }
+PB_ABI_CATCH
 
 extern "C" int pbrt_hip_camera_rays(PbrtHipScene* s, const PbrtCamera* camera, const PbrtRenderParams* params, int64_t capacity,
-                                    PbrtRay* rays, uint64_t* stream_keys, float* p_film, int32_t* pixel_sample, int64_t* n_out) {
+                                    PbrtRay* rays, uint64_t* stream_keys, float* p_film, int32_t* pixel_sample, int64_t* n_out) try {
     if (!s || !camera || !params || !n_out) return PBRT_HIP_ERR_INVALID;
     PbrtHipContext* ctx = s->ctx;
     PB_ENTER(ctx);
@@ -159,6 +164,7 @@ extern "C" int pbrt_hip_camera_rays(PbrtHipScene* s, const PbrtCamera* camera, c
     }
     return rc;
 }
+PB_ABI_CATCH
 
 // ------------------------------------------------------------------------------------
 // wavefront_render — host driver of the kernels in wavefront.h
@@ -276,7 +282,7 @@ __global__ void k_wide_refresh_flags(float4* __restrict__ wtris, const float4* _
 
 extern "C" int pbrt_hip_scene_set_shading_data(PbrtHipScene* s, const float* positions, int32_t n_verts,
                                                const int32_t* indices, int32_t n_tris, const float* normals,
-                                               const float* tangents, const float* uvs) {
+                                               const float* tangents, const float* uvs) try {
     if (!s) return PBRT_HIP_ERR_INVALID;
     PbrtHipContext* ctx = s->ctx;
     PB_ENTER(ctx);
@@ -320,6 +326,7 @@ extern "C" int pbrt_hip_scene_set_shading_data(PbrtHipScene* s, const float* pos
     s->d.bvh.has_uvs = uvs ? 1 : 0;
     return PBRT_HIP_OK;
 }
+PB_ABI_CATCH
 
 namespace pb {
 int sort_pairs_u32(hipStream_t st, void* temp, size_t* temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
@@ -997,7 +1004,7 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
 }
 
 #ifdef PB_LANE_STATS
-extern "C" int pbrt_hip_debug_wide_stats(unsigned long long* out24, int reset) {
+extern "C" int pbrt_hip_debug_wide_stats(unsigned long long* out24, int reset) try {
     if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(pb::g_wide_stats), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
     if (reset) {
         unsigned long long z[32] = {0};
@@ -1005,7 +1012,8 @@ extern "C" int pbrt_hip_debug_wide_stats(unsigned long long* out24, int reset) {
     }
     return 0;
 }
-extern "C" int pbrt_hip_debug_lane_stats(unsigned long long* out8, int reset) {
+PB_ABI_CATCH
+extern "C" int pbrt_hip_debug_lane_stats(unsigned long long* out8, int reset) try {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(pb::g_lane_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
     if (reset) {
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1013,4 +1021,5 @@ extern "C" int pbrt_hip_debug_lane_stats(unsigned long long* out8, int reset) {
     }
     return 0;
 }
+PB_ABI_CATCH
 #endif

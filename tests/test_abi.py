@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -141,6 +142,35 @@ def test_failed_context_creation_from_several_threads():
         t.join(120)
     assert not bad, bad[:3]
     assert L.pbrt_hip_context_is_lost(None) == -1
+
+
+def test_a_failed_host_allocation_is_a_status_not_an_exception():
+    """no exceptions or panics across the boundary. Every status-returning entry point is a function-try-block
+    (csrc/abi_guard.h); here the tile deal of a frame of 1.6e9 tiles (25 GB of keys) runs under a 3 GB address-space limit in
+    a child process: the call returns PBRT_HIP_ERR_OOM, the process lives on and the library still works."""
+    code = (
+        "import ctypes, resource, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import pbrt_hip\n"
+        "L = pbrt_hip.lib()\n"
+        "resource.setrlimit(resource.RLIMIT_AS, (3 << 30, 3 << 30))\n"
+        "n = ctypes.c_int32()\n"
+        "out = (ctypes.c_int32 * 8)()\n"
+        "rc = L.pbrt_hip_tile_partition_order(0, 0, 640000, 640000, 0, 1 << 30, 0, out, 4, ctypes.byref(n))\n"
+        "assert rc == 4, rc          # PBRT_HIP_ERR_OOM\n"
+        "assert len(pbrt_hip.tile_partition((0, 0, 64, 64), 0, 2)) == 8\n"
+        "print('survived')\n") % os.path.join(ROOT, "pbrt-rs_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "survived" in r.stdout, r.stderr[-1500:]
+    # every status-returning entry point of the library carries the guard
+    import glob
+    n_guarded = n_entry = 0
+    for f in glob.glob(os.path.join(ROOT, "pbrt-rs_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "pbrt-rs_amd", "csrc", "*.cpp")):
+        src = open(f).read()
+        for m in re.finditer(r'^extern "C" int [^;{]*\{', src, re.M):
+            n_entry += 1
+            n_guarded += m.group(0).rstrip().endswith("try {")
+    assert n_entry >= 45 and n_guarded == n_entry, (n_entry, n_guarded)
 
 
 def test_no_gpu_is_an_error_not_a_fallback():
