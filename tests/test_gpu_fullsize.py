@@ -235,3 +235,31 @@ def test_config3_samplers_full_frame(hip_ctx, config3, sampler):
     inner = (slice(bounds[1] + 1, bounds[3] - 1), slice(bounds[0] + 1, bounds[2] - 1))
     assert np.array_equal(a[inner][..., 3], film_g[inner][..., 3])
     assert np.allclose(a[inner], film_g[inner], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("w,h,spp", [(1920, 1080, 64), (3840, 2160, 8)])
+def test_film_properties_at_full_size(hip_ctx, w, h, spp):
+    """The film stage at BASELINE's frame sizes, through properties that need no oracle (tests/closed_forms_film.py at small sizes):
+    a constant-radiance scene reconstructs to that constant in EVERY pixel under the 0.5 box and under a Gaussian of radius 2
+    (k_film_accumulate / k_film_splat over 133 M / 66 M samples, several passes), the box film's weight channel holds every sample
+    once (bench.py's film_check), and the frame is the sum of eight ranks' Morton-dealt tile shares."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import closed_forms_film as cf
+    le = (0.7, 1.3, 2.1)
+    g = pbrt_hip.Scene(hip_ctx, cf.sky_scene(le))
+    cam = cf.sky_camera(w, h)
+    through = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]]) @ \
+        np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]]) @ np.array(le)
+    box, st = g.render(cam, w, h, spp, max_depth=5, seed=1)
+    assert st["camera_samples"] == w * h * spp == st["rays_closest"] and st["rays_shadow"] == 0
+    fc = bench.check_film_weights(box[..., 3].astype(np.float64), spp)
+    assert fc["ok"] and fc["excess"] > 0, fc          # (samples that round onto a pixel border count in both neighbours)
+    assert np.all(np.abs(pbrt_hip.film_to_rgb(box) - through) <= 2e-6 * max(le))
+    shares = sum(g.render(cam, w, h, spp, max_depth=5, seed=1, tile_rank=r, tile_world=8)[0] for r in range(8))
+    assert shares.tobytes() == box.tobytes()
+    wide, _ = g.render(cam, w, h, spp, max_depth=5, seed=1, filter=pbrt_hip.filter_table("gaussian", 2.0, 2.0, 2.0))
+    assert wide[..., 3].min() > 0.5 * spp
+    assert np.all(np.abs(pbrt_hip.film_to_rgb(wide) - through) <= 3e-6 * max(le))
+    g.close()
