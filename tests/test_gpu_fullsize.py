@@ -258,7 +258,12 @@ def test_film_properties_at_full_size(hip_ctx, w, h, spp):
     assert fc["ok"] and fc["excess"] > 0, fc          # (samples that round onto a pixel border count in both neighbours)
     assert np.all(np.abs(pbrt_hip.film_to_rgb(box) - through) <= 2e-6 * max(le))
     shares = sum(g.render(cam, w, h, spp, max_depth=5, seed=1, tile_rank=r, tile_world=8)[0] for r in range(8))
-    assert shares.tobytes() == box.tobytes()
+    # bit for bit wherever a pixel's samples all come from its own tile; a pixel on a tile border may also hold border samples of
+    # the neighbouring tiles (other ranks under the Morton deal), and then only the ORDER of the float additions differs
+    ys, xs = np.mgrid[0:h, 0:w]
+    inner = ((xs % 16 != 0) & (xs % 16 != 15) & (ys % 16 != 0) & (ys % 16 != 15))
+    assert np.array_equal(shares[inner], box[inner])
+    assert np.all(np.abs(shares - box) <= 2.5e-7 * np.abs(box)) and np.array_equal(shares[..., 3], box[..., 3])
     wide, _ = g.render(cam, w, h, spp, max_depth=5, seed=1, filter=pbrt_hip.filter_table("gaussian", 2.0, 2.0, 2.0))
     assert wide[..., 3].min() > 0.5 * spp
     assert np.all(np.abs(pbrt_hip.film_to_rgb(wide) - through) <= 3e-6 * max(le))
