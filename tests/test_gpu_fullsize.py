@@ -266,5 +266,8 @@ def test_film_properties_at_full_size(hip_ctx, w, h, spp):
     assert np.all(np.abs(shares - box) <= 2.5e-7 * np.abs(box)) and np.array_equal(shares[..., 3], box[..., 3])
     wide, _ = g.render(cam, w, h, spp, max_depth=5, seed=1, filter=pbrt_hip.filter_table("gaussian", 2.0, 2.0, 2.0))
     assert wide[..., 3].min() > 0.5 * spp
-    assert np.all(np.abs(pbrt_hip.film_to_rgb(wide) - through) <= 3e-6 * max(le))
+    # ~1600 float atomics per pixel in arbitrary order (64 spp x a 5 x 5 footprint), then xyz_to_rgb's cancelling sums of magnitude
+    # 3 |le|: 2e-5 of the largest channel (the small-size closed form with its ordered sums holds 2e-6; north_star's budget is 1e-4)
+    err = np.abs(pbrt_hip.film_to_rgb(wide) - through)
+    assert err.max() <= 2e-5 * max(le) and float(np.sqrt(np.mean(err ** 2))) <= 3e-6 * max(le), (err.max(), np.sqrt(np.mean(err ** 2)))
     g.close()
