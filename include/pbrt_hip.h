@@ -403,8 +403,10 @@ int pbrt_hip_probe_state_stream(PbrtHipContext* ctx, int64_t n_paths, int32_t de
 
 /* ---- Integrator::render (src/core/integrator.rs:29-42, 399-480) for this GPU's tile set ----
  * film_xyzw: width*height*4 floats {xyz[3], filter_weight_sum} = the first 16 bytes of the
- * reference's Pixel (src/core/film.rs:9-15); pixels outside this GPU's tiles are zero, so the
- * per-GPU films sum to the frame. pbrt_hip_render writes a host buffer; _device leaves the
+ * reference's Pixel (src/core/film.rs:9-15); pixels outside this GPU's tiles are zero — but for the footprint of its own
+ * samples across a tile border (wider filters; with the 0.5 box the few samples whose film position rounds onto a pixel
+ * border, which add_sample gives to both neighbours) — so the per-GPU films sum to the frame: bit for bit inside the tiles, up
+ * to the order of the float additions on their borders. pbrt_hip_render writes a host buffer; _device leaves the
  * film in a caller-supplied device buffer (e.g. for an RCCL reduce). stats may be NULL. */
 int pbrt_hip_render(PbrtHipScene* scene, const PbrtCamera* camera, const PbrtRenderParams* params,
                     float* film_xyzw, PbrtRenderStats* stats);

@@ -79,7 +79,9 @@ def test_two_ranks_on_one_gpu_reduce_to_the_one_process_frame(hip_ctx, tmp_path)
     g.close()
     film = np.load(film_path)
     assert film.shape == ref.shape
-    assert film.tobytes() == ref.tobytes()   # non-owned pixels are zero on every rank: the sum is a pure gather
+    # non-owned pixels are zero on every rank: the sum is a pure gather (at this size no pixel collects border samples of two
+    # foreign tiles; at full size tile-border pixels may differ by the order of float additions: test_film_properties_at_full_size)
+    assert film.tobytes() == ref.tobytes()
     assert line["config"]["rays_per_frame"] == st["rays_closest"] + st["rays_shadow"] == sum(r["rays_per_step"] for r in ranks)
 
 
