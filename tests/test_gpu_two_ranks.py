@@ -118,6 +118,13 @@ def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks(hip_ctx, tmp_path)
                                  scenes.random_triangles_camera(W, H), W, H, SPP, DEPTH)
     assert np.load(film_path).tobytes() == ref.tobytes()
     assert line["config"]["rays_per_frame"] == st["rays_closest"] + st["rays_shadow"] == sum(x["rays_per_step"] for x in ranks)
+    # --launcher torchrun: the same parent starts ONE child, `python -m torch.distributed.run --nproc-per-node 2 bench.py ...`
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + ARGS + ["--launcher", "torchrun"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line_t = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line_t["config"]["launcher"] == "torch.distributed.run" and line_t["config"]["film_check"]["ok"]
+    assert line_t["config"]["rays_per_frame"] == line["config"]["rays_per_frame"]
     # a rank that fails: the parent's exit code is the ranks' (4), not a launcher's 1
     env["PBRT_BENCH_FAIL"] = "render@1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + ARGS, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
