@@ -1,0 +1,388 @@
+// pbrt_hip.hpp — the host side above the C ABI in C++: a header-only mirror of the trait surface the hot path sits behind
+// in lazytiger/pbrt-rs, same names, argument meaning and error behaviour, over include/pbrt_hip.h.
+//
+// The reference is a Rust crate and rustc is not in this image, so the drop-in a maintainer would write in Rust
+// (`impl Integrator for HipIntegrator`, `impl Primitive for HipAggregate`) is shown here in the one compiled
+// host language the image has. Nothing in this header computes: every method forwards to a C entry point; no torch types,
+// no device pointers in the signatures.
+//
+//   reference (file:line)                                             here
+//   Primitive        src/core/primitive.rs:17-30                      pbrt::Primitive  (intersect mutates ray.t_max; intersect_p; world_bound)
+//   BVHAccel::new    src/accelerators/bvh.rs:216-271                  pbrt::BVHAccel   (host build -> resident in HBM; aggregates panic on get_material / get_area_light, bvh.rs:934-953)
+//   Scene            src/core/scene.rs:18-46                          pbrt::Scene      (intersect / intersect_p forward to the aggregate)
+//   Integrator       src/core/integrator.rs:29-42                     pbrt::Integrator (render(&scene)), pbrt::SamplerIntegrator (li)
+//   PathIntegrator::new            src/integrators/path.rs:31-46      pbrt::PathIntegrator
+//   DirectLightingIntegrator::new  src/integrators/directlighting.rs:33-46   pbrt::DirectLightingIntegrator
+//   Film, Film::write_image        src/core/film.rs:30-63, 153-178    pbrt::Film
+//   PerspectiveCamera::new         src/cameras/perspective.rs:34-82   pbrt::PerspectiveCamera
+//   RandomSampler::new             src/samplers/random.rs:12-20       pbrt::RandomSampler
+// Errors: the reference has no error channel — bool / Option for misses, panic! otherwise. A miss is `false` here
+// too; what would be a panic there (a failed device call, a bad argument) is a pbrt::Error carrying pbrt_hip_last_error.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "pbrt_hip.h"
+
+namespace pbrt {
+
+using Float = float;  // src/core/pbrt.rs:12
+struct Point3f {
+    Float x = 0, y = 0, z = 0;
+};
+using Vector3f = Point3f;
+struct Bounds3f {
+    Point3f min, max;
+};
+struct Spectrum {  // RGBSpectrum, src/core/spectrum.rs:653-716
+    Float c[3] = {0, 0, 0};
+    Float y_value() const { return 0.212671f * c[0] + 0.715160f * c[1] + 0.072169f * c[2]; }
+};
+// src/core/geometry.rs:757-763 (medium dropped: handle_media is false on every call of this path)
+struct Ray {
+    Point3f o;
+    Vector3f d;
+    Float t_max = std::numeric_limits<Float>::infinity();
+    Float time = 0;
+    Point3f point(Float t) const { return {o.x + d.x * t, o.y + d.y * t, o.z + d.z * t}; }
+};
+// What Primitive::intersect leaves behind at this boundary: the hit parameter, the watertight barycentrics and the primitive
+// (the full SurfaceInteraction of src/core/interaction.rs:224-245 is rebuilt from these inside the shading kernels).
+struct SurfaceInteraction {
+    Float t = std::numeric_limits<Float>::infinity();
+    Float b0 = 0, b1 = 0, b2 = 0;
+    int32_t primitive = -1;  // the caller's triangle index
+    int32_t instance = -1;   // TransformedPrimitive that was entered, -1 = none
+};
+
+class Error : public std::runtime_error {
+public:
+    Error(const std::string& what, int status) : std::runtime_error(what), status(status) {}
+    int status;
+};
+
+// one device, one stream; owns nothing the caller can see (include/pbrt_hip.h: context)
+class Context {
+public:
+    explicit Context(int device_id = 0) {
+        int rc = pbrt_hip_context_create(device_id, &h_);
+        if (rc != PBRT_HIP_OK) throw Error(std::string("pbrt_hip_context_create: ") + pbrt_hip_last_error(nullptr), rc);
+    }
+    ~Context() { pbrt_hip_context_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    PbrtHipContext* handle() const { return h_; }
+    void check(int rc, const char* what) const {
+        if (rc != PBRT_HIP_OK) throw Error(std::string(what) + ": " + pbrt_hip_last_error(h_), rc);
+    }
+
+private:
+    PbrtHipContext* h_ = nullptr;
+};
+
+// TriangleMesh (src/shapes/triangle.rs:17-26) + what GeometricPrimitive adds per triangle (material, area light)
+struct TriangleMesh {
+    std::vector<Float> p;                 // 3 per vertex
+    std::vector<int32_t> vertex_indices;  // 3 per triangle
+    std::vector<int32_t> material;        // per triangle, index into `materials`
+    std::vector<int32_t> area_light;      // per triangle, index into `lights` or -1
+    std::vector<PbrtMaterial> materials;
+    std::vector<PbrtLight> lights;  // DiffuseAreaLights on triangles, InfiniteAreaLight, point / spot / distant
+    int32_t n_triangles() const { return (int32_t)(vertex_indices.size() / 3); }
+    int32_t n_vertices() const { return (int32_t)(p.size() / 3); }
+};
+
+// src/core/primitive.rs:17-30
+class Primitive {
+public:
+    virtual ~Primitive() = default;
+    virtual Bounds3f world_bound() const = 0;
+    // true on a hit: ray.t_max is lowered to it (primitive.rs:70) and *isect filled
+    virtual bool intersect(Ray& ray, SurfaceInteraction* isect) const = 0;
+    virtual bool intersect_p(const Ray& ray) const = 0;
+    // aggregates do not answer these (bvh.rs:934-953: unimplemented!())
+    virtual const PbrtLight* get_area_light() const { throw Error("Primitive::get_area_light: aggregates do not hold one", PBRT_HIP_ERR_INVALID); }
+    virtual const PbrtMaterial* get_material() const { throw Error("Primitive::get_material: aggregates do not hold one", PBRT_HIP_ERR_INVALID); }
+};
+
+enum class SplitMethod { SAH = 0, HLBVH = 1, Middle = 2, EqualCounts = 3 };  // bvh.rs:30-35
+
+// BVHAccel over the mesh's triangles as GeometricPrimitives: built on the host in the reference's node order
+// (pbrt_hip_bvh_build), resident in HBM (pbrt_hip_scene_create), walked by the HIP traversal kernels.
+class BVHAccel : public Primitive {
+public:
+    BVHAccel(std::shared_ptr<Context> ctx, const TriangleMesh& mesh, int max_prims_in_node = 4, SplitMethod split_method = SplitMethod::SAH)
+        : ctx_(std::move(ctx)) {
+        PbrtLinearBVHNode* nodes = nullptr;
+        int32_t n_nodes = 0;
+        int32_t* order = nullptr;
+        int rc = pbrt_hip_bvh_build(mesh.p.data(), mesh.n_vertices(), mesh.vertex_indices.data(), mesh.n_triangles(), max_prims_in_node,
+                                    (int)split_method, &nodes, &n_nodes, &order);
+        if (rc != PBRT_HIP_OK) throw Error("BVHAccel::new: pbrt_hip_bvh_build failed", rc);
+        for (int k = 0; k < 3; ++k) {
+            (&bound_.min.x)[k] = nodes[0].bounds_min[k];
+            (&bound_.max.x)[k] = nodes[0].bounds_max[k];
+        }
+        n_nodes_ = n_nodes;
+        rc = pbrt_hip_scene_create(ctx_->handle(), mesh.p.data(), mesh.n_vertices(), mesh.vertex_indices.data(), mesh.n_triangles(),
+                                   mesh.material.data(), mesh.materials.data(), (int32_t)mesh.materials.size(), mesh.area_light.data(),
+                                   mesh.lights.data(), (int32_t)mesh.lights.size(), nodes, n_nodes, order, &h_);
+        pbrt_hip_free(nodes);
+        pbrt_hip_free(order);
+        ctx_->check(rc, "BVHAccel::new: pbrt_hip_scene_create");
+    }
+    ~BVHAccel() override { pbrt_hip_scene_destroy(h_); }
+    BVHAccel(const BVHAccel&) = delete;
+    BVHAccel& operator=(const BVHAccel&) = delete;
+
+    Bounds3f world_bound() const override { return bound_; }
+    bool intersect(Ray& ray, SurfaceInteraction* isect) const override {  // a batch of one
+        PbrtRay r = to_c(ray);
+        PbrtHit hit;
+        ctx_->check(pbrt_hip_intersect(h_, &r, 1, &hit), "BVHAccel::intersect");
+        if (hit.prim_id < 0) return false;
+        ray.t_max = hit.t;
+        if (isect) *isect = {hit.t, hit.b0, hit.b1, hit.b2, hit.prim_id, hit.instance_id};
+        return true;
+    }
+    bool intersect_p(const Ray& ray) const override {
+        PbrtRay r = to_c(ray);
+        uint8_t any = 0;
+        ctx_->check(pbrt_hip_intersect_p(h_, &r, 1, &any), "BVHAccel::intersect_p");
+        return any != 0;
+    }
+    // the batch forms the kernels are made for: rays[i].t_max is lowered on a hit exactly as the single call does
+    void intersect(std::vector<Ray>& rays, std::vector<SurfaceInteraction>& isects) const {
+        std::vector<PbrtRay> r(rays.size());
+        std::vector<PbrtHit> h(rays.size());
+        for (size_t i = 0; i < rays.size(); ++i) r[i] = to_c(rays[i]);
+        ctx_->check(pbrt_hip_intersect(h_, r.data(), (int64_t)r.size(), h.data()), "BVHAccel::intersect");
+        isects.resize(rays.size());
+        for (size_t i = 0; i < rays.size(); ++i) {
+            isects[i] = {h[i].t, h[i].b0, h[i].b1, h[i].b2, h[i].prim_id, h[i].instance_id};
+            if (h[i].prim_id >= 0) rays[i].t_max = h[i].t;
+        }
+    }
+    PbrtHipScene* handle() const { return h_; }
+    const std::shared_ptr<Context>& context() const { return ctx_; }
+    int32_t n_nodes() const { return n_nodes_; }
+
+private:
+    static PbrtRay to_c(const Ray& ray) { return {{ray.o.x, ray.o.y, ray.o.z}, {ray.d.x, ray.d.y, ray.d.z}, ray.t_max, ray.time}; }
+    std::shared_ptr<Context> ctx_;
+    PbrtHipScene* h_ = nullptr;
+    Bounds3f bound_;
+    int32_t n_nodes_ = 0;
+};
+
+// src/core/scene.rs:18-46: the aggregate and the lights (which travel with the mesh at this boundary)
+class Scene {
+public:
+    explicit Scene(std::shared_ptr<BVHAccel> aggregate) : aggregate_(std::move(aggregate)) {}
+    const Bounds3f world_bound() const { return aggregate_->world_bound(); }
+    bool intersect(Ray& ray, SurfaceInteraction* isect) const { return aggregate_->intersect(ray, isect); }
+    bool intersect_p(const Ray& ray) const { return aggregate_->intersect_p(ray); }
+    const BVHAccel& aggregate() const { return *aggregate_; }
+
+private:
+    std::shared_ptr<BVHAccel> aggregate_;
+};
+
+// Film::new (src/core/film.rs:30-63) with one of src/filters/*.rs; pixels = {xyz[3], filter_weight_sum} (film.rs:9-15)
+class Film {
+public:
+    Film(int width, int height, PbrtFilterType filter = PBRT_FILTER_BOX, Float radius = 0.5f, Float a = 0, Float b = 0, Float max_sample_luminance = 0)
+        : width(width), height(height), radius(radius), max_sample_luminance(max_sample_luminance), pixels((size_t)width * height * 4, 0.0f) {
+        box_ = filter == PBRT_FILTER_BOX && radius == 0.5f;
+        if (!box_ && pbrt_hip_filter_table((int32_t)filter, radius, radius, a, b, table_) != PBRT_HIP_OK) throw Error("Film::new: bad filter", PBRT_HIP_ERR_INVALID);
+    }
+    // Film::write_image (film.rs:153-178): xyz / weight -> RGB; the writer the reference leaves as todo!() (imageio.rs:3-5)
+    void write_image(const std::string& path) const {
+        std::vector<float> rgb((size_t)width * height * 3);
+        pbrt_hip_film_to_rgb(pixels.data(), (int64_t)width * height, rgb.data());
+        const bool pfm = path.size() > 4 && path.substr(path.size() - 4) == ".pfm", exr = path.size() > 4 && path.substr(path.size() - 4) == ".exr";
+        int rc = pfm ? pbrt_hip_write_pfm(path.c_str(), rgb.data(), width, height)
+                     : exr ? pbrt_hip_write_exr(path.c_str(), rgb.data(), width, height) : pbrt_hip_write_png(path.c_str(), rgb.data(), width, height);
+        if (rc != PBRT_HIP_OK) throw Error("Film::write_image: cannot write " + path, rc);
+    }
+    std::vector<float> rgb() const {
+        std::vector<float> out((size_t)width * height * 3);
+        pbrt_hip_film_to_rgb(pixels.data(), (int64_t)width * height, out.data());
+        return out;
+    }
+    const float* filter_table() const { return box_ ? nullptr : table_; }
+    int width, height;
+    Float radius, max_sample_luminance;
+    std::vector<float> pixels;
+
+private:
+    bool box_ = true;
+    float table_[256];
+};
+
+// PerspectiveCamera::new(camera_to_world, screen_window, shutter, lens_radius, focal_distance, fov, film):
+// perspective.rs:34-82 with transform.rs:510-566's look_at / perspective, computed in double and rounded once
+class PerspectiveCamera {
+public:
+    PerspectiveCamera(const Point3f& eye, const Point3f& look, const Vector3f& up_in, Float fov_deg, std::shared_ptr<Film> film_in, Float lens_radius = 0,
+                      Float focal_distance = 1e6f)
+        : film(std::move(film_in)) {
+        std::memset(&cam, 0, sizeof(cam));
+        double d[3] = {look.x - eye.x, look.y - eye.y, look.z - eye.z}, up[3] = {up_in.x, up_in.y, up_in.z}, right[3], new_up[3];
+        auto norm = [](double v[3]) {
+            double l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            v[0] /= l, v[1] /= l, v[2] /= l;
+        };
+        auto cross = [](const double a[3], const double b[3], double o[3]) {
+            o[0] = a[1] * b[2] - a[2] * b[1], o[1] = a[2] * b[0] - a[0] * b[2], o[2] = a[0] * b[1] - a[1] * b[0];
+        };
+        norm(d), norm(up);
+        cross(up, d, right);
+        norm(right);
+        cross(d, right, new_up);
+        const double e[3] = {eye.x, eye.y, eye.z};
+        for (int r = 0; r < 3; ++r) {
+            cam.camera_to_world[4 * r + 0] = (float)right[r];
+            cam.camera_to_world[4 * r + 1] = (float)new_up[r];
+            cam.camera_to_world[4 * r + 2] = (float)d[r];
+            cam.camera_to_world[4 * r + 3] = (float)e[r];
+        }
+        cam.camera_to_world[15] = 1.0f;
+        const int w = film->width, h = film->height;
+        const double n = 1e-2, f = 1000.0, A = f / (f - n), B = -f * n / (f - n);
+        const double inv_tan = 1.0 / std::tan(fov_deg * 3.14159265358979323846 / 360.0), aspect = (double)w / h;
+        const double sx0 = aspect > 1.0 ? -aspect : -1.0, sx1 = -sx0, sy0 = aspect > 1.0 ? -1.0 : -1.0 / aspect, sy1 = -sy0;
+        float* m = cam.raster_to_camera;  // inverse(camera_to_screen) * raster_to_screen
+        m[0] = (float)((sx1 - sx0) / (w * inv_tan));
+        m[3] = (float)(sx0 / inv_tan);
+        m[5] = (float)((sy0 - sy1) / (h * inv_tan));
+        m[7] = (float)(sy1 / inv_tan);
+        m[11] = 1.0f;
+        m[14] = (float)(1.0 / B);
+        m[15] = (float)(-A / B);
+        cam.lens_radius = lens_radius;
+        cam.focal_distance = focal_distance;
+        cam.shutter_close = 1.0f;
+        cam.kind = PBRT_CAMERA_PERSPECTIVE;
+    }
+    PbrtCamera cam;
+    std::shared_ptr<Film> film;
+};
+
+// RandomSampler::new(samples_per_pixel, seed) (random.rs:12-20); streams are keyed per (pixel, sample): DESIGN.md section 2
+struct RandomSampler {
+    int samples_per_pixel = 16;
+    uint64_t seed = 0;
+};
+struct Bounds2i {
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+};
+struct RenderStats {
+    uint64_t camera_samples = 0, rays_closest = 0, rays_shadow = 0;
+    double ms = 0;
+};
+
+// src/core/integrator.rs:29-42
+class Integrator {
+public:
+    virtual ~Integrator() = default;
+    virtual void render(const Scene& scene) = 0;  // called once, blocks until the film is complete
+};
+
+// SamplerIntegrator (integrator.rs:399-480): camera, sampler, pixel bounds; render = the tile / pixel / sample loop, on the device
+class SamplerIntegrator : public Integrator {
+public:
+    SamplerIntegrator(std::shared_ptr<const PerspectiveCamera> camera, RandomSampler sampler, Bounds2i pixel_bounds)
+        : camera(std::move(camera)), sampler(sampler), pixel_bounds(pixel_bounds) {}
+    void render(const Scene& scene) override {
+        PbrtRenderParams rp = params();
+        Film& film = *camera->film;
+        rp.spp = sampler.samples_per_pixel;
+        rp.seed = sampler.seed;
+        rp.width = film.width, rp.height = film.height;
+        if (pixel_bounds.x1 > pixel_bounds.x0) {
+            rp.x0 = pixel_bounds.x0, rp.y0 = pixel_bounds.y0, rp.x1 = pixel_bounds.x1, rp.y1 = pixel_bounds.y1;
+        } else {  // Film::get_sample_bounds (film.rs:76-81)
+            int32_t b[4];
+            pbrt_hip_sample_bounds(film.width, film.height, film.radius, film.radius, b);
+            rp.x0 = b[0], rp.y0 = b[1], rp.x1 = b[2], rp.y1 = b[3];
+        }
+        rp.tile_world = 1;
+        rp.filter_radius[0] = rp.filter_radius[1] = film.radius;
+        rp.filter_table = film.filter_table();
+        rp.max_sample_luminance = film.max_sample_luminance;
+        PbrtRenderStats st;
+        scene.aggregate().context()->check(pbrt_hip_render(scene.aggregate().handle(), &camera->cam, &rp, film.pixels.data(), &st), "Integrator::render");
+        stats = {st.camera_samples, st.rays_closest, st.rays_shadow, st.total_ms};
+    }
+    // li(&mut ray, scene, sampler, depth) -> Spectrum (integrator.rs:29-42, :452): the sampler argument is the stream the
+    // integrator draws from (RNG::set_sequence(stream_key), rng.rs:21-35). Re-entrant; depth is 0 at this boundary.
+    Spectrum li(const Ray& ray, const Scene& scene, uint64_t stream_key) const {
+        PbrtRenderParams rp = params();
+        PbrtLiParams lp = {rp.integrator, rp.max_depth, rp.rr_threshold, rp.light_strategy, rp.ao_samples, 0};
+        PbrtRay r = {{ray.o.x, ray.o.y, ray.o.z}, {ray.d.x, ray.d.y, ray.d.z}, ray.t_max, ray.time};
+        Spectrum l;
+        scene.aggregate().context()->check(pbrt_hip_li(scene.aggregate().handle(), &lp, &r, &stream_key, 1, l.c, nullptr), "Integrator::li");
+        return l;
+    }
+    std::shared_ptr<const PerspectiveCamera> camera;
+    RandomSampler sampler;
+    Bounds2i pixel_bounds;
+    RenderStats stats;
+
+protected:
+    virtual PbrtRenderParams params() const = 0;
+    static PbrtRenderParams zeroed() {
+        PbrtRenderParams rp;
+        std::memset(&rp, 0, sizeof(rp));
+        return rp;
+    }
+};
+
+enum class LightSampleStrategy { Uniform = 0, Power = 1, Spatial = 2 };  // lightdistrib.rs:222-232
+
+// PathIntegrator::new(max_depth, camera, sampler, pixel_bounds, rr_threshold, light_sample_strategy) (path.rs:31-46)
+class PathIntegrator : public SamplerIntegrator {
+public:
+    PathIntegrator(int max_depth, std::shared_ptr<const PerspectiveCamera> camera, RandomSampler sampler, Bounds2i pixel_bounds = Bounds2i(),
+                   Float rr_threshold = 1.0f, LightSampleStrategy light_sample_strategy = LightSampleStrategy::Spatial)
+        : SamplerIntegrator(std::move(camera), sampler, pixel_bounds), max_depth(max_depth), rr_threshold(rr_threshold), strategy(light_sample_strategy) {}
+    int max_depth;
+    Float rr_threshold;
+    LightSampleStrategy strategy;
+
+protected:
+    PbrtRenderParams params() const override {
+        PbrtRenderParams rp = zeroed();
+        rp.integrator = PBRT_INTEGRATOR_PATH, rp.max_depth = max_depth, rp.rr_threshold = rr_threshold, rp.light_strategy = (int)strategy;
+        return rp;
+    }
+};
+
+enum class LightStrategy { UniformSampleAll = 0, UniformSampleOne = 1 };  // directlighting.rs:21-24
+
+// DirectLightingIntegrator::new(strategy, max_depth, camera, sampler, pixel_bounds) (directlighting.rs:33-46)
+class DirectLightingIntegrator : public SamplerIntegrator {
+public:
+    DirectLightingIntegrator(LightStrategy strategy, int max_depth, std::shared_ptr<const PerspectiveCamera> camera, RandomSampler sampler,
+                             Bounds2i pixel_bounds = Bounds2i())
+        : SamplerIntegrator(std::move(camera), sampler, pixel_bounds), strategy(strategy), max_depth(max_depth) {}
+    LightStrategy strategy;
+    int max_depth;
+
+protected:
+    PbrtRenderParams params() const override {
+        PbrtRenderParams rp = zeroed();
+        rp.integrator = PBRT_INTEGRATOR_DIRECT, rp.max_depth = max_depth, rp.light_strategy = (int)strategy;
+        return rp;
+    }
+};
+
+}  // namespace pbrt
