@@ -65,11 +65,13 @@ def test_cpp_caller_renders_what_the_c_caller_renders(tmp_path):
     assert out.read_bytes() == (tmp_path / "c.png").read_bytes()
     # Primitive::intersect from the centre of the box straight down: the floor y = -1 at t = 1 exactly, ray.t_max lowered to it,
     # one of the floor's two triangles, barycentrics of the centre of the quad's diagonal (b0 = b2 = 0.5 or b1 = 0 ...)
-    hit = re.search(r"intersect: hit (\d) t ([0-9.]+) ray.t_max ([0-9.]+) primitive (-?\d+) barycentrics ([0-9.]+) ([0-9.]+) ([0-9.]+)", r.stdout)
+    hit = re.search(r"intersect: hit (\d) t ([0-9.]+) ray.t_max ([0-9.]+) primitive (-?\d+) barycentrics (-?[0-9.]+) (-?[0-9.]+) (-?[0-9.]+)", r.stdout)
     assert hit and hit.group(1) == "1" and float(hit.group(2)) == 1.0 and float(hit.group(3)) == 1.0 and int(hit.group(4)) in (0, 1)
     assert abs(sum(float(hit.group(k)) for k in (5, 6, 7)) - 1.0) < 1e-6
     p = re.search(r"intersect_p: blocked-short (\d) towards-floor (\d) through-the-opening (\d)", r.stdout)
-    assert p and p.group(1) == "0" and p.group(3) == "0"
+    # a shadow ray stopping short of the floor, the same ray once its t_max IS the hit distance (Bounds3f::intersect_p wants
+    # t_min < ray.t_max, geometry.rs:748: the floor at exactly t_max is not in front of it), a ray through the open side
+    assert p and p.groups() == ("0", "0", "0")
     li = re.search(r"li towards the emitter: ([0-9.]+) ([0-9.]+) ([0-9.]+)", r.stdout)
     assert li and all(float(v) >= 17.0 for v in li.groups())      # Le of the emitter it looks at, plus what the path gathers after it
     assert "aggregate.get_material(): Primitive::get_material: aggregates do not hold one" in r.stdout
