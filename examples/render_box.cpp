@@ -9,6 +9,7 @@
 //   g++ -std=c++17 -Wall -Iinclude examples/render_box.cpp -o render_box_cpp -Lpbrt-rs_amd/pbrt_hip -lpbrt_hip -Wl,-rpath,$PWD/pbrt-rs_amd/pbrt_hip
 //   ./render_box_cpp out.png [width height spp]
 #include <cstdio>
+#include <algorithm>
 #include <array>
 #include <cstdlib>
 
@@ -94,6 +95,31 @@ int main(int argc, char** argv) try {
     up_ray.d = {0, 1, 0};
     const Spectrum le = integrator.li(up_ray, scene, 12345);
     std::printf("li towards the emitter: %.4f %.4f %.4f\n", le.c[0], le.c[1], le.c[2]);
+    // TransformedPrimitive instances of the same box under a top-level BVHAccel (primitive.rs:105-159): a copy moved to x = +5
+    // and one turned a quarter about y at x = -5. From the centre of the moved copy straight down: its floor at t = 1, instance 0.
+    {
+        TriangleMesh object = mesh;
+        object.lights.clear();  // an instanced primitive cannot be an area light: an environment lights this scene
+        std::fill(object.area_light.begin(), object.area_light.end(), -1);
+        PbrtLight env{};
+        env.type = PBRT_LIGHT_INFINITE;
+        env.L[0] = env.L[1] = env.L[2] = 1.0f;
+        env.prim = -1;
+        env.n_samples = 1;
+        object.lights.push_back(env);
+        const double moved[16] = {1, 0, 0, 5, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, turned[16] = {0, 0, 1, -5, 0, 1, 0, 0, -1, 0, 0, 0, 0, 0, 0, 1};
+        auto instanced = std::make_shared<BVHAccel>(ctx, object, std::vector<PbrtInstance>{TransformedPrimitive(moved), TransformedPrimitive(turned, 1)});
+        Scene two(instanced);
+        Ray r;
+        r.o = {5, 0, 0};
+        r.d = {0, -1, 0};
+        SurfaceInteraction si;
+        const bool h2 = two.intersect(r, &si);
+        Ray between;  // from between the two copies towards +z: nothing there
+        between.d = {0, 0, 1};
+        std::printf("instanced: hit %d t %.6f instance %d world bound x [%.1f, %.1f] miss-between %d\n", (int)h2, si.t, si.instance, two.world_bound().min.x,
+                    two.world_bound().max.x, (int)two.intersect_p(between));
+    }
     try {
         aggregate->get_material();
     } catch (const Error& e) {

@@ -11,8 +11,10 @@
 //   BVHAccel::new    src/accelerators/bvh.rs:216-271                  pbrt::BVHAccel   (host build -> resident in HBM; aggregates panic on get_material / get_area_light, bvh.rs:934-953)
 //   Scene            src/core/scene.rs:18-46                          pbrt::Scene      (intersect / intersect_p forward to the aggregate)
 //   Integrator       src/core/integrator.rs:29-42                     pbrt::Integrator (render(&scene)), pbrt::SamplerIntegrator (li)
+//   TransformedPrimitive::new      src/core/primitive.rs:105-123      pbrt::TransformedPrimitive (instances of one aggregate under a top-level BVHAccel)
 //   PathIntegrator::new            src/integrators/path.rs:31-46      pbrt::PathIntegrator
 //   DirectLightingIntegrator::new  src/integrators/directlighting.rs:33-46   pbrt::DirectLightingIntegrator
+//   WhittedIntegrator::new / AOIntegrator::new   src/integrators/whitted.rs:22-45, ao.rs:20-34   pbrt::WhittedIntegrator, pbrt::AOIntegrator
 //   Film, Film::write_image        src/core/film.rs:30-63, 153-178    pbrt::Film
 //   PerspectiveCamera::new         src/cameras/perspective.rs:34-82   pbrt::PerspectiveCamera
 //   RandomSampler::new             src/samplers/random.rs:12-20       pbrt::RandomSampler
@@ -114,6 +116,31 @@ public:
 
 enum class SplitMethod { SAH = 0, HLBVH = 1, Middle = 2, EqualCounts = 3 };  // bvh.rs:30-35
 
+// TransformedPrimitive::new(primitive, primitive_to_world) with a static transform (primitive.rs:105-123): the record the
+// instanced BVHAccel constructor takes. to_world row-major 4 x 4 with last row (0, 0, 0, 1); the inverse is formed in double.
+// material >= 0 overrides the object's materials for this instance.
+inline PbrtInstance TransformedPrimitive(const double to_world[16], int32_t material = -1) {
+    PbrtInstance inst;
+    std::memset(&inst, 0, sizeof(inst));
+    const double* m = to_world;
+    const double det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+    if (det == 0.0) throw Error("TransformedPrimitive::new: singular transform", PBRT_HIP_ERR_INVALID);
+    double inv[16] = {0};
+    const double id = 1.0 / det;
+    inv[0] = (m[5] * m[10] - m[6] * m[9]) * id, inv[1] = (m[2] * m[9] - m[1] * m[10]) * id, inv[2] = (m[1] * m[6] - m[2] * m[5]) * id;
+    inv[4] = (m[6] * m[8] - m[4] * m[10]) * id, inv[5] = (m[0] * m[10] - m[2] * m[8]) * id, inv[6] = (m[2] * m[4] - m[0] * m[6]) * id;
+    inv[8] = (m[4] * m[9] - m[5] * m[8]) * id, inv[9] = (m[1] * m[8] - m[0] * m[9]) * id, inv[10] = (m[0] * m[5] - m[1] * m[4]) * id;
+    for (int r = 0; r < 3; ++r) inv[4 * r + 3] = -(inv[4 * r] * m[3] + inv[4 * r + 1] * m[7] + inv[4 * r + 2] * m[11]);
+    inv[15] = 1.0;
+    for (int k = 0; k < 16; ++k) {
+        inst.to_world[k] = (float)to_world[k];
+        inst.to_object[k] = (float)inv[k];
+    }
+    inst.to_world[12] = inst.to_world[13] = inst.to_world[14] = 0.0f, inst.to_world[15] = 1.0f;
+    inst.material = material;
+    return inst;
+}
+
 // BVHAccel over the mesh's triangles as GeometricPrimitives: built on the host in the reference's node order
 // (pbrt_hip_bvh_build), resident in HBM (pbrt_hip_scene_create), walked by the HIP traversal kernels.
 class BVHAccel : public Primitive {
@@ -137,6 +164,34 @@ public:
         pbrt_hip_free(nodes);
         pbrt_hip_free(order);
         ctx_->check(rc, "BVHAccel::new: pbrt_hip_scene_create");
+    }
+    // The top-level aggregate of a scene of TransformedPrimitives (primitive.rs:105-159): BVHAccel::new over the object's
+    // triangles (object space), TransformedPrimitive::new(object, to_world) per instance, BVHAccel::new over their world bounds.
+    // Lights: non-area lights only (an instanced primitive cannot be an area light).
+    BVHAccel(std::shared_ptr<Context> ctx, const TriangleMesh& object, const std::vector<PbrtInstance>& instances, int max_prims_in_node = 4,
+             SplitMethod split_method = SplitMethod::SAH)
+        : ctx_(std::move(ctx)) {
+        PbrtLinearBVHNode *blas = nullptr, *tlas = nullptr;
+        int32_t n_blas = 0, n_tlas = 0, *blas_order = nullptr, *tlas_order = nullptr;
+        int rc = pbrt_hip_bvh_build(object.p.data(), object.n_vertices(), object.vertex_indices.data(), object.n_triangles(), max_prims_in_node,
+                                    (int)split_method, &blas, &n_blas, &blas_order);
+        if (rc != PBRT_HIP_OK) throw Error("BVHAccel::new: pbrt_hip_bvh_build failed", rc);
+        const int32_t n = (int32_t)instances.size();
+        std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
+        rc = pbrt_hip_instance_bounds(blas[0].bounds_min, blas[0].bounds_max, instances.data(), n, lo.data(), hi.data());
+        if (rc == PBRT_HIP_OK) rc = pbrt_hip_bvh_build_boxes(lo.data(), hi.data(), n, max_prims_in_node, (int)split_method, &tlas, &n_tlas, &tlas_order);
+        if (rc == PBRT_HIP_OK) {
+            for (int k = 0; k < 3; ++k) {
+                (&bound_.min.x)[k] = tlas[0].bounds_min[k];
+                (&bound_.max.x)[k] = tlas[0].bounds_max[k];
+            }
+            n_nodes_ = n_tlas;
+            rc = pbrt_hip_scene_create_instanced(ctx_->handle(), object.p.data(), object.n_vertices(), object.vertex_indices.data(), object.n_triangles(),
+                                                 object.material.data(), object.materials.data(), (int32_t)object.materials.size(), object.lights.data(),
+                                                 (int32_t)object.lights.size(), blas, n_blas, blas_order, instances.data(), n, tlas, n_tlas, tlas_order, &h_);
+        }
+        pbrt_hip_free(blas), pbrt_hip_free(blas_order), pbrt_hip_free(tlas), pbrt_hip_free(tlas_order);
+        ctx_->check(rc, "BVHAccel::new (TransformedPrimitives)");
     }
     ~BVHAccel() override { pbrt_hip_scene_destroy(h_); }
     BVHAccel(const BVHAccel&) = delete;
@@ -381,6 +436,37 @@ protected:
     PbrtRenderParams params() const override {
         PbrtRenderParams rp = zeroed();
         rp.integrator = PBRT_INTEGRATOR_DIRECT, rp.max_depth = max_depth, rp.light_strategy = (int)strategy;
+        return rp;
+    }
+};
+
+// WhittedIntegrator::new(max_depth, camera, sampler, pixel_bounds) (whitted.rs:22-45)
+class WhittedIntegrator : public SamplerIntegrator {
+public:
+    WhittedIntegrator(int max_depth, std::shared_ptr<const PerspectiveCamera> camera, RandomSampler sampler, Bounds2i pixel_bounds = Bounds2i())
+        : SamplerIntegrator(std::move(camera), sampler, pixel_bounds), max_depth(max_depth) {}
+    int max_depth;
+
+protected:
+    PbrtRenderParams params() const override {
+        PbrtRenderParams rp = zeroed();
+        rp.integrator = PBRT_INTEGRATOR_WHITTED, rp.max_depth = max_depth;
+        return rp;
+    }
+};
+
+// AOIntegrator::new(cos_sample, n_samples, camera, sampler, pixel_bounds) (ao.rs:20-34)
+class AOIntegrator : public SamplerIntegrator {
+public:
+    AOIntegrator(bool cos_sample, int n_samples, std::shared_ptr<const PerspectiveCamera> camera, RandomSampler sampler, Bounds2i pixel_bounds = Bounds2i())
+        : SamplerIntegrator(std::move(camera), sampler, pixel_bounds), cos_sample(cos_sample), n_samples(n_samples) {}
+    bool cos_sample;
+    int n_samples;
+
+protected:
+    PbrtRenderParams params() const override {
+        PbrtRenderParams rp = zeroed();
+        rp.integrator = PBRT_INTEGRATOR_AO, rp.light_strategy = cos_sample ? 1 : 0, rp.ao_samples = n_samples;
         return rp;
     }
 };

@@ -30,7 +30,7 @@ def test_cpp_mirror_names_the_reference_surface():
     hpp = open(os.path.join(ROOT, "include", "pbrt_hip.hpp")).read()
     for name in ("class Primitive", "class BVHAccel : public Primitive", "class Scene", "class Integrator", "class SamplerIntegrator : public Integrator",
                  "class PathIntegrator : public SamplerIntegrator", "class DirectLightingIntegrator : public SamplerIntegrator", "class Film",
-                 "class PerspectiveCamera", "struct RandomSampler", "bool intersect(Ray& ray, SurfaceInteraction* isect) const",
+                 "class PerspectiveCamera", "struct RandomSampler", "PbrtInstance TransformedPrimitive(", "class WhittedIntegrator", "class AOIntegrator", "bool intersect(Ray& ray, SurfaceInteraction* isect) const",
                  "bool intersect_p(const Ray& ray) const", "Bounds3f world_bound() const", "void render(const Scene& scene)", "void write_image("):
         assert name in hpp, name
     for cite in ("src/core/primitive.rs:17-30", "src/accelerators/bvh.rs:216-271", "src/core/scene.rs:18-46", "src/core/integrator.rs:29-42",
@@ -75,3 +75,6 @@ def test_cpp_caller_renders_what_the_c_caller_renders(tmp_path):
     li = re.search(r"li towards the emitter: ([0-9.]+) ([0-9.]+) ([0-9.]+)", r.stdout)
     assert li and all(float(v) >= 17.0 for v in li.groups())      # Le of the emitter it looks at, plus what the path gathers after it
     assert "aggregate.get_material(): Primitive::get_material: aggregates do not hold one" in r.stdout
+    # TransformedPrimitives under a top-level BVHAccel (primitive.rs:105-159): the floor of the copy moved to x = +5, seen from its
+    # centre, is at t = 1 inside instance 0; the world bound spans both copies; nothing between them
+    assert "instanced: hit 1 t 1.000000 instance 0 world bound x [-6.0, 6.0] miss-between 0" in r.stdout, r.stdout
