@@ -298,3 +298,42 @@ def test_film_check_sees_a_missing_and_a_doubled_tile():
     assert not bench.check_film_weights(doubled, 16)["ok"]
     short = np.full((64, 96), 16.0); short[0, 0] = 15.0    # a lost sample: the total may exceed, never fall short
     assert not bench.check_film_weights(short, 16)["ok"]
+
+
+def test_ranks_do_not_outlive_the_parent(tmp_path):
+    """A driver that gives up on `python bench.py --gpus N` ends the parent: SIGTERM is forwarded to the ranks, and a rank
+    whose parent dies without a word (SIGKILL) is ended by the kernel (PR_SET_PDEATHSIG) — no orphan keeps a GPU busy."""
+    import signal
+    import time
+    rank = tmp_path / "rank.py"
+    rank.write_text("import os, sys, time\nopen(sys.argv[1] + os.environ['RANK'], 'w').write(str(os.getpid()))\ntime.sleep(120)\n")
+    parent_code = ("import sys, bench\n"
+                   "real = bench.launch_plan\n"
+                   f"bench.launch_plan = lambda a, argv, env, port, script=None: [([sys.executable, {str(rank)!r}, {str(tmp_path / 'pid')!r}], e) for _, e in real(a, argv, env, port)]\n"
+                   "sys.exit(bench.self_launch(bench.parse(['--gpus', '2']), ['--gpus', '2']))\n")
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        try:   # a zombie of our own child process tree still answers kill(0): look at its state
+            return open(f"/proc/{pid}/stat").read().split(") ")[1][0] != "Z"
+        except OSError:
+            return False
+
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        for f in tmp_path.glob("pid*"):
+            f.unlink()
+        parent = subprocess.Popen([sys.executable, "-c", parent_code], cwd=ROOT)
+        deadline = time.time() + 60
+        while time.time() < deadline and len(list(tmp_path.glob("pid*"))) < 2:
+            time.sleep(0.1)
+        pids = [int(f.read_text()) for f in sorted(tmp_path.glob("pid*"))]
+        assert len(pids) == 2 and all(alive(p) for p in pids)
+        parent.send_signal(sig)
+        parent.wait(30)
+        deadline = time.time() + 20
+        while time.time() < deadline and any(alive(p) for p in pids):
+            time.sleep(0.1)
+        assert not any(alive(p) for p in pids), (sig, pids)
