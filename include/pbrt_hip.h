@@ -350,6 +350,13 @@ int pbrt_hip_debug_wide_export(PbrtHipScene* scene, uint32_t* nodes, float* tris
  *   PBRT_WIDE_BUILD_NONE    not at all: the scene is traced over the binary records. */
 enum { PBRT_WIDE_BUILD_DEVICE = 0, PBRT_WIDE_BUILD_HOST = 1, PBRT_WIDE_BUILD_NONE = 2 };
 int pbrt_hip_context_set_wide_build(PbrtHipContext* ctx, int where);
+/* How the scenes created on this context from now on keep those records and their triangles in HBM: PBRT_WIDE_LAYOUT_AUTO (the
+ * default) = packed, 48 bytes apart, while records + triangles fit 8 MiB (a tree that L2 holds), else one 64-byte line each (no
+ * record straddles two lines: +1 % of a config-3 frame for a third more memory); _PACKED / _LINES force one or the other (the
+ * tests run every scene both ways: same hits, same exported bytes). pbrt_hip_scene_wide_stride: 48 or 64, 0 without wide records. */
+enum { PBRT_WIDE_LAYOUT_AUTO = 0, PBRT_WIDE_LAYOUT_PACKED = 1, PBRT_WIDE_LAYOUT_LINES = 2 };
+int pbrt_hip_context_set_wide_layout(PbrtHipContext* ctx, int layout);
+int pbrt_hip_scene_wide_stride(const PbrtHipScene* scene);
 
 /* ---- batch Primitive::intersect / intersect_p (src/core/primitive.rs:17-30 via
  * Scene::intersect / intersect_p, src/core/scene.rs:40-46) ----

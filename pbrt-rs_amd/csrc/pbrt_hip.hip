@@ -161,6 +161,20 @@ extern "C" int pbrt_hip_context_set_wide_build(PbrtHipContext* ctx, int where) t
 }
 PB_ABI_CATCH
 
+extern "C" int pbrt_hip_context_set_wide_layout(PbrtHipContext* ctx, int layout) try {
+    if (!ctx) return PBRT_HIP_ERR_INVALID;
+    PB_ENTER(ctx);
+    if (layout < PBRT_WIDE_LAYOUT_AUTO || layout > PBRT_WIDE_LAYOUT_LINES) {
+        ctx->last_error = "wide layout must be PBRT_WIDE_LAYOUT_AUTO, _PACKED or _LINES";
+        return PBRT_HIP_ERR_INVALID;
+    }
+    ctx->wide_layout = layout;
+    return PBRT_HIP_OK;
+}
+PB_ABI_CATCH
+
+extern "C" int pbrt_hip_scene_wide_stride(const PbrtHipScene* s) { return s ? (s->has_wide ? s->wide.vec_stride * 16 : 0) : -1; }
+
 extern "C" int pbrt_hip_context_set_traversal(PbrtHipContext* ctx, int traversal) try {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
     PB_ENTER(ctx);
@@ -964,6 +978,37 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
             }
         }
     }
+    // one 64-byte line per record / wide-order triangle where the tree is too large for L2 (wide_bvh.h: kWideLineAlignBytes;
+    // pbrt_hip_context_set_wide_layout overrides): the builders' packed arrays are spread on the device and released
+    s->wide.vec_stride = 3;
+    if (s->has_wide && ok) {
+        const size_t packed_bytes = ((size_t)std::max(s->n_wide_records, 1) + (size_t)n_prims) * 48;
+        const bool lines = ctx->wide_layout == PBRT_WIDE_LAYOUT_LINES || (ctx->wide_layout == PBRT_WIDE_LAYOUT_AUTO && packed_bytes > pb::kWideLineAlignBytes);
+        auto spread = [&](const void* packed, size_t count) -> void* {
+            void* out = nullptr;
+            count = count ? count : 1;
+            if (!hip_ok(ctx, hipMalloc(&out, count * 64), "hipMalloc wide lines")) return nullptr;
+            if (!hip_ok(ctx, hipMemset(out, 0, count * 64), "hipMemset") ||
+                !hip_ok(ctx, hipMemcpy2D(out, 64, packed, 48, 48, count, hipMemcpyDeviceToDevice), "hipMemcpy2D")) {
+                (void)hipFree(out);
+                return nullptr;
+            }
+            (void)hipFree(const_cast<void*>(packed));
+            std::replace(s->allocs.begin(), s->allocs.end(), const_cast<void*>(packed), out);
+            return out;
+        };
+        if (lines) {
+            void* n4 = spread(s->wide.nodes, (size_t)std::max(s->n_wide_records, 1));
+            void* t4 = n4 ? spread(s->wide.tris, (size_t)n_prims) : nullptr;
+            if (!n4 || !t4) {
+                ok = false;
+            } else {
+                s->wide.nodes = (const uint4*)n4;
+                s->wide.tris = (const float4*)t4;
+                s->wide.vec_stride = 4;
+            }
+        }
+    }
     // spill slab for the deepest stack entries of every resident lane of the traversal grid
     s->spill_lanes = ctx->n_cus * 2048;
     {
@@ -1064,9 +1109,10 @@ extern "C" int pbrt_hip_debug_wide_export(PbrtHipScene* s, uint32_t* nodes, floa
     PB_ENTER(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // the packed form, whatever the stride on the device (WideTrees::vec_stride)
     if (nodes && s->n_wide_records > 0)
-        HIP_TRY(ctx, hipMemcpy(nodes, s->wide.nodes, (size_t)s->n_wide_records * kWideNodeDwords * 4, hipMemcpyDeviceToHost));
-    if (tris) HIP_TRY(ctx, hipMemcpy(tris, s->wide.tris, (size_t)n_slots * 48, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy2D(nodes, 48, s->wide.nodes, (size_t)s->wide.vec_stride * 16, 48, (size_t)s->n_wide_records, hipMemcpyDeviceToHost));
+    if (tris) HIP_TRY(ctx, hipMemcpy2D(tris, 48, s->wide.tris, (size_t)s->wide.vec_stride * 16, 48, (size_t)n_slots, hipMemcpyDeviceToHost));
     if (boxes) HIP_TRY(ctx, hipMemcpy(boxes, s->wide.leaf_boxes, (size_t)n_slots * 32, hipMemcpyDeviceToHost));
     return PBRT_HIP_OK;
 }

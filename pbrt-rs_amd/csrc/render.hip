@@ -272,12 +272,12 @@ __global__ void k_set_shading(const int* __restrict__ slot_prim, const int* __re
 }
 
 // the wide-order triangle copies (wide_bvh.h) carry the kTriDegenerate flag too
-__global__ void k_wide_refresh_flags(float4* __restrict__ wtris, const float4* __restrict__ tris, int n) {
+__global__ void k_wide_refresh_flags(float4* __restrict__ wtris, int wide_stride, const float4* __restrict__ tris, int n) {
     int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= n) return;
-    float4 c = wtris[3 * (size_t)pos + 2];
+    float4 c = wtris[(size_t)wide_stride * (size_t)pos + 2];
     c.z = tris[3 * (size_t)__float_as_int(c.y) + 2].w;
-    wtris[3 * (size_t)pos + 2] = c;
+    wtris[(size_t)wide_stride * (size_t)pos + 2] = c;
 }
 
 extern "C" int pbrt_hip_scene_set_shading_data(PbrtHipScene* s, const float* positions, int32_t n_verts,
@@ -317,7 +317,7 @@ extern "C" int pbrt_hip_scene_set_shading_data(PbrtHipScene* s, const float* pos
                        n_tris, (float4*)out, const_cast<float4*>(s->d.bvh.tris));
     if (s->has_wide)
         hipLaunchKernelGGL(k_wide_refresh_flags, dim3((n_tris + 255) / 256), dim3(256), 0, st, const_cast<float4*>(s->wide.tris),
-                           s->d.bvh.tris, n_tris);
+                           s->wide.vec_stride, s->d.bvh.tris, n_tris);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));
     s->d.bvh.tri_shading = (const float4*)out;

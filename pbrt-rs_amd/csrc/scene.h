@@ -52,6 +52,7 @@ struct PbrtHipContext {
     int count_traversal = 0;
     int traversal = 0;  // PBRT_TRAVERSAL_*: pbrt_hip_context_set_traversal
     int wide_build = 0;  // PBRT_WIDE_BUILD_*: pbrt_hip_context_set_wide_build
+    int wide_layout = 0;  // PBRT_WIDE_LAYOUT_*: pbrt_hip_context_set_wide_layout
     unsigned long long* d_counters = nullptr;  // [0..3] mode 1: node, prim, rays, instance tests; [4..7] mode 2
     uint64_t counted_rays = 0;
     // ray-queue heads of the persistent traversal kernels: [0, kQueueSegments) the launch's segments,

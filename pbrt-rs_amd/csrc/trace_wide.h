@@ -409,7 +409,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             PB_WSTAT(0, 1);      // record iterations of this wave
             PB_WSTAT(1, popc64(__ballot(interior)));  // lanes stepping a record
             if (interior) {
-                const uint4* nd = wt.nodes + 3 * (size_t)cur;
+                const uint4* nd = wt.nodes + (size_t)wt.vec_stride * (size_t)cur;
                 uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
                 if (COUNT) c_rec += 1;
                 const uint32_t dw3 = q0.w;
@@ -610,7 +610,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             // The leaf's first triangle is fetched whatever the box test will say, and a leaf of several triangles fetches
             // its exact box in the same round trip (before round 3: the box first, then the triangles, one trip each).
             if (COUNT) c_tri += 1;
-            const float4* tp0 = wt.tris + 3 * (size_t)first;
+            const float4* tp0 = wt.tris + (size_t)wt.vec_stride * (size_t)first;
             float4 ta = tp0[0], tb = tp0[1], tc = tp0[2];
             float lox, loy, loz, hix, hiy, hiz;
             if (cnt == 1) {
@@ -665,7 +665,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 for (int i = 0; i < cnt; ++i) {
                     if (i > 0) {
                         if (COUNT) c_tri += 1;
-                        const float4* tp = wt.tris + 3 * (size_t)(first + i);
+                        const float4* tp = wt.tris + (size_t)wt.vec_stride * (size_t)(first + i);
                         ta = tp[0];
                         tb = tp[1];
                         tc = tp[2];

@@ -27,6 +27,7 @@
 //   m[s]    0xFF empty | 0x80 + k: interior child k | (triangle offset << 2) | (n - 1): leaf of n <= 4 triangles
 // Child reference (stack entry / `cur`): >= 0 record index; < 0 leaf, ~ref = first_wide_triangle << 2 | (n - 1).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -39,6 +40,13 @@
 namespace pb {
 
 constexpr int kWideNodeDwords = 12;
+// How the records and the wide-order triangles lie in HBM (WideTrees::vec_stride, chosen per scene). Builders, host arrays and
+// pbrt_hip_debug_wide_export speak the packed 48-byte form. A scene whose records + triangles exceed kWideLineAlignBytes spreads
+// both arrays to one 64-byte line per record / triangle when it takes them over (pbrt_hip.hip): the same three 16-B loads per
+// lane, but no record straddles two lines any more (at a 48-B stride every second one does) — dependent gathers from a table
+// beyond L2 run 11-14 % faster that way (tools/micro/probe_stride.hip), the config-3 frame +1.0 %; a tree that fits L2 keeps the
+// packed form (padding only costs it cache: config 5's 258 KB of records -0.6 %). profiles/r05_line_aligned.txt.
+constexpr size_t kWideLineAlignBytes = 8u << 20;
 constexpr int kExpMin = -32, kExpMax = 13;  // cell = 2^e, stored as a 6-bit signed field
 constexpr double kWideSlack = 1.0 / 256.0;   // every quantised plane lies at least this many cells outside the float box
 constexpr float kWideCoordLimit = 1048576.0f;  // |scene coordinate| <= 2^20, else the scene keeps the binary records
@@ -114,10 +122,11 @@ PB_HD bool wide_ray_covered(float ox, float oy, float oz, float idx, float idy, 
 #if defined(__HIPCC__)
 // device arrays of one scene's wide records (built by host_wide.cpp, uploaded by pbrt_hip.hip)
 struct WideTrees {
-    const uint4* __restrict__ nodes;        // 3 x uint4 per record
-    const float4* __restrict__ tris;        // 3 x float4 per wide-order triangle: (v0.xyz v1.x) (v1.yz v2.xy) (v2.z slot flags -)
+    const uint4* __restrict__ nodes;        // 3 x uint4 per record, at a stride of vec_stride
+    const float4* __restrict__ tris;        // 3 x float4 per wide-order triangle, at a stride of vec_stride: (v0.xyz v1.x) (v1.yz v2.xy) (v2.z slot flags -)
     const float4* __restrict__ leaf_boxes;  // 2 x float4 per wide-order triangle position (leaves of n >= 2)
     int root_ref;
+    int vec_stride;  // uint4 / float4 per record and per wide-order triangle: 3 packed, 4 one 64-byte line each
     uint2* __restrict__ spill;  // [entry][global lane]
     int spill_stride;
     uint32_t* __restrict__ special_list;  // tokens (IO::token) of the rays left to the binary kernel

@@ -24,6 +24,7 @@ INTEGRATOR_PATH, INTEGRATOR_DIRECT, INTEGRATOR_WHITTED, INTEGRATOR_AO = 0, 1, 2,
 SAMPLER_RANDOM, SAMPLER_STRATIFIED, SAMPLER_ZEROTWO, SAMPLER_HALTON = 0, 1, 2, 3
 TRAVERSAL_AUTO, TRAVERSAL_STACK, TRAVERSAL_STACKLESS = 0, 1, 2   # pbrt_hip_context_set_traversal
 WIDE_BUILD_DEVICE, WIDE_BUILD_HOST, WIDE_BUILD_NONE = 0, 1, 2       # pbrt_hip_context_set_wide_build
+WIDE_LAYOUT_AUTO, WIDE_LAYOUT_PACKED, WIDE_LAYOUT_LINES = 0, 1, 2    # pbrt_hip_context_set_wide_layout
 TILE_ORDER_MORTON, TILE_ORDER_ROW_MAJOR = 0, 1                     # PbrtRenderParams.tile_order
 
 EXPORTS = [
@@ -31,7 +32,7 @@ EXPORTS = [
     "pbrt_hip_free", "pbrt_hip_bvh_build_boxes", "pbrt_hip_instance_bounds", "pbrt_hip_scene_create",
     "pbrt_hip_scene_create_instanced", "pbrt_hip_scene_create_with_spheres", "pbrt_hip_scene_destroy", "pbrt_hip_intersect",
     "pbrt_hip_intersect_p", "pbrt_hip_intersect_device", "pbrt_hip_intersect_p_device", "pbrt_hip_synchronize",
-    "pbrt_hip_context_set_deadline", "pbrt_hip_context_set_traversal", "pbrt_hip_context_is_lost", "pbrt_hip_context_set_wide_build",
+    "pbrt_hip_context_set_deadline", "pbrt_hip_context_set_traversal", "pbrt_hip_context_is_lost", "pbrt_hip_context_set_wide_build", "pbrt_hip_context_set_wide_layout", "pbrt_hip_scene_wide_stride",
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
     "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_tile_partition_order", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png", "pbrt_hip_write_exr",
     "pbrt_hip_comm_unique_id", "pbrt_hip_comm_create", "pbrt_hip_comm_destroy", "pbrt_hip_film_reduce",
@@ -130,6 +131,8 @@ def lib():
         L.pbrt_hip_set_counting.argtypes = [vp, ctypes.c_int]
         L.pbrt_hip_context_set_traversal.argtypes = [vp, ctypes.c_int]
         L.pbrt_hip_context_set_wide_build.argtypes = [vp, ctypes.c_int]
+        L.pbrt_hip_context_set_wide_layout.argtypes = [vp, ctypes.c_int]
+        L.pbrt_hip_scene_wide_stride.argtypes = [vp]
         L.pbrt_hip_get_counters.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64 * 4)]
         L.pbrt_hip_get_wide_counters.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64 * 4)]
         L.pbrt_hip_probe_gather.argtypes = [vp, i64, i32, i32, i32, ctypes.POINTER(ctypes.c_double)]
@@ -197,6 +200,11 @@ class Context:
         """Where scenes created from now on get their 4-wide records: WIDE_BUILD_DEVICE (default), WIDE_BUILD_HOST (the host
         builder: same bytes) or WIDE_BUILD_NONE (binary records only)."""
         self.check(lib().pbrt_hip_context_set_wide_build(self.h, int(where)), "context_set_wide_build")
+
+    def set_wide_layout(self, layout):
+        """How scenes created from now on keep their 4-wide records and triangles: WIDE_LAYOUT_AUTO (packed while they fit 8 MiB,
+        else one 64-byte line each), WIDE_LAYOUT_PACKED, WIDE_LAYOUT_LINES."""
+        self.check(lib().pbrt_hip_context_set_wide_layout(self.h, int(layout)), "context_set_wide_layout")
 
     def set_counting(self, enable):
         """Instrumented traversal. True / 1: box / triangle test counts of the reference's loops (binary kernels);
@@ -431,6 +439,10 @@ class Scene:
         n, why = ctypes.c_int32(), ctypes.c_char_p()
         self.ctx.check(lib().pbrt_hip_scene_wide_records(self.h, ctypes.byref(n), ctypes.byref(why)), "scene_wide_records")
         return n.value, (why.value or b"").decode()
+
+    def wide_stride(self):
+        """Bytes between two 4-wide records (and two wide-order triangles) in HBM: 48 packed, 64 one line each, 0 = no wide records."""
+        return lib().pbrt_hip_scene_wide_stride(self.h)
 
     def _set_shading_data(self, scene):
         """TriangleMesh n / uv (triangle.rs:17-26): scene["normals"] / scene["tangents"] (n_verts, 3), scene["uvs"] (n_verts, 2), optional."""

@@ -334,3 +334,76 @@ def test_state_stream_probe_reports_what_its_lanes_ask_for(hip_ctx):
         assert ms > 0
     with pytest.raises(pbrt_hip.PbrtHipError):
         hip_ctx.probe_state_stream(100, 0.5, 1 << 20, 1)
+
+
+@pytest.mark.parametrize("which", ["cloud", "cornell", "instanced", "two_level", "device_built", "vertex_data"])
+def test_packed_and_line_aligned_layouts_are_the_same_scene(hip_ctx, which):
+    """pbrt_hip_context_set_wide_layout: the 4-wide records and their triangles 48 bytes apart (packed) or one 64-byte line each
+    (WideTrees::vec_stride 3 / 4; the builders always produce the packed form, the scene spreads it). Every kind of scene both
+    ways: the strides are what was asked for, the exported bytes are the same, hits / occlusion / counters are the same bit for
+    bit and equal the oracle's, a render is the same film — and the flags the shading data refreshes in the wide-order triangles
+    (pbrt_hip_scene_set_shading_data -> k_wide_refresh_flags) land in the right place at either stride."""
+    kw = {}
+    if which == "cloud":
+        sc = scenes.random_triangles(60_000, seq=4, size=0.04)
+    elif which == "cornell":
+        sc = scenes.cornell_box()
+    elif which == "instanced":
+        sc = scenes.instanced_scene(n_base_tris=3000, n_instances=300)
+    elif which == "two_level":
+        sc = scenes.two_level_scene(n_instances=70)
+    elif which == "vertex_data":
+        sc = scenes.with_vertex_shading(scenes.random_triangles(20_000, seq=6, size=0.05), seq=9)
+    else:
+        sc, kw = scenes.random_triangles(60_000, seq=4, size=0.04), dict(device_build=True)
+    got = {}
+    try:
+        for layout, stride in ((pbrt_hip.WIDE_LAYOUT_PACKED, 48), (pbrt_hip.WIDE_LAYOUT_LINES, 64)):
+            hip_ctx.set_wide_layout(layout)
+            g = pbrt_hip.Scene(hip_ctx, sc, **kw)
+            assert g.wide_records()[0] > 0 and g.wide_stride() == stride
+            got[stride] = g
+    finally:
+        hip_ctx.set_wide_layout(pbrt_hip.WIDE_LAYOUT_AUTO)        # the context is shared by the session
+    a, b = got[48], got[64]
+    assert a.wide_records() == b.wide_records()
+    if which not in ("instanced", "two_level"):
+        n = len(sc["indices"])
+        for x, y, what in zip(a.debug_wide_export(n), b.debug_wide_export(n), ("records", "triangles", "leaf boxes")):
+            assert x.tobytes() == y.tobytes(), what
+    if which == "device_built":
+        osc = oracle.OracleScene(sc, split_method=pbrt_hip.SPLIT_HLBVH)
+    else:
+        osc = oracle.OracleScene(sc, normals=sc.get("normals"), uvs=sc.get("uvs"), tangents=sc.get("tangents"))
+    root = osc.nodes()[0]
+    rays = _rays_into(root["bmin"], root["bmax"], 60_000, 43)
+    ha, pa, wca = _three_way(hip_ctx, a, osc, rays)
+    hb, pb, wcb = _three_way(hip_ctx, b, osc, rays)
+    assert ha.tobytes() == hb.tobytes() and np.array_equal(pa, pb) and wca == wcb and (ha["prim_id"] >= 0).sum() > 1000
+    if which in ("cornell", "vertex_data", "instanced"):
+        cam = {"cornell": scenes.cornell_camera, "instanced": scenes.instanced_camera}.get(which, scenes.random_triangles_camera)(64, 48)
+        fa, sta = a.render(cam, 64, 48, 4, max_depth=6, seed=5)
+        fb, stb = b.render(cam, 64, 48, 4, max_depth=6, seed=5)
+        assert fa.tobytes() == fb.tobytes() and sta["rays_closest"] == stb["rays_closest"] and sta["rays_shadow"] == stb["rays_shadow"]
+    osc.close()
+    a.close()
+    b.close()
+
+
+def test_wide_layout_follows_the_size_of_the_tree(hip_ctx):
+    """PBRT_WIDE_LAYOUT_AUTO: records + triangles that fit 8 MiB (a tree L2 can hold) stay packed — padding would only cost them
+    cache; larger ones get one line per record (no record straddles two 64-byte lines: profiles/r05_line_aligned.txt)."""
+    small = pbrt_hip.Scene(hip_ctx, scenes.random_triangles(50_000, seq=4, size=0.04))     # ~24 k records + 50 k triangles: 3.6 MB
+    large = pbrt_hip.Scene(hip_ctx, scenes.random_triangles(200_000, seq=4, size=0.03))    # ~98 k records + 200 k triangles: 14 MB
+    inst = pbrt_hip.Scene(hip_ctx, scenes.instanced_scene(n_base_tris=3000, n_instances=300))
+    assert (small.wide_stride(), large.wide_stride(), inst.wide_stride()) == (48, 64, 48)
+    with pytest.raises(pbrt_hip.PbrtHipError, match="PBRT_WIDE_LAYOUT"):
+        hip_ctx.set_wide_layout(3)
+    hip_ctx.set_wide_build(pbrt_hip.WIDE_BUILD_NONE)
+    try:
+        none = pbrt_hip.Scene(hip_ctx, scenes.cornell_box())
+    finally:
+        hip_ctx.set_wide_build(pbrt_hip.WIDE_BUILD_DEVICE)
+    assert none.wide_stride() == 0
+    for g in (small, large, inst, none):
+        g.close()
