@@ -353,7 +353,8 @@ int pbrt_hip_context_set_wide_build(PbrtHipContext* ctx, int where);
 /* How the scenes created on this context from now on keep those records and their triangles in HBM: PBRT_WIDE_LAYOUT_AUTO (the
  * default) = packed, 48 bytes apart, while records + triangles fit 8 MiB (a tree that L2 holds), else one 64-byte line each (no
  * record straddles two lines: +1 % of a config-3 frame for a third more memory); _PACKED / _LINES force one or the other (the
- * tests run every scene both ways: same hits, same exported bytes). pbrt_hip_scene_wide_stride: 48 or 64, 0 without wide records. */
+ * tests run every scene both ways: same hits, same exported bytes). Two-level scenes are always packed (the trees of a scene of
+ * instances are small). pbrt_hip_scene_wide_stride: 48 or 64, 0 without wide records. */
 enum { PBRT_WIDE_LAYOUT_AUTO = 0, PBRT_WIDE_LAYOUT_PACKED = 1, PBRT_WIDE_LAYOUT_LINES = 2 };
 int pbrt_hip_context_set_wide_layout(PbrtHipContext* ctx, int layout);
 int pbrt_hip_scene_wide_stride(const PbrtHipScene* scene);

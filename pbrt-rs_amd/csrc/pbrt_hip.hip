@@ -983,7 +983,8 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     s->wide.vec_stride = 3;
     if (s->has_wide && ok) {
         const size_t packed_bytes = ((size_t)std::max(s->n_wide_records, 1) + (size_t)n_prims) * 48;
-        const bool lines = ctx->wide_layout == PBRT_WIDE_LAYOUT_LINES || (ctx->wide_layout == PBRT_WIDE_LAYOUT_AUTO && packed_bytes > pb::kWideLineAlignBytes);
+        // (two-level scenes stay packed: the trees of a scene of instances are small, and trace_wide<.., INST> keeps its compile-time stride)
+        const bool lines = !instanced && (ctx->wide_layout == PBRT_WIDE_LAYOUT_LINES || (ctx->wide_layout == PBRT_WIDE_LAYOUT_AUTO && packed_bytes > pb::kWideLineAlignBytes));
         auto spread = [&](const void* packed, size_t count) -> void* {
             void* out = nullptr;
             count = count ? count : 1;

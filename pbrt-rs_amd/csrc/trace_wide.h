@@ -101,6 +101,11 @@ template <class IO, bool COUNT = false, int INST = 0>
 PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restrict__ work_counter, uint2* lds_stack,
                        int spill_lane, unsigned long long* counters = nullptr, float* lds_world = nullptr) {
     constexpr int kLds = wide_stack_lds(INST);  // stack entries per lane in LDS (the rest: wt.spill)
+    // record / wide-order triangle index -> uint4 / float4 offset: 3 per element packed, 4 one 64-byte line each (wide_bvh.h:
+    // vec_stride). Two-level scenes are always packed (their trees are small: a compile-time 3 keeps this kernel as it was);
+    // one-level: 4 i - (i & m) with m = ~0 packed, 0 lines — a shift, an and, a subtract, no 64-bit multiply by a register
+    const uint32_t packed_mask = INST ? ~0u : (wt.vec_stride == 3 ? ~0u : 0u);
+    auto wide_vec_offset = [&](int i) -> size_t { return INST ? (size_t)3 * (size_t)i : (size_t)(((uint32_t)i << 2) - ((uint32_t)i & packed_mask)); };
     const uint32_t n = io.n();
     const int lane = threadIdx.x & 63;
     TravRay r;
@@ -409,7 +414,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             PB_WSTAT(0, 1);      // record iterations of this wave
             PB_WSTAT(1, popc64(__ballot(interior)));  // lanes stepping a record
             if (interior) {
-                const uint4* nd = wt.nodes + (size_t)wt.vec_stride * (size_t)cur;
+                const uint4* nd = wt.nodes + wide_vec_offset(cur);
                 uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
                 if (COUNT) c_rec += 1;
                 const uint32_t dw3 = q0.w;
@@ -610,7 +615,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
             // The leaf's first triangle is fetched whatever the box test will say, and a leaf of several triangles fetches
             // its exact box in the same round trip (before round 3: the box first, then the triangles, one trip each).
             if (COUNT) c_tri += 1;
-            const float4* tp0 = wt.tris + (size_t)wt.vec_stride * (size_t)first;
+            const float4* tp0 = wt.tris + wide_vec_offset(first);
             float4 ta = tp0[0], tb = tp0[1], tc = tp0[2];
             float lox, loy, loz, hix, hiy, hiz;
             if (cnt == 1) {
@@ -665,7 +670,7 @@ PB_DEV void trace_wide(const WideTrees& wt, const IO& io, unsigned int* __restri
                 for (int i = 0; i < cnt; ++i) {
                     if (i > 0) {
                         if (COUNT) c_tri += 1;
-                        const float4* tp = wt.tris + (size_t)wt.vec_stride * (size_t)(first + i);
+                        const float4* tp = wt.tris + wide_vec_offset(first + i);
                         ta = tp[0];
                         tb = tp[1];
                         tc = tp[2];
