@@ -10,7 +10,10 @@ W, H, spp = 1920, 1080, int(os.environ.get("SPP", "8"))
 sc = scenes.random_triangles(int(os.environ.get("TRIS", "1000000")), seq=1)
 cam = scenes.random_triangles_camera(W, H)
 ctx = pbrt_hip.Context(0)
+layout = int(os.environ.get("LAYOUT", "0"))       # pbrt_hip.WIDE_LAYOUT_*: 0 auto, 1 packed (48-B stride), 2 one 64-byte line per record / triangle
+ctx.set_wide_layout(layout)
 scene = pbrt_hip.Scene(ctx, sc)
+print("wide stride:", scene.wide_stride())
 print("wide records:", scene.wide_records())
 mode = int(os.environ.get("TRAVERSAL", "0"))     # pbrt_hip.TRAVERSAL_*: 0 wide records, 1 binary + stack, 2 binary stackless
 ctx.set_traversal(mode)
