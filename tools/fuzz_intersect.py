@@ -147,9 +147,18 @@ def main():
     bad, n_wide, t0 = 0, 0, time.time()
     for seed in range(first, first + n_cases):
         sc, rays, max_prims, split, kw, n_inst, desc = make_case(seed)
+        # round 5: how the wide records lie in HBM (pbrt_hip_context_set_wide_layout: by size / packed / one 64-byte line each);
+        # its own generator, the draws of make_case stay what they were. The host-built copy below keeps the default layout:
+        # the exported bytes are the packed form either way.
+        layout = int(np.random.default_rng(seed ^ 0x11e5).integers(0, 3))
+        desc += f" layout {layout}"
         try:
             osc = oracle.OracleScene(sc, max_prims, split)
-            gsc = pbrt_hip.Scene(ctx, sc, max_prims_in_node=max_prims, split_method=split, **kw)
+            ctx.set_wide_layout(layout)
+            try:
+                gsc = pbrt_hip.Scene(ctx, sc, max_prims_in_node=max_prims, split_method=split, **kw)
+            finally:
+                ctx.set_wide_layout(pbrt_hip.WIDE_LAYOUT_AUTO)
             n_rec, why = gsc.wide_records()
             n_wide += n_rec > 0
             cpu, _ = osc.intersect(rays)

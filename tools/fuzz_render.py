@@ -157,11 +157,13 @@ def make_case(seed):
     gpu_only = dict(shade_order=int(rng.integers(0, 3)), spp_per_pass=int(rng.integers(0, 3)), ray_order=int(rng.integers(0, 2)))   # must not change the film
     # round 5: the dealing order of the tiles (its own generator: the draws of the cases above stay what they were)
     gpu_only["tile_order"] = int(np.random.default_rng(seed ^ 0x71e0).integers(0, 2))
+    opts_layout = int(np.random.default_rng(seed ^ 0x11e5).integers(0, 3))   # pbrt_hip_context_set_wide_layout: by size / packed / lines
     plain = "spheres" not in sc and "instances" not in sc and "objects" not in sc and "normals" not in sc and "uvs" not in sc and "tangents" not in sc
     opts = dict(device_build=bool(plain and rng.random() < 0.2),     # the tree built on the device (HLBVH) against the oracle's HLBVH
                 tile_split=int(rng.choice([1, 1, 2, 3])),              # the frame as the sum of the ranks' tile shares
                 # pbrt_hip_context_set_traversal: wide records / binary + stack / binary stackless (single-level triangle scenes)
                 # (its own generator: the draws of the cases above stay what they were in profiles/r03_fuzz.txt)
+                layout=opts_layout,
                 traversal=int(np.random.default_rng(seed ^ 0x7ac3).choice([0, 0, 1, 2] if ("spheres" not in sc and "instances" not in sc and "objects" not in sc) else [0, 0, 1])))
     r_f = rng.random()
     if r_f < 0.3:
@@ -191,7 +193,11 @@ def main():
                 gsc = pbrt_hip.Scene(ctx, sc, device_build=True)
             else:
                 osc = oracle.OracleScene(sc, normals=sc.get("normals"), uvs=sc.get("uvs"), tangents=sc.get("tangents"))
-                gsc = pbrt_hip.Scene(ctx, sc)
+                ctx.set_wide_layout(opts["layout"])
+                try:
+                    gsc = pbrt_hip.Scene(ctx, sc)
+                finally:
+                    ctx.set_wide_layout(pbrt_hip.WIDE_LAYOUT_AUTO)
             okw = dict(kw)
             film_c, st_c = osc.render(scenes.camera_dict_to_floats(cam), w, h, spp, n_threads=4, **okw)
             ctx.set_traversal(opts["traversal"])
