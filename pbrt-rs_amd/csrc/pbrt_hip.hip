@@ -173,7 +173,10 @@ extern "C" int pbrt_hip_context_set_wide_layout(PbrtHipContext* ctx, int layout)
 }
 PB_ABI_CATCH
 
-extern "C" int pbrt_hip_scene_wide_stride(const PbrtHipScene* s) { return s ? (s->has_wide ? s->wide.vec_stride * 16 : 0) : -1; }
+extern "C" int pbrt_hip_scene_wide_stride(const PbrtHipScene* s) try {
+    return s ? (s->has_wide ? s->wide.vec_stride * 16 : 0) : -1;
+}
+PB_ABI_CATCH
 
 extern "C" int pbrt_hip_context_set_traversal(PbrtHipContext* ctx, int traversal) try {
     if (!ctx) return PBRT_HIP_ERR_INVALID;
