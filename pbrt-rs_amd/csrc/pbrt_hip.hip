@@ -984,8 +984,6 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
     // one 64-byte line per record / wide-order triangle where the tree is too large for L2 (wide_bvh.h: kWideLineAlignBytes;
     // pbrt_hip_context_set_wide_layout overrides): the builders' packed arrays are spread on the device and released
     s->wide.vec_stride = 3;
-    d.bvh.shade_tris = d.bvh.tris;
-    d.bvh.shade_stride = 3;
     if (s->has_wide && ok) {
         const size_t packed_bytes = ((size_t)std::max(s->n_wide_records, 1) + (size_t)n_prims) * 48;
         // (two-level scenes stay packed: the trees of a scene of instances are small, and trace_wide<.., INST> keeps its compile-time stride)
@@ -1012,19 +1010,6 @@ static int scene_create_impl(PbrtHipContext* ctx, const float* positions, int32_
                 s->wide.nodes = (const uint4*)n4;
                 s->wide.tris = (const float4*)t4;
                 s->wide.vec_stride = 4;
-            }
-            // ... and a line-aligned COPY of the leaf-order triangle records for the shading kernels (DevBVH::shade_tris): the
-            // traversal kernels over the binary records and the builders keep reading the packed ones
-            void* st = nullptr;
-            if (ok && hip_ok(ctx, hipMalloc(&st, (size_t)n_prims * 64), "hipMalloc shade triangles")) {
-                s->allocs.push_back(st);
-                if (!hip_ok(ctx, hipMemset(st, 0, (size_t)n_prims * 64), "hipMemset") ||
-                    !hip_ok(ctx, hipMemcpy2D(st, 64, d.bvh.tris, 48, 48, (size_t)n_prims, hipMemcpyDeviceToDevice), "hipMemcpy2D"))
-                    ok = false;
-                d.bvh.shade_tris = (const float4*)st;
-                d.bvh.shade_stride = 4;
-            } else {
-                ok = false;
             }
         }
     }

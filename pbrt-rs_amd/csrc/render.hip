@@ -320,8 +320,6 @@ extern "C" int pbrt_hip_scene_set_shading_data(PbrtHipScene* s, const float* pos
                            s->wide.vec_stride, s->d.bvh.tris, n_tris);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (s->d.bvh.shade_tris != s->d.bvh.tris)  // the shading kernels' line-aligned copy takes the refreshed flags over
-        HIP_TRY(ctx, hipMemcpy2D(const_cast<float4*>(s->d.bvh.shade_tris), 64, s->d.bvh.tris, 48, 48, (size_t)n_tris, hipMemcpyDeviceToDevice));
     s->d.bvh.tri_shading = (const float4*)out;
     s->d.bvh.has_normals = normals ? 1 : 0;
     s->d.bvh.has_tangents = tangents ? 1 : 0;

@@ -25,11 +25,6 @@ namespace pb {
 struct DevBVH {
     const float4* __restrict__ inodes;  // 4 x float4 per interior node
     const float4* __restrict__ tris;    // 3 x float4 per leaf slot
-    // what the SHADING kernels read per hit (make_surface, the light tables): the same records, but one per 64-byte line
-    // (shade_stride 4) where the scene keeps its wide records that way (wide_bvh.h: a 48-byte gather at a 48-byte stride moves
-    // 1.5 lines); = tris with stride 3 otherwise. The traversal kernels and the builders always read `tris`.
-    const float4* __restrict__ shade_tris;
-    int shade_stride;
     float root_min[3], root_max[3];
     int root_ref;     // child-style reference of the root (leaf if the tree is a single leaf)
     int count_bits;   // bits of (n_primitives - 1) in a leaf reference
@@ -207,15 +202,6 @@ PB_DEV bool triangle_test(V3 p0, V3 p1, V3 p2, const TravRay& r, const TriRayCon
     *b2o = b2;
     *to = t;
     return true;
-}
-
-PB_DEV float4 shade_tri(const DevBVH& bvh, int slot, int k) { return bvh.shade_tris[(size_t)bvh.shade_stride * (size_t)slot + k]; }
-PB_DEV void load_shade_tri(const DevBVH& bvh, int slot, V3* p0, V3* p1, V3* p2, int* flags) {
-    float4 a = shade_tri(bvh, slot, 0), b = shade_tri(bvh, slot, 1), c = shade_tri(bvh, slot, 2);
-    *p0 = V3{a.x, a.y, a.z};
-    *p1 = V3{a.w, b.x, b.y};
-    *p2 = V3{b.z, b.w, c.x};
-    *flags = __float_as_int(c.w);
 }
 
 PB_DEV void load_tri(const float4* __restrict__ tris, int slot, V3* p0, V3* p1, V3* p2, int* flags) {

@@ -89,8 +89,8 @@ PB_DEV void light_sample_li(const ShadeConsts& sc, const Surf& sf, const DevLigh
     V3 p1 = V3{0.0f, 0.0f, 0.0f}, p1_err = V3{0.0f, 0.0f, 0.0f}, p1_n = V3{0.0f, 0.0f, 0.0f};
     V3 Lc = V3{lt.L[0], lt.L[1], lt.L[2]};
     if (lt.type == PBRT_LIGHT_DIFFUSE_AREA && sc.bvh.has_spheres &&
-        (__float_as_int(shade_tri(sc.bvh, lt.slot, 2).w) & kPrimSphere)) {
-        float4 rec = shade_tri(sc.bvh, lt.slot, 0);
+        (__float_as_int(sc.bvh.tris[3 * (size_t)lt.slot + 2].w) & kPrimSphere)) {
+        float4 rec = sc.bvh.tris[3 * (size_t)lt.slot];
         float pdf;
         sphere_light_sample(rec.x, rec.y, rec.z, rec.w, sf, ul0, ul1, &p1, &p1_err, &p1_n, &pdf);
         // DiffuseAreaLight::sample_li (diffuse.rs:60-81)
@@ -105,7 +105,7 @@ PB_DEV void light_sample_li(const ShadeConsts& sc, const Surf& sf, const DevLigh
         // Triangle::sample (triangle.rs:330-348) + Shape::sample2 (shape.rs:38-53)
         V3 q0, q1, q2;
         int fl;
-        load_shade_tri(sc.bvh, lt.slot, &q0, &q1, &q2, &fl);
+        load_tri(sc.bvh.tris, lt.slot, &q0, &q1, &q2, &fl);
         float su0 = __builtin_sqrtf(ul0);
         float bx = 1.0f - su0, by = ul1 * su0;
         float bz = 1.0f - bx - by;
@@ -303,9 +303,9 @@ PB_DEV int estimate_direct_emit(const ShadeConsts& sc, const PathState& ps, uint
     if (ok && !is_black(f2) && spdf > 0.0f) {
         float lpdf;
         if (lt.type == PBRT_LIGHT_DIFFUSE_AREA && sc.bvh.has_spheres &&
-            (__float_as_int(shade_tri(sc.bvh, lt.slot, 2).w) & kPrimSphere)) {
+            (__float_as_int(sc.bvh.tris[3 * (size_t)lt.slot + 2].w) & kPrimSphere)) {
             // Sphere::pdf2 (sphere.rs:181-192)
-            float4 rec = shade_tri(sc.bvh, lt.slot, 0);
+            float4 rec = sc.bvh.tris[3 * (size_t)lt.slot];
             float radius = rec.w;
             V3 pc = V3{1.0f * 0.0f + 0.0f * 0.0f + 0.0f * 0.0f + rec.x, 0.0f * 0.0f + 1.0f * 0.0f + 0.0f * 0.0f + rec.y,
                        0.0f * 0.0f + 0.0f * 0.0f + 1.0f * 0.0f + rec.z};
@@ -390,7 +390,7 @@ PB_DEV V3 estimate_direct_resolve(const ShadeConsts& sc, const PathState& ps, ui
         if (hslot >= 0) {
             // D26 (intended): Le only when the hit primitive's area light is this light (an RS_MIS_BOOL ray left 0 for
             // "found" here, not a leaf slot: it is never queued for an area light)
-            int hl = lt.type == PBRT_LIGHT_DIFFUSE_AREA ? (__float_as_int(shade_tri(sc.bvh, hslot, 2).w) & kPrimLightMask) - 1 : -2;
+            int hl = lt.type == PBRT_LIGHT_DIFFUSE_AREA ? (__float_as_int(sc.bvh.tris[3 * (size_t)hslot + 2].w) & kPrimLightMask) - 1 : -2;
             if (hl == light_id) {
                 // (the MIS ray's direction and the hit's barycentrics are read only here: an area light's emitter was hit)
                 float4 r0 = ps.ray[ray_index(ps, p, RS_MIS)], r1 = ps.ray[ray_index(ps, p, RS_MIS) + 1];

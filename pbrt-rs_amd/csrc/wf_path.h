@@ -21,7 +21,7 @@ PB_DEV uint32_t shade_key(const ShadeConsts& sc, const PathState& ps, uint32_t p
         const size_t hb = hit_index(ps, p, RS_CONT);
         int slot = __float_as_int(ps.hit[hb].x), inst = hit_instance(ps, hb);
         if (slot >= 0) {
-            int mat = __float_as_int(shade_tri(sc.bvh, slot, 2).z);
+            int mat = __float_as_int(sc.bvh.tris[3 * (size_t)slot + 2].z);
             if (sc.bvh.instanced && inst >= 0) {
                 int over = __float_as_int(sc.bvh.instances[7 * (size_t)inst + 6].x);
                 if (over >= 0) mat = over;

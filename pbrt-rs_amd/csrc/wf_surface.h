@@ -12,7 +12,7 @@ struct Surf {  // the parts of SurfaceInteraction the path needs
 };
 
 PB_DEV void tri_vertices(const DevBVH& bvh, int slot, V3* p0, V3* p1, V3* p2, int* prim, int* mat, int* light) {
-    float4 a = shade_tri(bvh, slot, 0), b = shade_tri(bvh, slot, 1), c = shade_tri(bvh, slot, 2);
+    float4 a = bvh.tris[3 * (size_t)slot], b = bvh.tris[3 * (size_t)slot + 1], c = bvh.tris[3 * (size_t)slot + 2];
     *p0 = V3{a.x, a.y, a.z};
     *p1 = V3{a.w, b.x, b.y};
     *p2 = V3{b.z, b.w, c.x};
@@ -151,7 +151,7 @@ PB_DEV void instance_to_world(const DevBVH& bvh, int inst_slot, Surf* s) {
 // derivatives, SurfaceInteraction::new, then pbrt-v3's Transform(SurfaceInteraction) through that translation (every
 // product of the general matrix formulas is kept, as in sphere_object_ray). ph = the refined object-space hit point.
 PB_DEV Surf make_surface_sphere(const DevBVH& bvh, int slot, V3 ph, V3 rd) {
-    float4 a = shade_tri(bvh, slot, 0), c4 = shade_tri(bvh, slot, 2);
+    float4 a = bvh.tris[3 * (size_t)slot], c4 = bvh.tris[3 * (size_t)slot + 2];
     float cx = a.x, cy = a.y, cz = a.z, radius = a.w;
     Surf s;
     s.material = __float_as_int(c4.z);
@@ -191,7 +191,7 @@ PB_DEV Surf make_surface_sphere(const DevBVH& bvh, int slot, V3 ph, V3 rd) {
 }
 // Hit record -> world-space surface. `rd` is the world-space ray direction.
 PB_DEV Surf surface_from_hit(const DevBVH& bvh, int slot, int inst_slot, float b0, float b1, float b2, V3 rd) {
-    if (bvh.has_spheres && (__float_as_int(shade_tri(bvh, slot, 2).w) & kPrimSphere))
+    if (bvh.has_spheres && (__float_as_int(bvh.tris[3 * (size_t)slot + 2].w) & kPrimSphere))
         return make_surface_sphere(bvh, slot, V3{b0, b1, b2}, rd);
     if (bvh.instanced && inst_slot >= 0) {
         const float4* m = bvh.instances + 7 * (size_t)inst_slot;
@@ -207,7 +207,7 @@ PB_DEV Surf surface_from_hit(const DevBVH& bvh, int slot, int inst_slot, float b
 }
 // SurfaceInteraction::n of a hit at barycentrics (b0, b1, b2): the geometric normal, on the shading normal's side
 PB_DEV V3 tri_interaction_normal(const DevBVH& bvh, int slot, float b0, float b1, float b2) {
-    if (bvh.has_spheres && (__float_as_int(shade_tri(bvh, slot, 2).w) & kPrimSphere))
+    if (bvh.has_spheres && (__float_as_int(bvh.tris[3 * (size_t)slot + 2].w) & kPrimSphere))
         return make_surface_sphere(bvh, slot, V3{b0, b1, b2}, V3{0.0f, 0.0f, 1.0f}).n;  // (b0, b1, b2) = the hit point
     V3 p0, p1, p2;
     int a, b, c;
@@ -296,7 +296,7 @@ PB_DEV float sample_continuous2(const float* func, const float* cdf, float func_
 PB_DEV bool light_triangle_intersect(const DevBVH& bvh, int slot, V3 o, V3 d, V3* p_hit, V3* n_hit) {
     V3 p0, p1, p2;
     int flags;
-    load_shade_tri(bvh, slot, &p0, &p1, &p2, &flags);
+    load_tri(bvh.tris, slot, &p0, &p1, &p2, &flags);
     TravRay r{o.x, o.y, o.z, d.x, d.y, d.z, kInf};
     TriRayConst c = tri_ray_setup(r);
     float b0, b1, b2, t;
