@@ -733,106 +733,9 @@ def run_rank(args):
         value = rays / elapsed / 1e6
 
         if rank == 0:
-            launches_per_frame = trace_launches / args.steps
-            trace_s_per_launch = trace_ms * 1e-3 / max(trace_launches, 1)
-            rays_per_launch = my_rays / max(trace_launches, 1)
-            # ---- untimed, instrumented renders of this rank's tile set (per-ray figures do not depend on spp: one pass of the
-            # frame is enough where the frame has several) ----
-            instr_spp = min(spp_total, args.spp_per_pass) if args.spp_per_pass > 0 else min(spp_total, 256 if not inst else 32)
-            # (1) the reference's loops: box / triangle tests of BVHAccel::intersect for exactly these rays -> SURVEY 8(d)
-            ctx.set_counting(1)
-            ctx.counters(reset=True)
-            st_c = render_into(films[0], spp=instr_spp)
-            c = ctx.counters(reset=True)
-            frame_rays = st_c["rays_closest"] + st_c["rays_shadow"]
-            alg_bytes = algorithmic_bytes(st_c["rays_closest"], st_c["rays_shadow"], c["node_tests"], c["prim_tests"])
-            # (2) what the kernel itself fetches: 48-B records and 48-B triangles, three 16-B lane requests each
-            wc = None
-            if n_wide >= 0:
-                ctx.set_counting(2)
-                ctx.wide_counters(reset=True)
-                st_w = render_into(films[0], spp=instr_spp)
-                wc = ctx.wide_counters(reset=True)
-                wide_rays = st_w["rays_closest"] + st_w["rays_shadow"]
-            ctx.set_counting(0)
-            if wc is not None:
-                rec_per_ray = (wc["records"] + wc["triangles"]) / max(wide_rays, 1)
-                rec_bytes, table_bytes, waves = 48, max(n_wide, 1) * 48, 5
-            else:   # binary child-pair records: one 64-B record per two box tests
-                rec_per_ray = (c["node_tests"] / 2 + c["prim_tests"]) / max(frame_rays, 1)
-                rec_bytes, table_bytes, waves = 64, scene_interior_bytes(scene), 6
-            rec_per_launch = rec_per_ray * rays_per_launch
-            achieved_rec = rec_per_launch / trace_s_per_launch / 1e9
-            # ---- measured ceilings of the fetch pattern (dependent random record fetches, nothing else to do) ----
-            ceil = {
-                "same_footprint_kernel_occupancy": ctx.probe_gather(table_bytes, rec_bytes, waves) / 1e9,
-                "same_footprint_8_waves": ctx.probe_gather(table_bytes, rec_bytes, 8) / 1e9,
-                "l2_resident_8_waves": ctx.probe_gather(2 << 20, rec_bytes, 8) / 1e9,
-                "l1_resident_8_waves": ctx.probe_gather(16 << 10, rec_bytes, 8) / 1e9,
-            }
-            peak_rec = ceil["l1_resident_8_waves"]
-            gather = {"achieved": round(achieved_rec, 2), "peak": round(peak_rec, 2), "unit": "G records/s",
-                      "frac": round(achieved_rec / peak_rec, 4), "record_bytes": rec_bytes, "records_per_launch": round(rec_per_launch),
-                      "table_bytes": table_bytes, "ceilings_G_records_per_s": {k: round(v, 2) for k, v in ceil.items()}}
-            # ---- the stamped counter profile of this command (fabric bytes, issue, texture addressers) ----
-            tri_bytes = len(sc["indices"]) * 48
-            closest_share = st_c["rays_closest"] / max(frame_rays, 1)
-            compulsory_per_ray = 32 + 16 * closest_share + 4 * (1 - closest_share) + 4                       # ray in, hit out, queue entry
-            compulsory_per_launch = compulsory_per_ray * rays_per_launch + (table_bytes + tri_bytes)       # + the tree, once
-            rec, why_not, hash_differs = measured_traffic(args, world, spp_total, kernel)
-            roofline = roofline_block(
-                kernel_label, trace_s_per_launch, launches_per_frame, rays_per_launch, alg_bytes / max(frame_rays, 1),
-                {"node_tests_per_ray": round(c["node_tests"] / max(c["rays"], 1), 2), "tri_tests_per_ray": round(c["prim_tests"] / max(c["rays"], 1), 2)},
-                gather, compulsory_per_launch, rec, why_not, hash_differs,
-                round(trace_ms * 1e-3 / args.steps / (my_elapsed / args.steps), 3))
-            shade = shade_block(rec, roofline["stale"])
-            if shade:
-                roofline["shade"] = shade
-            if wc is not None:
-                roofline["wide"] = {"records_per_ray": round(wc["records"] / max(wide_rays, 1), 2),
-                                    "leaf_candidates_per_ray": round(wc["leaf_candidates"] / max(wide_rays, 1), 2),
-                                    "triangles_per_ray": round(wc["triangles"] / max(wide_rays, 1), 2),
-                                    "rays_left_to_binary_kernel": wc["special_rays"], "n_records": n_wide}
-            secondary = None
-            config4_n1 = None
-            if world == 1 and config_name == "config3" and not args.no_secondary:
-                try:   # reported beside the measurement, never instead of it
-                    secondary = secondary_config5(torch, pbrt_hip, scenes, ctx, device, peak_rec)
-                except Exception as e:  # noqa: BLE001
-                    secondary = {"error": f"{type(e).__name__}: {e}"}
-                # The N > 1 job is BASELINE config 4 (256 spp, the tiles of the one frame split over the ranks): its
-                # one-GPU point, so that the 1 / 2 / 4 / 8 curve has an anchor on the same workload. Untimed for `value`.
-                try:
-                    runs4 = [scene.render(cam, W, H, 256, max_depth=args.max_depth, rr_threshold=1.0, light_strategy=1, seed=0,
-                                          tile_order=tile_order, d_film_ptr=films[0].data_ptr())[1] for _ in range(2)]
-                    ms4 = [r["total_ms"] for r in runs4]
-                    rays4 = runs4[0]["rays_closest"] + runs4[0]["rays_shadow"]
-                    config4_n1 = {"workload": f"config4 on ONE GPU: the same scene, {W}x{H}x256spp (what --gpus N splits over N ranks); "
-                                              f"mean of {len(ms4)} frames, HIP-event time of the render call, no film reduce; not part of `value`",
-                                  "value": round(rays4 / (sum(ms4) / len(ms4)) / 1e3, 1), "unit": "Mrays/s",
-                                  "ms_per_frame": round(sum(ms4) / len(ms4), 2), "rays_per_frame": int(rays4)}
-                except Exception as e:  # noqa: BLE001
-                    config4_n1 = {"error": f"{type(e).__name__}: {e}"}
-            cpu_baseline = None
-            if world == 1 and not args.no_cpu_baseline:
-                # ---- CPU baseline: the oracle (C++ restatement; the Rust reference cannot be built) on a
-                # bounded crop of the same frame, all host cores this process may use ----
-                sys.path.insert(0, os.path.join(ROOT, "oracle"))
-                import oracle
-                cores = host_cores()
-                cw, ch = min(args.cpu_crop[0], W), min(args.cpu_crop[1], H)
-                x0, y0 = (W - cw) // 2, (H - ch) // 2
-                osc = oracle.OracleScene(sc)
-                _, st_o = osc.render(scenes.camera_dict_to_floats(cam), W, H, args.cpu_spp, max_depth=args.max_depth,
-                                     rr_threshold=1.0, light_strategy=1, seed=0, bounds=(x0, y0, x0 + cw, y0 + ch),
-                                     n_threads=cores)
-                cpu_baseline = {
-                    "value": round(st_o["rays"] / st_o["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": cores,
-                    "kind": "port",
-                    "sample": f"{cw}x{ch} centre crop of the {W}x{H} frame at {args.cpu_spp} spp, same scene/seed, "
-                              f"{cores} oracle threads ({st_o['rays']} rays in {st_o['seconds']:.1f} s)",
-                }
-                osc.close()
+            # The measured line first: value, timing, configuration, the ranks' reports. What follows it — instrumented renders, gather
+            # probes, the config-5 / config-4 side blocks, the CPU oracle — is untimed diagnostics: a failure THERE is reported in the
+            # line (`warnings`, roofline.error) and cannot take the measurement with it.
             split = "one GPU" if world == 1 else (f"{args.spp} spp per GPU" if args.scaling == "weak" else "tiles of the one frame split over the GPUs")
             scene_txt = (f"{args.tris} base triangles x {args.instances} instances, matte / mirror / glass by instance, constant env light"
                          if inst else f"{args.tris} random triangles + constant env light")
@@ -851,7 +754,7 @@ def run_rank(args):
                     "bvh_build_s_host": round(t_bvh, 2),
                     "traversal": f"{kernel_label}" + (f" ({n_wide} 4-wide records)" if n_wide >= 0 else f" (binary records: {wide_reason})"),
                 },
-                "roofline": roofline, "cpu_baseline": cpu_baseline, "secondary": secondary, "config4_n1": config4_n1,
+                "roofline": None, "cpu_baseline": None, "secondary": None, "config4_n1": None,
             })
             out["config"]["dist_backend"] = args.dist_backend if use_dist else None
             out["config"]["launcher"] = ("bench.py --gpus N (its own child processes)" if os.environ.get("PBRT_BENCH_PARENT") and "TORCHELASTIC_RUN_ID" not in os.environ
@@ -870,6 +773,122 @@ def run_rank(args):
                 out["scaling_vs_config4_n1"] = dict(anchor, ratio=round(value / anchor["value"], 3),
                                                     note="this job's rate over the one-GPU rate of the same frame from ANOTHER run (see source): a reading aid; "
                                                          "the driver computes the curve from its own per-N runs")
+
+            def diagnostics():
+                stage.inject("diagnostics")   # test hook (PBRT_BENCH_FAIL=diagnostics@0)
+                launches_per_frame = trace_launches / args.steps
+                trace_s_per_launch = trace_ms * 1e-3 / max(trace_launches, 1)
+                rays_per_launch = my_rays / max(trace_launches, 1)
+                # ---- untimed, instrumented renders of this rank's tile set (per-ray figures do not depend on spp: one pass of the
+                # frame is enough where the frame has several) ----
+                instr_spp = min(spp_total, args.spp_per_pass) if args.spp_per_pass > 0 else min(spp_total, 256 if not inst else 32)
+                # (1) the reference's loops: box / triangle tests of BVHAccel::intersect for exactly these rays -> SURVEY 8(d)
+                ctx.set_counting(1)
+                ctx.counters(reset=True)
+                st_c = render_into(films[0], spp=instr_spp)
+                c = ctx.counters(reset=True)
+                frame_rays = st_c["rays_closest"] + st_c["rays_shadow"]
+                alg_bytes = algorithmic_bytes(st_c["rays_closest"], st_c["rays_shadow"], c["node_tests"], c["prim_tests"])
+                # (2) what the kernel itself fetches: 48-B records and 48-B triangles, three 16-B lane requests each
+                wc = None
+                if n_wide >= 0:
+                    ctx.set_counting(2)
+                    ctx.wide_counters(reset=True)
+                    st_w = render_into(films[0], spp=instr_spp)
+                    wc = ctx.wide_counters(reset=True)
+                    wide_rays = st_w["rays_closest"] + st_w["rays_shadow"]
+                ctx.set_counting(0)
+                if wc is not None:
+                    rec_per_ray = (wc["records"] + wc["triangles"]) / max(wide_rays, 1)
+                    rec_bytes, table_bytes, waves = 48, max(n_wide, 1) * 48, 5
+                else:   # binary child-pair records: one 64-B record per two box tests
+                    rec_per_ray = (c["node_tests"] / 2 + c["prim_tests"]) / max(frame_rays, 1)
+                    rec_bytes, table_bytes, waves = 64, scene_interior_bytes(scene), 6
+                rec_per_launch = rec_per_ray * rays_per_launch
+                achieved_rec = rec_per_launch / trace_s_per_launch / 1e9
+                # ---- measured ceilings of the fetch pattern (dependent random record fetches, nothing else to do) ----
+                ceil = {
+                    "same_footprint_kernel_occupancy": ctx.probe_gather(table_bytes, rec_bytes, waves) / 1e9,
+                    "same_footprint_8_waves": ctx.probe_gather(table_bytes, rec_bytes, 8) / 1e9,
+                    "l2_resident_8_waves": ctx.probe_gather(2 << 20, rec_bytes, 8) / 1e9,
+                    "l1_resident_8_waves": ctx.probe_gather(16 << 10, rec_bytes, 8) / 1e9,
+                }
+                peak_rec = ceil["l1_resident_8_waves"]
+                gather = {"achieved": round(achieved_rec, 2), "peak": round(peak_rec, 2), "unit": "G records/s",
+                          "frac": round(achieved_rec / peak_rec, 4), "record_bytes": rec_bytes, "records_per_launch": round(rec_per_launch),
+                          "table_bytes": table_bytes, "ceilings_G_records_per_s": {k: round(v, 2) for k, v in ceil.items()}}
+                # ---- the stamped counter profile of this command (fabric bytes, issue, texture addressers) ----
+                tri_bytes = len(sc["indices"]) * 48
+                closest_share = st_c["rays_closest"] / max(frame_rays, 1)
+                compulsory_per_ray = 32 + 16 * closest_share + 4 * (1 - closest_share) + 4                       # ray in, hit out, queue entry
+                compulsory_per_launch = compulsory_per_ray * rays_per_launch + (table_bytes + tri_bytes)       # + the tree, once
+                rec, why_not, hash_differs = measured_traffic(args, world, spp_total, kernel)
+                roofline = roofline_block(
+                    kernel_label, trace_s_per_launch, launches_per_frame, rays_per_launch, alg_bytes / max(frame_rays, 1),
+                    {"node_tests_per_ray": round(c["node_tests"] / max(c["rays"], 1), 2), "tri_tests_per_ray": round(c["prim_tests"] / max(c["rays"], 1), 2)},
+                    gather, compulsory_per_launch, rec, why_not, hash_differs,
+                    round(trace_ms * 1e-3 / args.steps / (my_elapsed / args.steps), 3))
+                shade = shade_block(rec, roofline["stale"])
+                if shade:
+                    roofline["shade"] = shade
+                if wc is not None:
+                    roofline["wide"] = {"records_per_ray": round(wc["records"] / max(wide_rays, 1), 2),
+                                        "leaf_candidates_per_ray": round(wc["leaf_candidates"] / max(wide_rays, 1), 2),
+                                        "triangles_per_ray": round(wc["triangles"] / max(wide_rays, 1), 2),
+                                        "rays_left_to_binary_kernel": wc["special_rays"], "n_records": n_wide}
+                secondary = None
+                config4_n1 = None
+                if world == 1 and config_name == "config3" and not args.no_secondary:
+                    try:   # reported beside the measurement, never instead of it
+                        secondary = secondary_config5(torch, pbrt_hip, scenes, ctx, device, peak_rec)
+                    except Exception as e:  # noqa: BLE001
+                        secondary = {"error": f"{type(e).__name__}: {e}"}
+                    # The N > 1 job is BASELINE config 4 (256 spp, the tiles of the one frame split over the ranks): its
+                    # one-GPU point, so that the 1 / 2 / 4 / 8 curve has an anchor on the same workload. Untimed for `value`.
+                    try:
+                        runs4 = [scene.render(cam, W, H, 256, max_depth=args.max_depth, rr_threshold=1.0, light_strategy=1, seed=0,
+                                              tile_order=tile_order, d_film_ptr=films[0].data_ptr())[1] for _ in range(2)]
+                        ms4 = [r["total_ms"] for r in runs4]
+                        rays4 = runs4[0]["rays_closest"] + runs4[0]["rays_shadow"]
+                        config4_n1 = {"workload": f"config4 on ONE GPU: the same scene, {W}x{H}x256spp (what --gpus N splits over N ranks); "
+                                                  f"mean of {len(ms4)} frames, HIP-event time of the render call, no film reduce; not part of `value`",
+                                      "value": round(rays4 / (sum(ms4) / len(ms4)) / 1e3, 1), "unit": "Mrays/s",
+                                      "ms_per_frame": round(sum(ms4) / len(ms4), 2), "rays_per_frame": int(rays4)}
+                    except Exception as e:  # noqa: BLE001
+                        config4_n1 = {"error": f"{type(e).__name__}: {e}"}
+                cpu_baseline = None
+                if world == 1 and not args.no_cpu_baseline:
+                    # ---- CPU baseline: the oracle (C++ restatement; the Rust reference cannot be built) on a
+                    # bounded crop of the same frame, all host cores this process may use ----
+                    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                    import oracle
+                    cores = host_cores()
+                    cw, ch = min(args.cpu_crop[0], W), min(args.cpu_crop[1], H)
+                    x0, y0 = (W - cw) // 2, (H - ch) // 2
+                    osc = oracle.OracleScene(sc)
+                    _, st_o = osc.render(scenes.camera_dict_to_floats(cam), W, H, args.cpu_spp, max_depth=args.max_depth,
+                                         rr_threshold=1.0, light_strategy=1, seed=0, bounds=(x0, y0, x0 + cw, y0 + ch),
+                                         n_threads=cores)
+                    cpu_baseline = {
+                        "value": round(st_o["rays"] / st_o["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": cores,
+                        "kind": "port",
+                        "sample": f"{cw}x{ch} centre crop of the {W}x{H} frame at {args.cpu_spp} spp, same scene/seed, "
+                                  f"{cores} oracle threads ({st_o['rays']} rays in {st_o['seconds']:.1f} s)",
+                    }
+                    osc.close()
+                return roofline, cpu_baseline, secondary, config4_n1
+
+            try:
+                out["roofline"], out["cpu_baseline"], out["secondary"], out["config4_n1"] = diagnostics()
+            except Exception as e:  # noqa: BLE001 - the measurement stands
+                try:
+                    ctx.set_counting(0)
+                except Exception:  # noqa: BLE001
+                    pass
+                out["roofline"] = {"kernel": kernel_label, "bound": "HBM", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": None, "frac": None,
+                                   "traffic": None, "error": f"{type(e).__name__}: {e}"}
+                out.setdefault("warnings", []).append(f"untimed diagnostics failed ({type(e).__name__}: {e}); value and timing are unaffected")
+                print(f"[bench rank {rank}] untimed diagnostics failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
 
         want_abi_check = args.abi_reduce_check or (world > 1 and not args.no_abi_reduce_check)
         if want_abi_check and use_dist and not staged:

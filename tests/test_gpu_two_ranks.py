@@ -191,3 +191,27 @@ def test_a_rank_that_fails_its_render_ends_both_ranks_with_code_4(tmp_path):
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=540) for p in procs]
     assert [p.returncode for p in procs] == [4, 4], [o[1][-1500:] for o in outs]
+
+
+@pytest.mark.timeout(600)
+def test_a_failure_in_the_untimed_diagnostics_does_not_take_the_line():
+    """What follows the timed steps on rank 0 — instrumented renders, gather probes, side blocks, the CPU oracle — is diagnostics:
+    when it fails (PBRT_BENCH_FAIL=diagnostics@0) the line still carries value, timing, configuration and the film check, says
+    what failed (`warnings`, roofline.error), and the exit code stays 0."""
+    env = _env()
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["PBRT_BENCH_FAIL"] = "diagnostics@0"
+    args = ["--steps", "1", "--warmup", "1", "--width", str(W), "--height", str(H), "--spp", str(SPP), "--tris", str(TRIS), "--max-depth", str(DEPTH),
+            "--no-cpu-baseline", "--no-secondary", "--watchdog-s", "240"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["value"] > 0 and line["ms_per_step"] > 0 and line["config"]["film_check"]["ok"] and line["config"]["rays_per_frame"] > 0
+    assert line["roofline"]["bound"] == "HBM" and line["roofline"]["frac"] is None and "injected failure" in line["roofline"]["error"]
+    assert any("untimed diagnostics failed" in w for w in line["warnings"]) and "untimed diagnostics failed" in r.stderr
+    # ... and without the injection the same command fills the block in
+    env.pop("PBRT_BENCH_FAIL")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert r.returncode == 0 and "warnings" not in line and line["roofline"]["gather_frac"] > 0 and "error" not in line["roofline"]
