@@ -480,6 +480,8 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
     if (rank < 0 || rank >= world) return invalid("tile_rank outside [0, tile_world)");
     if (rp.tile_order != PBRT_TILE_ORDER_MORTON && rp.tile_order != PBRT_TILE_ORDER_ROW_MAJOR)
         return invalid("tile_order must be a PbrtTileOrder");
+    if (rp.samples_per_wave < 0 || rp.samples_per_wave > 64 || (rp.samples_per_wave & (rp.samples_per_wave - 1)) != 0)
+        return invalid("samples_per_wave must be 0 (library default) or a power of two up to 64");
     hipStream_t st = ctx->stream;
 
     size_t film_bytes = (size_t)rp.width * rp.height * 4 * sizeof(float);
@@ -772,6 +774,12 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         pp.smp = smp;
         pp.n_pix = n_pix;
         pp.n_samples = std::min(spp_pass, rp.spp - s0);
+        {   // PbrtRenderParams.samples_per_wave: the largest power of two <= the request that divides the pass's samples per pixel
+            const int want = rp.samples_per_wave > 0 ? rp.samples_per_wave : 16;
+            pp.group_shift = 0;
+            while ((2 << pp.group_shift) <= want && pp.group_shift < 6 && pp.n_samples % (2 << pp.group_shift) == 0) ++pp.group_shift;
+            if (li_mode || export_mode) pp.group_shift = 0;  // batches of rays / the exported camera rays keep the caller's order
+        }
         pp.sample0 = s0;
         pp.spp = rp.spp;
         pp.width = rp.width;

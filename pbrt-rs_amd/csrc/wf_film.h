@@ -21,7 +21,7 @@ __global__ void k_film_accumulate(PathState ps, PassParams pp, TileList tiles, f
     if (!(x >= pp.x0 && x < pp.x1 && y >= pp.y0 && y < pp.y1)) return;
     float4 acc = accum[pix];
     for (int s = 0; s < pp.n_samples; ++s) {
-        uint32_t p = (uint32_t)s * pp.n_pix + pix;
+        uint32_t p = sample_pixel_to_path(pp, s, pix);
         float4 Lq = ps.L[p];
         V3 L = V3{Lq.x, Lq.y, Lq.z};
         float yv = 0.212671f * L.x + 0.715160f * L.y + 0.072169f * L.z;

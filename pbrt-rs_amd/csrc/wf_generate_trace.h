@@ -8,7 +8,8 @@ __global__ void k_generate(PathState ps, Queues q, PassParams pp, DevCamera cam,
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = (uint32_t)pp.n_pix * pp.n_samples;
     if (p >= n) return;
-    int s_local = p / pp.n_pix, pix = p % pp.n_pix;
+    int s_local, pix;
+    path_to_sample_pixel(pp, p, &s_local, &pix);
     int tile = pix >> 8, within = pix & 255;
     int2 org = tiles.origin[tile];
     int x = org.x + (within & 15), y = org.y + (within >> 4);
@@ -139,7 +140,8 @@ __global__ void k_camera_rays_out(PathState ps, PassParams pp, TileList tiles, P
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = (uint32_t)pp.n_pix * pp.n_samples;
     if (p >= n) return;
-    int s_local = p / pp.n_pix, pix = p % pp.n_pix;
+    int s_local, pix;
+    path_to_sample_pixel(pp, p, &s_local, &pix);
     int2 org = tiles.origin[pix >> 8];
     int x = org.x + (pix & 15), y = org.y + ((pix & 255) >> 4);
     bool valid = (__float_as_int(ps.beta[p].w) & PF_VALID) != 0;

@@ -93,6 +93,9 @@ struct PassParams {
     SamplerParams smp;
     int n_pix;         // pixels in this GPU's tile set (n_tiles * 256)
     int n_samples;     // samples of this pass
+    int group_shift;   // path layout: a wave of 64 paths = (64 >> group_shift) consecutive pixels x (1 << group_shift) consecutive
+                       // samples of each (0: 64 pixels of one sample index; 6: the 64 samples of one pixel); n_samples is a
+                       // multiple of 1 << group_shift (path_to_sample_pixel / sample_pixel_to_path)
     int sample0;       // first sample index of this pass
     int spp;           // total samples per pixel (RNG keying)
     int width, height;
@@ -108,6 +111,23 @@ struct PassParams {
     // pbrt_hip_li: the caller's stream key of every path (RNG::set_sequence argument); nullptr = the (pixel, sample) keys
     const uint64_t* stream_keys;
 };
+
+// path number <-> (sample of the pass, pixel of the tile set). Paths are laid out wave by wave: wave w holds the pixel block
+// b = w % (n_pix / Pw) (Pw = 64 >> group_shift consecutive pixels) and the sample group g = w / (n_pix / Pw) (G = 1 << group_shift
+// consecutive samples); lane l of it is pixel b Pw + l % Pw, sample g G + l / Pw. group_shift 0 is path = sample * n_pix + pixel.
+PB_DEV void path_to_sample_pixel(const PassParams& pp, uint32_t p, int* s_local, int* pix) {
+    const uint32_t sh = (uint32_t)pp.group_shift, pw_bits = 6u - sh;
+    const uint32_t w = p >> 6, l = p & 63u, blocks = (uint32_t)pp.n_pix >> pw_bits;
+    const uint32_t g = w / blocks, b = w - g * blocks;
+    *pix = (int)((b << pw_bits) | (l & ((1u << pw_bits) - 1u)));
+    *s_local = (int)((g << sh) | (l >> pw_bits));
+}
+PB_DEV uint32_t sample_pixel_to_path(const PassParams& pp, int s_local, uint32_t pix) {
+    const uint32_t sh = (uint32_t)pp.group_shift, pw_bits = 6u - sh;
+    const uint32_t g = (uint32_t)s_local >> sh, b = pix >> pw_bits, blocks = (uint32_t)pp.n_pix >> pw_bits;
+    const uint32_t l = (((uint32_t)s_local & ((1u << sh) - 1u)) << pw_bits) | (pix & ((1u << pw_bits) - 1u));
+    return ((g * blocks + b) << 6) | l;
+}
 
 struct Queues {
     uint32_t* trace;   // entries: path*4 + slot

@@ -363,7 +363,8 @@ PB_DEV Samp path_sampler(const PathState& ps, const PassParams& pp, const TileLi
         sm.h_offset = 0;
         return sm;
     }
-    int s_local = p / pp.n_pix, pix = p % pp.n_pix;
+    int s_local, pix;
+    path_to_sample_pixel(pp, p, &s_local, &pix);
     int2 org = tiles.origin[pix >> 8];
     int x = org.x + (pix & 15), y = org.y + ((pix & 255) >> 4);
     sm.rng.inc = (sample_sequence(pp, x, y, pp.sample0 + s_local) << 1) | 1;

@@ -50,7 +50,8 @@ class RenderParams(ctypes.Structure):
                 ("filter_radius", ctypes.c_float * 2), ("filter_table", ctypes.c_void_p),
                 ("sampler", ctypes.c_int32), ("sampler_x", ctypes.c_int32), ("sampler_y", ctypes.c_int32),
                 ("sampler_jitter", ctypes.c_int32), ("sampler_dims", ctypes.c_int32), ("max_sample_luminance", ctypes.c_float),
-                ("shade_order", ctypes.c_int32), ("ray_order", ctypes.c_int32), ("tile_order", ctypes.c_int32)]
+                ("shade_order", ctypes.c_int32), ("ray_order", ctypes.c_int32), ("tile_order", ctypes.c_int32),
+                ("samples_per_wave", ctypes.c_int32)]
 
 
 class PbrtObject(ctypes.Structure):
@@ -550,7 +551,7 @@ class Scene:
 
     def _params(self, width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
                 tile_rank, tile_world, spp_per_pass, filter=None, ao_samples=64, sampler=None, max_sample_luminance=0.0,
-                shade_order=0, ray_order=0, tile_order=0):
+                shade_order=0, ray_order=0, tile_order=0, samples_per_wave=0):
         rx, ry, table = (0.5, 0.5, None) if filter is None else filter
         if table is not None:
             table = np.ascontiguousarray(table, dtype=np.float32)
@@ -569,12 +570,12 @@ class Scene:
         return RenderParams(integrator, max_depth, rr_threshold, light_strategy, spp, width, height, x0, y0, x1, y1,
                             seed, tile_rank, tile_world, spp_per_pass, ao_samples, (ctypes.c_float * 2)(rx, ry),
                             None if table is None else table.ctypes.data, *smp, float(max_sample_luminance), int(shade_order), int(ray_order),
-                            int(tile_order))
+                            int(tile_order), int(samples_per_wave))
 
     def render(self, camera, width, height, spp, integrator=INTEGRATOR_PATH, max_depth=5, rr_threshold=1.0,
                light_strategy=1, seed=0, bounds=None, tile_rank=0, tile_world=1, spp_per_pass=0, d_film_ptr=None,
                filter=None, ao_samples=64, cos_sample=True, sampler=None, max_sample_luminance=0.0, shade_order=0, ray_order=0,
-               tile_order=0):
+               tile_order=0, samples_per_wave=0):
         """Integrator::render. Returns (film[h,w,4] or None when d_film_ptr is given, stats dict).
         integrator: INTEGRATOR_PATH / _DIRECT / _WHITTED / _AO (ao_samples, cos_sample: AOIntegrator::new).
         sampler: None (RandomSampler), ("stratified", nx, ny, jitter, n_dims) or ("zerotwo", n_dims); the samples
@@ -582,13 +583,14 @@ class Scene:
         filter = (radius_x, radius_y, table256) from filter_table(), None = 0.5 box.
         shade_order: 0 queue order, 1 by material inside blocks, 2 sorted queue (PbrtRenderParams.shade_order).
         ray_order: 0 ray queues in Morton order from the second bounce on, 1 queue order (PbrtRenderParams.ray_order).
-        tile_order: TILE_ORDER_MORTON (0) / TILE_ORDER_ROW_MAJOR (1): how the 16x16 tiles are dealt to the tile_world ranks."""
+        tile_order: TILE_ORDER_MORTON (0) / TILE_ORDER_ROW_MAJOR (1): how the 16x16 tiles are dealt to the tile_world ranks.
+        samples_per_wave: consecutive samples of a pixel that share a wave (0 = library default 16, 1 = rounds 1-4's layout)."""
         camera = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
         if integrator == INTEGRATOR_AO:
             light_strategy = int(bool(cos_sample))
         rp = self._params(width, height, spp, integrator, max_depth, rr_threshold, light_strategy, seed, bounds,
                           tile_rank, tile_world, spp_per_pass, filter, ao_samples, sampler, max_sample_luminance, shade_order, ray_order,
-                          tile_order)
+                          tile_order, samples_per_wave)
         st = RenderStats()
         if d_film_ptr is None:
             film = np.zeros((height, width, 4), dtype=np.float32)

@@ -27,17 +27,17 @@ def test_header_symbols_exported():
 
 
 def test_struct_sizes_match_header(tmp_path):
-    assert ctypes.sizeof(pbrt_hip.RenderParams) == 128  # 11 x i32, pad, u64 seed, 4 x i32, 2 x f32, pointer, 9 x i32, pad
+    assert ctypes.sizeof(pbrt_hip.RenderParams) == 128  # 11 x i32, pad, u64 seed, 4 x i32, 2 x f32, pointer, 10 x i32
     # ... and against the header itself: a C99 translation unit prints what the compiler lays out
     src = tmp_path / "layout.c"
     src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "pbrt_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu\\n", '
                    'sizeof(PbrtRenderParams), offsetof(PbrtRenderParams, seed), offsetof(PbrtRenderParams, filter_table), '
-                   'offsetof(PbrtRenderParams, tile_order), sizeof(PbrtRenderStats)); return 0; }\n')
+                   'offsetof(PbrtRenderParams, samples_per_wave), sizeof(PbrtRenderStats)); return 0; }\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)], text=True).split()]
     P = pbrt_hip.RenderParams
-    assert got == [ctypes.sizeof(P), P.seed.offset, P.filter_table.offset, P.tile_order.offset, ctypes.sizeof(pbrt_hip.RenderStats)]
+    assert got == [ctypes.sizeof(P), P.seed.offset, P.filter_table.offset, P.samples_per_wave.offset, ctypes.sizeof(pbrt_hip.RenderStats)]
     assert ctypes.sizeof(pbrt_hip.RenderStats) == 48
     assert scenes.CAMERA_DTYPE.itemsize == 160
 

@@ -718,3 +718,39 @@ def test_boolean_mis_rays_leave_the_film_and_the_ray_counts_alone(hip_ctx):
         assert (st["rays_closest"], st["rays_shadow"]) == (st_c["rays_closest"], st_c["rays_shadow"])
         assert c["rays"] == st["rays_closest"] + st["rays_shadow"] and c["node_tests"] > 10 * c["rays"]
         g.close()
+
+
+def test_samples_per_wave_is_only_a_layout(hip_ctx):
+    """PbrtRenderParams.samples_per_wave: how the (pixel, sample) paths of a pass are numbered over the 64-lane waves (64 pixels of
+    one sample index, or k consecutive samples of 64 / k neighbouring pixels). Streams are keyed by (pixel, sample) and the film sums
+    a pixel's samples in sample order, so every layout gives the SAME bits as the oracle-checked default: random and tabulated
+    samplers, ragged sample counts (the library falls back to the largest power of two that divides the pass), several passes,
+    tile shares, direct lighting; a wide filter (float atomics) to the usual tolerance. Bad values are refused."""
+    w, h = 112, 80
+    sc, cam = scenes.mixed_materials_scene(), scenes.random_triangles_camera(w, h)
+    g = pbrt_hip.Scene(hip_ctx, sc)
+    cases = [dict(spp=16), dict(spp=6), dict(spp=64, spp_per_pass=16), dict(spp=12, spp_per_pass=5), dict(spp=16, sampler=("stratified", 4, 4, True, 4)),
+             dict(spp=16, sampler=("zerotwo", 3)), dict(spp=8, sampler=("halton",)), dict(spp=8, integrator=pbrt_hip.INTEGRATOR_DIRECT, max_depth=3)]
+    for kw in cases:
+        spp = kw.pop("spp")
+        kw.setdefault("max_depth", 6)
+        ref, st = g.render(cam, w, h, spp, seed=21, samples_per_wave=1, **kw)
+        assert ref[..., :3].max() > 0
+        for k in (0, 2, 4, 16, 64):
+            f, st_k = g.render(cam, w, h, spp, seed=21, samples_per_wave=k, **kw)
+            assert f.tobytes() == ref.tobytes(), (kw, k)
+            assert (st_k["rays_closest"], st_k["rays_shadow"], st_k["camera_samples"]) == (st["rays_closest"], st["rays_shadow"], st["camera_samples"])
+    ref, _ = g.render(cam, w, h, 16, seed=21, samples_per_wave=1)
+    shares = sum(g.render(cam, w, h, 16, seed=21, samples_per_wave=16, tile_rank=r, tile_world=3)[0] for r in range(3))
+    assert np.array_equal(shares, ref)
+    filt = pbrt_hip.filter_table("gaussian", 2.0, 2.0, 2.0)
+    a, _ = g.render(cam, w, h, 16, seed=21, filter=filt, samples_per_wave=1)
+    b, _ = g.render(cam, w, h, 16, seed=21, filter=filt, samples_per_wave=16)
+    assert np.allclose(a, b, rtol=2e-5, atol=2e-5)
+    for bad in (3, -1, 128):
+        with pytest.raises(pbrt_hip.PbrtHipError, match="samples_per_wave"):
+            g.render(cam, w, h, 4, samples_per_wave=bad)
+    # the exported camera rays keep their documented order whatever the parameter says (the layout is the renderer's own)
+    r1 = g.camera_rays(cam, w, h, 4, seed=21)
+    assert len(r1[0]) == ((w + 15) // 16) * ((h + 15) // 16) * 256 * 4
+    g.close()

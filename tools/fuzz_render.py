@@ -157,6 +157,7 @@ def make_case(seed):
     gpu_only = dict(shade_order=int(rng.integers(0, 3)), spp_per_pass=int(rng.integers(0, 3)), ray_order=int(rng.integers(0, 2)))   # must not change the film
     # round 5: the dealing order of the tiles (its own generator: the draws of the cases above stay what they were)
     gpu_only["tile_order"] = int(np.random.default_rng(seed ^ 0x71e0).integers(0, 2))
+    gpu_only["samples_per_wave"] = int(np.random.default_rng(seed ^ 0x5a3e).choice([0, 0, 1, 2, 4, 16, 64]))   # the path layout over the waves
     opts_layout = int(np.random.default_rng(seed ^ 0x11e5).integers(0, 3))   # pbrt_hip_context_set_wide_layout: by size / packed / lines
     plain = "spheres" not in sc and "instances" not in sc and "objects" not in sc and "normals" not in sc and "uvs" not in sc and "tangents" not in sc
     opts = dict(device_build=bool(plain and rng.random() < 0.2),     # the tree built on the device (HLBVH) against the oracle's HLBVH
