@@ -18,18 +18,18 @@ scene = pbrt_hip.Scene(ctx, sc, bvh=bvh)
 print("wide records:", scene.wide_records())
 ctx.set_traversal(int(os.environ.get("TRAVERSAL", "0")))   # 3 = PBRT_TRAVERSAL_ROUNDS
 for it in range(2):
-    film, st = scene.render(cam, W, H, spp, max_depth=16, seed=0, shade_order=ORDER)
+    film, st = scene.render(cam, W, H, spp, max_depth=16, seed=0, shade_order=ORDER, samples_per_wave=int(os.environ.get("SPW", "0")))
 rays = st["rays_closest"] + st["rays_shadow"]
 print(f"{W}x{H}x{spp}: total {st['total_ms']:.1f} ms trace {st['trace_ms']:.1f} ms ({st['trace_launches']} launches) "
       f"rays {rays/1e6:.1f}M -> {rays/st['total_ms']/1e3:.0f} Mrays/s")
 if os.environ.get("NO_COUNT"): sys.exit(0)
 if scene.wide_records()[0] > 0:
     ctx.set_counting(2); ctx.wide_counters(reset=True)
-    scene.render(cam, W, H, spp, max_depth=16, seed=0, shade_order=ORDER)
+    scene.render(cam, W, H, spp, max_depth=16, seed=0, shade_order=ORDER, samples_per_wave=int(os.environ.get("SPW", "0")))
     wc = ctx.wide_counters(reset=True)
     print("wide per ray: " + " ".join(f"{k} {v/rays:.2f}" for k, v in wc.items()))
 ctx.set_counting(True); ctx.counters(reset=True)
-film, st2 = scene.render(cam, W, H, spp, max_depth=16, seed=0, shade_order=ORDER)
+film, st2 = scene.render(cam, W, H, spp, max_depth=16, seed=0, shade_order=ORDER, samples_per_wave=int(os.environ.get("SPW", "0")))
 c = ctx.counters(reset=True); ctx.set_counting(False)
 rays = c["rays"]
 alg = 32*rays + 32*c["node_tests"] + 48*c["prim_tests"] + 112*c.get("inst_tests",0) + 16*st2["rays_closest"] + 4*st2["rays_shadow"]

@@ -19,7 +19,7 @@ mode = int(os.environ.get("TRAVERSAL", "0"))     # pbrt_hip.TRAVERSAL_*: 0 wide 
 ctx.set_traversal(mode)
 print("traversal:", {0: "auto (4-wide records)", 1: "binary records, stack", 2: "binary records, stackless"}[mode])
 for it in range(3):
-    film, st = scene.render(cam, W, H, spp, max_depth=5, seed=0)
+    film, st = scene.render(cam, W, H, spp, max_depth=5, seed=0, samples_per_wave=int(os.environ.get("SPW", "0")))   # SPW: PbrtRenderParams.samples_per_wave
 rays = st["rays_closest"] + st["rays_shadow"]
 print(f"{os.path.basename(pbrt_hip.LIB_PATH)}: total {st['total_ms']:.1f} ms trace {st['trace_ms']:.1f} ms "
       f"({st['trace_launches']} launches) rays {rays/1e6:.1f}M -> {rays/st['total_ms']/1e3:.0f} Mrays/s, "
