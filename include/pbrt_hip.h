@@ -194,11 +194,12 @@ typedef struct PbrtRenderParams {
                          * then owns whole tile COLUMNS). A rank renders its own tiles in row-major order either way (with one rank
                          * the two settings are the same job). The merged film does not depend on it. */
     int32_t samples_per_wave; /* How the paths of a pass are laid out over the 64-lane waves: a wave holds samples_per_wave consecutive
-                         * samples of each of 64 / samples_per_wave neighbouring pixels. 0 = the library's choice (16 where the pass
-                         * has a multiple of 16 samples per pixel, else the largest power of two that divides it); 1 = 64 pixels of
-                         * one sample index (rounds 1-4); a power of two up to 64. The camera rays of a wave — and the first bounce,
-                         * which keeps their order — then start from the same few pixels (profiles/r05_path_layout.txt: +1.5 % of a
-                         * config-3 frame at 16). Streams are keyed by (pixel, sample): the film is the same bits whatever this is. */
+                         * samples of each of 64 / samples_per_wave neighbouring pixels. 0 = the library's choice: the samples of ONE
+                         * pixel per wave (64, or the largest power of two that divides the pass's samples per pixel; the stratified
+                         * and (0,2) samplers, whose tables are read per pixel, keep 1); 1 = 64 pixels of one sample index (rounds
+                         * 1-4); a power of two up to 64. The camera rays of a wave — and the first bounce, which keeps their order
+                         * — then start from the same pixel: +2.5 % of a config-3 frame, +4 % on config 5
+                         * (profiles/r05_path_layout.txt). Streams are keyed by (pixel, sample): the film is the same bits. */
 } PbrtRenderParams;
 
 typedef struct PbrtRenderStats {

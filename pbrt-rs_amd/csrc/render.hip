@@ -775,7 +775,9 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
         pp.n_pix = n_pix;
         pp.n_samples = std::min(spp_pass, rp.spp - s0);
         {   // PbrtRenderParams.samples_per_wave: the largest power of two <= the request that divides the pass's samples per pixel
-            const int want = rp.samples_per_wave > 0 ? rp.samples_per_wave : 16;
+            // default: a wave = the samples of ONE pixel (as many as the pass has, up to 64). The tabulating samplers keep the
+            // old layout: their tables are [element][pixel], read coalesced when a wave's lanes are 64 pixels of one sample
+            const int want = rp.samples_per_wave > 0 ? rp.samples_per_wave : ((tabulated && rp.sampler != PBRT_SAMPLER_HALTON) ? 1 : 64);
             pp.group_shift = 0;
             while ((2 << pp.group_shift) <= want && pp.group_shift < 6 && pp.n_samples % (2 << pp.group_shift) == 0) ++pp.group_shift;
             if (li_mode || export_mode) pp.group_shift = 0;  // batches of rays / the exported camera rays keep the caller's order

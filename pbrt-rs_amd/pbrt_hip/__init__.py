@@ -584,7 +584,7 @@ class Scene:
         shade_order: 0 queue order, 1 by material inside blocks, 2 sorted queue (PbrtRenderParams.shade_order).
         ray_order: 0 ray queues in Morton order from the second bounce on, 1 queue order (PbrtRenderParams.ray_order).
         tile_order: TILE_ORDER_MORTON (0) / TILE_ORDER_ROW_MAJOR (1): how the 16x16 tiles are dealt to the tile_world ranks.
-        samples_per_wave: consecutive samples of a pixel that share a wave (0 = library default 16, 1 = rounds 1-4's layout)."""
+        samples_per_wave: consecutive samples of a pixel that share a wave (0 = library default: one pixel per wave, 1 = rounds 1-4's layout)."""
         camera = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
         if integrator == INTEGRATOR_AO:
             light_strategy = int(bool(cos_sample))
