@@ -987,7 +987,10 @@ int wavefront_render(PbrtHipScene* s, const PbrtCamera& camera, const PbrtRender
             RENDER_TRY(hipGetLastError());
             continue;
         }
-        hipLaunchKernelGGL(k_film_accumulate, dim3((n_pix + 255) / 256), dim3(256), 0, st, ps, pp, tiles, accum, d_film);
+        if (pp.group_shift == 6)  // a wave of paths = one pixel's samples: sixteen lanes per pixel, coalesced reads, ordered row sums
+            hipLaunchKernelGGL(k_film_accumulate_rows, dim3((unsigned)(((size_t)n_pix * 16 + 255) / 256)), dim3(256), 0, st, ps, pp, tiles, accum, d_film);
+        else
+            hipLaunchKernelGGL(k_film_accumulate, dim3((n_pix + 255) / 256), dim3(256), 0, st, ps, pp, tiles, accum, d_film);
         RENDER_TRY(hipGetLastError());
         if (s0 + spp_pass >= rp.spp) {
             hipLaunchKernelGGL(k_film_merge, dim3((n_pix + 255) / 256), dim3(256), 0, st, pp, tiles, accum, d_film);

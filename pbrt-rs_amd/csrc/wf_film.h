@@ -73,6 +73,61 @@ __global__ void k_film_accumulate(PathState ps, PassParams pp, TileList tiles, f
     accum[pix] = acc;
 }
 
+// The same accumulation where a wave of paths is the 64 samples of ONE pixel (PassParams::group_shift == 6, the default layout):
+// sixteen lanes serve a pixel and fetch sixteen consecutive samples in one coalesced piece (a wave = four pixels x 256 bytes per
+// load instruction, as line-efficient as the sample-major layout was for k_film_accumulate); every lane forms its own sample's
+// contribution, then the sixteen are added to the pixel IN SAMPLE ORDER — lane after lane through the row — because float addition
+// is not associative and the reference's loop (and the oracle's) adds them one after the other.
+__global__ void k_film_accumulate_rows(PathState ps, PassParams pp, TileList tiles, float4* accum, float* d_film) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t pix = t >> 4, k = t & 15u;
+    if (pix >= (uint32_t)pp.n_pix) return;  // (whole rows of sixteen lanes leave together)
+    int tile = pix >> 8, within = pix & 255;
+    int2 org = tiles.origin[tile];
+    int x = org.x + (within & 15), y = org.y + (within >> 4);
+    if (!(x >= pp.x0 && x < pp.x1 && y >= pp.y0 && y < pp.y1)) return;
+    const int row0 = (int)(threadIdx.x & 63u & ~15u);
+    float4 acc = accum[pix];
+    for (int s0 = 0; s0 < pp.n_samples; s0 += 16) {
+        const uint32_t p = sample_pixel_to_path(pp, s0 + (int)k, pix);
+        const float4 Lq = ps.L[p];
+        const float2 pf = ps.pfilm[p];
+        V3 L = V3{Lq.x, Lq.y, Lq.z};
+        float yv = 0.212671f * L.x + 0.715160f * L.y + 0.072169f * L.z;
+        // integrator.rs:455 (D23 intended: is_infinite)
+        if (__builtin_isnan(L.x) || __builtin_isnan(L.y) || __builtin_isnan(L.z) || yv < -1e-5f || __builtin_isinf(yv))
+            L = V3{0.0f, 0.0f, 0.0f};
+        L = clamp_sample_luminance(L, pp.max_sample_luminance);
+        float dx = pf.x - 0.5f, dy = pf.y - 0.5f;
+        int px0 = max((int)__builtin_ceilf(dx - 0.5f), 0), py0 = max((int)__builtin_ceilf(dy - 0.5f), 0);
+        int px1 = min((int)__builtin_floorf(dx + 0.5f) + 1, pp.width), py1 = min((int)__builtin_floorf(dy + 0.5f) + 1, pp.height);
+        float own = 0.0f;  // the sample's weight in its own pixel (1 unless its footprint misses it: a film position outside the pixel)
+        for (int yy = py0; yy < py1; ++yy)
+            for (int xx = px0; xx < px1; ++xx) {
+                if (xx == x && yy == y) {
+                    own = 1.0f;
+                } else {  // a sample on a pixel border also lands on the neighbour, which may belong to another tile / GPU
+                    float* fp = d_film + ((size_t)yy * pp.width + xx) * 4;
+                    atomicAdd(fp + 0, 0.412453f * L.x + 0.357580f * L.y + 0.180423f * L.z);
+                    atomicAdd(fp + 1, 0.212671f * L.x + 0.715160f * L.y + 0.072169f * L.z);
+                    atomicAdd(fp + 2, 0.019334f * L.x + 0.119193f * L.y + 0.950227f * L.z);
+                    atomicAdd(fp + 3, 1.0f);
+                }
+            }
+        for (int j = 0; j < 16; ++j) {  // sample s0 + j: every lane of the row adds it to its copy of the pixel, in order
+            const float cx = __shfl(L.x, row0 + j, 64), cy = __shfl(L.y, row0 + j, 64), cz = __shfl(L.z, row0 + j, 64);
+            const float w = __shfl(own, row0 + j, 64);
+            if (w != 0.0f) {
+                acc.x += cx;
+                acc.y += cy;
+                acc.z += cz;
+                acc.w += 1.0f;
+            }
+        }
+    }
+    if (k == 0) accum[pix] = acc;
+}
+
 // General reconstruction filter: FilmTile::add_sample (film.rs:252-295) as a scatter. Each sample adds
 // L * weight * filter and the filter weight to every pixel of its footprint with float atomics (the
 // footprints of neighbouring samples, tiles and GPUs overlap); XYZ conversion is linear, so it is applied
