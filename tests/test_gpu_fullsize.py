@@ -257,6 +257,8 @@ def test_film_properties_at_full_size(hip_ctx, w, h, spp):
     fc = bench.check_film_weights(box[..., 3].astype(np.float64), spp)
     assert fc["ok"] and fc["excess"] > 0, fc          # (samples that round onto a pixel border count in both neighbours)
     assert np.all(np.abs(pbrt_hip.film_to_rgb(box) - through) <= 2e-6 * max(le))
+    clamped, _ = g.render(cam, w, h, spp, max_depth=5, seed=1, max_sample_luminance=1.0)   # film.rs:253-255 through the same kernels
+    assert np.all(np.abs(cf.luminance(pbrt_hip.film_to_rgb(clamped)) - 1.0) <= 3e-6)
     shares = sum(g.render(cam, w, h, spp, max_depth=5, seed=1, tile_rank=r, tile_world=8)[0] for r in range(8))
     # bit for bit wherever a pixel's samples all come from its own tile; a pixel on a tile border may also hold border samples of
     # the neighbouring tiles (other ranks under the Morton deal), and then only the ORDER of the float additions differs

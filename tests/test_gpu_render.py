@@ -725,11 +725,13 @@ def test_samples_per_wave_is_only_a_layout(hip_ctx):
     one sample index, or k consecutive samples of 64 / k neighbouring pixels). Streams are keyed by (pixel, sample) and the film sums
     a pixel's samples in sample order, so every layout gives the SAME bits as the oracle-checked default: random and tabulated
     samplers, ragged sample counts (the library falls back to the largest power of two that divides the pass), several passes,
-    tile shares, direct lighting; a wide filter (float atomics) to the usual tolerance. Bad values are refused."""
+    tile shares, direct lighting, the luminance clamp, 64 and 128 samples per pixel (k_film_accumulate_rows: one pixel per wave); a wide
+    filter (float atomics) to the usual tolerance. Bad values are refused."""
     w, h = 112, 80
     sc, cam = scenes.mixed_materials_scene(), scenes.random_triangles_camera(w, h)
     g = pbrt_hip.Scene(hip_ctx, sc)
-    cases = [dict(spp=16), dict(spp=6), dict(spp=64, spp_per_pass=16), dict(spp=12, spp_per_pass=5), dict(spp=16, sampler=("stratified", 4, 4, True, 4)),
+    cases = [dict(spp=16), dict(spp=6), dict(spp=64), dict(spp=128, max_depth=3), dict(spp=64, spp_per_pass=16), dict(spp=12, spp_per_pass=5),
+             dict(spp=64, max_sample_luminance=0.05, max_depth=3), dict(spp=16, sampler=("stratified", 4, 4, True, 4)),
              dict(spp=16, sampler=("zerotwo", 3)), dict(spp=8, sampler=("halton",)), dict(spp=8, integrator=pbrt_hip.INTEGRATOR_DIRECT, max_depth=3)]
     for kw in cases:
         spp = kw.pop("spp")
