@@ -148,6 +148,8 @@ def make_case(seed):
         kw.update(ao_samples=int(rng.integers(1, 9)), cos_sample=bool(rng.integers(0, 2)))
     smp = rng.choice(["random", "random", "stratified", "zerotwo", "halton"])
     spp = int(rng.choice([1, 2, 4]))
+    if np.random.default_rng(seed ^ 0x64a).random() < 0.03:   # round 5: a pass of 64 samples = one pixel per wave (k_film_accumulate_rows)
+        spp = 64
     if smp == "stratified":
         kw["sampler"] = ("stratified", 2, spp, bool(rng.integers(0, 2)), int(rng.integers(0, 5)))
     elif smp == "zerotwo":
