@@ -628,6 +628,13 @@ def run_rank(args):
         raise SystemExit("bench.py needs an MI355X: no GPU is visible (the HIP path has no CPU fallback)")
     if args.one_gpu:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        # a node with fewer visible devices than ranks: say so and leave with the stage-failure code BEFORE the rendezvous, so
+        # that the launcher (or the parent above) ends the job in seconds instead of the peers waiting for this rank
+        print(f"[bench rank {rank}] LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible "
+              f"(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?): --gpus {args.gpus} needs one device per rank", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(4)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run the RCCL path runs even with one rank

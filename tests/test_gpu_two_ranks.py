@@ -215,3 +215,20 @@ def test_a_failure_in_the_untimed_diagnostics_does_not_take_the_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert r.returncode == 0 and "warnings" not in line and line["roofline"]["gather_frac"] > 0 and "error" not in line["roofline"]
+
+
+@pytest.mark.timeout(600)
+def test_more_ranks_than_visible_devices_ends_quickly_with_code_4():
+    """`python bench.py --gpus 2` on this one-GPU box WITHOUT --one-gpu: rank 1 finds no device for itself, says so and leaves with
+    code 4 before the rendezvous; the parent gives rank 0 (waiting for its peer) the grace period, ends it by pid and returns 4 —
+    in well under a minute, not after the 600-second watchdog."""
+    import time
+    env = _env()
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    args = [a for a in ARGS if a != "--one-gpu"]
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 4, (r.returncode, r.stderr[-2000:])
+    assert "only 1 GPU(s) are visible" in r.stderr and time.time() - t0 < 240
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
