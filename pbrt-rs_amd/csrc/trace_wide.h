@@ -16,8 +16,12 @@
 
 namespace pb {
 
+// Waves per SIMD of the one-level kernel. 6 since round 5: the kernel needs 84 VGPRs, the compiler reaches the 80 that six waves
+// allow without scratch, and six blocks' stacks (6 x 24.5 KB) still fit the CU's 160 KB of LDS: -1.6 % of the traversal time
+// (profiles/r05_path_layout.txt item 6; in round 3, at 86 VGPRs, six waves spilled and gained nothing). Seven would need 72 VGPRs
+// (24 bytes of scratch) and a 10-entry LDS stack. The two-level kernels stay at 5: their 31.7 KB of LDS per block allow no more.
 #ifndef PB_WIDE_WAVES
-#define PB_WIDE_WAVES 5
+#define PB_WIDE_WAVES 6
 #endif
 #ifndef PB_WIDE_INST_WAVES
 #define PB_WIDE_INST_WAVES 5
