@@ -4,8 +4,10 @@
 set -o pipefail
 tag=${1:-run}
 mkdir -p gpurun_out
+if [ -z "$SKIP_SUITE" ]; then   # SKIP_SUITE=1: only the stamped profile and the bench lines (the suite ran on these sources already)
 timeout -k 10 1100 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee gpurun_out/r5_suite_$tag.txt
 grep -q " passed" gpurun_out/r5_suite_$tag.txt && ! grep -q "failed\|error" gpurun_out/r5_suite_$tag.txt || exit 1
+fi
 PB_COMMIT=$(cat .pb_commit 2>/dev/null) timeout -k 10 1500 bash tools/measure_traffic.sh > gpurun_out/r5_measure_traffic_$tag.txt 2>&1 || { tail -20 gpurun_out/r5_measure_traffic_$tag.txt; exit 1; }
 tail -3 gpurun_out/r5_measure_traffic_$tag.txt
 timeout -k 10 600 python bench.py > gpurun_out/r5_bench_line_$tag.json 2> gpurun_out/r5_bench_err_$tag.txt || { tail -20 gpurun_out/r5_bench_err_$tag.txt; exit 1; }
