@@ -16,8 +16,11 @@
 //   DirectLightingIntegrator::new  src/integrators/directlighting.rs:33-46   pbrt::DirectLightingIntegrator
 //   WhittedIntegrator::new / AOIntegrator::new   src/integrators/whitted.rs:22-45, ao.rs:20-34   pbrt::WhittedIntegrator, pbrt::AOIntegrator
 //   Film, Film::write_image        src/core/film.rs:30-63, 153-178    pbrt::Film
-//   PerspectiveCamera::new         src/cameras/perspective.rs:34-82   pbrt::PerspectiveCamera
-//   RandomSampler::new             src/samplers/random.rs:12-20       pbrt::RandomSampler
+//   Filter + src/filters/*.rs       src/core/filter.rs:10-15           pbrt::Filter, BoxFilter, TriangleFilter, GaussianFilter, MitchellFilter, LanczosSincFilter
+//   Camera, PerspectiveCamera::new src/core/camera.rs:17-60, src/cameras/perspective.rs:34-82   pbrt::Camera, pbrt::PerspectiveCamera
+//   OrthographicCamera::new / EnvironmentCamera::new   src/cameras/orthographic.rs:37-80, environment.rs:19-29   pbrt::OrthographicCamera, pbrt::EnvironmentCamera
+//   Sampler, RandomSampler::new    src/core/sampler.rs:12-60, src/samplers/random.rs:12-20      pbrt::Sampler, pbrt::RandomSampler
+//   StratifiedSampler::new / ZeroTwoSequenceSampler::new / HaltonSampler::new   src/samplers/stratified.rs:22-40, zerotwosequence.rs:17-23, halton.rs:63-98
 // Errors: the reference has no error channel — bool / Option for misses, panic! otherwise. A miss is `false` here
 // too; what would be a panic there (a failed device call, a bad argument) is a pbrt::Error carrying pbrt_hip_last_error.
 #pragma once
@@ -250,14 +253,43 @@ private:
     std::shared_ptr<BVHAccel> aggregate_;
 };
 
+struct Vector2f {
+    Float x = 0, y = 0;
+};
+// Filter (src/core/filter.rs:10-15: radius, evaluate) with the five of src/filters/: what Film::new tabulates (film.rs:52-63)
+struct Filter {
+    PbrtFilterType kind = PBRT_FILTER_BOX;
+    Vector2f radius{0.5f, 0.5f};
+    Float a = 0, b = 0;  // GaussianFilter alpha / MitchellFilter B, C / LanczosSincFilter tau
+};
+struct BoxFilter : Filter {  // src/filters/boxf.rs
+    explicit BoxFilter(Vector2f r = {0.5f, 0.5f}) { kind = PBRT_FILTER_BOX, radius = r; }
+};
+struct TriangleFilter : Filter {  // src/filters/triangle.rs
+    explicit TriangleFilter(Vector2f r = {2.0f, 2.0f}) { kind = PBRT_FILTER_TRIANGLE, radius = r; }
+};
+struct GaussianFilter : Filter {  // src/filters/gaussian.rs:12-31
+    explicit GaussianFilter(Vector2f r = {2.0f, 2.0f}, Float alpha = 2.0f) { kind = PBRT_FILTER_GAUSSIAN, radius = r, a = alpha; }
+};
+struct MitchellFilter : Filter {  // src/filters/mitchell.rs:12-41
+    explicit MitchellFilter(Vector2f r = {2.0f, 2.0f}, Float B = 1.0f / 3.0f, Float C = 1.0f / 3.0f) { kind = PBRT_FILTER_MITCHELL, radius = r, a = B, b = C; }
+};
+struct LanczosSincFilter : Filter {  // src/filters/sinc.rs:12-45
+    explicit LanczosSincFilter(Vector2f r = {4.0f, 4.0f}, Float tau = 3.0f) { kind = PBRT_FILTER_LANCZOS, radius = r, a = tau; }
+};
+
 // Film::new (src/core/film.rs:30-63) with one of src/filters/*.rs; pixels = {xyz[3], filter_weight_sum} (film.rs:9-15)
 class Film {
 public:
-    Film(int width, int height, PbrtFilterType filter = PBRT_FILTER_BOX, Float radius = 0.5f, Float a = 0, Float b = 0, Float max_sample_luminance = 0)
-        : width(width), height(height), radius(radius), max_sample_luminance(max_sample_luminance), pixels((size_t)width * height * 4, 0.0f) {
-        box_ = filter == PBRT_FILTER_BOX && radius == 0.5f;
-        if (!box_ && pbrt_hip_filter_table((int32_t)filter, radius, radius, a, b, table_) != PBRT_HIP_OK) throw Error("Film::new: bad filter", PBRT_HIP_ERR_INVALID);
+    Film(int width, int height, const Filter& filter, Float max_sample_luminance = 0)
+        : width(width), height(height), radius(filter.radius.x), radius_y(filter.radius.y), max_sample_luminance(max_sample_luminance),
+          pixels((size_t)width * height * 4, 0.0f) {
+        box_ = filter.kind == PBRT_FILTER_BOX && filter.radius.x == 0.5f && filter.radius.y == 0.5f;
+        if (!box_ && pbrt_hip_filter_table((int32_t)filter.kind, filter.radius.x, filter.radius.y, filter.a, filter.b, table_) != PBRT_HIP_OK)
+            throw Error("Film::new: bad filter", PBRT_HIP_ERR_INVALID);
     }
+    Film(int width, int height, PbrtFilterType filter = PBRT_FILTER_BOX, Float radius = 0.5f, Float a = 0, Float b = 0, Float max_sample_luminance = 0)
+        : Film(width, height, make_filter(filter, radius, a, b), max_sample_luminance) {}
     // Film::write_image (film.rs:153-178): xyz / weight -> RGB; the writer the reference leaves as todo!() (imageio.rs:3-5)
     void write_image(const std::string& path) const {
         std::vector<float> rgb((size_t)width * height * 3);
@@ -274,21 +306,28 @@ public:
     }
     const float* filter_table() const { return box_ ? nullptr : table_; }
     int width, height;
-    Float radius, max_sample_luminance;
+    Float radius, radius_y, max_sample_luminance;  // filter radius in x (`radius`) and y
     std::vector<float> pixels;
 
 private:
+    static Filter make_filter(PbrtFilterType kind, Float r, Float a, Float b) {
+        Filter f;
+        f.kind = kind, f.radius = {r, r}, f.a = a, f.b = b;
+        return f;
+    }
     bool box_ = true;
     float table_[256];
 };
 
-// PerspectiveCamera::new(camera_to_world, screen_window, shutter, lens_radius, focal_distance, fov, film):
-// perspective.rs:34-82 with transform.rs:510-566's look_at / perspective, computed in double and rounded once
-class PerspectiveCamera {
+// Camera (src/core/camera.rs:17-60): camera_to_world, the shutter, the film. look_at as transform.rs:510-545, in double, rounded once
+class Camera {
 public:
-    PerspectiveCamera(const Point3f& eye, const Point3f& look, const Vector3f& up_in, Float fov_deg, std::shared_ptr<Film> film_in, Float lens_radius = 0,
-                      Float focal_distance = 1e6f)
-        : film(std::move(film_in)) {
+    virtual ~Camera() = default;
+    PbrtCamera cam;
+    std::shared_ptr<Film> film;
+
+protected:
+    Camera(const Point3f& eye, const Point3f& look, const Vector3f& up_in, std::shared_ptr<Film> film_in, PbrtCameraKind kind) : film(std::move(film_in)) {
         std::memset(&cam, 0, sizeof(cam));
         double d[3] = {look.x - eye.x, look.y - eye.y, look.z - eye.z}, up[3] = {up_in.x, up_in.y, up_in.z}, right[3], new_up[3];
         auto norm = [](double v[3]) {
@@ -310,6 +349,22 @@ public:
             cam.camera_to_world[4 * r + 3] = (float)e[r];
         }
         cam.camera_to_world[15] = 1.0f;
+        cam.shutter_close = 1.0f;
+        cam.kind = kind;
+    }
+    // inverse(screen_to_raster) for the screen window [sx0, sx1] x [sy0, sy1] (camera.rs:120-135): raster (x, y) -> screen
+    void raster_to_screen(double sx0, double sx1, double sy0, double sy1, double out[4]) const {
+        out[0] = (sx1 - sx0) / film->width, out[1] = sx0, out[2] = (sy0 - sy1) / film->height, out[3] = sy1;
+    }
+};
+
+// PerspectiveCamera::new(camera_to_world, screen_window, shutter, lens_radius, focal_distance, fov, film):
+// perspective.rs:34-82 with transform.rs:510-566's look_at / perspective, computed in double and rounded once
+class PerspectiveCamera : public Camera {
+public:
+    PerspectiveCamera(const Point3f& eye, const Point3f& look, const Vector3f& up, Float fov_deg, std::shared_ptr<Film> film_in, Float lens_radius = 0,
+                      Float focal_distance = 1e6f)
+        : Camera(eye, look, up, std::move(film_in), PBRT_CAMERA_PERSPECTIVE) {
         const int w = film->width, h = film->height;
         const double n = 1e-2, f = 1000.0, A = f / (f - n), B = -f * n / (f - n);
         const double inv_tan = 1.0 / std::tan(fov_deg * 3.14159265358979323846 / 360.0), aspect = (double)w / h;
@@ -324,17 +379,67 @@ public:
         m[15] = (float)(-A / B);
         cam.lens_radius = lens_radius;
         cam.focal_distance = focal_distance;
-        cam.shutter_close = 1.0f;
-        cam.kind = PBRT_CAMERA_PERSPECTIVE;
     }
-    PbrtCamera cam;
-    std::shared_ptr<Film> film;
 };
 
-// RandomSampler::new(samples_per_pixel, seed) (random.rs:12-20); streams are keyed per (pixel, sample): DESIGN.md section 2
-struct RandomSampler {
+// OrthographicCamera::new (orthographic.rs:37-80): camera_to_screen = orthographic(0, 1), the identity in z; the screen window is
+// [-aspect, aspect] x [-1, 1] scaled by `half_height` (pbrt's "screenwindow")
+class OrthographicCamera : public Camera {
+public:
+    OrthographicCamera(const Point3f& eye, const Point3f& look, const Vector3f& up, Float half_height, std::shared_ptr<Film> film_in, Float lens_radius = 0,
+                       Float focal_distance = 1e6f)
+        : Camera(eye, look, up, std::move(film_in), PBRT_CAMERA_ORTHOGRAPHIC) {
+        const double aspect = (double)film->width / film->height, hh = half_height;
+        double r[4];
+        raster_to_screen(-aspect * hh, aspect * hh, -hh, hh, r);
+        float* m = cam.raster_to_camera;
+        m[0] = (float)r[0], m[3] = (float)r[1], m[5] = (float)r[2], m[7] = (float)r[3];
+        m[10] = 1.0f, m[15] = 1.0f;
+        cam.lens_radius = lens_radius;
+        cam.focal_distance = focal_distance;
+    }
+};
+
+// EnvironmentCamera::new (environment.rs:19-29): every direction of the sphere, from one point; only camera_to_world is used
+class EnvironmentCamera : public Camera {
+public:
+    EnvironmentCamera(const Point3f& eye, const Point3f& look, const Vector3f& up, std::shared_ptr<Film> film_in)
+        : Camera(eye, look, up, std::move(film_in), PBRT_CAMERA_ENVIRONMENT) {
+        for (int k = 0; k < 4; ++k) cam.raster_to_camera[5 * k] = 1.0f;
+    }
+};
+
+// Sampler (src/core/sampler.rs:12-60): samples_per_pixel and what its constructor fixes. A value: the device draws the samples
+struct Sampler {
     int samples_per_pixel = 16;
     uint64_t seed = 0;
+    PbrtSamplerKind kind = PBRT_SAMPLER_RANDOM;
+    int x_pixel_samples = 0, y_pixel_samples = 0;  // StratifiedSampler
+    bool jitter_samples = true;
+    int n_sampled_dimensions = 0;  // PixelSampler::new (sampler.rs:252-275)
+};
+// RandomSampler::new(samples_per_pixel, seed) (random.rs:12-20); streams are keyed per (pixel, sample): DESIGN.md section 2
+struct RandomSampler : Sampler {
+    RandomSampler(int spp = 16, uint64_t seed_in = 0) { samples_per_pixel = spp, seed = seed_in; }
+};
+// StratifiedSampler::new(x_pixel_samples, y_pixel_samples, jitter_samples, n_sampled_dimensions) (stratified.rs:22-40)
+struct StratifiedSampler : Sampler {
+    StratifiedSampler(int x, int y, bool jitter, int n_dims, uint64_t seed_in = 0) {
+        kind = PBRT_SAMPLER_STRATIFIED, x_pixel_samples = x, y_pixel_samples = y, jitter_samples = jitter, n_sampled_dimensions = n_dims;
+        samples_per_pixel = x * y, seed = seed_in;
+    }
+};
+// ZeroTwoSequenceSampler::new(samples_per_pixel, n_sampled_dimensions) (zerotwosequence.rs:17-23: rounded up to a power of two)
+struct ZeroTwoSequenceSampler : Sampler {
+    ZeroTwoSequenceSampler(int spp, int n_dims = 4, uint64_t seed_in = 0) {
+        kind = PBRT_SAMPLER_ZEROTWO, n_sampled_dimensions = n_dims, seed = seed_in, x_pixel_samples = y_pixel_samples = 1;
+        samples_per_pixel = 1;
+        while (samples_per_pixel < spp) samples_per_pixel *= 2;
+    }
+};
+// HaltonSampler::new(samples_per_pixel, sample_bounds, sample_at_pixel_center = false) (halton.rs:63-98); the bounds are the film's
+struct HaltonSampler : Sampler {
+    explicit HaltonSampler(int spp, uint64_t seed_in = 0) { kind = PBRT_SAMPLER_HALTON, samples_per_pixel = spp, seed = seed_in, x_pixel_samples = y_pixel_samples = 1; }
 };
 struct Bounds2i {
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
@@ -354,23 +459,26 @@ public:
 // SamplerIntegrator (integrator.rs:399-480): camera, sampler, pixel bounds; render = the tile / pixel / sample loop, on the device
 class SamplerIntegrator : public Integrator {
 public:
-    SamplerIntegrator(std::shared_ptr<const PerspectiveCamera> camera, RandomSampler sampler, Bounds2i pixel_bounds)
+    SamplerIntegrator(std::shared_ptr<const Camera> camera, Sampler sampler, Bounds2i pixel_bounds)
         : camera(std::move(camera)), sampler(sampler), pixel_bounds(pixel_bounds) {}
     void render(const Scene& scene) override {
         PbrtRenderParams rp = params();
         Film& film = *camera->film;
         rp.spp = sampler.samples_per_pixel;
         rp.seed = sampler.seed;
+        rp.sampler = sampler.kind, rp.sampler_x = sampler.x_pixel_samples, rp.sampler_y = sampler.y_pixel_samples;
+        rp.sampler_jitter = sampler.jitter_samples ? 1 : 0, rp.sampler_dims = sampler.n_sampled_dimensions;
         rp.width = film.width, rp.height = film.height;
         if (pixel_bounds.x1 > pixel_bounds.x0) {
             rp.x0 = pixel_bounds.x0, rp.y0 = pixel_bounds.y0, rp.x1 = pixel_bounds.x1, rp.y1 = pixel_bounds.y1;
         } else {  // Film::get_sample_bounds (film.rs:76-81)
             int32_t b[4];
-            pbrt_hip_sample_bounds(film.width, film.height, film.radius, film.radius, b);
+            pbrt_hip_sample_bounds(film.width, film.height, film.radius, film.radius_y, b);
             rp.x0 = b[0], rp.y0 = b[1], rp.x1 = b[2], rp.y1 = b[3];
         }
-        rp.tile_world = 1;
-        rp.filter_radius[0] = rp.filter_radius[1] = film.radius;
+        // the 16x16 tiles of the frame (integrator.rs:404-409) this process renders: tile_rank of tile_world, dealt in Morton order
+        rp.tile_rank = tile_rank, rp.tile_world = tile_world;
+        rp.filter_radius[0] = film.radius, rp.filter_radius[1] = film.radius_y;
         rp.filter_table = film.filter_table();
         rp.max_sample_luminance = film.max_sample_luminance;
         PbrtRenderStats st;
@@ -387,10 +495,11 @@ public:
         scene.aggregate().context()->check(pbrt_hip_li(scene.aggregate().handle(), &lp, &r, &stream_key, 1, l.c, nullptr), "Integrator::li");
         return l;
     }
-    std::shared_ptr<const PerspectiveCamera> camera;
-    RandomSampler sampler;
+    std::shared_ptr<const Camera> camera;
+    Sampler sampler;
     Bounds2i pixel_bounds;
     RenderStats stats;
+    int tile_rank = 0, tile_world = 1;  // one process per GPU: the films of the tile_world processes add up to the frame
 
 protected:
     virtual PbrtRenderParams params() const = 0;
@@ -406,7 +515,7 @@ enum class LightSampleStrategy { Uniform = 0, Power = 1, Spatial = 2 };  // ligh
 // PathIntegrator::new(max_depth, camera, sampler, pixel_bounds, rr_threshold, light_sample_strategy) (path.rs:31-46)
 class PathIntegrator : public SamplerIntegrator {
 public:
-    PathIntegrator(int max_depth, std::shared_ptr<const PerspectiveCamera> camera, RandomSampler sampler, Bounds2i pixel_bounds = Bounds2i(),
+    PathIntegrator(int max_depth, std::shared_ptr<const Camera> camera, Sampler sampler, Bounds2i pixel_bounds = Bounds2i(),
                    Float rr_threshold = 1.0f, LightSampleStrategy light_sample_strategy = LightSampleStrategy::Spatial)
         : SamplerIntegrator(std::move(camera), sampler, pixel_bounds), max_depth(max_depth), rr_threshold(rr_threshold), strategy(light_sample_strategy) {}
     int max_depth;
@@ -426,7 +535,7 @@ enum class LightStrategy { UniformSampleAll = 0, UniformSampleOne = 1 };  // dir
 // DirectLightingIntegrator::new(strategy, max_depth, camera, sampler, pixel_bounds) (directlighting.rs:33-46)
 class DirectLightingIntegrator : public SamplerIntegrator {
 public:
-    DirectLightingIntegrator(LightStrategy strategy, int max_depth, std::shared_ptr<const PerspectiveCamera> camera, RandomSampler sampler,
+    DirectLightingIntegrator(LightStrategy strategy, int max_depth, std::shared_ptr<const Camera> camera, Sampler sampler,
                              Bounds2i pixel_bounds = Bounds2i())
         : SamplerIntegrator(std::move(camera), sampler, pixel_bounds), strategy(strategy), max_depth(max_depth) {}
     LightStrategy strategy;
@@ -443,7 +552,7 @@ protected:
 // WhittedIntegrator::new(max_depth, camera, sampler, pixel_bounds) (whitted.rs:22-45)
 class WhittedIntegrator : public SamplerIntegrator {
 public:
-    WhittedIntegrator(int max_depth, std::shared_ptr<const PerspectiveCamera> camera, RandomSampler sampler, Bounds2i pixel_bounds = Bounds2i())
+    WhittedIntegrator(int max_depth, std::shared_ptr<const Camera> camera, Sampler sampler, Bounds2i pixel_bounds = Bounds2i())
         : SamplerIntegrator(std::move(camera), sampler, pixel_bounds), max_depth(max_depth) {}
     int max_depth;
 
@@ -458,7 +567,7 @@ protected:
 // AOIntegrator::new(cos_sample, n_samples, camera, sampler, pixel_bounds) (ao.rs:20-34)
 class AOIntegrator : public SamplerIntegrator {
 public:
-    AOIntegrator(bool cos_sample, int n_samples, std::shared_ptr<const PerspectiveCamera> camera, RandomSampler sampler, Bounds2i pixel_bounds = Bounds2i())
+    AOIntegrator(bool cos_sample, int n_samples, std::shared_ptr<const Camera> camera, Sampler sampler, Bounds2i pixel_bounds = Bounds2i())
         : SamplerIntegrator(std::move(camera), sampler, pixel_bounds), cos_sample(cos_sample), n_samples(n_samples) {}
     bool cos_sample;
     int n_samples;

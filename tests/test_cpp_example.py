@@ -16,10 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_DIR = os.path.dirname(pbrt_hip.LIB_PATH)
 
 
-def _build(tmp_path):
-    exe = str(tmp_path / "render_box_cpp")
+def _build(tmp_path, source="render_box.cpp"):
+    exe = str(tmp_path / source.replace(".cpp", "_cpp"))
     cmd = ["g++", "-std=c++17", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", "render_box.cpp"), "-o", exe, "-L" + LIB_DIR, "-lpbrt_hip", "-Wl,-rpath," + LIB_DIR]
+           os.path.join(ROOT, "examples", source), "-o", exe, "-L" + LIB_DIR, "-lpbrt_hip", "-Wl,-rpath," + LIB_DIR]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe
@@ -31,10 +31,15 @@ def test_cpp_mirror_names_the_reference_surface():
     for name in ("class Primitive", "class BVHAccel : public Primitive", "class Scene", "class Integrator", "class SamplerIntegrator : public Integrator",
                  "class PathIntegrator : public SamplerIntegrator", "class DirectLightingIntegrator : public SamplerIntegrator", "class Film",
                  "class PerspectiveCamera", "struct RandomSampler", "PbrtInstance TransformedPrimitive(", "class WhittedIntegrator", "class AOIntegrator", "bool intersect(Ray& ray, SurfaceInteraction* isect) const",
-                 "bool intersect_p(const Ray& ray) const", "Bounds3f world_bound() const", "void render(const Scene& scene)", "void write_image("):
+                 "bool intersect_p(const Ray& ray) const", "Bounds3f world_bound() const", "void render(const Scene& scene)", "void write_image(",
+                 "struct Filter", "struct BoxFilter : Filter", "struct TriangleFilter : Filter", "struct GaussianFilter : Filter", "struct MitchellFilter : Filter",
+                 "struct LanczosSincFilter : Filter", "class Camera", "class PerspectiveCamera : public Camera", "class OrthographicCamera : public Camera",
+                 "class EnvironmentCamera : public Camera", "struct Sampler", "struct RandomSampler : Sampler", "struct StratifiedSampler : Sampler",
+                 "struct ZeroTwoSequenceSampler : Sampler", "struct HaltonSampler : Sampler"):
         assert name in hpp, name
     for cite in ("src/core/primitive.rs:17-30", "src/accelerators/bvh.rs:216-271", "src/core/scene.rs:18-46", "src/core/integrator.rs:29-42",
-                 "src/integrators/path.rs:31-46", "src/core/film.rs:30-63", "src/cameras/perspective.rs:34-82", "bvh.rs:934-953"):
+                 "src/integrators/path.rs:31-46", "src/core/film.rs:30-63", "src/cameras/perspective.rs:34-82", "bvh.rs:934-953",
+                 "src/core/filter.rs:10-15", "orthographic.rs:37-80", "environment.rs:19-29", "stratified.rs:22-40", "zerotwosequence.rs:17-23", "halton.rs:63-98"):
         assert cite in hpp, cite
     assert "#include <torch" not in hpp and "hip_runtime" not in hpp and "#include <hip" not in hpp   # plain C++ over the C ABI
 
@@ -78,3 +83,88 @@ def test_cpp_caller_renders_what_the_c_caller_renders(tmp_path):
     # TransformedPrimitives under a top-level BVHAccel (primitive.rs:105-159): the floor of the copy moved to x = +5, seen from its
     # centre, is at t = 1 inside instance 0; the world bound spans both copies; nothing between them
     assert "instanced: hit 1 t 1.000000 instance 0 world bound x [-6.0, 6.0] miss-between 0" in r.stdout, r.stdout
+
+
+def test_cpp_variants_caller_compiles_and_refuses_to_run_without_a_gpu(tmp_path):
+    import torch
+    exe = _build(tmp_path, "render_variants.cpp")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present (covered by the gpu test)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "pbrt::Error (3)" in r.stderr and "no CPU fallback" in r.stderr and r.stdout == ""
+
+
+def _open_box():
+    """The scene of examples/render_variants.cpp (= render_box.c), array for array."""
+    import numpy as np
+    from pbrt_hip import scenes
+    c = {k: (float(2 * int(k[0]) - 1), float(2 * int(k[1]) - 1), float(2 * int(k[2]) - 1)) for k in ("000", "100", "010", "110", "001", "101", "011", "111")}
+    quads = [((c["000"], c["100"], c["101"], c["001"]), 0, False), ((c["010"], c["011"], c["111"], c["110"]), 0, False),
+             ((c["001"], c["101"], c["111"], c["011"]), 0, False), ((c["000"], c["001"], c["011"], c["010"]), 1, False),
+             ((c["100"], c["110"], c["111"], c["101"]), 2, False),
+             (((-0.3, 0.99, -0.3), (0.3, 0.99, -0.3), (0.3, 0.99, 0.3), (-0.3, 0.99, 0.3)), 0, True)]
+    pos, idx, mat, tri_light, lights = [], [], [], [], []
+    for corners, m, emitter in quads:
+        v0 = len(pos)
+        pos.extend(corners)
+        for t in ((0, 1, 2), (0, 2, 3)):
+            idx.append([v0 + t[0], v0 + t[1], v0 + t[2]])
+            mat.append(m)
+            if emitter:
+                tri_light.append(len(lights))
+                lights.append((scenes.LIGHT_DIFFUSE_AREA, (17.0, 17.0, 17.0), len(idx) - 1, 1, 1))
+            else:
+                tri_light.append(-1)
+    materials = scenes._materials([(scenes.MAT_MATTE, kd, (0, 0, 0), 1.0) for kd in ((0.73, 0.73, 0.73), (0.65, 0.05, 0.05), (0.12, 0.45, 0.15))])
+    return dict(positions=np.asarray(pos, dtype=np.float32), indices=np.asarray(idx, dtype=np.int32), tri_material=np.asarray(mat, dtype=np.int32),
+                materials=materials, tri_light=np.asarray(tri_light, dtype=np.int32), lights=scenes._lights(lights))
+
+
+@pytest.mark.gpu
+def test_cpp_variants_are_the_jobs_the_python_binding_sets_up(tmp_path):
+    """Filters, samplers, cameras and integrators named as the reference names them (include/pbrt_hip.hpp) arrive at the C ABI
+    as the same jobs the Python binding of that ABI sets up: equal ray counts, equal films (their sums, in double)."""
+    import numpy as np
+    from pbrt_hip import scenes
+    W, H = 64, 48
+    r = subprocess.run([_build(tmp_path, "render_variants.cpp"), str(W), str(H)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = {m.group(1): (int(m.group(2)), int(m.group(3)), int(m.group(4)), float(m.group(5)), float(m.group(6)))
+           for m in re.finditer(r"variant (\S+): (\d+) camera samples, (\d+) closest-hit \+ (\d+) shadow rays; film xyz (\S+) weight (\S+)", r.stdout)}
+    cams = {m.group(1): np.array([float.fromhex(v) for v in m.group(2).split()], dtype=np.float32) for m in re.finditer(r"camera (\S+):((?: \S+){32})", r.stdout)}
+    assert len(got) == 11 and set(cams) == {"orthographic", "environment"}, r.stdout
+    ctx = pbrt_hip.Context(0)
+    scene = pbrt_hip.Scene(ctx, _open_box())
+    eye, look, up = (0.0, 0.0, -3.4), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)
+    persp = scenes.perspective_camera(eye, look, up, 40.0, W, H)
+
+    def same(name, film, st):
+        n, closest, shadow, xyz, weight = got[name]
+        assert (st["camera_samples"], st["rays_closest"], st["rays_shadow"]) == (n, closest, shadow), (name, st, got[name])
+        f = film.astype(np.float64)
+        # wider filters splat with float atomics in whatever order the waves arrive: equal up to the order of the additions
+        tol = 1e-6 if name in ("triangle", "gaussian", "mitchell", "lanczos") else 1e-9
+        assert abs(f[..., :3].sum() - xyz) <= tol * abs(xyz) and abs(f[..., 3].sum() - weight) <= tol * abs(weight), (name, f[..., :3].sum(), xyz)
+
+    for name, ft in (("box", None), ("triangle", pbrt_hip.filter_table("triangle", 2.0, 1.5)), ("gaussian", pbrt_hip.filter_table("gaussian", 2.0, 2.0, 2.0)),
+                     ("mitchell", pbrt_hip.filter_table("mitchell", 2.0, 2.0, 1.0 / 3.0, 1.0 / 3.0)), ("lanczos", pbrt_hip.filter_table("lanczos", 3.0, 3.0, 3.0))):
+        same(name, *scene.render(persp, W, H, 16, max_depth=5, seed=7, light_strategy=1, filter=ft))
+    for name, smp, spp in (("stratified", ("stratified", 4, 4, True, 4), 16), ("zerotwo", ("zerotwo", 4), 16), ("halton", ("halton",), 16)):
+        same(name, *scene.render(persp, W, H, spp, max_depth=4, seed=3, light_strategy=2, sampler=smp))
+
+    def camera_from(values, like):
+        cam = like.copy()
+        cam["camera_to_world"], cam["raster_to_camera"] = values[:16], values[16:]
+        return cam
+    ortho = scenes.orthographic_camera(eye, look, up, 1.2, W, H)
+    env = scenes.environment_camera((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), up)
+    for key, cam in (("orthographic", ortho), ("environment", env)):   # the C++ constructors against the Python ones, then bit for bit the C++ values
+        ref = np.concatenate([np.asarray(cam["camera_to_world"]).reshape(-1), np.asarray(cam["raster_to_camera"]).reshape(-1)])
+        np.testing.assert_allclose(cams[key], ref, rtol=0, atol=1e-6)
+    same("orthographic-direct", *scene.render(camera_from(cams["orthographic"], ortho), W, H, 8, integrator=pbrt_hip.INTEGRATOR_DIRECT, max_depth=3, seed=1, light_strategy=0))
+    same("environment-whitted", *scene.render(camera_from(cams["environment"], env), W, H, 4, integrator=pbrt_hip.INTEGRATOR_WHITTED, max_depth=3, seed=2, light_strategy=0))
+    same("environment-ao", *scene.render(camera_from(cams["environment"], env), W, H, 4, integrator=pbrt_hip.INTEGRATOR_AO, ao_samples=16, cos_sample=True, seed=2, max_depth=0))
+    m = re.search(r"two shares: (\d+) rays against (\d+) of the whole frame, (\d+) of (\d+) film values differ", r.stdout)
+    assert m and m.group(1) == m.group(2) and m.group(3) == "0" and int(m.group(4)) == W * H * 4, r.stdout
+    scene.close()
+    ctx.close()
