@@ -7,6 +7,7 @@
 //   g++ -std=c++17 -Wall -Iinclude examples/render_variants.cpp -o render_variants -Lpbrt-rs_amd/pbrt_hip -lpbrt_hip -Wl,-rpath,$PWD/pbrt-rs_amd/pbrt_hip
 //   ./render_variants [width height]
 #include <array>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -132,6 +133,53 @@ int main(int argc, char** argv) try {
         AOIntegrator ao(true, 16, camera_ao, RandomSampler(4, 2));
         ao.render(scene);
         report("environment-ao", ao, *film_ao);
+    }
+
+    // the other ways a BVHAccel comes to be: HLBVH built on the device (the same tree as the host's, so the same film), a Sphere
+    // beside the triangles (sphere.rs), per-vertex shading normals on the mesh (triangle.rs:252-312)
+    {
+        auto on_device = std::make_shared<BVHAccel>(ctx, mesh, 4, BuildOnDevice{});
+        auto on_host = std::make_shared<BVHAccel>(ctx, mesh, 4, SplitMethod::HLBVH);
+        std::shared_ptr<Film> films[2];
+        int k = 0;
+        for (const auto& aggregate : {on_device, on_host}) {
+            films[k] = std::make_shared<Film>(width, height);
+            auto camera = std::make_shared<PerspectiveCamera>(eye, look, up, 40.0f, films[k]);
+            PathIntegrator integrator(5, camera, RandomSampler(16, 5));
+            integrator.render(Scene(aggregate));
+            if (k == 0) report("hlbvh-device", integrator, *films[k]);
+            ++k;
+        }
+        std::printf("hlbvh device against host: films %s, world bound y [%.2f, %.2f] / [%.2f, %.2f]\n", films[0]->pixels == films[1]->pixels ? "equal" : "DIFFER",
+                    on_device->world_bound().min.y, on_device->world_bound().max.y, on_host->world_bound().min.y, on_host->world_bound().max.y);
+    }
+    {
+        Sphere ball;
+        ball.centre = {0.2f, -0.6f, 0.1f}, ball.radius = 0.4f, ball.material = 1;
+        Scene with_ball(std::make_shared<BVHAccel>(ctx, mesh, std::vector<Sphere>{ball}));
+        auto film = std::make_shared<Film>(width, height);
+        auto camera = std::make_shared<PerspectiveCamera>(eye, look, up, 40.0f, film);
+        DirectLightingIntegrator integrator(LightStrategy::UniformSampleOne, 3, camera, RandomSampler(8, 9));
+        integrator.render(with_ball);
+        report("sphere", integrator, *film);
+        Ray at_ball;  // from the opening towards the ball's centre: the sphere's near side, primitive n_triangles + 0
+        at_ball.o = {0.2f, -0.6f, -3.0f}, at_ball.d = {0, 0, 1};
+        SurfaceInteraction si;
+        const bool hit = with_ball.intersect(at_ball, &si);
+        std::printf("sphere: hit %d t %.4f primitive %d\n", (int)hit, si.t, si.primitive);
+    }
+    {
+        TriangleMesh smooth = mesh;  // shading normals bent towards the middle of the box
+        for (int v = 0; v < smooth.n_vertices(); ++v) {
+            const float* q = &smooth.p[3 * (size_t)v];
+            const float l = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+            for (int k = 0; k < 3; ++k) smooth.n.push_back(-q[k] / l);
+        }
+        auto film = std::make_shared<Film>(width, height);
+        auto camera = std::make_shared<PerspectiveCamera>(eye, look, up, 40.0f, film);
+        PathIntegrator integrator(3, camera, RandomSampler(8, 11));
+        integrator.render(Scene(std::make_shared<BVHAccel>(ctx, smooth, 4, SplitMethod::SAH)));
+        report("vertex-normals", integrator, *film);
     }
 
     // one frame as the two shares two processes (one per GPU) would render: the films add up to the frame

@@ -12,6 +12,7 @@
 //   Scene            src/core/scene.rs:18-46                          pbrt::Scene      (intersect / intersect_p forward to the aggregate)
 //   Integrator       src/core/integrator.rs:29-42                     pbrt::Integrator (render(&scene)), pbrt::SamplerIntegrator (li)
 //   TransformedPrimitive::new      src/core/primitive.rs:105-123      pbrt::TransformedPrimitive (instances of one aggregate under a top-level BVHAccel)
+//   TriangleMesh (n, s, uv), Sphere::new   src/shapes/triangle.rs:17-26, sphere.rs:38-62   pbrt::TriangleMesh, pbrt::Sphere
 //   PathIntegrator::new            src/integrators/path.rs:31-46      pbrt::PathIntegrator
 //   DirectLightingIntegrator::new  src/integrators/directlighting.rs:33-46   pbrt::DirectLightingIntegrator
 //   WhittedIntegrator::new / AOIntegrator::new   src/integrators/whitted.rs:22-45, ao.rs:20-34   pbrt::WhittedIntegrator, pbrt::AOIntegrator
@@ -100,9 +101,21 @@ struct TriangleMesh {
     std::vector<int32_t> area_light;      // per triangle, index into `lights` or -1
     std::vector<PbrtMaterial> materials;
     std::vector<PbrtLight> lights;  // DiffuseAreaLights on triangles, InfiniteAreaLight, point / spot / distant
+    std::vector<Float> n, s, uv;    // optional per-vertex shading normals (3), tangents (3), texture coordinates (2): triangle.rs:22-25
     int32_t n_triangles() const { return (int32_t)(vertex_indices.size() / 3); }
     int32_t n_vertices() const { return (int32_t)(p.size() / 3); }
 };
+
+// Sphere::new(object_to_world = translate(centre), radius, z_min = -radius, z_max = radius, phi_max = 360) (src/shapes/sphere.rs:38-62)
+// as a GeometricPrimitive with a material and, optionally, a DiffuseAreaLight (index into the mesh's lights, whose `prim` is
+// n_triangles + the sphere's index)
+struct Sphere {
+    Point3f centre;
+    Float radius = 1;
+    int32_t material = 0;
+    int32_t area_light = -1;
+};
+struct BuildOnDevice {};  // tag: BVHAccel::new(HLBVH) built and laid out on the GPU (bvh.rs:475-568), nothing of the tree crosses PCIe
 
 // src/core/primitive.rs:17-30
 class Primitive {
@@ -167,6 +180,54 @@ public:
         pbrt_hip_free(nodes);
         pbrt_hip_free(order);
         ctx_->check(rc, "BVHAccel::new: pbrt_hip_scene_create");
+        set_shading_data(mesh);
+    }
+    // BVHAccel::new(primitives, max_prims_in_node, SplitMethod::HLBVH) with the tree built on the device; the same tree, byte for
+    // byte, as the host builder's (include/pbrt_hip.h: pbrt_hip_scene_create_hlbvh)
+    BVHAccel(std::shared_ptr<Context> ctx, const TriangleMesh& mesh, int max_prims_in_node, BuildOnDevice) : ctx_(std::move(ctx)) {
+        bound_ = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+        for (int32_t v : mesh.vertex_indices)
+            for (int k = 0; k < 3; ++k) {
+                (&bound_.min.x)[k] = std::fmin((&bound_.min.x)[k], mesh.p[3 * (size_t)v + k]);
+                (&bound_.max.x)[k] = std::fmax((&bound_.max.x)[k], mesh.p[3 * (size_t)v + k]);
+            }
+        ctx_->check(pbrt_hip_scene_create_hlbvh(ctx_->handle(), mesh.p.data(), mesh.n_vertices(), mesh.vertex_indices.data(), mesh.n_triangles(),
+                                                mesh.material.data(), mesh.materials.data(), (int32_t)mesh.materials.size(), mesh.area_light.data(),
+                                                mesh.lights.data(), (int32_t)mesh.lights.size(), max_prims_in_node, &h_, &build_ms, &layout_ms),
+                    "BVHAccel::new: pbrt_hip_scene_create_hlbvh");
+        set_shading_data(mesh);
+    }
+    // Triangles and Spheres side by side under one BVHAccel (BASELINE config 1's shapes): the tree is built over the primitives'
+    // world bounds, triangles first (Triangle::world_bound triangle.rs:175-180, Sphere::world_bound through translate(centre))
+    BVHAccel(std::shared_ptr<Context> ctx, const TriangleMesh& mesh, const std::vector<Sphere>& spheres, int max_prims_in_node = 4,
+             SplitMethod split_method = SplitMethod::SAH)
+        : ctx_(std::move(ctx)) {
+        const size_t nt = (size_t)mesh.n_triangles(), ns = spheres.size();
+        std::vector<float> lo(3 * (nt + ns)), hi(3 * (nt + ns)), sph(4 * ns);
+        std::vector<int32_t> sph_material(ns), sph_light(ns);
+        for (size_t t = 0; t < nt; ++t)
+            for (int k = 0; k < 3; ++k) {
+                const float a = mesh.p[3 * (size_t)mesh.vertex_indices[3 * t] + k], b = mesh.p[3 * (size_t)mesh.vertex_indices[3 * t + 1] + k],
+                            c = mesh.p[3 * (size_t)mesh.vertex_indices[3 * t + 2] + k];
+                lo[3 * t + k] = std::fmin(a, std::fmin(b, c)), hi[3 * t + k] = std::fmax(a, std::fmax(b, c));
+            }
+        for (size_t i = 0; i < ns; ++i) {
+            const float c[3] = {spheres[i].centre.x, spheres[i].centre.y, spheres[i].centre.z}, r = spheres[i].radius;
+            for (int k = 0; k < 3; ++k) lo[3 * (nt + i) + k] = c[k] + (-r), hi[3 * (nt + i) + k] = c[k] + r, sph[4 * i + k] = c[k];
+            sph[4 * i + 3] = r, sph_material[i] = spheres[i].material, sph_light[i] = spheres[i].area_light;
+        }
+        PbrtLinearBVHNode* nodes = nullptr;
+        int32_t n_nodes = 0, *order = nullptr;
+        int rc = pbrt_hip_bvh_build_boxes(lo.data(), hi.data(), (int32_t)(nt + ns), max_prims_in_node, (int)split_method, &nodes, &n_nodes, &order);
+        if (rc != PBRT_HIP_OK) throw Error("BVHAccel::new: pbrt_hip_bvh_build_boxes failed", rc);
+        for (int k = 0; k < 3; ++k) (&bound_.min.x)[k] = nodes[0].bounds_min[k], (&bound_.max.x)[k] = nodes[0].bounds_max[k];
+        n_nodes_ = n_nodes;
+        rc = pbrt_hip_scene_create_with_spheres(ctx_->handle(), mesh.p.data(), mesh.n_vertices(), mesh.vertex_indices.data(), mesh.n_triangles(),
+                                                mesh.material.data(), mesh.materials.data(), (int32_t)mesh.materials.size(), mesh.area_light.data(),
+                                                mesh.lights.data(), (int32_t)mesh.lights.size(), sph.data(), sph_material.data(), sph_light.data(), (int32_t)ns,
+                                                nodes, n_nodes, order, &h_);
+        pbrt_hip_free(nodes), pbrt_hip_free(order);
+        ctx_->check(rc, "BVHAccel::new: pbrt_hip_scene_create_with_spheres");
     }
     // The top-level aggregate of a scene of TransformedPrimitives (primitive.rs:105-159): BVHAccel::new over the object's
     // triangles (object space), TransformedPrimitive::new(object, to_world) per instance, BVHAccel::new over their world bounds.
@@ -230,9 +291,17 @@ public:
     }
     PbrtHipScene* handle() const { return h_; }
     const std::shared_ptr<Context>& context() const { return ctx_; }
-    int32_t n_nodes() const { return n_nodes_; }
+    int32_t n_nodes() const { return n_nodes_; }  // 0 for a tree that never left the device
+    double build_ms = 0, layout_ms = 0;           // BuildOnDevice: HIP-event times of the build and of the re-layout
 
 private:
+    void set_shading_data(const TriangleMesh& mesh) {
+        if (mesh.n.empty() && mesh.s.empty() && mesh.uv.empty()) return;
+        ctx_->check(pbrt_hip_scene_set_shading_data(h_, mesh.p.data(), mesh.n_vertices(), mesh.vertex_indices.data(), mesh.n_triangles(),
+                                                    mesh.n.empty() ? nullptr : mesh.n.data(), mesh.s.empty() ? nullptr : mesh.s.data(),
+                                                    mesh.uv.empty() ? nullptr : mesh.uv.data()),
+                    "TriangleMesh: pbrt_hip_scene_set_shading_data");
+    }
     static PbrtRay to_c(const Ray& ray) { return {{ray.o.x, ray.o.y, ray.o.z}, {ray.d.x, ray.d.y, ray.d.z}, ray.t_max, ray.time}; }
     std::shared_ptr<Context> ctx_;
     PbrtHipScene* h_ = nullptr;

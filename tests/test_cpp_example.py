@@ -132,7 +132,7 @@ def test_cpp_variants_are_the_jobs_the_python_binding_sets_up(tmp_path):
     got = {m.group(1): (int(m.group(2)), int(m.group(3)), int(m.group(4)), float(m.group(5)), float(m.group(6)))
            for m in re.finditer(r"variant (\S+): (\d+) camera samples, (\d+) closest-hit \+ (\d+) shadow rays; film xyz (\S+) weight (\S+)", r.stdout)}
     cams = {m.group(1): np.array([float.fromhex(v) for v in m.group(2).split()], dtype=np.float32) for m in re.finditer(r"camera (\S+):((?: \S+){32})", r.stdout)}
-    assert len(got) == 11 and set(cams) == {"orthographic", "environment"}, r.stdout
+    assert len(got) == 14 and set(cams) == {"orthographic", "environment"}, r.stdout
     ctx = pbrt_hip.Context(0)
     scene = pbrt_hip.Scene(ctx, _open_box())
     eye, look, up = (0.0, 0.0, -3.4), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)
@@ -164,6 +164,20 @@ def test_cpp_variants_are_the_jobs_the_python_binding_sets_up(tmp_path):
     same("orthographic-direct", *scene.render(camera_from(cams["orthographic"], ortho), W, H, 8, integrator=pbrt_hip.INTEGRATOR_DIRECT, max_depth=3, seed=1, light_strategy=0))
     same("environment-whitted", *scene.render(camera_from(cams["environment"], env), W, H, 4, integrator=pbrt_hip.INTEGRATOR_WHITTED, max_depth=3, seed=2, light_strategy=0))
     same("environment-ao", *scene.render(camera_from(cams["environment"], env), W, H, 4, integrator=pbrt_hip.INTEGRATOR_AO, ao_samples=16, cos_sample=True, seed=2, max_depth=0))
+    # BVHAccel::new(HLBVH) on the device, a Sphere beside the triangles, per-vertex shading normals
+    assert "hlbvh device against host: films equal, world bound y [-1.00, 1.00] / [-1.00, 1.00]" in r.stdout, r.stdout
+    box = _open_box()
+    on_device = pbrt_hip.Scene(ctx, box, device_build=True)
+    same("hlbvh-device", *on_device.render(persp, W, H, 16, max_depth=5, seed=5, light_strategy=2))
+    on_device.close()
+    with_ball = pbrt_hip.Scene(ctx, dict(box, spheres=np.array([[0.2, -0.6, 0.1, 0.4, 1, -1, 0, 0]], dtype=np.float32)))
+    same("sphere", *with_ball.render(persp, W, H, 8, integrator=pbrt_hip.INTEGRATOR_DIRECT, max_depth=3, seed=9, light_strategy=1))
+    with_ball.close()
+    assert re.search(r"sphere: hit 1 t 2\.7000 primitive 12", r.stdout), r.stdout       # z = 0.1 - 0.4 seen from z = -3; 12 triangles come first
+    p32 = box["positions"]
+    smooth = pbrt_hip.Scene(ctx, dict(box, normals=(-p32 / np.sqrt((p32 * p32).sum(axis=1, dtype=np.float32))[:, None]).astype(np.float32)))
+    same("vertex-normals", *smooth.render(persp, W, H, 8, max_depth=3, seed=11, light_strategy=2))
+    smooth.close()
     m = re.search(r"two shares: (\d+) rays against (\d+) of the whole frame, (\d+) of (\d+) film values differ", r.stdout)
     assert m and m.group(1) == m.group(2) and m.group(3) == "0" and int(m.group(4)) == W * H * 4, r.stdout
     scene.close()
