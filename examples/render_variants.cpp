@@ -182,6 +182,44 @@ int main(int argc, char** argv) try {
         report("vertex-normals", integrator, *film);
     }
 
+    // the general top level: TransformedPrimitives of two different aggregates and world-space triangles (with the area lights) beside them
+    {
+        TriangleMesh walls;  // object 0: the five walls of the box; object 1: a square blade in the plane y = 0
+        walls.p = mesh.p, walls.vertex_indices.assign(mesh.vertex_indices.begin(), mesh.vertex_indices.begin() + 30);
+        walls.material.assign(mesh.material.begin(), mesh.material.begin() + 10);
+        TriangleMesh blade;
+        blade.p = {-0.5f, 0, -0.5f, 0.5f, 0, -0.5f, 0.5f, 0, 0.5f, -0.5f, 0, 0.5f};
+        blade.vertex_indices = {0, 1, 2, 0, 2, 3};
+        blade.material = {1, 1};
+        TriangleMesh world;  // a floor under everything and an emitter above, facing down
+        world.p = {-8, -1.25f, -8, 8, -1.25f, -8, 8, -1.25f, 8, -8, -1.25f, 8, -1, 3, -1, 1, 3, -1, 1, 3, 1, -1, 3, 1};
+        world.vertex_indices = {0, 2, 1, 0, 3, 2, 4, 5, 6, 4, 6, 7};
+        world.material = {0, 0, 0, 0};
+        world.area_light = {-1, -1, 0, 1};
+        world.materials = mesh.materials;
+        for (int t = 2; t < 4; ++t) {
+            PbrtLight l{};
+            l.type = PBRT_LIGHT_DIFFUSE_AREA, l.L[0] = l.L[1] = l.L[2] = 30.0f, l.prim = t, l.two_sided = 0, l.n_samples = 1;
+            world.lights.push_back(l);
+        }
+        const double moved[16] = {1, 0, 0, 3, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, turned[16] = {0, 0, 1, -3, 0, 1, 0, 0, -1, 0, 0, 0, 0, 0, 0, 1},
+                     lowered[16] = {1, 0, 0, 0, 0, 1, 0, -0.5, 0, 0, 1, 0, 0, 0, 0, 1};
+        auto top = std::make_shared<BVHAccel>(ctx, std::vector<TriangleMesh>{walls, blade},
+                                              std::vector<PbrtInstance>{TransformedPrimitive(moved), TransformedPrimitive(turned, 2), TransformedPrimitive(lowered)},
+                                              std::vector<int32_t>{0, 0, 1}, world);
+        auto film = std::make_shared<Film>(width, height);
+        auto camera = std::make_shared<PerspectiveCamera>(Point3f{0, 1.5f, -9}, look, up, 40.0f, film);
+        PathIntegrator integrator(4, camera, RandomSampler(8, 13));
+        integrator.render(Scene(top));
+        report("two-level", integrator, *film);
+        Ray down;  // onto the blade from above: instance 2, its first or second triangle, t = 1.5 from y = 1
+        down.o = {0.1f, 1, 0.2f}, down.d = {0, -1, 0};
+        SurfaceInteraction si;
+        const bool hit = top->intersect(down, &si);
+        std::printf("two-level: hit %d t %.4f instance %d primitive %d; world bound x [%.1f, %.1f]\n", (int)hit, si.t, si.instance, si.primitive,
+                    top->world_bound().min.x, top->world_bound().max.x);
+    }
+
     // one frame as the two shares two processes (one per GPU) would render: the films add up to the frame
     {
         auto whole = std::make_shared<Film>(width, height);

@@ -11,7 +11,7 @@
 //   BVHAccel::new    src/accelerators/bvh.rs:216-271                  pbrt::BVHAccel   (host build -> resident in HBM; aggregates panic on get_material / get_area_light, bvh.rs:934-953)
 //   Scene            src/core/scene.rs:18-46                          pbrt::Scene      (intersect / intersect_p forward to the aggregate)
 //   Integrator       src/core/integrator.rs:29-42                     pbrt::Integrator (render(&scene)), pbrt::SamplerIntegrator (li)
-//   TransformedPrimitive::new      src/core/primitive.rs:105-123      pbrt::TransformedPrimitive (instances of one aggregate under a top-level BVHAccel)
+//   TransformedPrimitive::new      src/core/primitive.rs:105-123      pbrt::TransformedPrimitive (instances of one or of several aggregates under a top-level BVHAccel, world triangles beside them)
 //   TriangleMesh (n, s, uv), Sphere::new   src/shapes/triangle.rs:17-26, sphere.rs:38-62   pbrt::TriangleMesh, pbrt::Sphere
 //   PathIntegrator::new            src/integrators/path.rs:31-46      pbrt::PathIntegrator
 //   DirectLightingIntegrator::new  src/integrators/directlighting.rs:33-46   pbrt::DirectLightingIntegrator
@@ -256,6 +256,60 @@ public:
         }
         pbrt_hip_free(blas), pbrt_hip_free(blas_order), pbrt_hip_free(tlas), pbrt_hip_free(tlas_order);
         ctx_->check(rc, "BVHAccel::new (TransformedPrimitives)");
+    }
+    // The general top-level aggregate (primitive.rs:105-159 beside :33-103): TransformedPrimitives of SEVERAL object aggregates
+    // (instance i shows objects[instance_object[i]]) and plain world-space triangles beside them — the only primitives that can
+    // carry area lights here. Materials and lights are the WORLD mesh's (`world.materials`, `world.lights`; an object's triangles
+    // index the same material table); `world` may hold no triangles.
+    BVHAccel(std::shared_ptr<Context> ctx, const std::vector<TriangleMesh>& objects, const std::vector<PbrtInstance>& instances,
+             const std::vector<int32_t>& instance_object, const TriangleMesh& world, int max_prims_in_node = 4, SplitMethod split_method = SplitMethod::SAH)
+        : ctx_(std::move(ctx)) {
+        struct Tree {
+            PbrtLinearBVHNode* nodes = nullptr;
+            int32_t n = 0, *order = nullptr;
+        };
+        std::vector<Tree> trees(objects.size());
+        Tree top;
+        auto release = [&]() {
+            for (Tree& t : trees) pbrt_hip_free(t.nodes), pbrt_hip_free(t.order);
+            pbrt_hip_free(top.nodes), pbrt_hip_free(top.order);
+        };
+        int rc = instances.size() == instance_object.size() ? PBRT_HIP_OK : PBRT_HIP_ERR_INVALID;
+        for (size_t k = 0; k < objects.size() && rc == PBRT_HIP_OK; ++k)
+            rc = pbrt_hip_bvh_build(objects[k].p.data(), objects[k].n_vertices(), objects[k].vertex_indices.data(), objects[k].n_triangles(), max_prims_in_node,
+                                    (int)split_method, &trees[k].nodes, &trees[k].n, &trees[k].order);
+        const size_t ni = instances.size(), nw = (size_t)world.n_triangles();
+        std::vector<float> lo(3 * (ni + nw)), hi(3 * (ni + nw));
+        for (size_t i = 0; i < ni && rc == PBRT_HIP_OK; ++i) {  // TransformedPrimitive::world_bound (primitive.rs:126-134)
+            const int32_t o = instance_object[i];
+            rc = o >= 0 && (size_t)o < objects.size()
+                     ? pbrt_hip_instance_bounds(trees[o].nodes[0].bounds_min, trees[o].nodes[0].bounds_max, &instances[i], 1, &lo[3 * i], &hi[3 * i])
+                     : PBRT_HIP_ERR_INVALID;
+        }
+        for (size_t t = 0; t < nw; ++t)
+            for (int k = 0; k < 3; ++k) {
+                const float a = world.p[3 * (size_t)world.vertex_indices[3 * t] + k], b = world.p[3 * (size_t)world.vertex_indices[3 * t + 1] + k],
+                            c = world.p[3 * (size_t)world.vertex_indices[3 * t + 2] + k];
+                lo[3 * (ni + t) + k] = std::fmin(a, std::fmin(b, c)), hi[3 * (ni + t) + k] = std::fmax(a, std::fmax(b, c));
+            }
+        if (rc == PBRT_HIP_OK) rc = pbrt_hip_bvh_build_boxes(lo.data(), hi.data(), (int32_t)(ni + nw), max_prims_in_node, (int)split_method, &top.nodes, &top.n, &top.order);
+        if (rc != PBRT_HIP_OK) {
+            release();
+            throw Error("BVHAccel::new (two levels): bad arguments or a host build failed", rc);
+        }
+        for (int k = 0; k < 3; ++k) (&bound_.min.x)[k] = top.nodes[0].bounds_min[k], (&bound_.max.x)[k] = top.nodes[0].bounds_max[k];
+        n_nodes_ = top.n;
+        std::vector<PbrtObject> objs(objects.size());
+        for (size_t k = 0; k < objects.size(); ++k)
+            objs[k] = {objects[k].p.data(), objects[k].n_vertices(), objects[k].vertex_indices.data(), objects[k].n_triangles(),
+                       objects[k].material.empty() ? nullptr : objects[k].material.data(), trees[k].nodes, trees[k].n, trees[k].order};
+        rc = pbrt_hip_scene_create_two_level(ctx_->handle(), objs.data(), (int32_t)objs.size(), instances.data(), instance_object.data(), (int32_t)ni,
+                                             nw ? world.p.data() : nullptr, nw ? world.n_vertices() : 0, nw ? world.vertex_indices.data() : nullptr, (int32_t)nw,
+                                             nw ? world.material.data() : nullptr, nw ? world.area_light.data() : nullptr, world.materials.data(),
+                                             (int32_t)world.materials.size(), world.lights.empty() ? nullptr : world.lights.data(), (int32_t)world.lights.size(),
+                                             top.nodes, top.n, top.order, &h_);
+        release();
+        ctx_->check(rc, "BVHAccel::new: pbrt_hip_scene_create_two_level");
     }
     ~BVHAccel() override { pbrt_hip_scene_destroy(h_); }
     BVHAccel(const BVHAccel&) = delete;

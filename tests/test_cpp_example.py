@@ -132,7 +132,7 @@ def test_cpp_variants_are_the_jobs_the_python_binding_sets_up(tmp_path):
     got = {m.group(1): (int(m.group(2)), int(m.group(3)), int(m.group(4)), float(m.group(5)), float(m.group(6)))
            for m in re.finditer(r"variant (\S+): (\d+) camera samples, (\d+) closest-hit \+ (\d+) shadow rays; film xyz (\S+) weight (\S+)", r.stdout)}
     cams = {m.group(1): np.array([float.fromhex(v) for v in m.group(2).split()], dtype=np.float32) for m in re.finditer(r"camera (\S+):((?: \S+){32})", r.stdout)}
-    assert len(got) == 14 and set(cams) == {"orthographic", "environment"}, r.stdout
+    assert len(got) == 15 and set(cams) == {"orthographic", "environment"}, r.stdout
     ctx = pbrt_hip.Context(0)
     scene = pbrt_hip.Scene(ctx, _open_box())
     eye, look, up = (0.0, 0.0, -3.4), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)
@@ -178,6 +178,23 @@ def test_cpp_variants_are_the_jobs_the_python_binding_sets_up(tmp_path):
     smooth = pbrt_hip.Scene(ctx, dict(box, normals=(-p32 / np.sqrt((p32 * p32).sum(axis=1, dtype=np.float32))[:, None]).astype(np.float32)))
     same("vertex-normals", *smooth.render(persp, W, H, 8, max_depth=3, seed=11, light_strategy=2))
     smooth.close()
+    # the general top level: instances of two aggregates, world triangles with the area lights beside them
+    inst = np.zeros((3, 2, 4, 4), dtype=np.float32)
+    for i, m4 in enumerate(([[1, 0, 0, 3], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], [[0, 0, 1, -3], [0, 1, 0, 0], [-1, 0, 0, 0], [0, 0, 0, 1]],
+                            [[1, 0, 0, 0], [0, 1, 0, -0.5], [0, 0, 1, 0], [0, 0, 0, 1]])):
+        inst[i, 0], inst[i, 1] = np.array(m4, dtype=np.float64), np.linalg.inv(np.array(m4, dtype=np.float64))
+    two = dict(objects=[dict(positions=box["positions"], indices=box["indices"][:10], tri_material=box["tri_material"][:10]),
+                        dict(positions=np.array([[-0.5, 0, -0.5], [0.5, 0, -0.5], [0.5, 0, 0.5], [-0.5, 0, 0.5]], dtype=np.float32),
+                             indices=np.array([[0, 1, 2], [0, 2, 3]], dtype=np.int32), tri_material=np.array([1, 1], dtype=np.int32))],
+               instances=inst, instance_object=np.array([0, 0, 1], dtype=np.int32), instance_material=np.array([-1, 2, -1], dtype=np.int32),
+               world=dict(positions=np.array([[-8, -1.25, -8], [8, -1.25, -8], [8, -1.25, 8], [-8, -1.25, 8], [-1, 3, -1], [1, 3, -1], [1, 3, 1], [-1, 3, 1]], dtype=np.float32),
+                          indices=np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7]], dtype=np.int32), tri_material=np.zeros(4, dtype=np.int32),
+                          tri_light=np.array([-1, -1, 0, 1], dtype=np.int32)),
+               materials=box["materials"], lights=scenes._lights([(scenes.LIGHT_DIFFUSE_AREA, (30.0, 30.0, 30.0), t, 0, 1) for t in (2, 3)]))
+    top = pbrt_hip.Scene(ctx, two)
+    same("two-level", *top.render(scenes.perspective_camera((0.0, 1.5, -9.0), look, up, 40.0, W, H), W, H, 8, max_depth=4, seed=13, light_strategy=2))
+    top.close()
+    assert re.search(r"two-level: hit 1 t 1\.5000 instance 2 primitive [01]; world bound x \[-8\.0, 8\.0\]", r.stdout), r.stdout
     m = re.search(r"two shares: (\d+) rays against (\d+) of the whole frame, (\d+) of (\d+) film values differ", r.stdout)
     assert m and m.group(1) == m.group(2) and m.group(3) == "0" and int(m.group(4)) == W * H * 4, r.stdout
     scene.close()
