@@ -242,6 +242,20 @@ int main(int argc, char** argv) try {
         std::printf("two shares: %llu rays against %llu of the whole frame, %zu of %zu film values differ\n", rays,
                     (unsigned long long)(all.stats.rays_closest + all.stats.rays_shadow), differing, sum.size());
     }
+    // ... and as a job of one process per GPU would run it (here: a world of one): the share rendered into a film on the device,
+    // one RCCL reduce, the frame fetched by the root
+    {
+        auto whole = std::make_shared<Film>(width, height);
+        auto camera = std::make_shared<PerspectiveCamera>(eye, look, up, 40.0f, whole);
+        PathIntegrator all(5, camera, RandomSampler(16, 7), Bounds2i(), 1.0f, LightSampleStrategy::Power);
+        all.render(scene);
+        auto merged = std::make_shared<Film>(width, height);
+        auto cam = std::make_shared<PerspectiveCamera>(eye, look, up, 40.0f, merged);
+        PathIntegrator rank0(5, cam, RandomSampler(16, 7), Bounds2i(), 1.0f, LightSampleStrategy::Power);
+        Comm comm(ctx, 1, 0, Comm::unique_id());
+        rank0.render(scene, comm);
+        std::printf("world of one over RCCL: film %s\n", merged->pixels == whole->pixels ? "equal" : "DIFFERS");
+    }
     return 0;
 } catch (const pbrt::Error& e) {
     std::fprintf(stderr, "pbrt::Error (%d): %s\n", e.status, e.what());

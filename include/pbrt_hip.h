@@ -459,6 +459,15 @@ int pbrt_hip_li_device(PbrtHipScene* scene, const PbrtLiParams* params, const Pb
 int pbrt_hip_camera_rays(PbrtHipScene* scene, const PbrtCamera* camera, const PbrtRenderParams* params, int64_t capacity,
                          PbrtRay* rays, uint64_t* stream_keys, float* p_film, int32_t* pixel_sample, int64_t* n_out);
 
+/* A film on the context's device ({xyz[3], filter_weight_sum} per pixel, zero-filled) for a host that has no HIP binding of
+ * its own (a Rust or C caller of this header): pbrt_hip_render_device renders into it, pbrt_hip_film_reduce merges the ranks'
+ * films in it, pbrt_hip_film_download (which first waits for the context's stream) copies it to the host. Destroy before the
+ * context. PBRT_HIP_ERR_OOM when the device has no room. A host WITH a device allocator (bench.py: a torch tensor) may pass
+ * its own pointer to the same calls instead. */
+int pbrt_hip_film_create(PbrtHipContext* ctx, int64_t n_pixels, float** d_film_out);
+int pbrt_hip_film_download(PbrtHipContext* ctx, const float* d_film_xyzw, int64_t n_pixels, float* film_xyzw);
+void pbrt_hip_film_destroy(PbrtHipContext* ctx, float* d_film_xyzw);
+
 /* ---- multi-GPU film merge (replaces the cross-tile part of Film::merge_film_tile,
  * src/core/film.rs:93-123, and parallel_for_2d's join, src/core/parallel.rs:4-21) ----
  * One process per GPU. Rank 0 draws a communicator id and hands it to the other ranks out of band (the host

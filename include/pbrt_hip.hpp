@@ -572,6 +572,33 @@ struct RenderStats {
     double ms = 0;
 };
 
+// The film merge of a job that runs one process per GPU (what replaces parallel_for_2d's join, parallel.rs:4-21,
+// across GPUs): rank 0 draws an id (Comm::unique_id) and hands the bytes to the other processes by whatever means the host
+// has; every process builds its Comm and renders its share with SamplerIntegrator::render(scene, comm).
+class Comm {
+public:
+    static std::vector<uint8_t> unique_id() {
+        std::vector<uint8_t> id(PBRT_HIP_COMM_ID_BYTES);
+        const int rc = pbrt_hip_comm_unique_id(id.data());
+        if (rc != PBRT_HIP_OK) throw Error(std::string("pbrt_hip_comm_unique_id: ") + pbrt_hip_comm_last_error(), rc);
+        return id;
+    }
+    Comm(std::shared_ptr<Context> ctx, int world, int rank, const std::vector<uint8_t>& id) : world(world), rank(rank), ctx_(std::move(ctx)) {
+        if (id.size() != PBRT_HIP_COMM_ID_BYTES) throw Error("Comm: the id is PBRT_HIP_COMM_ID_BYTES bytes", PBRT_HIP_ERR_INVALID);
+        const int rc = pbrt_hip_comm_create(ctx_->handle(), world, rank, id.data(), &h_);
+        if (rc != PBRT_HIP_OK) throw Error(std::string("pbrt_hip_comm_create: ") + pbrt_hip_comm_last_error(), rc);
+    }
+    ~Comm() { pbrt_hip_comm_destroy(h_); }
+    Comm(const Comm&) = delete;
+    Comm& operator=(const Comm&) = delete;
+    PbrtHipComm* handle() const { return h_; }
+    const int world, rank;
+
+private:
+    std::shared_ptr<Context> ctx_;
+    PbrtHipComm* h_ = nullptr;
+};
+
 // src/core/integrator.rs:29-42
 class Integrator {
 public:
@@ -584,7 +611,16 @@ class SamplerIntegrator : public Integrator {
 public:
     SamplerIntegrator(std::shared_ptr<const Camera> camera, Sampler sampler, Bounds2i pixel_bounds)
         : camera(std::move(camera)), sampler(sampler), pixel_bounds(pixel_bounds) {}
-    void render(const Scene& scene) override {
+    void render(const Scene& scene) override { render_into(scene, nullptr); }
+    // The same frame as one of comm.world processes: this process renders the tiles dealt to comm.rank into a film on its
+    // device, the films are summed with one RCCL reduce, and rank `root` (every rank if root < 0) holds the frame in camera->film.
+    void render(const Scene& scene, const Comm& comm, int root = 0) {
+        tile_rank = comm.rank, tile_world = comm.world;
+        render_into(scene, &comm, root);
+    }
+
+private:
+    void render_into(const Scene& scene, const Comm* comm, int root = 0) {
         PbrtRenderParams rp = params();
         Film& film = *camera->film;
         rp.spp = sampler.samples_per_pixel;
@@ -605,9 +641,25 @@ public:
         rp.filter_table = film.filter_table();
         rp.max_sample_luminance = film.max_sample_luminance;
         PbrtRenderStats st;
-        scene.aggregate().context()->check(pbrt_hip_render(scene.aggregate().handle(), &camera->cam, &rp, film.pixels.data(), &st), "Integrator::render");
+        const auto& ctx = scene.aggregate().context();
+        if (!comm) {
+            ctx->check(pbrt_hip_render(scene.aggregate().handle(), &camera->cam, &rp, film.pixels.data(), &st), "Integrator::render");
+        } else {
+            const int64_t n_pixels = (int64_t)film.width * film.height;
+            float* d_film = nullptr;
+            ctx->check(pbrt_hip_film_create(ctx->handle(), n_pixels, &d_film), "Integrator::render: pbrt_hip_film_create");
+            int rc = pbrt_hip_render_device(scene.aggregate().handle(), &camera->cam, &rp, d_film, &st);
+            const char* what = "Integrator::render: pbrt_hip_render_device";
+            if (rc == PBRT_HIP_OK) rc = pbrt_hip_film_reduce(comm->handle(), d_film, n_pixels, root), what = "Integrator::render: pbrt_hip_film_reduce";
+            if (rc == PBRT_HIP_OK && (root < 0 || root == comm->rank))
+                rc = pbrt_hip_film_download(ctx->handle(), d_film, n_pixels, film.pixels.data()), what = "Integrator::render: pbrt_hip_film_download";
+            pbrt_hip_film_destroy(ctx->handle(), d_film);
+            ctx->check(rc, what);
+        }
         stats = {st.camera_samples, st.rays_closest, st.rays_shadow, st.total_ms};
     }
+
+public:
     // li(&mut ray, scene, sampler, depth) -> Spectrum (integrator.rs:29-42, :452): the sampler argument is the stream the
     // integrator draws from (RNG::set_sequence(stream_key), rng.rs:21-35). Re-entrant; depth is 0 at this boundary.
     Spectrum li(const Ray& ray, const Scene& scene, uint64_t stream_key) const {

@@ -51,6 +51,49 @@ extern "C" int pbrt_hip_render(PbrtHipScene* s, const PbrtCamera* camera, const 
 }
 PB_ABI_CATCH
 
+// A film on the context's device for hosts that have no HIP binding of their own (a Rust or C caller): what
+// pbrt_hip_render_device renders into, pbrt_hip_film_reduce merges and pbrt_hip_film_download brings home.
+extern "C" int pbrt_hip_film_create(PbrtHipContext* ctx, int64_t n_pixels, float** d_film_out) try {
+    if (!ctx || !d_film_out || n_pixels <= 0) return PBRT_HIP_ERR_INVALID;
+    *d_film_out = nullptr;
+    PB_ENTER(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)n_pixels * 4 * sizeof(float);
+    float* d = nullptr;
+    hipError_t e = hipMalloc((void**)&d, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        ctx->last_error = "pbrt_hip_film_create: out of device memory";
+        return PBRT_HIP_ERR_OOM;
+    }
+    HIP_TRY(ctx, e);
+    if (!hip_ok(ctx, hipMemsetAsync(d, 0, bytes, ctx->stream), "hipMemsetAsync (film)") ||
+        !hip_ok(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize (film)")) {
+        (void)hipFree(d);
+        return PBRT_HIP_ERR_DEVICE;
+    }
+    *d_film_out = d;
+    return PBRT_HIP_OK;
+}
+PB_ABI_CATCH
+
+extern "C" int pbrt_hip_film_download(PbrtHipContext* ctx, const float* d_film_xyzw, int64_t n_pixels, float* film_xyzw) try {
+    if (!ctx || !d_film_xyzw || !film_xyzw || n_pixels < 0) return PBRT_HIP_ERR_INVALID;
+    PB_ENTER(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // renders and reduces of this context run on its stream
+    HIP_TRY(ctx, hipMemcpy(film_xyzw, d_film_xyzw, (size_t)n_pixels * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return PBRT_HIP_OK;
+}
+PB_ABI_CATCH
+
+extern "C" void pbrt_hip_film_destroy(PbrtHipContext* ctx, float* d_film_xyzw) {
+    if (!ctx || !d_film_xyzw) return;
+    PB_LOCK(ctx);
+    if (ctx->lost) return;  // an abandoned kernel may still write it and hipFree would wait for the device: it goes with the process
+    if (hipSetDevice(ctx->device) == hipSuccess) (void)hipFree(d_film_xyzw);
+}
+
 // ------------------------------------------------------------------------------------
 // Integrator::li in batch form (integrator.rs:29-42) and the camera-ray stage on its own
 // ------------------------------------------------------------------------------------

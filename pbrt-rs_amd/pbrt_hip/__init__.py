@@ -36,6 +36,7 @@ EXPORTS = [
     "pbrt_hip_trace_timing", "pbrt_hip_set_counting", "pbrt_hip_get_counters", "pbrt_hip_render", "pbrt_hip_render_device", "pbrt_hip_film_to_rgb",
     "pbrt_hip_bvh_build_hlbvh_device", "pbrt_hip_scene_create_hlbvh", "pbrt_hip_scene_set_shading_data", "pbrt_hip_tile_partition", "pbrt_hip_tile_partition_order", "pbrt_hip_filter_table", "pbrt_hip_sample_bounds", "pbrt_hip_write_pfm", "pbrt_hip_write_png", "pbrt_hip_write_exr",
     "pbrt_hip_comm_unique_id", "pbrt_hip_comm_create", "pbrt_hip_comm_destroy", "pbrt_hip_film_reduce",
+    "pbrt_hip_film_create", "pbrt_hip_film_download", "pbrt_hip_film_destroy",
     "pbrt_hip_comm_last_error", "pbrt_hip_scene_wide_records", "pbrt_hip_get_wide_counters", "pbrt_hip_probe_gather", "pbrt_hip_probe_state_stream",
     "pbrt_hip_li", "pbrt_hip_li_device", "pbrt_hip_camera_rays", "pbrt_hip_scene_create_two_level", "pbrt_hip_debug_wide_export",
 ]
@@ -122,6 +123,10 @@ def lib():
         L.pbrt_hip_comm_destroy.argtypes = [vp]
         L.pbrt_hip_comm_destroy.restype = None
         L.pbrt_hip_film_reduce.argtypes = [vp, vp, i64, i32]
+        L.pbrt_hip_film_create.argtypes = [vp, i64, ctypes.POINTER(vp)]
+        L.pbrt_hip_film_download.argtypes = [vp, vp, i64, vp]
+        L.pbrt_hip_film_destroy.argtypes = [vp, vp]
+        L.pbrt_hip_film_destroy.restype = None
         L.pbrt_hip_comm_last_error.argtypes = []
         L.pbrt_hip_comm_last_error.restype = ctypes.c_char_p
         L.pbrt_hip_synchronize.argtypes = [vp]
@@ -680,6 +685,34 @@ class Comm:
         if getattr(self, "h", None):
             lib().pbrt_hip_comm_destroy(self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceFilm:
+    """A film on the context's device (pbrt_hip_film_create): what Scene.render(d_film_ptr=film.ptr) renders into and
+    Comm.film_reduce merges, for a host without a device allocator of its own. download() -> [height, width, 4] float32."""
+
+    def __init__(self, ctx, width, height):
+        self.ctx, self.width, self.height = ctx, width, height
+        h = ctypes.c_void_p()
+        ctx.check(lib().pbrt_hip_film_create(ctx.h, width * height, ctypes.byref(h)), "pbrt_hip_film_create")
+        self.ptr = h.value
+        ctx._scenes.add(self)   # closed with the scenes, before the context
+
+    def download(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        self.ctx.check(lib().pbrt_hip_film_download(self.ctx.h, ctypes.c_void_p(self.ptr), self.width * self.height, _p(out)), "pbrt_hip_film_download")
+        return out
+
+    def close(self):
+        if getattr(self, "ptr", None) and self.ctx.h:
+            lib().pbrt_hip_film_destroy(self.ctx.h, ctypes.c_void_p(self.ptr))
+        self.ptr = None
 
     def __del__(self):
         try:

@@ -196,6 +196,10 @@ def test_comm_without_a_gpu_is_an_error():
     assert L.pbrt_hip_comm_create(None, 2, 0, buf, ctypes.byref(out)) == 1 and not out.value      # no context
     assert L.pbrt_hip_film_reduce(None, None, 0, 0) == 1
     L.pbrt_hip_comm_destroy(None)                                                                   # a no-op
+    film = ctypes.c_void_p()
+    assert L.pbrt_hip_film_create(None, 16, ctypes.byref(film)) == 1 and not film.value             # the ABI's own device film: no context
+    assert L.pbrt_hip_film_download(None, None, 16, None) == 1
+    L.pbrt_hip_film_destroy(None, None)                                                             # a no-op
 
 
 def test_null_handles_are_errors_on_the_round4_entry_points():

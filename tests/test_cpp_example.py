@@ -197,5 +197,6 @@ def test_cpp_variants_are_the_jobs_the_python_binding_sets_up(tmp_path):
     assert re.search(r"two-level: hit 1 t 1\.5000 instance 2 primitive [01]; world bound x \[-8\.0, 8\.0\]", r.stdout), r.stdout
     m = re.search(r"two shares: (\d+) rays against (\d+) of the whole frame, (\d+) of (\d+) film values differ", r.stdout)
     assert m and m.group(1) == m.group(2) and m.group(3) == "0" and int(m.group(4)) == W * H * 4, r.stdout
+    assert "world of one over RCCL: film equal" in r.stdout, r.stdout   # pbrt::Comm + the ABI's own device film (pbrt_hip_film_create / _reduce / _download)
     scene.close()
     ctx.close()

@@ -68,3 +68,33 @@ def test_comm_create_rejects_bad_ranks(hip_ctx):
             pbrt_hip.Comm(hip_ctx, world, rank, uid)
     with pytest.raises(ValueError):
         pbrt_hip.Comm(hip_ctx, 1, 0, uid[:64])
+
+
+def test_the_abis_own_device_film(hip_ctx):
+    """pbrt_hip_film_create / _download / _destroy: the film a host WITHOUT a device allocator renders into and merges (a Rust or
+    C caller of include/pbrt_hip.h). Zero-filled; two tile shares rendered into two such films and added = the frame; the one-rank
+    reduce leaves it; bad arguments are errors."""
+    w, h = 96, 64
+    sc = pbrt_hip.Scene(hip_ctx, scenes.cornell_box())
+    cam = scenes.cornell_camera(w, h)
+    host, _ = sc.render(cam, w, h, 4, max_depth=3, seed=5)
+    film = pbrt_hip.DeviceFilm(hip_ctx, w, h)
+    assert not film.download().any()
+    shares = []
+    for rank in range(2):
+        sc.render(cam, w, h, 4, max_depth=3, seed=5, tile_rank=rank, tile_world=2, d_film_ptr=film.ptr)
+        shares.append(film.download())
+    assert np.array_equal(shares[0] + shares[1], host) and shares[0].any() and shares[1].any()
+    sc.render(cam, w, h, 4, max_depth=3, seed=5, d_film_ptr=film.ptr)
+    comm = pbrt_hip.Comm(hip_ctx, 1, 0, pbrt_hip.comm_unique_id())
+    comm.film_reduce(film.ptr, w * h, root=0)
+    assert np.array_equal(film.download(), host)
+    comm.close()
+    L = pbrt_hip.lib()
+    out = ctypes.c_void_p()
+    assert L.pbrt_hip_film_create(hip_ctx.h, 0, ctypes.byref(out)) == 1 and L.pbrt_hip_film_create(hip_ctx.h, 16, None) == 1
+    assert L.pbrt_hip_film_download(hip_ctx.h, None, 16, None) == 1
+    L.pbrt_hip_film_destroy(hip_ctx.h, None)       # a no-op
+    film.close()
+    film.close()                                   # idempotent
+    sc.close()
