@@ -179,6 +179,31 @@ int main(int argc, char** argv) {
         rc = pbrt_hip_write_png(out_path, rgb, width, height);
         if (rc != PBRT_HIP_OK) fprintf(stderr, "pbrt_hip_write_png(%s) failed (%d)\n", out_path, rc);
     }
+    /* The same frame the way a job of one process per GPU produces it, here with a world of one: this rank's tiles
+     * rendered into a film on the device (the ABI's own: a C host has no device allocator), the ranks' films summed with one
+     * RCCL reduce, the frame fetched by the root. With N processes: rank 0 hands `id` to the others, rp.tile_rank = rank,
+     * rp.tile_world = N, everything else unchanged. */
+    if (rc == PBRT_HIP_OK) {
+        uint8_t id[PBRT_HIP_COMM_ID_BYTES];
+        PbrtHipComm* comm = NULL;
+        float* d_film = NULL;
+        float* merged = (float*)calloc((size_t)width * height * 4, sizeof(float));
+        const int64_t n_pixels = (int64_t)width * height;
+        rc = pbrt_hip_comm_unique_id(id);
+        if (rc == PBRT_HIP_OK) rc = pbrt_hip_comm_create(ctx, 1, 0, id, &comm);
+        if (rc == PBRT_HIP_OK) rc = pbrt_hip_film_create(ctx, n_pixels, &d_film);
+        rp.tile_rank = 0, rp.tile_world = 1;
+        if (rc == PBRT_HIP_OK) rc = pbrt_hip_render_device(scene, &cam, &rp, d_film, NULL);
+        if (rc == PBRT_HIP_OK) rc = pbrt_hip_film_reduce(comm, d_film, n_pixels, 0);
+        if (rc == PBRT_HIP_OK) rc = pbrt_hip_film_download(ctx, d_film, n_pixels, merged);
+        if (rc == PBRT_HIP_OK)
+            printf("one rank over RCCL: the merged film %s the one-call film\n", memcmp(merged, film, (size_t)n_pixels * 16) == 0 ? "equals" : "DIFFERS FROM");
+        else
+            fprintf(stderr, "multi-GPU path failed (%d): %s / %s\n", rc, pbrt_hip_last_error(ctx), pbrt_hip_comm_last_error());
+        pbrt_hip_film_destroy(ctx, d_film);
+        pbrt_hip_comm_destroy(comm);
+        free(merged);
+    }
     free(film);
     free(rgb);
     pbrt_hip_scene_destroy(scene);

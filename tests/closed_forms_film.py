@@ -136,3 +136,49 @@ def lit_radius_px(rgb, width, height, threshold):
     if len(xs) == 0:
         return 0.0
     return float(np.max(np.hypot(xs + 0.5 - width / 2.0, ys + 0.5 - height / 2.0)))
+
+
+# ---- orthographic camera (orthographic.rs:82-104) and environment camera (environment.rs:37-56) ----
+def offaxis_emitter_scene(cx, cy, depth, half_size, le=(5.0, 5.0, 5.0)):
+    """A two-sided square emitter centred at CAMERA-space (cx, cy, depth) of a camera at LENS["eye"] looking along LENS["look"]:
+    look_at gives camera +x = world -x, +y = world +y, +z = world -z (transform.rs:510-545), so the world centre is (-cx, cy, -depth)."""
+    s, x, y, z = half_size, -cx, cy, -depth
+    quad = ((x - s, y - s, z), (x + s, y - s, z), (x + s, y + s, z), (x - s, y + s, z))
+    return scenes._assemble([(quad, 0, le, True)], [(scenes.MAT_MATTE, (0.0, 0.0, 0.0), (0, 0, 0), 1.0)])
+
+
+def ortho_camera(width, height, half_height):
+    return scenes.orthographic_camera(LENS["eye"], LENS["look"], LENS["up"], half_height, width, height)
+
+
+def ortho_raster_of_camera_point(width, height, half_height, cx, cy):
+    """raster_to_camera of the orthographic projection inverted by hand: the screen window is [-a hh, a hh] x [-hh, hh]
+    (a = width / height), raster y runs downwards; depth plays no part."""
+    a = width / height
+    return np.array([(cx + a * half_height) / (2 * a * half_height) * width, (half_height - cy) / (2 * half_height) * height])
+
+
+def env_direction(theta, phi):
+    """EnvironmentCamera::generate_ray's direction for film position (x, y): theta = pi y / H, phi = 2 pi x / W."""
+    return np.array([np.sin(theta) * np.cos(phi), np.cos(theta), np.sin(theta) * np.sin(phi)])
+
+
+def env_emitter_scene(theta, phi, dist, half_size, le=(5.0, 5.0, 5.0)):
+    """A two-sided square emitter facing the origin from direction (theta, phi), `dist` away, its sides along the directions
+    of growing phi and growing theta."""
+    c = dist * env_direction(theta, phi)
+    t_phi = np.array([-np.sin(phi), 0.0, np.cos(phi)])
+    t_theta = np.array([np.cos(theta) * np.cos(phi), -np.sin(theta), np.cos(theta) * np.sin(phi)])
+    s = half_size
+    quad = tuple(tuple(c + a * s * t_phi + b * s * t_theta) for a, b in ((-1, -1), (1, -1), (1, 1), (-1, 1)))
+    return scenes._assemble([(quad, 0, le, True)], [(scenes.MAT_MATTE, (0.0, 0.0, 0.0), (0, 0, 0), 1.0)])
+
+
+def env_camera():
+    return scenes.environment_camera((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), (0.0, 1.0, 0.0))   # look_at = identity: camera space is world space
+
+
+def lit_box(rgb, threshold):
+    """(x0, x1, y0, y1) of the pixels brighter than `threshold`, in raster coordinates (pixel i spans [i, i + 1])."""
+    ys, xs = np.nonzero(luminance(rgb) > threshold)
+    return (float(xs.min()), float(xs.max() + 1), float(ys.min()), float(ys.max() + 1)) if len(xs) else None

@@ -45,6 +45,7 @@ def test_c_caller_renders(tmp_path):
     assert int(m.group(1)) == 96 * 64 * 32
     assert int(m.group(2)) > int(m.group(1)) and int(m.group(3)) > 0
     assert 0.05 < float(m.group(4)) < 2.0                          # a lit, closed box
+    assert "one rank over RCCL: the merged film equals the one-call film" in r.stdout, r.stdout + r.stderr   # film_create / render_device / film_reduce / film_download from C
     raw = out.read_bytes()
     assert raw[:8] == b"\x89PNG\r\n\x1a\n"
     import struct

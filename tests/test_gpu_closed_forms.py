@@ -103,7 +103,9 @@ def test_light_pick_strategies_and_roulette_on_the_device(hip_ctx):
 # ---- the film and the lens: the HIP path against the closed forms of tests/closed_forms_film.py ----
 import closed_forms_film as cf   # noqa: E402
 from test_oracle_render import (FILM_FILTERS, FILM_H, FILM_LE, FILM_SEED, FILM_SPP, FILM_W, LENS_EMITTER, LENS_FOCUS, LENS_H, LENS_W,   # noqa: E402
-                                check_constant_radiance_film, check_luminance_clamp, check_thin_lens)
+                                check_constant_radiance_film, check_luminance_clamp, check_thin_lens, CAM_W, CAM_H, ORTHO_HALF_HEIGHT,
+                                ORTHO_EMITTER, ORTHO_CENTRE, ENV_THETA, ENV_PHI, ENV_DIST, ENV_EMITTER, check_orthographic_camera,
+                                check_environment_camera)
 
 
 def test_film_reconstructs_a_constant_and_sums_the_analytic_table_on_the_device(hip_ctx):
@@ -145,3 +147,21 @@ def test_thin_lens_focus_and_blur_disc_on_the_device(hip_ctx):
         g.close()
         return pbrt_hip.film_to_rgb(film)
     check_thin_lens(render)
+
+
+def test_orthographic_camera_keeps_sizes_at_every_depth_on_the_device(hip_ctx):
+    def render(depth):
+        g = pbrt_hip.Scene(hip_ctx, cf.offaxis_emitter_scene(*ORTHO_CENTRE, depth, ORTHO_EMITTER))
+        film, _ = g.render(cf.ortho_camera(CAM_W, CAM_H, ORTHO_HALF_HEIGHT), CAM_W, CAM_H, 16, max_depth=1, seed=4)
+        g.close()
+        return pbrt_hip.film_to_rgb(film)
+    check_orthographic_camera(render)
+
+
+def test_environment_camera_puts_directions_where_the_angles_say_on_the_device(hip_ctx):
+    def render():
+        g = pbrt_hip.Scene(hip_ctx, cf.env_emitter_scene(ENV_THETA, ENV_PHI, ENV_DIST, ENV_EMITTER))
+        film, _ = g.render(cf.env_camera(), CAM_W, CAM_H, 16, max_depth=1, seed=4)
+        g.close()
+        return pbrt_hip.film_to_rgb(film)
+    check_environment_camera(render)

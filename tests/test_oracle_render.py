@@ -523,3 +523,62 @@ def test_thin_lens_focus_and_blur_disc():
         osc.close()
         return oracle.film_to_rgb(film)
     check_thin_lens(render)
+
+
+CAM_W, CAM_H = 96, 64
+ORTHO_HALF_HEIGHT, ORTHO_EMITTER, ORTHO_CENTRE = 1.5, 0.3, (0.6, -0.45)
+ENV_THETA, ENV_PHI, ENV_DIST, ENV_EMITTER = np.radians(60.0), np.radians(135.0), 10.0, 1.8
+
+
+def check_orthographic_camera(render):
+    """orthographic.rs:82-104: the ray starts at raster_to_camera(p_film) and runs along the camera's +z — an object's image does
+    not depend on its depth. render(depth) -> rgb of a square emitter centred at camera-space ORTHO_CENTRE at `depth`, 16 spp.
+    The lit box = the square through the screen window by hand (within one pixel: partially covered border pixels), the same at
+    every depth; fully covered pixels hold exactly Le."""
+    cx, cy = ORTHO_CENTRE
+    lo = cf.ortho_raster_of_camera_point(CAM_W, CAM_H, ORTHO_HALF_HEIGHT, cx - ORTHO_EMITTER, cy + ORTHO_EMITTER)   # raster y runs down
+    hi = cf.ortho_raster_of_camera_point(CAM_W, CAM_H, ORTHO_HALF_HEIGHT, cx + ORTHO_EMITTER, cy - ORTHO_EMITTER)
+    assert hi[0] - lo[0] > 10 and hi[1] - lo[1] > 10        # the test has something to see
+    boxes = []
+    for depth in (2.0, 5.0, 11.0):
+        rgb = render(depth)
+        box = cf.lit_box(rgb, 1e-6)
+        assert box is not None and max(abs(box[0] - lo[0]), abs(box[1] - hi[0]), abs(box[2] - lo[1]), abs(box[3] - hi[1])) <= 1.0, (depth, box, lo, hi)
+        inner = rgb[int(np.ceil(lo[1])) + 1:int(np.floor(hi[1])) - 1, int(np.ceil(lo[0])) + 1:int(np.floor(hi[0])) - 1]
+        assert inner.size and np.allclose(inner, 5.0, rtol=1e-6, atol=0.0), depth
+        boxes.append(box)
+    assert boxes[0] == boxes[1] == boxes[2]
+
+
+def check_environment_camera(render):
+    """environment.rs:37-56: film position (x, y) looks along (sin t cos p, cos t, sin t sin p), t = pi y / H, p = 2 pi x / W.
+    render() -> rgb of a small square emitter facing the camera from (ENV_THETA, ENV_PHI): it is seen where those two angles put
+    it — centroid within 0.6 px — and as large as its angular size makes it (half-size / distance radians, over sin(theta) in x)."""
+    rgb = render()
+    ys, xs = np.nonzero(cf.luminance(rgb) > 1e-6)
+    assert len(xs) > 20
+    x_c, y_c = ENV_PHI / (2 * np.pi) * CAM_W, ENV_THETA / np.pi * CAM_H
+    assert abs(xs.mean() + 0.5 - x_c) <= 0.6 and abs(ys.mean() + 0.5 - y_c) <= 0.6, (xs.mean() + 0.5, x_c, ys.mean() + 0.5, y_c)
+    ang = np.arctan(ENV_EMITTER / ENV_DIST)
+    box = cf.lit_box(rgb, 1e-6)
+    half_y, half_x = ang / np.pi * CAM_H, ang / np.sin(ENV_THETA) / (2 * np.pi) * CAM_W
+    # the square's corners reach a little further in phi than its edge midpoints (they sit at other thetas): one more pixel of slack in x
+    assert abs((box[3] - box[2]) / 2 - half_y) <= 1.0 and abs((box[1] - box[0]) / 2 - half_x) <= 1.5, (box, half_x, half_y)
+
+
+def test_orthographic_camera_keeps_sizes_at_every_depth():
+    def render(depth):
+        osc = oracle.OracleScene(cf.offaxis_emitter_scene(*ORTHO_CENTRE, depth, ORTHO_EMITTER))
+        film, _ = osc.render(_cam(cf.ortho_camera(CAM_W, CAM_H, ORTHO_HALF_HEIGHT)), CAM_W, CAM_H, 16, max_depth=1, seed=4)
+        osc.close()
+        return oracle.film_to_rgb(film)
+    check_orthographic_camera(render)
+
+
+def test_environment_camera_puts_directions_where_the_angles_say():
+    def render():
+        osc = oracle.OracleScene(cf.env_emitter_scene(ENV_THETA, ENV_PHI, ENV_DIST, ENV_EMITTER))
+        film, _ = osc.render(_cam(cf.env_camera()), CAM_W, CAM_H, 16, max_depth=1, seed=4)
+        osc.close()
+        return oracle.film_to_rgb(film)
+    check_environment_camera(render)
