@@ -452,7 +452,8 @@ int pbrt_hip_li_device(PbrtHipScene* scene, const PbrtLiParams* params, const Pb
                        int64_t n, float* d_rgb, PbrtRenderStats* stats);
 /* The camera-ray stage of pbrt_hip_render on its own: Sampler::get_camera_sample (src/core/sampler.rs:27-33) +
  * Camera::generate_ray (src/cameras/perspective.rs:90-112 ...) for every sample of this GPU's tiles (params as for
- * pbrt_hip_render; whole 16x16 tiles, all params->spp samples in one pass). Per path: the ray, its stream key, the
+ * pbrt_hip_render; whole 16x16 tiles, all samples of a pixel in one pass: params->spp of them, or what the sampler makes of that
+ * count — sampler_x * sampler_y, the next power of two — and n_out says so). Per path: the ray, its stream key, the
  * film position p_film (x, y) and {pixel x, pixel y, sample index}; pixels of border tiles outside the pixel bounds
  * carry pixel = (-1, -1) and a ray with t_max < 0. n_out = number of paths; PBRT_HIP_ERR_INVALID with n_out set if
  * capacity is too small. A host without a Camera of its own (tests, the C example) feeds pbrt_hip_li from this. */

@@ -331,6 +331,26 @@ def sampler_spec(sampler, max_sample_luminance=0.0):
     return out
 
 
+def sampler_tables(sampler, spp, seed=0, pixel_index=0):
+    """The PixelSampler tables of one pixel after start_pixel: (samples_1d[n_dims, spp'], samples_2d[n_dims, spp', 2]) with
+    spp' = the samples per pixel the sampler takes. Stratified and (0,2) samplers only."""
+    spec = sampler_spec(sampler)
+    n_dims = int(spec[4])
+    cap = max(int(spec[1]) * int(spec[2]), 1)
+    while cap < spp:
+        cap *= 2
+    cap = max(cap, spp) * 2
+    a, b = np.zeros((n_dims, cap), dtype=np.float32), np.zeros((n_dims, cap, 2), dtype=np.float32)
+    L = lib()
+    L.orc_sampler_tables.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    n = L.orc_sampler_tables(_p(spec), spp, seed, pixel_index, None, None, 0)
+    if n <= 0:
+        raise ValueError("no tables for this sampler")
+    a, b = np.zeros((n_dims, n), dtype=np.float32), np.zeros((n_dims, n, 2), dtype=np.float32)
+    assert L.orc_sampler_tables(_p(spec), spp, seed, pixel_index, _p(a), _p(b), n) == n
+    return a, b
+
+
 FILTERS = dict(box=0, gaussian=1, mitchell=2, lanczos=3, triangle=4)
 
 

@@ -514,6 +514,26 @@ void orc_halton_probe(int res_x, int res_y, int px, int py, int sample_num, int 
     out6[4] = h.base_scales[0];
     out6[5] = h.base_scales[1];
 }
+// PixelSampler tables of ONE pixel after start_pixel (stratified.rs:44-104, zerotwosequence.rs:28-60): out_1d[d * spp + s],
+// out_2d[(d * spp + s) * 2 + c] for the n_dims tabulated dimensions; spec5 as oracle.sampler_spec. Returns the samples per pixel
+// the sampler takes (nx * ny / the next power of two), 0 for a sampler without tables.
+int orc_sampler_tables(const int32_t* spec5, int spp_requested, uint64_t seed, int64_t pixel_index, float* out_1d, float* out_2d, int cap_spp) {
+    SamplerSpec spec;
+    spec.kind = spec5[0], spec.nx = spec5[1], spec.ny = spec5[2], spec.jitter = spec5[3] != 0, spec.n_dims = spec5[4];
+    if (spec.kind != SAMPLER_STRATIFIED && spec.kind != SAMPLER_ZEROTWO) return 0;
+    const int spp = (int)spec.samples_per_pixel(spp_requested);
+    if (spp > cap_spp) return spp;
+    Sampler smp;
+    smp.spec = &spec;
+    smp.start_pixel(seed, pixel_index, spp);
+    for (int d = 0; d < spec.n_dims; ++d)
+        for (int k = 0; k < spp; ++k) {
+            out_1d[(size_t)d * spp + k] = smp.samples_1d[d][k];
+            out_2d[((size_t)d * spp + k) * 2] = smp.samples_2d[d][k].x;
+            out_2d[((size_t)d * spp + k) * 2 + 1] = smp.samples_2d[d][k].y;
+        }
+    return spp;
+}
 // digit permutation of the base-th prime (compute_radical_inverse_permutations), n = that prime
 int orc_halton_permutation(int base_index, int32_t* out, int cap) {
     const PrimeTables& t = prime_tables();

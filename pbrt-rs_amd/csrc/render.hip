@@ -164,6 +164,7 @@ extern "C" int pbrt_hip_li(PbrtHipScene* s, const PbrtLiParams* lp, const PbrtRa
 }
 PB_ABI_CATCH
 
+static int round_up_pow2(int v);
 extern "C" int pbrt_hip_camera_rays(PbrtHipScene* s, const PbrtCamera* camera, const PbrtRenderParams* params, int64_t capacity,
                                     PbrtRay* rays, uint64_t* stream_keys, float* p_film, int32_t* pixel_sample, int64_t* n_out) try {
     if (!s || !camera || !params || !n_out) return PBRT_HIP_ERR_INVALID;
@@ -179,7 +180,23 @@ extern "C" int pbrt_hip_camera_rays(PbrtHipScene* s, const PbrtCamera* camera, c
         ctx->last_error = "camera rays: bad tile_rank / tile_world / tile_order";
         return PBRT_HIP_ERR_INVALID;
     }
-    const int64_t n = (int64_t)n_tiles * kTile * kTile * params->spp;  // whole tiles: pixels outside the bounds carry pixel = (-1, -1)
+    // the samples per pixel the sampler takes, as wavefront_render will fix them (stratified.rs:30-33: nx * ny; zerotwosequence.rs:20:
+    // the next power of two): the outputs are sized by THAT count, not by the caller's spp
+    int64_t spp = params->spp;
+    if (params->sampler == PBRT_SAMPLER_STRATIFIED) {
+        if (params->sampler_x < 1 || params->sampler_y < 1 || (int64_t)params->sampler_x * params->sampler_y > 65536) {
+            ctx->last_error = "stratified sampler: sampler_x * sampler_y must be in [1, 65536]";
+            return PBRT_HIP_ERR_INVALID;
+        }
+        spp = (int64_t)params->sampler_x * params->sampler_y;
+    } else if (params->sampler == PBRT_SAMPLER_ZEROTWO) {
+        if (params->spp > 65536) {
+            ctx->last_error = "(0,2)-sequence sampler: spp too large";
+            return PBRT_HIP_ERR_INVALID;
+        }
+        spp = round_up_pow2(params->spp);
+    }
+    const int64_t n = (int64_t)n_tiles * kTile * kTile * spp;  // whole tiles: pixels outside the bounds carry pixel = (-1, -1)
     *n_out = n;
     if (n == 0) return PBRT_HIP_OK;
     if (capacity < n || !rays || !stream_keys || !p_film || !pixel_sample) {

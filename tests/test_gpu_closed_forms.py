@@ -165,3 +165,78 @@ def test_environment_camera_puts_directions_where_the_angles_say_on_the_device(h
         g.close()
         return pbrt_hip.film_to_rgb(film)
     check_environment_camera(render)
+
+
+import closed_forms_samplers as cs   # noqa: E402  (numpy only)
+
+
+def _camera_samples(hip_ctx, sampler, spp, seed):
+    """Per pixel of a 16 x 16 frame: the sampler's first 2D draw of every sample (p_film - pixel, sampler.rs:66-73) through
+    pbrt_hip_camera_rays. Exact for pixel (0, 0); elsewhere p_film = pixel + u was rounded at the pixel's magnitude (2^-20)."""
+    g = pbrt_hip.Scene(hip_ctx, cf.sky_scene())
+    _, _, pfilm, pix = g.camera_rays(cf.sky_camera(16, 16), 16, 16, spp, seed=seed, sampler=sampler)
+    g.close()
+    ok = pix[:, 0] >= 0
+    return pfilm[ok], pix[ok]
+
+
+def _per_pixel(pfilm, pix, n, boundaries_x, boundaries_y):
+    """Yields (px, py, u[n, 2] in sample order) for the pixels none of whose samples lies within 2e-6 of a box boundary (where the
+    rounding of p_film could have moved it across); pixel (0, 0) always. At most a few pixels may be left out."""
+    skipped = 0
+    for py in range(16):
+        for px in range(16):
+            sel = (pix[:, 0] == px) & (pix[:, 1] == py)
+            assert sorted(pix[sel, 2]) == list(range(n))
+            u = (pfilm[sel].astype(np.float64) - (px, py))[np.argsort(pix[sel, 2])]
+            near = min(np.abs(u[:, 0, None] - boundaries_x).min(), np.abs(u[:, 1, None] - boundaries_y).min())
+            if (px, py) != (0, 0) and near < 2e-6:
+                skipped += 1
+                continue
+            yield px, py, u
+    assert skipped <= 8, skipped
+
+
+def test_stratified_sampler_one_sample_per_stratum_on_the_device(hip_ctx):
+    for nx, ny in ((4, 4), (3, 5), (8, 2)):
+        n = nx * ny
+        bx, by = np.arange(nx + 1) / nx, np.arange(ny + 1) / ny
+        for seed in (0, 5):
+            pfilm, pix = _camera_samples(hip_ctx, ("stratified", nx, ny, True, 3), n, seed)
+            assert len(pfilm) == 256 * n
+            orders = set()
+            for px, py, u in _per_pixel(pfilm, pix, n, bx, by):
+                assert np.all(u >= 0.0) and np.all(u < 1.0)
+                cs.check_one_per_stratum(u, nx, ny)
+                orders.add(tuple(np.floor(u[:, 0] * nx).astype(int) + nx * np.floor(u[:, 1] * ny).astype(int)))
+            assert len(orders) > 200                   # shuffled pixel by pixel
+            first = (pix[:, 0] == 0) & (pix[:, 1] == 0)
+            cs.check_unit_interval(pfilm[first])       # pixel (0, 0): p_film IS the sample, bit for bit
+        pfilm, pix = _camera_samples(hip_ctx, ("stratified", nx, ny, False, 3), n, 1)
+        cs.check_stratum_centres(pfilm[(pix[:, 0] == 0) & (pix[:, 1] == 0)], nx, ny)
+
+
+def test_camera_rays_are_sized_by_the_samplers_own_count(hip_ctx):
+    """StratifiedSampler takes nx * ny samples whatever was asked for (stratified.rs:30-33): pbrt_hip_camera_rays sizes its outputs
+    by that count (it wrote nx * ny per pixel into buffers sized for the requested spp before round 5)."""
+    pfilm, pix = _camera_samples(hip_ctx, ("stratified", 4, 4, True, 3), 1, 0)
+    assert len(pfilm) == 256 * 16 and sorted(pix[(pix[:, 0] == 3) & (pix[:, 1] == 7), 2]) == list(range(16))
+    pfilm, pix = _camera_samples(hip_ctx, ("stratified", 2, 2, True, 3), 64, 0)
+    assert len(pfilm) == 256 * 4
+
+
+def test_zerotwo_sampler_is_a_net_on_the_device(hip_ctx):
+    for requested, n in ((16, 16), (12, 16), (64, 64)):
+        pfilm, pix = _camera_samples(hip_ctx, ("zerotwo", 3), requested, 3)
+        # rounded up to a power of two (zerotwosequence.rs:20) — and the outputs sized by that count (until round 5 they were sized
+        # by the REQUESTED count while the kernels wrote the rounded one: found by this test)
+        assert len(pfilm) == 256 * n
+        b = np.arange(n + 1) / n                       # every dyadic boundary is one of these
+        tables = set()
+        for px, py, u in _per_pixel(pfilm, pix, n, b, b):
+            assert np.all(u >= 0.0) and np.all(u < 1.0)
+            cs.check_02_net(u, n)
+            tables.add(np.round(u, 5).tobytes())
+        assert len(tables) > 240                       # each pixel under its own scramble
+        first = (pix[:, 0] == 0) & (pix[:, 1] == 0)
+        cs.check_unit_interval(pfilm[first])

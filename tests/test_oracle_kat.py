@@ -374,3 +374,47 @@ def test_halton_radical_inverse_and_pixel_mapping():
         n = L.orc_halton_permutation(base_index, perm.ctypes.data, len(perm))
         assert sorted(perm[:n].tolist()) == list(range(n))
     assert L.orc_halton_permutation(999, perm.ctypes.data, len(perm)) == 7919
+
+
+import closed_forms_samplers as cs   # noqa: E402  (numpy only)
+
+SAMPLER_PIXELS, SAMPLER_SEEDS = (0, 77, 4095), (0, 5)
+
+
+def test_stratified_sampler_one_sample_per_stratum():
+    """StratifiedSampler::start_pixel (stratified.rs:44-104): every tabulated 1D dimension holds one sample per interval, every 2D
+    dimension one per stratum, in a shuffled order that differs between pixels; jitter off = the stratum centres."""
+    for nx, ny in ((4, 4), (3, 5), (8, 2), (1, 1)):
+        orders = set()
+        for pixel in SAMPLER_PIXELS:
+            for seed in SAMPLER_SEEDS:
+                a, b = oracle.sampler_tables(("stratified", nx, ny, True, 3), nx * ny, seed=seed, pixel_index=pixel)
+                assert a.shape == (3, nx * ny) and b.shape == (3, nx * ny, 2)
+                cs.check_unit_interval(a), cs.check_unit_interval(b)
+                for d in range(3):
+                    cs.check_one_per_interval(a[d], nx * ny)
+                    cs.check_one_per_stratum(b[d], nx, ny)
+                orders.add(tuple(np.floor(a[0].astype(np.float64) * nx * ny).astype(int)))
+        assert nx * ny == 1 or len(orders) > 1          # shuffled per pixel, not one fixed order
+        a, b = oracle.sampler_tables(("stratified", nx, ny, False, 2), nx * ny, seed=1, pixel_index=9)
+        for d in range(2):
+            cs.check_stratum_centres(b[d], nx, ny)
+            cs.check_one_per_interval(a[d], nx * ny)
+
+
+def test_zerotwo_sampler_is_a_net_in_every_dimension():
+    """ZeroTwoSequenceSampler::start_pixel (zerotwosequence.rs:28-60): the samples per pixel are rounded up to a power of two
+    (:20), every 1D dimension holds one sample per interval of that length, every 2D dimension one per dyadic box of that area —
+    of every shape (what "(0,2)-sequence" means), under each pixel's own random scramble."""
+    for requested, n in ((16, 16), (12, 16), (64, 64), (1, 1), (2, 2)):
+        tables = set()
+        for pixel in SAMPLER_PIXELS:
+            for seed in SAMPLER_SEEDS:
+                a, b = oracle.sampler_tables(("zerotwo", 3), requested, seed=seed, pixel_index=pixel)
+                assert a.shape == (3, n) and b.shape == (3, n, 2)
+                cs.check_unit_interval(a), cs.check_unit_interval(b)
+                for d in range(3):
+                    cs.check_one_per_interval(a[d], n)
+                    cs.check_02_net(b[d], n)
+                tables.add(b[0].tobytes())
+        assert len(tables) == len(SAMPLER_PIXELS) * len(SAMPLER_SEEDS)   # scrambled per pixel and seed
