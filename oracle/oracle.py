@@ -19,8 +19,12 @@ QUIRKS = dict(D2=1 << 0, D9=1 << 1, D10=1 << 2, D11=1 << 3, D13=1 << 4, D36=1 <<
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB_PATH):
+    """make is incremental: a library older than its sources is rebuilt (a stale checker would check nothing)."""
+    try:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    except (OSError, subprocess.CalledProcessError):
+        if force or not os.path.exists(_LIB_PATH):
+            raise
     return _LIB_PATH
 
 
@@ -329,6 +333,23 @@ def sampler_spec(sampler, max_sample_luminance=0.0):
     out[:5] = spec
     out[5:6] = np.array([max_sample_luminance], dtype=np.float32).view(np.int32)
     return out
+
+
+def brute_force(positions, indices, rays, to_object=None, n_threads=8):
+    """Closest hit of every ray over ALL triangles (of every instance given by its world-to-object matrix), no aggregate:
+    (t[n] (inf = miss), prim[n], instance[n], ties[n] = triangles reaching exactly the smallest t)."""
+    positions, indices = _f32(positions), np.ascontiguousarray(indices, dtype=np.int32)
+    r = np.ascontiguousarray(rays)   # RAY_DTYPE: o[3], d[3], t_max, time = 8 floats
+    assert r.dtype.itemsize == 32
+    n = len(r)
+    t, prim, inst, ties = np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    m = None if to_object is None else np.ascontiguousarray(to_object, dtype=np.float32).reshape(-1, 16)
+    L = lib()
+    L.orc_brute_force.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.orc_brute_force.restype = None
+    L.orc_brute_force(_p(positions), _p(indices), len(indices), _p(m), 0 if m is None else len(m), _p(r), n, _p(t), _p(prim), _p(inst), _p(ties), n_threads)
+    return t, prim, inst, ties
 
 
 def sampler_tables(sampler, spp, seed=0, pixel_index=0):

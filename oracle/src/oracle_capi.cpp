@@ -334,6 +334,38 @@ void orc_intersect(void* h, const float* rays, int64_t n, void* out_hits, uint64
         counters[3] = s.inst_tests;
     }
 }
+// Closest hit WITHOUT an aggregate: every triangle of the mesh (of every instance, if `to_object` holds n_instances 4 x 4
+// world-to-object matrices) is put to Triangle::intersect's test with the ray's OWN t_max, and the smallest t wins — the
+// order-free definition BVHAccel::intersect (bvh.rs:828-879) must agree with, whatever its tree and its walk look like.
+// out_t[i] (inf: miss), out_prim[i] / out_inst[i] = the first triangle / instance reaching it, out_ties[i] = how many reach exactly it.
+void orc_brute_force(const float* positions, const int32_t* indices, int n_tris, const float* to_object, int n_instances, const float* rays,
+                     int64_t n, float* out_t, int32_t* out_prim, int32_t* out_inst, int32_t* out_ties, int n_threads) {
+    parallel_chunks(n, n_threads, [&](int, int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i) {
+            const float* r = rays + 8 * i;
+            const Ray world(Point3f(r[0], r[1], r[2]), Vector3f(r[3], r[4], r[5]), r[6], r[7]);
+            float best = FLOAT_INF;
+            int32_t prim = -1, inst = -1, ties = 0;
+            for (int k = 0; k < std::max(1, n_instances); ++k) {
+                Ray ray = world;
+                if (n_instances > 0) {
+                    Matrix4 m;
+                    std::memcpy(m.m, to_object + 16 * (size_t)k, sizeof(m.m));
+                    ray = xform_ray(m, world);  // TransformedPrimitive::intersect (primitive.rs:136-145): t is kept
+                }
+                for (int t = 0; t < n_tris; ++t) {
+                    const int32_t* v = indices + 3 * (size_t)t;
+                    auto P = [&](int32_t a) { return Point3f(positions[3 * (size_t)a], positions[3 * (size_t)a + 1], positions[3 * (size_t)a + 2]); };
+                    const TriHit h = triangle_intersect_test(P(v[0]), P(v[1]), P(v[2]), ray, 0);
+                    if (!h.hit) continue;
+                    if (h.t < best) best = h.t, prim = t, inst = n_instances > 0 ? k : -1, ties = 1;
+                    else if (h.t == best) ++ties;
+                }
+            }
+            out_t[i] = best, out_prim[i] = prim, out_inst[i] = inst, out_ties[i] = ties;
+        }
+    });
+}
 // Instrumentation for the layout study of the wide records (tools/wide_fill_study.py): for a single-level scene, how many of
 // these rays pass the box test of every node of BVHAccel::intersect's walk (any == 0) or intersect_p's (any != 0).
 void orc_node_visits(void* h, const float* rays, int64_t n, int any, uint64_t* entered_per_node) {

@@ -1,0 +1,133 @@
+"""BVHAccel::intersect / intersect_p (bvh.rs:828-933) against the definition that needs no tree: the closest hit is the smallest t
+over ALL triangles put to Triangle::intersect's test (itself held to exact rationals in test_exact_rational_pin.py). The brute-force
+loop shares nothing with the builders or the walks — the oracle's (o_bvh.h) and, on the GPU, the library's host builder, wide
+records and three traversal kernels.
+What the reference's algorithm promises, and what is asserted: (1) a ray hits something iff the brute force does (and intersect_p
+says so); (2) the hit an aggregate returns IS a hit of the triangle it names: that triangle alone is hit at the same t, bit for
+bit; (3) nothing is closer by more than a few ulps. Not "bit for bit the smallest t": once a hit has lowered ray.t_max, a
+neighbour sharing the hit edge or vertex whose own t comes out ONE ULP smaller can fail Bounds3f::intersect_p's `t_min < ray.t_max`
+(geometry.rs:748: t_min is not widened) or the triangle test's `t_scaled < t_max * det` comparison (triangle.rs:137-141, both
+sides rounded) — pbrt-v3 behaves the same; on a cloud of separate triangles — no shared edges or vertices — (4) the two agree bit for bit."""
+import numpy as np
+import pytest
+
+import oracle
+import pbrt_hip
+from pbrt_hip import scenes
+
+
+def _height_field(n, seq):
+    """(n + 1)^2 shared vertices, 2 n^2 triangles: every edge and vertex shared — where ties at equal t live."""
+    u = scenes.pcg32_float(seq, (n + 1) * (n + 1)).reshape(n + 1, n + 1)
+    xs = np.linspace(-1.0, 1.0, n + 1, dtype=np.float32)
+    pos = np.stack([np.repeat(xs[None, :], n + 1, 0), 0.3 * u.astype(np.float32), np.repeat(xs[:, None], n + 1, 1)], axis=-1).reshape(-1, 3)
+    idx = []
+    for j in range(n):
+        for i in range(n):
+            a = j * (n + 1) + i
+            idx += [[a, a + 1, a + n + 2], [a, a + n + 2, a + n + 1]]
+    return pos.astype(np.float32), np.asarray(idx, dtype=np.int32)
+
+
+def _rays_at(pos, idx, n, seq):
+    """Rays from above through random points of the mesh's triangles, through its VERTICES and through its EDGE midpoints."""
+    u = scenes.pcg32_float(seq, n * 5).reshape(n, 5)
+    tri = pos[idx[(u[:, 0] * len(idx)).astype(int) % len(idx)]]
+    kind = np.arange(n) % 3
+    b = np.where(kind[:, None] == 0, np.stack([u[:, 1] * (1 - u[:, 2]), u[:, 2], 1 - u[:, 1] * (1 - u[:, 2]) - u[:, 2]], 1),
+                 np.where(kind[:, None] == 1, np.array([1.0, 0.0, 0.0]), np.array([0.5, 0.5, 0.0])))
+    target = (b[:, :, None] * tri).sum(axis=1).astype(np.float32)
+    rays = np.zeros(n, dtype=pbrt_hip.RAY_DTYPE)
+    rays["o"] = np.stack([(u[:, 3] * 2 - 1) * 0.5, np.full(n, 2.0), (u[:, 4] * 2 - 1) * 0.5], axis=1).astype(np.float32)
+    rays["d"] = target - rays["o"]
+    rays["t_max"] = np.inf
+    return rays
+
+
+def _scenes():
+    out = {}
+    sc = scenes.random_triangles(3000, seq=3, extent=1.0, size=0.12)
+    out["cloud"] = (sc["positions"], sc["indices"], scenes.random_rays(3000, 11))
+    pos, idx = _height_field(24, 5)
+    out["height field"] = (pos, idx, _rays_at(pos, idx, 3000, 6))
+    sc = scenes.cornell_box()
+    r = scenes.random_rays(2000, 4, origin_extent=500.0)
+    r["o"] = np.abs(r["o"])
+    out["cornell"] = (sc["positions"], sc["indices"], r)
+    return out
+
+
+def _as_scene(pos, idx):
+    return dict(positions=pos, indices=idx, tri_material=np.zeros(len(idx), dtype=np.int32),
+                materials=scenes._materials([(scenes.MAT_MATTE, (0.5, 0.5, 0.5), (0, 0, 0), 1.0)]),
+                tri_light=np.full(len(idx), -1, dtype=np.int32), lights=scenes._lights([(scenes.LIGHT_INFINITE, (1.0, 1.0, 1.0), -1, 0, 1)]))
+
+
+def _check(name, hits, any_hit, pos, idx, rays, to_object=None, exact=False):
+    t, prim, inst, ties = oracle.brute_force(pos, idx, rays, to_object)
+    found = hits["prim_id"] >= 0
+    assert np.array_equal(found, np.isfinite(t)), (name, int((found != np.isfinite(t)).sum()))              # (1)
+    assert np.array_equal(any_hit.astype(bool), found), name
+    tb, th = t[found].astype(np.float64), hits["t"][found].astype(np.float64)
+    assert np.all(th >= tb) and np.all(th - tb <= 4 * 2.0 ** -23 * tb), (name, float(np.max((th - tb) / tb)))  # (3): within 4 ulps
+    off = np.flatnonzero(found & ((hits["t"] != t) | (hits["prim_id"] != prim) | ((hits["instance_id"] != inst) if to_object is not None else False)))
+    if exact:
+        assert not np.any(hits["t"][found] != t[found]), (name, len(off))                                      # (4)
+    m = None if to_object is None else np.asarray(to_object).reshape(-1, 16)
+    for i in off[:400]:                                                                                        # (2)
+        one = idx[hits["prim_id"][i]:hits["prim_id"][i] + 1]
+        mi = None if m is None else m[hits["instance_id"][i]:hits["instance_id"][i] + 1]
+        assert oracle.brute_force(pos, one, rays[i:i + 1], mi)[0][0] == hits["t"][i], (name, i)
+    return int(found.sum()), len(off)
+
+
+@pytest.mark.parametrize("split", [0, 1, 2, 3])
+def test_oracle_aggregate_is_the_brute_force(split):
+    """Every split method's tree (SAH, HLBVH, Middle, EqualCounts), leaves of 1 and 4 primitives."""
+    for name, (pos, idx, rays) in _scenes().items():
+        for max_prims in (1, 4):
+            osc = oracle.OracleScene(_as_scene(pos, idx), max_prims_in_node=max_prims, split_method=split)
+            hits, _ = osc.intersect(rays)
+            any_hit, _ = osc.intersect_p(rays)
+            n_hit, n_tied = _check(f"{name} split {split} max_prims {max_prims}", hits, any_hit, pos, idx, rays, exact=name == "cloud")
+            assert n_hit > len(rays) // 10
+            osc.close()
+
+
+def test_oracle_instances_are_the_brute_force():
+    """TransformedPrimitive::intersect (primitive.rs:136-159): every instance's triangles under its world-to-object matrix."""
+    sc = scenes.instanced_scene(300, 12, extent=1.0, base_extent=0.4, tri_size=0.12)
+    osc = oracle.OracleScene(sc)
+    rays = scenes.random_rays(2000, 8, origin_extent=1.5)
+    hits, _ = osc.intersect(rays)
+    any_hit, _ = osc.intersect_p(rays)
+    to_object = np.asarray(sc["instances"], dtype=np.float32)[:, 1].reshape(-1, 16)
+    n_hit, _ = _check("instanced", hits, any_hit, sc["positions"], sc["indices"], rays, to_object)
+    assert n_hit > 100
+    osc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("traversal", [0, 1, 2])
+def test_device_aggregate_is_the_brute_force(hip_ctx, traversal):
+    """The library's builder, its 4-wide records (0), binary records with a stack (1) and stackless (2)."""
+    hip_ctx.set_traversal(traversal)
+    try:
+        for name, (pos, idx, rays) in _scenes().items():
+            for split in (0, 1):
+                g = pbrt_hip.Scene(hip_ctx, _as_scene(pos, idx), split_method=split)
+                _check(f"{name} traversal {traversal} split {split}", g.intersect(rays), g.intersect_p(rays), pos, idx, rays, exact=name == "cloud")
+                g.close()
+    finally:
+        hip_ctx.set_traversal(0)
+
+
+@pytest.mark.gpu
+def test_device_instances_are_the_brute_force(hip_ctx):
+    sc = scenes.instanced_scene(300, 12, extent=1.0, base_extent=0.4, tri_size=0.12)
+    g = pbrt_hip.Scene(hip_ctx, sc)
+    rays = scenes.random_rays(2000, 8, origin_extent=1.5)
+    to_object = np.asarray(sc["instances"], dtype=np.float32)[:, 1].reshape(-1, 16)
+    n_hit, _ = _check("instanced on the device", g.intersect(rays), g.intersect_p(rays), sc["positions"], sc["indices"], rays, to_object)
+    assert n_hit > 100
+    g.close()
