@@ -63,7 +63,7 @@ def _as_scene(pos, idx):
                 tri_light=np.full(len(idx), -1, dtype=np.int32), lights=scenes._lights([(scenes.LIGHT_INFINITE, (1.0, 1.0, 1.0), -1, 0, 1)]))
 
 
-def _check(name, hits, any_hit, pos, idx, rays, to_object=None, exact=False):
+def _check_once(name, hits, any_hit, pos, idx, rays, to_object, exact):
     t, prim, inst, ties = oracle.brute_force(pos, idx, rays, to_object)
     found = hits["prim_id"] >= 0
     assert np.array_equal(found, np.isfinite(t)), (name, int((found != np.isfinite(t)).sum()))              # (1)
@@ -78,7 +78,20 @@ def _check(name, hits, any_hit, pos, idx, rays, to_object=None, exact=False):
         one = idx[hits["prim_id"][i]:hits["prim_id"][i] + 1]
         mi = None if m is None else m[hits["instance_id"][i]:hits["instance_id"][i] + 1]
         assert oracle.brute_force(pos, one, rays[i:i + 1], mi)[0][0] == hits["t"][i], (name, i)
-    return int(found.sum()), len(off)
+    return t, int(found.sum()), len(off)
+
+
+def _check(name, intersect, intersect_p, pos, idx, rays, to_object=None, exact=False):
+    """Unbounded rays, then the same rays cut short: t_max at 0.5 x, 0.999 x, 1.001 x and 2 x the closest hit — segments that stop
+    before the surface, just before it, just behind it and well behind it (shadow rays are such segments: Ray::t_max is what
+    intersect_p is about, bvh.rs:881-933). Clear of the one-ulp zone around t_max itself (see the module text)."""
+    t, n_hit, n_off = _check_once(name, intersect(rays), intersect_p(rays), pos, idx, rays, to_object, exact)
+    cut = rays.copy()
+    factor = np.array([0.5, 0.999, 1.001, 2.0], dtype=np.float32)[np.arange(len(rays)) % 4]
+    cut["t_max"] = np.where(np.isfinite(t), t * factor, np.float32(1.0))
+    t_cut, n_cut, _ = _check_once(name + " (segments)", intersect(cut), intersect_p(cut), pos, idx, cut, to_object, exact)
+    assert 0 < n_cut < n_hit or n_hit == 0
+    return n_hit, n_off
 
 
 @pytest.mark.parametrize("split", [0, 1, 2, 3])
@@ -87,9 +100,8 @@ def test_oracle_aggregate_is_the_brute_force(split):
     for name, (pos, idx, rays) in _scenes().items():
         for max_prims in (1, 4):
             osc = oracle.OracleScene(_as_scene(pos, idx), max_prims_in_node=max_prims, split_method=split)
-            hits, _ = osc.intersect(rays)
-            any_hit, _ = osc.intersect_p(rays)
-            n_hit, n_tied = _check(f"{name} split {split} max_prims {max_prims}", hits, any_hit, pos, idx, rays, exact=name == "cloud")
+            n_hit, n_tied = _check(f"{name} split {split} max_prims {max_prims}", lambda r: osc.intersect(r)[0], lambda r: osc.intersect_p(r)[0],
+                                   pos, idx, rays, exact=name == "cloud")
             assert n_hit > len(rays) // 10
             osc.close()
 
@@ -99,10 +111,8 @@ def test_oracle_instances_are_the_brute_force():
     sc = scenes.instanced_scene(300, 12, extent=1.0, base_extent=0.4, tri_size=0.12)
     osc = oracle.OracleScene(sc)
     rays = scenes.random_rays(2000, 8, origin_extent=1.5)
-    hits, _ = osc.intersect(rays)
-    any_hit, _ = osc.intersect_p(rays)
     to_object = np.asarray(sc["instances"], dtype=np.float32)[:, 1].reshape(-1, 16)
-    n_hit, _ = _check("instanced", hits, any_hit, sc["positions"], sc["indices"], rays, to_object)
+    n_hit, _ = _check("instanced", lambda r: osc.intersect(r)[0], lambda r: osc.intersect_p(r)[0], sc["positions"], sc["indices"], rays, to_object)
     assert n_hit > 100
     osc.close()
 
@@ -116,7 +126,7 @@ def test_device_aggregate_is_the_brute_force(hip_ctx, traversal):
         for name, (pos, idx, rays) in _scenes().items():
             for split in (0, 1):
                 g = pbrt_hip.Scene(hip_ctx, _as_scene(pos, idx), split_method=split)
-                _check(f"{name} traversal {traversal} split {split}", g.intersect(rays), g.intersect_p(rays), pos, idx, rays, exact=name == "cloud")
+                _check(f"{name} traversal {traversal} split {split}", g.intersect, g.intersect_p, pos, idx, rays, exact=name == "cloud")
                 g.close()
     finally:
         hip_ctx.set_traversal(0)
@@ -128,6 +138,6 @@ def test_device_instances_are_the_brute_force(hip_ctx):
     g = pbrt_hip.Scene(hip_ctx, sc)
     rays = scenes.random_rays(2000, 8, origin_extent=1.5)
     to_object = np.asarray(sc["instances"], dtype=np.float32)[:, 1].reshape(-1, 16)
-    n_hit, _ = _check("instanced on the device", g.intersect(rays), g.intersect_p(rays), sc["positions"], sc["indices"], rays, to_object)
+    n_hit, _ = _check("instanced on the device", g.intersect, g.intersect_p, sc["positions"], sc["indices"], rays, to_object)
     assert n_hit > 100
     g.close()
