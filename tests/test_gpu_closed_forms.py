@@ -240,3 +240,42 @@ def test_zerotwo_sampler_is_a_net_on_the_device(hip_ctx):
         assert len(tables) > 240                       # each pixel under its own scramble
         first = (pix[:, 0] == 0) & (pix[:, 1] == 0)
         cs.check_unit_interval(pfilm[first])
+
+
+def test_camera_rays_against_the_generate_ray_formulas(hip_ctx):
+    """Camera::generate_ray in float64 numpy at the film positions the device reports: perspective (perspective.rs:90-99: the ray
+    from the origin through raster_to_camera(p_film), normalised), orthographic (orthographic.rs:82-90: from raster_to_camera(p_film)
+    along +z), environment (environment.rs:37-45), each through camera_to_world; every (pixel, sample) of the bounds once; the
+    stream of sample s of pixel number n is seed ^ (n spp + s)."""
+    w, h, spp, seed = 48, 32, 3, 0x1234
+    g = pbrt_hip.Scene(hip_ctx, cf.sky_scene())
+    cams = {"perspective": scenes.perspective_camera((1.0, 2.0, -5.0), (0.2, 0.1, 0.0), (0.0, 1.0, 0.0), 35.0, w, h),
+            "orthographic": scenes.orthographic_camera((1.0, 2.0, -5.0), (0.2, 0.1, 0.0), (0.0, 1.0, 0.0), 1.7, w, h),
+            "environment": scenes.environment_camera((1.0, 2.0, -5.0), (0.2, 0.1, 0.0), (0.0, 1.0, 0.0))}
+    for name, cam in cams.items():
+        rays, keys, pfilm, pix = g.camera_rays(cam, w, h, spp, seed=seed)
+        ok = pix[:, 0] >= 0
+        assert ok.sum() == w * h * spp and len(rays) == w * h * spp      # 48 x 32 is whole tiles: no padding paths
+        n = pix[:, 1].astype(np.int64) * w + pix[:, 0]
+        assert sorted((n * spp + pix[:, 2]).tolist()) == list(range(w * h * spp))
+        assert np.array_equal(keys, np.uint64(seed) ^ (n * spp + pix[:, 2]).astype(np.uint64))
+        u = pfilm.astype(np.float64) - pix[:, :2]
+        assert np.all(u > -1e-6) and np.all(u < 1.0 + 1e-6)
+        c2w = np.asarray(cam["camera_to_world"], dtype=np.float64).reshape(4, 4)
+        r2c = np.asarray(cam["raster_to_camera"], dtype=np.float64).reshape(4, 4)
+        pf = np.concatenate([pfilm.astype(np.float64), np.zeros((len(pfilm), 1)), np.ones((len(pfilm), 1))], axis=1)
+        pc = pf @ r2c.T
+        pc = pc[:, :3] / pc[:, 3:4]
+        if name == "perspective":
+            o_c, d_c = np.zeros_like(pc), pc / np.linalg.norm(pc, axis=1, keepdims=True)
+        elif name == "orthographic":
+            o_c, d_c = pc, np.tile([0.0, 0.0, 1.0], (len(pc), 1))
+        else:
+            theta, phi = np.pi * pfilm[:, 1].astype(np.float64) / h, 2 * np.pi * pfilm[:, 0].astype(np.float64) / w
+            o_c, d_c = np.zeros_like(pc), np.stack([np.sin(theta) * np.cos(phi), np.cos(theta), np.sin(theta) * np.sin(phi)], axis=1)
+        o_w = o_c @ c2w[:3, :3].T + c2w[:3, 3]
+        d_w = d_c @ c2w[:3, :3].T
+        assert np.abs(rays["o"] - o_w).max() <= 4e-6 * max(1.0, np.abs(o_w).max()), (name, np.abs(rays["o"] - o_w).max())
+        assert np.abs(rays["d"] - d_w).max() <= 4e-6, (name, np.abs(rays["d"] - d_w).max())
+        assert np.all(np.isinf(rays["t_max"]))
+    g.close()
