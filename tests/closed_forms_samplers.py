@@ -48,3 +48,52 @@ def check_02_net(p, n):
         b = k - a
         cell = np.floor(p[:, 0] * 2 ** a).astype(int) * 2 ** b + np.floor(p[:, 1] * 2 ** b).astype(int)
         assert sorted(cell) == list(range(n)), (a, b, np.sort(cell))
+
+
+def radical_inverse(base, i):
+    """Phi_base(i) in float64 (lowdiscrepancy.rs:293-320): the digits of i mirrored about the radix point."""
+    i = np.asarray(i, dtype=np.int64).copy()
+    out, scale = np.zeros(i.shape, dtype=np.float64), 1.0 / base
+    while np.any(i > 0):
+        out += (i % base) * scale
+        i //= base
+        scale /= base
+    return out
+
+
+def halton_camera_samples(width, height, spp):
+    """HaltonSampler over a width x height film (halton.rs:63-142) from its definition: sample i of the 2D Halton sequence
+    (Phi_2(i), Phi_3(i)), scaled by the smallest 2^j >= width and 3^k >= height, lies in pixel (floor x, floor y); in every run of
+    2^j 3^k consecutive indices every pixel of that grid is visited once, so the s-th sample of a pixel is the one of the s-th run.
+    Returns u[height, width, spp, 2] = the positions inside the pixels (the sampler's first two dimensions) and the indices."""
+    sx = 1
+    while sx < min(width, 128):
+        sx *= 2
+    sy = 1
+    while sy < min(height, 128):
+        sy *= 3
+    stride = sx * sy
+    i = np.arange(stride * spp, dtype=np.int64)
+    x, y = radical_inverse(2, i) * sx, radical_inverse(3, i) * sy
+    # Phi_3 in float64 can land a hair under an integer it equals exactly: floor on the exact digits instead
+    px = np.zeros(len(i), dtype=np.int64)
+    t, m = i.copy(), sx
+    while m > 1:
+        m //= 2
+        px += (t % 2) * m
+        t //= 2
+    py = np.zeros(len(i), dtype=np.int64)
+    t, m = i.copy(), sy
+    while m > 1:
+        m //= 3
+        py += (t % 3) * m
+        t //= 3
+    u = np.full((height, width, spp, 2), np.nan)
+    idx = np.full((height, width, spp), -1, dtype=np.int64)
+    s = i // stride
+    inside = (px < width) & (py < height)
+    u[py[inside], px[inside], s[inside], 0] = (x - px)[inside]
+    u[py[inside], px[inside], s[inside], 1] = (y - py)[inside]
+    idx[py[inside], px[inside], s[inside]] = i[inside]
+    assert not np.isnan(u).any()          # every pixel once per run
+    return u, idx

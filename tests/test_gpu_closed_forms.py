@@ -279,3 +279,18 @@ def test_camera_rays_against_the_generate_ray_formulas(hip_ctx):
         assert np.abs(rays["d"] - d_w).max() <= 4e-6, (name, np.abs(rays["d"] - d_w).max())
         assert np.all(np.isinf(rays["t_max"]))
     g.close()
+
+
+def test_halton_sampler_points_on_the_device(hip_ctx):
+    """The device's HaltonSampler (k_generate's samp_2d over the radical inverses) against the sequence's definition: film
+    position = pixel + the point of the 2D Halton sequence that falls into the pixel, the s-th one for sample s."""
+    spp = 4
+    g = pbrt_hip.Scene(hip_ctx, cf.sky_scene())
+    _, _, pfilm, pix = g.camera_rays(cf.sky_camera(16, 16), 16, 16, spp, seed=0, sampler=("halton",))
+    g.close()
+    assert len(pfilm) == 256 * spp and np.all(pix[:, 0] >= 0)
+    u, _ = cs.halton_camera_samples(16, 16, spp)
+    want = pix[:, :2] + u[pix[:, 1], pix[:, 0], pix[:, 2]]
+    assert np.abs(pfilm.astype(np.float64) - want).max() <= 2e-6, np.abs(pfilm.astype(np.float64) - want).max()
+    first = (pix[:, 0] == 0) & (pix[:, 1] == 0)            # pixel (0, 0): p_film is the sample itself
+    assert np.abs(pfilm[first].astype(np.float64) - u[0, 0][pix[first, 2]]).max() <= 2e-7

@@ -418,3 +418,22 @@ def test_zerotwo_sampler_is_a_net_in_every_dimension():
                     cs.check_02_net(b[d], n)
                 tables.add(b[0].tobytes())
         assert len(tables) == len(SAMPLER_PIXELS) * len(SAMPLER_SEEDS)   # scrambled per pixel and seed
+
+
+def test_halton_sampler_points_are_the_halton_sequence():
+    """HaltonSampler's camera samples over a 16 x 16 and a 20 x 11 film against the sequence's definition
+    (closed_forms_samplers.halton_camera_samples): the global index of every (pixel, sample) exactly, the position inside the
+    pixel (the sampler's dimensions 0 and 1) to float32 rounding."""
+    import ctypes
+    L = oracle.lib()
+    L.orc_halton_probe.argtypes = [ctypes.c_int] * 6 + [ctypes.c_void_p]
+    out = np.zeros(6)
+    for w, h, spp in ((16, 16, 4), (20, 11, 3)):
+        u, idx = cs.halton_camera_samples(w, h, spp)
+        for py in range(h):
+            for px in range(w):
+                for s in range(spp):
+                    for dim in (0, 1):
+                        L.orc_halton_probe(w, h, px, py, s, dim, out.ctypes.data)
+                        assert int(out[0]) == idx[py, px, s], (w, h, px, py, s)
+                        assert abs(out[1] - u[py, px, s, dim]) <= 2e-7, (w, h, px, py, s, dim, out[1], u[py, px, s, dim])
