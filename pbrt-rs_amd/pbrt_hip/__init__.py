@@ -621,11 +621,11 @@ class Scene:
         self.ctx.check(lib().pbrt_hip_li(self.h, ctypes.byref(lp), _p(rays), _p(keys), len(rays), _p(rgb), ctypes.byref(st)), "pbrt_hip_li")
         return rgb, {name: getattr(st, name) for name, _ in RenderStats._fields_}
 
-    def camera_rays(self, camera, width, height, spp, seed=0, bounds=None, tile_rank=0, tile_world=1, tile_order=0, sampler=None):
+    def camera_rays(self, camera, width, height, spp, seed=0, bounds=None, tile_rank=0, tile_world=1, tile_order=0, sampler=None, filter=None):
         """The camera-ray stage of render(): (rays[RAY_DTYPE], stream_keys[uint64], p_film[n, 2], pixel_sample[n, 3]).
         sampler as in render(): the camera sample is the sampler's first 2D, first 1D (ray.time) and second 2D draw (sampler.rs:66-73)."""
         camera = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
-        rp = self._params(width, height, spp, INTEGRATOR_PATH, 5, 1.0, 1, seed, bounds, tile_rank, tile_world, 0, None, 64, sampler, 0.0,
+        rp = self._params(width, height, spp, INTEGRATOR_PATH, 5, 1.0, 1, seed, bounds, tile_rank, tile_world, 0, filter, 64, sampler, 0.0,
                           tile_order=tile_order)
         n = ctypes.c_int64()
         lib().pbrt_hip_camera_rays(self.h, _p(camera), ctypes.byref(rp), 0, None, None, None, None, ctypes.byref(n))

@@ -294,3 +294,25 @@ def test_halton_sampler_points_on_the_device(hip_ctx):
     assert np.abs(pfilm.astype(np.float64) - want).max() <= 2e-6, np.abs(pfilm.astype(np.float64) - want).max()
     first = (pix[:, 0] == 0) & (pix[:, 1] == 0)            # pixel (0, 0): p_film is the sample itself
     assert np.abs(pfilm[first].astype(np.float64) - u[0, 0][pix[first, 2]]).max() <= 2e-7
+
+
+def test_camera_samples_over_the_sample_bounds_of_a_wide_filter(hip_ctx):
+    """With a filter wider than the 0.5 box the samples run over Film::get_sample_bounds (film.rs:76-81): pixels outside the film,
+    negative coordinates included; the pixel NUMBER that keys a sample's stream counts row-major over THOSE bounds."""
+    w, h, spp, seed = 40, 24, 2, 77
+    g = pbrt_hip.Scene(hip_ctx, cf.sky_scene())
+    flt = pbrt_hip.filter_table("gaussian", 2.0, 1.5, 2.0)
+    x0, y0, x1, y1 = pbrt_hip.sample_bounds(w, h, 2.0, 1.5)
+    assert (x0, y0, x1, y1) == (-2, -1, w + 2, h + 1)                  # floor(0.5 - r), ceil(w - 0.5 + r)
+    rays, keys, pfilm, pix = g.camera_rays(cf.sky_camera(w, h), w, h, spp, seed=seed, filter=flt)
+    ok = pix[:, 0] > -1000000
+    inside = (pix[:, 0] >= x0) & (pix[:, 0] < x1) & (pix[:, 1] >= y0) & (pix[:, 1] < y1) & (rays["t_max"] > 0)
+    n_pix = (x1 - x0) * (y1 - y0)
+    assert inside.sum() == n_pix * spp                                 # padding paths of border tiles carry t_max < 0
+    n = (pix[inside, 1].astype(np.int64) - y0) * (x1 - x0) + (pix[inside, 0] - x0)
+    assert sorted((n * spp + pix[inside, 2]).tolist()) == list(range(n_pix * spp))
+    assert np.array_equal(keys[inside], np.uint64(seed) ^ (n * spp + pix[inside, 2]).astype(np.uint64))
+    u = pfilm[inside].astype(np.float64) - pix[inside, :2]
+    assert np.all(u > -1e-6) and np.all(u < 1.0 + 1e-6)
+    assert (pix[inside, 0] < 0).any() and (pix[inside, 1] < 0).any()   # the test has the negative side in it
+    g.close()
