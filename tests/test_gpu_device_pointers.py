@@ -78,3 +78,22 @@ def test_device_buffer_calls_equal_the_host_buffer_calls(hip_ctx, name):
     for b in (d_rays, d_hits, d_any, d_part):
         b.free()
     g.close()
+
+
+def test_trace_timing_accumulates_what_the_render_calls_report(hip_ctx):
+    """pbrt_hip_trace_timing: the context's running total of HIP-event time in the traversal kernel and of its launches = the sum
+    of what every render call reported (PbrtRenderStats.trace_ms / trace_launches); reading with reset starts over."""
+    g = pbrt_hip.Scene(hip_ctx, scenes.cornell_box())
+    cam = scenes.cornell_camera(64, 64)
+    hip_ctx.trace_timing(reset=True)
+    assert hip_ctx.trace_timing() == (0.0, 0)
+    total_ms, total_n = 0.0, 0
+    for spp in (2, 4):
+        _, st = g.render(cam, 64, 64, spp, max_depth=4, seed=1)
+        assert st["trace_launches"] >= 2 and st["trace_ms"] > 0.0
+        total_ms, total_n = total_ms + st["trace_ms"], total_n + st["trace_launches"]
+        ms, n = hip_ctx.trace_timing()
+        assert n == total_n and abs(ms - total_ms) <= 1e-9 * total_ms
+    assert hip_ctx.trace_timing(reset=True)[1] == total_n        # the read that resets still returns the totals
+    assert hip_ctx.trace_timing() == (0.0, 0)
+    g.close()
