@@ -141,3 +141,56 @@ def test_device_instances_are_the_brute_force(hip_ctx):
     n_hit, _ = _check("instanced on the device", g.intersect, g.intersect_p, sc["positions"], sc["indices"], rays, to_object)
     assert n_hit > 100
     g.close()
+
+
+def _brute_two_level(sc, rays):
+    """The general top level (primitive.rs:105-159 beside :33-103) without any tree: every instance's object triangles under its
+    world-to-object matrix, and the world-space triangles, all put to the triangle test; the smallest t, and who reaches it."""
+    n = len(rays)
+    best = np.full(n, np.inf, dtype=np.float32)
+    prim, inst = np.full(n, -1, dtype=np.int32), np.full(n, -1, dtype=np.int32)
+    to_object = np.asarray(sc["instances"], dtype=np.float32)[:, 1].reshape(-1, 16)
+    io = np.asarray(sc["instance_object"])
+    for k, obj in enumerate(sc["objects"]):
+        sel = np.flatnonzero(io == k)
+        if len(sel) == 0:
+            continue
+        t, p, i, _ = oracle.brute_force(obj["positions"], obj["indices"], rays, to_object[sel])
+        closer = t < best
+        best, prim, inst = np.where(closer, t, best), np.where(closer, p, prim), np.where(closer, sel[np.maximum(i, 0)], inst)
+    w = sc["world"]
+    if len(w["indices"]):
+        t, p, _, _ = oracle.brute_force(w["positions"], w["indices"], rays)
+        closer = t < best
+        best, prim, inst = np.where(closer, t, best), np.where(closer, p, prim), np.where(closer, -1, inst)
+    return best, prim, inst
+
+
+def _check_two_level(name, hits, any_hit, sc, rays):
+    t, prim, inst = _brute_two_level(sc, rays)
+    found = hits["prim_id"] >= 0
+    assert np.array_equal(found, np.isfinite(t)) and np.array_equal(any_hit.astype(bool), found), name
+    tb, th = t[found].astype(np.float64), hits["t"][found].astype(np.float64)
+    assert np.all(th >= tb) and np.all(th - tb <= 4 * 2.0 ** -23 * tb), (name, float(np.max((th - tb) / tb)))
+    # clouds of separate triangles: no shared edges, the aggregate and the brute force name the same hit
+    assert np.array_equal(hits["t"][found], t[found]) and np.array_equal(hits["prim_id"][found], prim[found]), name
+    assert np.array_equal(hits["instance_id"][found], inst[found]), name
+    assert (inst[found] >= 0).sum() > 100 and (inst[found] < 0).sum() > 100, name      # both kinds of primitive were hit
+    return int(found.sum())
+
+
+def test_oracle_general_two_level_scene_is_the_brute_force():
+    sc = scenes.two_level_scene(30)
+    osc = oracle.OracleScene(sc)
+    rays = scenes.random_rays(6000, 9, origin_extent=3.0)
+    _check_two_level("two-level", osc.intersect(rays)[0], osc.intersect_p(rays)[0], sc, rays)
+    osc.close()
+
+
+@pytest.mark.gpu
+def test_device_general_two_level_scene_is_the_brute_force(hip_ctx):
+    sc = scenes.two_level_scene(30)
+    g = pbrt_hip.Scene(hip_ctx, sc)
+    rays = scenes.random_rays(6000, 9, origin_extent=3.0)
+    _check_two_level("two-level on the device", g.intersect(rays), g.intersect_p(rays), sc, rays)
+    g.close()
