@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: two processes (gloo) each take their tile share from the library's host-side
+"""N > 1 path on CPU: two and four processes (gloo) each take their tile share from the library's host-side
 tile partition (pbrt_hip_tile_partition, the function pbrt_hip_render uses), render those tiles —
 here with the CPU oracle standing in for the GPU kernels — into a zero-initialised full-size film,
 and reduce(SUM) to rank 0 exactly as bench.py does over RCCL. The sum must equal the one-process frame."""
@@ -148,7 +148,8 @@ def test_bench_stage_failure_ends_every_rank_nonzero(tmp_path, fail):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_tile_sharding_and_film_reduce(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])   # from four ranks on the Morton deal is a 2-D lattice, not tile columns
+def test_tile_sharding_and_film_reduce(tmp_path, world):
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
@@ -158,7 +159,7 @@ def test_two_rank_tile_sharding_and_film_reduce(tmp_path):
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / "film.npy")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     got = np.load(out)
     film, n_owned = got[:-1].reshape(H, W, 4), got[-1]
     osc = oracle.OracleScene(scenes.cornell_box())
