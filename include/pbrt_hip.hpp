@@ -615,8 +615,15 @@ public:
     // The same frame as one of comm.world processes: this process renders the tiles dealt to comm.rank into a film on its
     // device, the films are summed with one RCCL reduce, and rank `root` (every rank if root < 0) holds the frame in camera->film.
     void render(const Scene& scene, const Comm& comm, int root = 0) {
+        const int rank0 = tile_rank, world0 = tile_world;  // the share is the communicator's for this call only
         tile_rank = comm.rank, tile_world = comm.world;
-        render_into(scene, &comm, root);
+        try {
+            render_into(scene, &comm, root);
+        } catch (...) {
+            tile_rank = rank0, tile_world = world0;
+            throw;
+        }
+        tile_rank = rank0, tile_world = world0;
     }
 
 private:
